@@ -1,0 +1,164 @@
+/*
+ * spaa_hip.h — C-ABI of libspaa_hip.so: the MI355X (gfx950) kernels behind the SPAA attack loop.
+ *
+ * The reference (BingyaoHuang/SPAA) is pure Python over ATen; it has no FFI layer.  The drop-in boundary is
+ * therefore the set of tensor operations its hot path dispatches (SURVEY.md §2.1 G0–G16, §8b).  Every entry point
+ * takes raw device pointers, plain sizes and a hipStream_t, returns 0 on success or a hipError_t value, never
+ * allocates, frees or synchronises (graph-capture safe), and names the reference call it replaces
+ * (paths relative to /root/reference/src/python).
+ *
+ * Layout convention: activations are NHWC fp32 with an explicit channel stride (`cstride`, multiple of 4) and
+ * channel offset (`coff`, multiple of 4); 3-channel images are stored NHWC with cstride 4 ("NHWC4", pad lane = 0).
+ * The reference's NCHW tensors are converted at the Python boundary by spaa_nchw_to_nhwc4 / spaa_nhwc4_to_nchw.
+ */
+#ifndef SPAA_HIP_H
+#define SPAA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* spaa_stream_t; /* hipStream_t */
+
+#define SPAA_MAX_CLASSES 4
+#define SPAA_MAX_TAPS 64
+
+/* activation applied after bias + residual add */
+enum { SPAA_ACT_NONE = 0, SPAA_ACT_RELU = 1, SPAA_ACT_RELU_CLAMP1 = 2, SPAA_ACT_LEAKY01 = 3 };
+/* gate applied last (ReLU / clamp backward):  out = pass(gate) ? v : 0 */
+enum { SPAA_GATE_NONE = 0, SPAA_GATE_POS = 1 /* gate > 0 */, SPAA_GATE_POS_LE1 = 2 /* 0 < gate <= 1 */ };
+
+typedef struct {
+    int32_t oy0, ox0;  /* output offset of this parity class */
+    int32_t ntaps;     /* taps of this class */
+    int32_t tap_off;   /* first tap in `taps` */
+    int32_t K;         /* ntaps * Cin */
+    int32_t Kpad;      /* K rounded up to 32 */
+    int64_t w_off;     /* float offset of this class's packed weights [Npad][Kpad] */
+} spaa_tapclass_t;
+
+/*
+ * Generic "tap-list" convolution as an implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32):
+ *   out[b, oy0 + s_out*y, ox0 + s_out*x, n] = gate( act( bias[n] + add[...] +
+ *        sum_{t<ntaps, c<Cin} in[b, s_in*y + dy_t, s_in*x + dx_t, c] * W[n][t*Cin + c] ) )
+ * for y < Hm, x < Wm, zero padding outside the input.  One primitive covers
+ *   - nn.Conv2d forward, stride 1/2            (models.py:223-252 conv*, skipConv*; torchvision convs)
+ *   - nn.ConvTranspose2d forward, stride 2     (models.py:237-238; = 4 output-parity classes)
+ *   - aten::convolution_backward w.r.t. input  (autograd of the above, projector_based_attack.py:302,310)
+ * by the choice of taps / weight packing (spaa_amd/convplan.py).
+ */
+typedef struct {
+    const float* in;
+    int32_t Hin, Win, Cin, in_cstride, in_coff;
+    float* out;
+    int32_t Hout, Wout, Cout, out_cstride, out_coff;
+    int32_t B, Hm, Wm, s_in, s_out;
+    const float* weights; /* packed, see spaa_tapclass_t.w_off; rows padded to a multiple of 128 */
+    const int32_t* taps;  /* device array of (dy, dx) pairs */
+    const float* bias;    /* [Cout] or NULL */
+    const float* add;     /* residual, indexed like `out`, or NULL */
+    int32_t add_cstride, add_coff;
+    const float* gate;    /* indexed like `out`, or NULL */
+    int32_t gate_cstride, gate_coff, gate_mode;
+    int32_t act;
+    float* aux_out;       /* optional second output: value BEFORE the clamp of SPAA_ACT_RELU_CLAMP1 (same indexing) */
+    int32_t nclass;
+    spaa_tapclass_t cls[SPAA_MAX_CLASSES];
+} spaa_tapconv_t;
+
+int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream);
+
+/* ---- layout conversion at the NCHW boundary ---------------------------------------------------------------- */
+/* src [B,3,H,W] -> dst [B,H,W,4] (lane 3 = 0); optional clamp to [0,1] (projector_based_attack.py:265) */
+int spaa_nchw_to_nhwc4(const float* src, float* dst, int B, int H, int W, int clamp01, spaa_stream_t stream);
+int spaa_nhwc4_to_nchw(const float* src, float* dst, int B, int H, int W, spaa_stream_t stream);
+
+/* ---- WarpingNet (models.py:163-185, pytorch_tps.py:29-106) ----------------------------------------------- */
+/* Coarse grid: F.affine_grid(affine_mat) sampled at tps_grid(theta, ctrl) (models.py:168-172), batch 1.
+ * out: [Hout, Wout, 4] = (gx, gy, 0, 0) in normalised [-1,1] coordinates. theta: [T+2][2], ctrl: [T][2]. */
+int spaa_warp_coarse_grid(const float* affine6, const float* theta, const float* ctrl, int T, int Hin, int Win,
+                          int Hout, int Wout, float* out, spaa_stream_t stream);
+/* fine = clamp(refine + coarse, -1, 1) (models.py:176); all [Hout, Wout, 4] */
+int spaa_warp_finish_grid(const float* coarse, const float* refine, float* fine, int npix, spaa_stream_t stream);
+/* F.grid_sample(clamp(x,0,1), fine_grid, bilinear, zeros, align_corners=True) * mask (models.py:184,340), and the
+ * rough input [s, xw*s] (models.py:342).  x: [B,Hp,Wp,4]; grid: [Hc,Wc,4]; mask: [Hc,Wc]; s: [B,Hc,Wc,4];
+ * xw: [B,Hc,Wc,4]; cat8: [B,Hc,Wc,8] = (s.rgb, xw*s .rgb, 0, 0) or NULL. */
+int spaa_warp_fwd(const float* x, const float* grid, const float* mask, const float* s, float* xw, float* cat8,
+                  int B, int Hp, int Wp, int Hc, int Wc, int clamp01, spaa_stream_t stream);
+/* Backward of the above w.r.t. x (grid_sampler_2d_backward + clamp mask): g_x must be zeroed by the caller
+ * (spaa_zero); contributions are accumulated with float atomics.
+ * g_xw: [B,Hc,Wc,4] gradient w.r.t. xw (conv1 path); g_xs: [B,Hc,Wc,4] gradient w.r.t. xw*s (channels 3..5 of
+ * conv1_s's input) or NULL:  g_total = (g_xw + g_xs * s) * mask. */
+int spaa_warp_bwd(const float* g_xw, const float* g_xs, const float* x, const float* grid, const float* mask,
+                  const float* s, float* g_x, int B, int Hp, int Wp, int Hc, int Wc, int clamp01,
+                  spaa_stream_t stream);
+
+/* ---- stealthiness losses (projector_based_attack.py:275-287; perc_al/differential_color_functions.py) ----- */
+/* rgb [B,H,W,4] -> lab [B,H,W,4]  (rgb2lab_diff :39-64) */
+int spaa_rgb2lab(const float* rgb, float* lab, int npix, spaa_stream_t stream);
+/* per-pixel CIEDE2000 map (ciede2000_diff :109-180) of two Lab images -> de [npix] */
+int spaa_ciede2000(const float* lab1, const float* lab2, float* de, int npix, spaa_stream_t stream);
+/* Fused camera-side stealth loss + gradient (one launch replaces ~600 ATen ops):
+ *   caml2_px = ||scene - y||_2 over rgb ; camdE_px = dE00(lab(y), scene_lab)
+ *   g_y      = gscale * (caml2_w * d caml2_px/dy + camdE_w * d camdE_px/dy)      gscale = 1/(B*H*W)
+ * y, scene, scene_lab, g_y: [B,HW,4]; partial: [B][nblk][2] block partial sums (caml2, camdE) with
+ * nblk = ceil(HW/256), reduced in fixed order by spaa_decide. */
+int spaa_stealth_loss_fwd_bwd(const float* y, const float* scene, const float* scene_lab, float caml2_w,
+                              float camdE_w, float gscale, float* g_y, float* partial, int B, int HW,
+                              spaa_stream_t stream);
+
+/* ---- classifier pre/post-processing (classifier.py:55-72, img_proc.py:117-132) --------------------------- */
+/* center_crop + F.interpolate(mode='area') + Normalize, NHWC4 in -> NHWC4 out; mean3/std3 are HOST pointers */
+int spaa_preproc_fwd(const float* y, float* out, int B, int H, int W, int cy0, int cx0, int ch, int cw, int oh,
+                     int ow, const float* mean3, const float* std3, spaa_stream_t stream);
+/* adjoint: g_out [B,oh,ow,4] -> g_y [B,H,W,4] (zero outside the crop) */
+int spaa_preproc_bwd(const float* g_out, float* g_y, int B, int H, int W, int cy0, int cx0, int ch, int cw,
+                     int oh, int ow, const float* std3, spaa_stream_t stream);
+/* max_pool2d k3 s2 p1 forward (writes argmax offset 0..8 per element) and backward (gather; optional ReLU gate of
+ * the pooled tensor's producer), NHWC, C % 4 == 0 */
+int spaa_maxpool3s2_fwd(const float* in, float* out, uint8_t* argmax, int B, int Hin, int Win, int C, int Hout,
+                        int Wout, spaa_stream_t stream);
+int spaa_maxpool3s2_bwd(const float* g_out, const uint8_t* argmax, const float* gate_in, float* g_in, int B,
+                        int Hin, int Win, int C, int Hout, int Wout, spaa_stream_t stream);
+/* adaptive_avg_pool2d(1): [B,HW,C] -> [B,C]; backward broadcasts g/HW and applies the ReLU gate of `act` */
+int spaa_avgpool_fwd(const float* in, float* out, int B, int HW, int C, spaa_stream_t stream);
+int spaa_avgpool_bwd(const float* g_out, const float* act, float* g_in, int B, int HW, int C,
+                     spaa_stream_t stream);
+
+/* ---- SPAA Algorithm 1 control on device (projector_based_attack.py:269-328) ------------------------------ */
+/* Per-sample decision, one workgroup per sample: softmax top-1 / argmax of logits (classifier.py:64-68), loss
+ * reduction, masks (:290-299), best bookkeeping (:318-320), and the seed of the adversarial backward pass
+ * g_logits[b][c] = (c == target_b) ? -/+adv_scale : 0  (adv_scale = adv_w / B).
+ * state (int32 [B][4]): 0 succ, 1 best_adv, 2 best, 3 top1.   stats (float [B][8]): 0 p1, 1 caml2, 2 camdE,
+ * 3 col_loss, 4 prjl2, 5 col_loss_best (in/out, init 1e6), 6 target logit, 7 reserved.  prjl2 may be NULL. */
+int spaa_decide(const float* logits, int ncls, const int32_t* target, int targeted, const float* partial, int nblk,
+                int HW, const float* prjl2, float prjl2_w, float caml2_w, float camdE_w, float d_thr,
+                float p_thresh, float adv_scale, int32_t* state, float* stats, float* g_logits, int B,
+                spaa_stream_t stream);
+/* Cotangent at the PCNet output: g = best_adv_b ? g_col : g_adv (one backward pass serves both of the reference's,
+ * :302,310), then the backward of clamp(relu(pre), max=1) (models.py:301): pass where 0 < ypre <= 1 (ypre NULL: none).
+ * all [B,npix,4] */
+int spaa_select_grad(const float* g_adv, const float* g_col, const int32_t* state, const float* ypre, float* g,
+                     int B, int npix, spaa_stream_t stream);
+/* prjl2_b = mean_px ||gray - x||_2 (:275) */
+int spaa_prjl2_fwd(const float* x, float gray, float* prjl2, int B, int HW, spaa_stream_t stream);
+/* In place g += prjl2_scale * d prjl2_px/dx for colour-step samples (prjl2_scale = prjl2_w/(B*HW), 0 = off), and
+ * block partials of ||g_b||^2 -> partial [B][ceil(HW/256)] */
+int spaa_grad_sumsq(float* g, const float* x, float gray, float prjl2_scale, const int32_t* state, float* partial,
+                    int B, int HW, spaa_stream_t stream);
+/* x_b -= lr_b * g_b/||g_b||_2 with lr = best_adv ? col_lr : adv_lr (:307,315); then where succ: x_best_b = x_b
+ * (post-step, Q4) and cam_best_b = cam_b (:323-328).   x, g, x_best: [B,HWp,4]; cam, cam_best: [B,HWc,4] */
+int spaa_step_and_track(float* x, const float* g, const float* partial, const int32_t* state, float adv_lr,
+                        float col_lr, float* x_best, const float* cam, float* cam_best, int B, int HWp, int HWc,
+                        spaa_stream_t stream);
+
+/* misc */
+int spaa_zero(void* p, int64_t bytes, spaa_stream_t stream);
+const char* spaa_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,235 @@
+// classifier_ops.hip — the non-convolution pieces of the classifier path, NHWC fp32.
+//
+// Replaces (paths relative to /root/reference/src/python):
+//   center_crop + F.interpolate(mode='area') + T.Normalize   classifier.py:59, img_proc.py:117-132, and autograd
+//   torchvision max_pool2d(3,2,1) / adaptive_avg_pool2d(1)   classifier.py:60 (third-party net bodies), and autograd
+// 'area' interpolation is adaptive average pooling with ATen's window rule
+//   start = floor(i*in/out), end = ceil((i+1)*in/out)  (float arithmetic, as in ATen's start_index/end_index).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/spaa_hip.h"
+
+namespace {
+
+__device__ __forceinline__ int win_start(int i, int out, int in) {
+    return (int)floorf((float)(i * in) / (float)out);
+}
+__device__ __forceinline__ int win_end(int i, int out, int in) {
+    return (int)ceilf((float)((i + 1) * in) / (float)out);
+}
+
+__global__ void preproc_fwd_kernel(const float4* __restrict__ y, float4* __restrict__ out, int B, int H, int W,
+                                   int cy0, int cx0, int ch, int cw, int oh, int ow, float m0, float m1, float m2,
+                                   float s0, float s1, float s2) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * oh * ow) return;
+    const int b = idx / (oh * ow);
+    const int r = idx - b * oh * ow;
+    const int oy = r / ow, ox = r - oy * ow;
+    const int ys = win_start(oy, oh, ch), ye = win_end(oy, oh, ch);
+    const int xs = win_start(ox, ow, cw), xe = win_end(ox, ow, cw);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int iy = ys; iy < ye; ++iy) {
+        const float4* row = y + ((size_t)b * H + (cy0 + iy)) * W + cx0;
+        for (int ix = xs; ix < xe; ++ix) {
+            const float4 v = row[ix];
+            a0 += v.x;
+            a1 += v.y;
+            a2 += v.z;
+        }
+    }
+    const float cnt = (float)((ye - ys) * (xe - xs));
+    out[idx] = make_float4((a0 / cnt - m0) / s0, (a1 / cnt - m1) / s1, (a2 / cnt - m2) / s2, 0.f);
+}
+
+// adjoint as a gather: every input pixel sums the output windows that cover it (deterministic, no atomics)
+__global__ void preproc_bwd_kernel(const float4* __restrict__ g_out, float4* __restrict__ g_y, int B, int H, int W,
+                                   int cy0, int cx0, int ch, int cw, int oh, int ow, float s0, float s1, float s2) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * H * W) return;
+    const int b = idx / (H * W);
+    const int r = idx - b * H * W;
+    const int py = r / W - cy0, px = r % W - cx0;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if ((unsigned)py < (unsigned)ch && (unsigned)px < (unsigned)cw) {
+        // candidate outputs: o in [floor(p*out/in) - 1, ... + 1]
+        const int oyc = (int)(((int64_t)py * oh) / ch), oxc = (int)(((int64_t)px * ow) / cw);
+        for (int oy = max(oyc - 2, 0); oy <= min(oyc + 2, oh - 1); ++oy) {
+            const int ys = win_start(oy, oh, ch), ye = win_end(oy, oh, ch);
+            if (py < ys || py >= ye) continue;
+            for (int ox = max(oxc - 2, 0); ox <= min(oxc + 2, ow - 1); ++ox) {
+                const int xs = win_start(ox, ow, cw), xe = win_end(ox, ow, cw);
+                if (px < xs || px >= xe) continue;
+                const float inv = 1.f / (float)((ye - ys) * (xe - xs));
+                const float4 g = g_out[((size_t)b * oh + oy) * ow + ox];
+                a0 += g.x * inv;
+                a1 += g.y * inv;
+                a2 += g.z * inv;
+            }
+        }
+    }
+    g_y[idx] = make_float4(a0 / s0, a1 / s1, a2 / s2, 0.f);
+}
+
+// max_pool2d(kernel 3, stride 2, padding 1), NHWC, 4 channels per thread; first maximum in row-major window order
+// wins (ATen CPU kernel: `val > maxval || isnan(val)`).
+__global__ void maxpool_fwd_kernel(const float4* __restrict__ in, float4* __restrict__ out,
+                                   uchar4* __restrict__ argmax, int B, int Hin, int Win, int C4, int Hout, int Wout) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * Hout * Wout * C4) return;
+    const int c = idx % C4;
+    int r = idx / C4;
+    const int ox = r % Wout;
+    r /= Wout;
+    const int oy = r % Hout;
+    const int b = r / Hout;
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    uchar4 am = make_uchar4(0, 0, 0, 0);
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+        if ((unsigned)iy >= (unsigned)Hin) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - 1 + kx;
+            if ((unsigned)ix >= (unsigned)Win) continue;
+            const float4 v = in[(((size_t)b * Hin + iy) * Win + ix) * C4 + c];
+            const unsigned char k = (unsigned char)(ky * 3 + kx);
+            if (v.x > best.x || v.x != v.x) { best.x = v.x; am.x = k; }
+            if (v.y > best.y || v.y != v.y) { best.y = v.y; am.y = k; }
+            if (v.z > best.z || v.z != v.z) { best.z = v.z; am.z = k; }
+            if (v.w > best.w || v.w != v.w) { best.w = v.w; am.w = k; }
+        }
+    }
+    out[idx] = best;
+    argmax[idx] = am;
+}
+
+// backward as a gather over the (at most 4) windows covering each input pixel; optional ReLU gate of the input
+__global__ void maxpool_bwd_kernel(const float4* __restrict__ g_out, const uchar4* __restrict__ argmax,
+                                   const float4* __restrict__ gate_in, float4* __restrict__ g_in, int B, int Hin,
+                                   int Win, int C4, int Hout, int Wout) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * Hin * Win * C4) return;
+    const int c = idx % C4;
+    int r = idx / C4;
+    const int ix = r % Win;
+    r /= Win;
+    const int iy = r % Hin;
+    const int b = r / Hin;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ky = 0; ky < 3; ++ky) {
+        const int t = iy + 1 - ky;
+        if (t < 0 || (t & 1)) continue;
+        const int oy = t >> 1;
+        if (oy >= Hout) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int s = ix + 1 - kx;
+            if (s < 0 || (s & 1)) continue;
+            const int ox = s >> 1;
+            if (ox >= Wout) continue;
+            const size_t o = (((size_t)b * Hout + oy) * Wout + ox) * C4 + c;
+            const uchar4 am = argmax[o];
+            const float4 g = g_out[o];
+            const unsigned char k = (unsigned char)(ky * 3 + kx);
+            if (am.x == k) acc.x += g.x;
+            if (am.y == k) acc.y += g.y;
+            if (am.z == k) acc.z += g.z;
+            if (am.w == k) acc.w += g.w;
+        }
+    }
+    if (gate_in != nullptr) {
+        const float4 a = gate_in[idx];
+        acc.x = a.x > 0.f ? acc.x : 0.f;
+        acc.y = a.y > 0.f ? acc.y : 0.f;
+        acc.z = a.z > 0.f ? acc.z : 0.f;
+        acc.w = a.w > 0.f ? acc.w : 0.f;
+    }
+    g_in[idx] = acc;
+}
+
+// adaptive_avg_pool2d(1): one thread per (b, c); HW is small (49)
+__global__ void avgpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int HW, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * C) return;
+    const int b = idx / C, c = idx - b * C;
+    const float* p = in + (size_t)b * HW * C + c;
+    float a = 0.f;
+    for (int i = 0; i < HW; ++i) a += p[(size_t)i * C];
+    out[idx] = a / (float)HW;
+}
+
+__global__ void avgpool_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ act,
+                                   float* __restrict__ g_in, int B, int HW, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * HW * C) return;
+    const int c = idx % C;
+    const int b = idx / (HW * C);
+    const float g = g_out[(size_t)b * C + c] / (float)HW;
+    g_in[idx] = (act == nullptr || act[idx] > 0.f) ? g : 0.f;
+}
+
+inline int nblk(int64_t n) { return (int)((n + 255) / 256); }
+
+}  // namespace
+
+extern "C" {
+
+int spaa_preproc_fwd(const float* y, float* out, int B, int H, int W, int cy0, int cx0, int ch, int cw, int oh,
+                     int ow, const float* mean3, const float* std3, spaa_stream_t stream) {
+    if (!y || !out || !mean3 || !std3 || B < 1 || cy0 < 0 || cx0 < 0 || cy0 + ch > H || cx0 + cw > W || oh < 1 ||
+        ow < 1 || ch < 1 || cw < 1)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(preproc_fwd_kernel, dim3(nblk((int64_t)B * oh * ow)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)y, (float4*)out, B, H, W, cy0, cx0, ch, cw, oh, ow, mean3[0], mean3[1],
+                       mean3[2], std3[0], std3[1], std3[2]);
+    return (int)hipGetLastError();
+}
+
+int spaa_preproc_bwd(const float* g_out, float* g_y, int B, int H, int W, int cy0, int cx0, int ch, int cw, int oh,
+                     int ow, const float* std3, spaa_stream_t stream) {
+    if (!g_out || !g_y || !std3 || B < 1 || cy0 < 0 || cx0 < 0 || cy0 + ch > H || cx0 + cw > W || oh < 1 ||
+        ow < 1 || ch < 1 || cw < 1)
+        return hipErrorInvalidValue;
+    // the +-2 candidate search of the gather is exact while a window spans at most 3 inputs
+    if (ch > 2 * oh || cw > 2 * ow) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(preproc_bwd_kernel, dim3(nblk((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)g_out, (float4*)g_y, B, H, W, cy0, cx0, ch, cw, oh, ow, std3[0], std3[1],
+                       std3[2]);
+    return (int)hipGetLastError();
+}
+
+int spaa_maxpool3s2_fwd(const float* in, float* out, uint8_t* argmax, int B, int Hin, int Win, int C, int Hout,
+                        int Wout, spaa_stream_t stream) {
+    if (!in || !out || !argmax || (C & 3) || B < 1 || Hout != (Hin + 2 - 3) / 2 + 1 || Wout != (Win + 2 - 3) / 2 + 1)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblk((int64_t)B * Hout * Wout * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)in, (float4*)out, (uchar4*)argmax, B, Hin, Win, C / 4,
+                       Hout, Wout);
+    return (int)hipGetLastError();
+}
+
+int spaa_maxpool3s2_bwd(const float* g_out, const uint8_t* argmax, const float* gate_in, float* g_in, int B, int Hin,
+                        int Win, int C, int Hout, int Wout, spaa_stream_t stream) {
+    if (!g_out || !argmax || !g_in || (C & 3) || B < 1 || Hout != (Hin + 2 - 3) / 2 + 1 ||
+        Wout != (Win + 2 - 3) / 2 + 1)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk((int64_t)B * Hin * Win * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)g_out, (const uchar4*)argmax, (const float4*)gate_in,
+                       (float4*)g_in, B, Hin, Win, C / 4, Hout, Wout);
+    return (int)hipGetLastError();
+}
+
+int spaa_avgpool_fwd(const float* in, float* out, int B, int HW, int C, spaa_stream_t stream) {
+    if (!in || !out || B < 1 || HW < 1 || C < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(nblk((int64_t)B * C)), dim3(256), 0, (hipStream_t)stream, in, out, B,
+                       HW, C);
+    return (int)hipGetLastError();
+}
+
+int spaa_avgpool_bwd(const float* g_out, const float* act, float* g_in, int B, int HW, int C, spaa_stream_t stream) {
+    if (!g_out || !g_in || B < 1 || HW < 1 || C < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(nblk((int64_t)B * HW * C)), dim3(256), 0, (hipStream_t)stream, g_out,
+                       act, g_in, B, HW, C);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

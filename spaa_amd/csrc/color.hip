@@ -1,0 +1,351 @@
+// color.hip — differentiable sRGB -> CIELAB and the per-pixel CIEDE2000 map, plus the fused stealthiness loss.
+//
+// Replaces (perc_al/differential_color_functions.py): rgb2xyz :12-24, xyz_lab :27-36, rgb2lab_diff :39-64,
+// hpf/dhpf/ahpf :73-106, ciede2000_diff :109-180 and their autograd, and the L2 stealth term
+// projector_based_attack.py:279.  The reference's constants are reproduced as written (sRGB threshold 0.0405,
+// 4-decimal RGB->XYZ matrix, white 95.0489/100/108.8840, f(0)=0, T's `aHP - 39`, the +1e-4 guards), not the
+// textbook ones.
+//
+// One launch computes, per camera pixel, both loss terms and their analytic gradient w.r.t. the inferred camera
+// image (hand-written reverse mode of the ~300-op ATen graph), i.e. ~600 elementwise ATen launches become one
+// pass: read y, scene, scene_lab (48 B/px), write g_y (16 B/px).  Pixel sums are reduced per block in a fixed
+// order (no atomics) so results are run-to-run reproducible.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/spaa_hip.h"
+
+namespace {
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kDeg = (float)(180.0 / 3.14159265358979323846);   // degrees(n) = n * (180/pi)
+constexpr float kRad = (float)(3.14159265358979323846 / 180.0);   // radians(n) = n * (pi/180)
+constexpr float kXn = 95.0489f, kYn = 100.f, kZn = 108.8840f;
+constexpr float k25_7 = 6103515625.f;  // 25^7
+
+__device__ __forceinline__ float srgb_lin(float v, float& dv) {
+    // rgb2xyz :16-20
+    if (v > 0.0405f) {
+        const float t = (v + 0.055f) / 1.055f;
+        const float p14 = powf(t, 1.4f);
+        dv = 100.f * (2.4f / 1.055f) * p14;
+        return 100.f * (p14 * t);  // t^2.4 = t^1.4 * t  (within an ulp of powf(t, 2.4f))
+    }
+    dv = 100.f / 12.92f;
+    return 100.f * (v / 12.92f);
+}
+
+__device__ __forceinline__ float srgb_lin_fwd(float v) {
+    if (v > 0.0405f) return 100.f * powf((v + 0.055f) / 1.055f, 2.4f);
+    return 100.f * (v / 12.92f);
+}
+
+__device__ __forceinline__ float lab_f(float t, float& dt) {
+    // xyz_lab :27-36 ; exactly-zero input maps to 0 with zero slope (Q3)
+    if (t == 0.f) {
+        dt = 0.f;
+        return 0.f;
+    }
+    if (t > 0.008856f) {
+        const float c = cbrtf(t);
+        dt = (1.f / 3.f) / (c * c);
+        return c;
+    }
+    dt = 7.787f;
+    return 7.787f * t + (float)(16.0 / 116.0);
+}
+
+__device__ __forceinline__ void rgb_to_lab(float r, float g, float b, float& L, float& A, float& Bv) {
+    float d;
+    const float lr = srgb_lin_fwd(r), lg = srgb_lin_fwd(g), lb = srgb_lin_fwd(b);
+    const float X = 0.4124f * lr + 0.3576f * lg + 0.1805f * lb;
+    const float Y = 0.2126f * lr + 0.7152f * lg + 0.0722f * lb;
+    const float Z = 0.0193f * lr + 0.1192f * lg + 0.9504f * lb;
+    const float fx = lab_f(X / kXn, d), fy = lab_f(Y / kYn, d), fz = lab_f(Z / kZn, d);
+    L = 116.f * fy - 16.f;
+    A = 500.f * (fx - fy);
+    Bv = 200.f * (fy - fz);
+}
+
+__device__ __forceinline__ float pow7(float x) {
+    const float x2 = x * x, x4 = x2 * x2;
+    return x4 * x2 * x;
+}
+
+// hue angle of hpf_diff :73-81 (x = b, y = a'), in degrees in [0, 360)
+__device__ __forceinline__ float hue_deg(float x, float y) {
+    if (x == 0.f && y == 0.f) return 0.f;
+    const float t = atan2f(x, y) * kDeg;
+    return t >= 0.f ? t : 360.f + t;
+}
+
+struct DE {
+    float de;
+    float gL, gA, gB;  // d de / d (L1, A1, B1)
+};
+
+// CIEDE2000 of (L1,A1,B1) vs (L2,A2,B2) as the reference computes it, with the gradient w.r.t. the first colour.
+template <bool GRAD>
+__device__ __forceinline__ DE ciede2000(float L1, float A1, float B1, float L2, float A2, float B2) {
+    DE out;
+    const bool m01 = (A1 == 0.f) && (B1 == 0.f);
+    const bool m02 = (A2 == 0.f) && (B2 == 0.f);
+    if (m01) B1 += 0.0001f;
+    if (m02) B2 += 0.0001f;
+    const float C1 = sqrtf(A1 * A1 + B1 * B1);
+    const float C2 = sqrtf(A2 * A2 + B2 * B2);
+    const float aC = (C1 + C2) / 2.f;
+    const float aC7 = pow7(aC);
+    const float fG = aC7 / (aC7 + k25_7);
+    const float sfG = sqrtf(fG);
+    const float G = 0.5f * (1.f - sfG);
+    const float a1P = (1.f + G) * A1;
+    const float a2P = (1.f + G) * A2;
+    const float c1P = sqrtf(a1P * a1P + B1 * B1);
+    const float c2P = sqrtf(a2P * a2P + B2 * B2);
+    const float h1P = m01 ? 0.f : hue_deg(B1, a1P);
+    const float h2P = m02 ? 0.f : hue_deg(B2, a2P);
+    const float dLP = L2 - L1;
+    const float dCP = c2P - c1P;
+    const bool mc0 = (C1 * C2) == 0.f;
+    const float dh = h2P - h1P;
+    float dhP = 0.f;
+    if (!mc0) dhP = (fabsf(dh) <= 180.f) ? dh : (dh > 180.f ? dh - 360.f : dh + 360.f);
+    const float sq = sqrtf(c1P * c2P);
+    const float half = (dhP * kRad) / 2.f;
+    const float sn = sinf(half), cs = cosf(half);
+    const float m_no = (m01 || m02) ? 0.f : 1.f;
+    const float dHP = 2.f * sq * sn * m_no;
+    const float aL = (L1 + L2) / 2.f;
+    const float aCP = (c1P + c2P) / 2.f;
+    const float hs = h1P + h2P;
+    float aHP = 0.f;
+    if (!mc0) {
+        const float r = (fabsf(dh) <= 180.f) ? hs : ((fabsf(hs) < 360.f) ? hs + 360.f : hs - 360.f);
+        aHP = r * 0.5f;
+    }
+    const float t1 = (aHP - 39.f) * kRad, t2 = (2.f * aHP) * kRad, t3 = (3.f * aHP + 6.f) * kRad,
+                t4 = (4.f * aHP - 63.f) * kRad;
+    const float T = 1.f - 0.17f * cosf(t1) + 0.24f * cosf(t2) + 0.32f * cosf(t3) - 0.2f * cosf(t4);
+    const float e = (aHP - 275.f) / 25.f;
+    const float dRO = 30.f * expf(-1.f * (e * e));
+    const float aCP7 = pow7(aCP);
+    const float fR = aCP7 / (aCP7 + k25_7);
+    const float rC = sqrtf(fR);
+    const float q = (aL - 50.f) * (aL - 50.f);
+    const float sq20 = sqrtf(20.f + q);
+    const float sL = 1.f + (0.015f * q) / sq20;
+    const float sC = 1.f + 0.045f * aCP;
+    const float sH = 1.f + 0.015f * aCP * T;
+    const float ang = (2.f * dRO) * kRad;
+    const float sa = sinf(ang);
+    const float rT = -2.f * rC * sa;
+    const float u = dLP / sL, v = dCP / sC, w = dHP / sH;
+    const float rs = u * u + (v * v) * m_no + (w * w) * m_no + rT * v * w * m_no;
+    const bool m0 = rs <= 0.f;
+    out.de = m0 ? 0.f : sqrtf(rs);
+    out.gL = out.gA = out.gB = 0.f;
+    if (!GRAD || m0) return out;
+
+    // ---- reverse mode -----------------------------------------------------------------------------------
+    const float rs_b = 0.5f / out.de;
+    const float u_b = rs_b * 2.f * u;
+    const float v_b = rs_b * m_no * (2.f * v + rT * w);
+    const float w_b = rs_b * m_no * (2.f * w + rT * v);
+    const float rT_b = rs_b * m_no * v * w;
+    const float dLP_b = u_b / sL;
+    const float sL_b = -u_b * dLP / (sL * sL);
+    const float dCP_b = v_b / sC;
+    const float sC_b = -v_b * dCP / (sC * sC);
+    const float dHP_b = w_b / sH;
+    const float sH_b = -w_b * dHP / (sH * sH);
+    const float rC_b = rT_b * (-2.f * sa);
+    const float dRO_b = rT_b * (-2.f * rC * cosf(ang)) * (2.f * kRad);
+    float aCP_b = sH_b * 0.015f * T + sC_b * 0.045f;
+    const float T_b = sH_b * 0.015f * aCP;
+    const float q_b = sL_b * 0.015f * (1.f / sq20 - 0.5f * q / (sq20 * sq20 * sq20));
+    const float aL_b = q_b * 2.f * (aL - 50.f);
+    {
+        const float den = aCP7 + k25_7;
+        const float aCP6 = aCP7 / aCP;
+        aCP_b += rC_b * (0.5f / rC) * (k25_7 / (den * den)) * 7.f * aCP6;
+    }
+    float aHP_b = dRO_b * dRO * (-2.f * e / 25.f);
+    aHP_b += T_b * kRad * (0.17f * sinf(t1) - 0.48f * sinf(t2) - 0.96f * sinf(t3) + 0.8f * sinf(t4));
+    const float dHPm_b = dHP_b * m_no;
+    const float sq_b = dHPm_b * 2.f * sn;
+    const float dhP_b = dHPm_b * 2.f * sq * cs * (kRad / 2.f);
+    float c1P_b = 0.f, c2P_b = 0.f;
+    if (sq_b != 0.f) {
+        c1P_b = sq_b * (0.5f / sq) * c2P;
+        c2P_b = sq_b * (0.5f / sq) * c1P;
+    }
+    c1P_b += aCP_b * 0.5f - dCP_b;
+    c2P_b += aCP_b * 0.5f + dCP_b;
+    float L1_b = aL_b * 0.5f - dLP_b;
+    float h1P_b = 0.f, h2P_b = 0.f;
+    if (!mc0) {
+        h1P_b = aHP_b * 0.5f - dhP_b;
+        h2P_b = aHP_b * 0.5f + dhP_b;
+    }
+    float a1P_b = 0.f, a2P_b = 0.f, B1_b = 0.f;
+    if (!m01 && !(B1 == 0.f && a1P == 0.f)) {
+        const float den = B1 * B1 + a1P * a1P;
+        B1_b += h1P_b * kDeg * (a1P / den);
+        a1P_b += h1P_b * kDeg * (-B1 / den);
+    }
+    if (!m02 && !(B2 == 0.f && a2P == 0.f)) {
+        const float den = B2 * B2 + a2P * a2P;
+        a2P_b += h2P_b * kDeg * (-B2 / den);
+    }
+    a1P_b += c1P_b * (a1P / c1P);
+    B1_b += c1P_b * (B1 / c1P);
+    a2P_b += c2P_b * (a2P / c2P);
+    float A1_b = a1P_b * (1.f + G);
+    const float G_b = a1P_b * A1 + a2P_b * A2;
+    float aC_b = 0.f;
+    if (G_b != 0.f) {
+        const float den = aC7 + k25_7;
+        const float aC6 = aC7 / aC;
+        aC_b = G_b * (-0.25f / sfG) * (k25_7 / (den * den)) * 7.f * aC6;
+    }
+    const float C1_b = aC_b * 0.5f;
+    A1_b += C1_b * (A1 / C1);
+    B1_b += C1_b * (B1 / C1);
+    out.gL = L1_b;
+    out.gA = A1_b;
+    out.gB = B1_b;
+    return out;
+}
+
+__global__ void rgb2lab_kernel(const float4* __restrict__ rgb, float4* __restrict__ lab, int npix) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix) return;
+    const float4 v = rgb[idx];
+    float L, A, B;
+    rgb_to_lab(v.x, v.y, v.z, L, A, B);
+    lab[idx] = make_float4(L, A, B, 0.f);
+}
+
+__global__ void ciede2000_kernel(const float4* __restrict__ lab1, const float4* __restrict__ lab2,
+                                 float* __restrict__ de, int npix) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix) return;
+    const float4 a = lab1[idx], b = lab2[idx];
+    de[idx] = ciede2000<false>(a.x, a.y, a.z, b.x, b.y, b.z).de;
+}
+
+// d dE(lab(rgb), lab2) / d rgb, and dE
+__device__ __forceinline__ float de_rgb_grad(float r, float g, float b, float L2, float A2, float B2, float& gr,
+                                             float& gg, float& gb) {
+    float dr, dg, db;
+    const float lr = srgb_lin(r, dr), lg = srgb_lin(g, dg), lb = srgb_lin(b, db);
+    const float X = 0.4124f * lr + 0.3576f * lg + 0.1805f * lb;
+    const float Y = 0.2126f * lr + 0.7152f * lg + 0.0722f * lb;
+    const float Z = 0.0193f * lr + 0.1192f * lg + 0.9504f * lb;
+    float dfx, dfy, dfz;
+    const float fx = lab_f(X / kXn, dfx), fy = lab_f(Y / kYn, dfy), fz = lab_f(Z / kZn, dfz);
+    const float L = 116.f * fy - 16.f, A = 500.f * (fx - fy), Bv = 200.f * (fy - fz);
+    const DE d = ciede2000<true>(L, A, Bv, L2, A2, B2);
+    const float fy_b = 116.f * d.gL - 500.f * d.gA + 200.f * d.gB;
+    const float fx_b = 500.f * d.gA;
+    const float fz_b = -200.f * d.gB;
+    const float X_b = fx_b * dfx / kXn, Y_b = fy_b * dfy / kYn, Z_b = fz_b * dfz / kZn;
+    gr = (0.4124f * X_b + 0.2126f * Y_b + 0.0193f * Z_b) * dr;
+    gg = (0.3576f * X_b + 0.7152f * Y_b + 0.1192f * Z_b) * dg;
+    gb = (0.1805f * X_b + 0.0722f * Y_b + 0.9504f * Z_b) * db;
+    return d.de;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    // wave64 shuffle reduction then 4 partials through LDS, fixed order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// grid: (nblk, B); block 256 px
+__global__ __launch_bounds__(256) void stealth_loss_kernel(const float4* __restrict__ y,
+                                                           const float4* __restrict__ scene,
+                                                           const float4* __restrict__ scene_lab, float caml2_w,
+                                                           float camdE_w, float gscale, float4* __restrict__ g_y,
+                                                           float* __restrict__ partial, int HW) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    float l2 = 0.f, de = 0.f;
+    if (pix < HW) {
+        const size_t idx = (size_t)b * HW + pix;
+        const float4 yv = y[idx];
+        const float4 sv = scene[idx];
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        // caml2 = || scene - y ||_2 over channels (projector_based_attack.py:279); norm backward is 0 at 0
+        const float d0 = sv.x - yv.x, d1 = sv.y - yv.y, d2 = sv.z - yv.z;
+        l2 = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+        if (caml2_w != 0.f && l2 != 0.f) {
+            const float k = -caml2_w / l2;
+            g0 = k * d0;
+            g1 = k * d1;
+            g2 = k * d2;
+        }
+        if (camdE_w != 0.f) {
+            const float4 lv = scene_lab[idx];
+            float r0, r1, r2;
+            de = de_rgb_grad(yv.x, yv.y, yv.z, lv.x, lv.y, lv.z, r0, r1, r2);
+            g0 += camdE_w * r0;
+            g1 += camdE_w * r1;
+            g2 += camdE_w * r2;
+        } else {
+            const float4 lv = scene_lab[idx];
+            float L, A, Bv;
+            rgb_to_lab(yv.x, yv.y, yv.z, L, A, Bv);
+            de = ciede2000<false>(L, A, Bv, lv.x, lv.y, lv.z).de;
+        }
+        g_y[idx] = make_float4(g0 * gscale, g1 * gscale, g2 * gscale, 0.f);
+    }
+    const float s_l2 = block_sum_256(l2, red);
+    const float s_de = block_sum_256(de, red);
+    if (threadIdx.x == 0) {
+        float* p = partial + 2 * ((size_t)b * gridDim.x + blockIdx.x);
+        p[0] = s_l2;
+        p[1] = s_de;
+    }
+}
+
+// gradient of  sum_px w_px * dE(lab1, lab(rgb2))  w.r.t. rgb2 is not needed by SPAA; PerC-AL uses
+// dE(inputs_LAB, lab(x)) with the *second* argument variable (perc_al/__init__.py:197): provided by the
+// symmetric kernel below (argument order swapped inside ciede2000 is NOT equivalent, so it has its own adjoint).
+
+}  // namespace
+
+extern "C" {
+
+int spaa_rgb2lab(const float* rgb, float* lab, int npix, spaa_stream_t stream) {
+    if (!rgb || !lab || npix < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rgb2lab_kernel, dim3((npix + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)rgb, (float4*)lab, npix);
+    return (int)hipGetLastError();
+}
+
+int spaa_ciede2000(const float* lab1, const float* lab2, float* de, int npix, spaa_stream_t stream) {
+    if (!lab1 || !lab2 || !de || npix < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ciede2000_kernel, dim3((npix + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)lab1, (const float4*)lab2, de, npix);
+    return (int)hipGetLastError();
+}
+
+int spaa_stealth_loss_fwd_bwd(const float* y, const float* scene, const float* scene_lab, float caml2_w,
+                              float camdE_w, float gscale, float* g_y, float* partial, int B, int HW,
+                              spaa_stream_t stream) {
+    if (!y || !scene || !scene_lab || !g_y || !partial || B < 1 || HW < 1) return hipErrorInvalidValue;
+    dim3 grid((HW + 255) / 256, B);
+    hipLaunchKernelGGL(stealth_loss_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)y,
+                       (const float4*)scene, (const float4*)scene_lab, caml2_w, camdE_w, gscale, (float4*)g_y,
+                       partial, HW);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,265 @@
+// tapconv.hip — generic tap-list convolution as implicit GEMM on the fp32 matrix cores of gfx950.
+//
+// GEMM view:  M = B*Hm*Wm output pixels of one parity class, N = Cout, K = ntaps*Cin.
+//   A[m][k] = in[b, s_in*y + dy_t, s_in*x + dx_t, c]   (gathered on the fly, zero outside the image)
+//   B[k][n] = W[n][k]                                   (pre-packed, K contiguous)
+// One workgroup = 4 waves (one per SIMD) computes a BM x BN tile; each wave owns a WM x WN sub-tile built from
+// 32x32 accumulators of v_mfma_f32_32x32x2_f32 (exact fp32: bitwise an fmaf chain, so results match the
+// reference's fp32 CPU path to rounding).  K is consumed in steps of BK = 32: global -> registers (prefetch of the
+// next step issued before the MFMAs of the current one) -> LDS (row stride 36 floats: ds_write_b128 /
+// ds_read_b128 conflict-free) -> ds_read_b128 fragments.  fp32 MFMA is 64 cycles per instruction per SIMD, so one
+// K-step is >= 2048 MFMA-cycles per wave and hides the HBM/L2 latency of the prefetch.
+//
+// Replaces: aten::convolution / aten::convolution_backward(input) as dispatched by the reference at
+// models.py:284-301 and their autograd (projector_based_attack.py:302,310), and torchvision's convs
+// (classifier.py:60).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/spaa_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = 36;           // LDS row stride in floats (BK + 4): 144 B rows, 16-B aligned
+constexpr int TAP_SMEM_FLOATS = 2 * SPAA_MAX_TAPS;
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void tapconv_kernel(const spaa_tapconv_t p, const int m_tiles,
+                                                         const int n_tiles) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int A_LD = BM * 8 / 256;
+    constexpr int B_LD = (BN * 8 + 255) / 256;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int2* s_taps = reinterpret_cast<int2*>(smem);
+    float* As = smem + TAP_SMEM_FLOATS;
+    float* Bs = As + 2 * BM * LDK;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const spaa_tapclass_t cl = p.cls[blockIdx.y];
+
+    // XCD-aware tile order: workgroups that land on one XCD (blockIdx.x % 8) walk a contiguous range of tiles,
+    // N-tiles of one M-tile first, so im2col rows / halos are re-read from that XCD's L2.
+    const int nwg = m_tiles * n_tiles;
+    int tile;
+    {
+        const int orig = blockIdx.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int n_blk = (tile % n_tiles) * BN;
+    const int m_blk = (tile / n_tiles) * BM;
+
+    for (int i = tid; i < cl.ntaps; i += 256) {
+        s_taps[i] = make_int2(p.taps[2 * (cl.tap_off + i)], p.taps[2 * (cl.tap_off + i) + 1]);
+    }
+
+    const int HWm = p.Hm * p.Wm;
+    const int M = p.B * HWm;
+    const int kq = tid & 7;
+
+    int a_iy[A_LD], a_ix[A_LD];
+    uint32_t a_base[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        const int m = m_blk + (tid >> 3) + 32 * i;
+        const bool ok = m < M;
+        const int mm = ok ? m : 0;
+        const int b = mm / HWm;
+        const int r = mm - b * HWm;
+        const int y = r / p.Wm;
+        const int x = r - y * p.Wm;
+        a_iy[i] = ok ? y * p.s_in : -(1 << 28);
+        a_ix[i] = x * p.s_in;
+        a_base[i] = (uint32_t)b * (uint32_t)(p.Hin * p.Win);
+    }
+    const float* wrow[B_LD];
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+        const int n = n_blk + (tid >> 3) + 32 * i;
+        wrow[i] = p.weights + cl.w_off + (int64_t)n * cl.Kpad + 4 * kq;
+    }
+    constexpr bool B_ALL = (BN * 8 >= 256);  // BN >= 32: every thread loads
+    const bool b_active = B_ALL || (tid >> 3) < BN;
+
+    float4 ra[A_LD], rb[B_LD];
+    const int nk = cl.Kpad / BK;
+    const int Cin = p.Cin;
+
+    __syncthreads();  // taps visible
+
+    auto load_tile = [&](int ks) {
+        const int k = ks * BK + 4 * kq;
+        const bool kval = k < cl.K;
+        const int tap = kval ? k / Cin : 0;
+        const int c = k - tap * Cin;
+        const int2 d = s_taps[tap];
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int iy = a_iy[i] + d.x;
+            const int ix = a_ix[i] + d.y;
+            const bool v = kval && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            if (v) {
+                const size_t off = (size_t)(a_base[i] + (uint32_t)(iy * p.Win + ix)) * (size_t)p.in_cstride +
+                                   (size_t)(p.in_coff + c);
+                ra[i] = *reinterpret_cast<const float4*>(p.in + off);
+            } else {
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            if (b_active) rb[i] = *reinterpret_cast<const float4*>(wrow[i] + ks * BK);
+        }
+    };
+    auto store_tile = [&](int stage) {
+        float* as = As + stage * BM * LDK;
+        float* bs = Bs + stage * BN * LDK;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            *reinterpret_cast<float4*>(as + ((tid >> 3) + 32 * i) * LDK + 4 * kq) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            if (b_active) *reinterpret_cast<float4*>(bs + ((tid >> 3) + 32 * i) * LDK + 4 * kq) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm0 = (wave / WAVES_N) * WM;
+    const int wn0 = (wave % WAVES_N) * WN;
+    const int frag_off = (lane & 31) * LDK + 4 * (lane >> 5);
+
+    if (nk > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    for (int ks = 0; ks < nk; ++ks) {
+        const int stage = ks & 1;
+        if (ks + 1 < nk) load_tile(ks + 1);
+        const float* as = As + stage * BM * LDK + wm0 * LDK + frag_off;
+        const float* bs = Bs + stage * BN * LDK + wn0 * LDK + frag_off;
+#pragma unroll
+        for (int kb = 0; kb < BK / 8; ++kb) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDK + kb * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDK + kb * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (ks + 1 < nk) store_tile(stage ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D map of the 32x32 accumulator: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool linear = (p.s_out == 1) && (cl.oy0 == 0) && (cl.ox0 == 0) && (p.Hm == p.Hout) && (p.Wm == p.Wout);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n_blk + wn0 + 32 * j + (lane & 31);
+        const bool n_ok = n < p.Cout;
+        const float bias = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_blk + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= M || !n_ok) continue;
+                size_t o;
+                if (linear) {
+                    o = (size_t)m;
+                } else {
+                    const int b = m / HWm;
+                    const int rr = m - b * HWm;
+                    const int y = rr / p.Wm;
+                    const int x = rr - y * p.Wm;
+                    const int oy = cl.oy0 + y * p.s_out;
+                    const int ox = cl.ox0 + x * p.s_out;
+                    if (oy >= p.Hout || ox >= p.Wout) continue;
+                    o = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+                }
+                float v = acc[i][j][r] + bias;
+                if (p.add != nullptr) v += p.add[o * p.add_cstride + p.add_coff + n];
+                if (p.act == SPAA_ACT_RELU) {
+                    v = fmaxf(v, 0.f);
+                } else if (p.act == SPAA_ACT_RELU_CLAMP1) {
+                    v = fmaxf(v, 0.f);
+                    if (p.aux_out != nullptr) p.aux_out[o * p.out_cstride + p.out_coff + n] = v;
+                    v = fminf(v, 1.f);
+                } else if (p.act == SPAA_ACT_LEAKY01) {
+                    v = v > 0.f ? v : 0.1f * v;
+                }
+                if (p.gate != nullptr) {
+                    const float g = p.gate[o * p.gate_cstride + p.gate_coff + n];
+                    const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (g > 0.f && g <= 1.f) : (g > 0.f);
+                    v = pass ? v : 0.f;
+                }
+                p.out[o * p.out_cstride + p.out_coff + n] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch(const spaa_tapconv_t& d, hipStream_t stream) {
+    const int64_t M = (int64_t)d.B * d.Hm * d.Wm;
+    const int m_tiles = (int)((M + BM - 1) / BM);
+    const int n_tiles = (d.Cout + BN - 1) / BN;
+    const size_t smem = (size_t)(TAP_SMEM_FLOATS + 2 * (BM + BN) * LDK) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<BM, BN, WM, WN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid(m_tiles * n_tiles, d.nclass, 1);
+    hipLaunchKernelGGL((tapconv_kernel<BM, BN, WM, WN>), grid, dim3(256), smem, stream, d, m_tiles, n_tiles);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream_) {
+    const spaa_tapconv_t& d = *desc;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    // host-side shape checks: a faulting kernel can take the whole node down
+    if (d.in == nullptr || d.out == nullptr || d.weights == nullptr || d.taps == nullptr) return hipErrorInvalidValue;
+    if (d.Cin <= 0 || (d.Cin & 3) || (d.in_cstride & 3) || (d.in_coff & 3) || d.in_coff + d.Cin > d.in_cstride)
+        return hipErrorInvalidValue;
+    if (d.Cout <= 0 || d.out_coff + d.Cout > d.out_cstride) return hipErrorInvalidValue;
+    if (d.nclass < 1 || d.nclass > SPAA_MAX_CLASSES || d.B <= 0 || d.Hm <= 0 || d.Wm <= 0) return hipErrorInvalidValue;
+    if (d.s_in < 1 || d.s_out < 1) return hipErrorInvalidValue;
+    for (int c = 0; c < d.nclass; ++c) {
+        const spaa_tapclass_t& cl = d.cls[c];
+        if (cl.ntaps < 0 || cl.ntaps > SPAA_MAX_TAPS || cl.K != cl.ntaps * d.Cin || (cl.Kpad % BK) || cl.Kpad < cl.K)
+            return hipErrorInvalidValue;
+    }
+    if ((int64_t)d.B * d.Hin * d.Win * d.in_cstride >= (int64_t)1 << 32) return hipErrorInvalidValue;
+    if (d.Cout > 64) return launch<128, 128, 64, 64>(d, stream);
+    if (d.Cout > 32) return launch<256, 64, 64, 64>(d, stream);
+    return launch<256, 32, 64, 32>(d, stream);
+}

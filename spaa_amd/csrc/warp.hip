@@ -1,0 +1,291 @@
+// warp.hip — WarpingNet: sampling-grid construction and bilinear grid_sample forward / backward.
+//
+// Replaces (paths relative to /root/reference/src/python):
+//   F.affine_grid + pytorch_tps.tps_grid + F.grid_sample(affine, tps)        models.py:168-172, pytorch_tps.py:54-106
+//   clamp(refine + tps, -1, 1)                                               models.py:176
+//   F.grid_sample(clamp(x,0,1), fine_grid, align_corners=True) * mask ; x*s  models.py:184,340,342;
+//                                                                            projector_based_attack.py:265
+//   grid_sampler_2d_backward (w.r.t. the image only; the grid is frozen)     autograd of the above
+// The fine grid does not depend on the optimised image, so it is built once per attack (batch 1) instead of once
+// per iteration replicated B times as the reference does.  All images are NHWC4 (float4 per pixel): one 16-byte
+// load per bilinear tap instead of three scalar gathers.  HBM-bound: algorithmic traffic per scene-iteration is
+// read x (Hp*Wp*16 B) + write xw + cat8 (Hc*Wc*48 B) forward.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/spaa_hip.h"
+
+namespace {
+
+// torch.linspace(start, end, steps)[i] as computed by ATen's CPU kernel (symmetric halves)
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+    if (steps == 1) return start;
+    const float step = (end - start) / (float)(steps - 1);
+    return (i < steps / 2) ? start + step * (float)i : end - step * (float)(steps - 1 - i);
+}
+
+struct Bilinear {
+    int x0, y0;          // north-west tap
+    float nw, ne, sw, se;
+};
+
+// ATen CPU bilinear grid_sample (GridSamplerKernel.cpp): unnormalise with align_corners=True, floor, weights
+// w = x - floor(x), e = 1 - w, n = y - floor(y), s = 1 - n.
+__device__ __forceinline__ Bilinear bilinear_setup(float gx, float gy, int W, int H) {
+    const float x = (gx + 1.f) * (0.5f * (float)(W - 1));
+    const float y = (gy + 1.f) * (0.5f * (float)(H - 1));
+    const float xw = floorf(x), yn = floorf(y);
+    const float w = x - xw, e = 1.f - w, n = y - yn, s = 1.f - n;
+    Bilinear b;
+    b.x0 = (int)xw;
+    b.y0 = (int)yn;
+    b.nw = e * s;
+    b.ne = w * s;
+    b.sw = e * n;
+    b.se = w * n;
+    return b;
+}
+
+__global__ void coarse_grid_kernel(const float* __restrict__ affine6, const float* __restrict__ theta,
+                                   const float* __restrict__ ctrl, int T, int Hin, int Win, int Hout, int Wout,
+                                   float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Hout * Wout) return;
+    const int oy = idx / Wout, ox = idx - oy * Wout;
+    // pytorch_tps.tps_grid: homogeneous grid (1, x, y) over [0,1]
+    const float px = linspace_at(0.f, 1.f, Wout, ox);
+    const float py = linspace_at(0.f, 1.f, Hout, oy);
+    // reduced form: theta has T+2 rows: T-1 free weights, then 3 affine rows; w_0 = -sum(others)   (:65-69)
+    float bx = 0.f, by = 0.f, wsx = 0.f, wsy = 0.f, u0 = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float dx = px - ctrl[2 * t], dy = py - ctrl[2 * t + 1];
+        const float d = sqrtf(dx * dx + dy * dy);
+        const float u = (d * d) * logf(d + 1e-6f);
+        if (t == 0) {
+            u0 = u;
+        } else {
+            const float wx = theta[2 * (t - 1)], wy = theta[2 * (t - 1) + 1];
+            bx += u * wx;
+            by += u * wy;
+            wsx += wx;
+            wsy += wy;
+        }
+    }
+    bx += u0 * (-wsx);
+    by += u0 * (-wsy);
+    const float* a = theta + 2 * (T - 1);
+    const float zx = (a[0] + px * a[2] + py * a[4]) + bx;
+    const float zy = (a[1] + px * a[3] + py * a[5]) + by;
+    const float tx = (px + zx) * 2.f - 1.f;
+    const float ty = (py + zy) * 2.f - 1.f;
+    // sample the affine grid (evaluated analytically at the four taps; zeros outside)
+    const Bilinear bl = bilinear_setup(tx, ty, Win, Hin);
+    float gx = 0.f, gy = 0.f;
+    auto tap = [&](int yy, int xx, float wgt) {
+        if ((unsigned)yy < (unsigned)Hin && (unsigned)xx < (unsigned)Win) {
+            const float bxn = linspace_at(-1.f, 1.f, Win, xx);
+            const float byn = linspace_at(-1.f, 1.f, Hin, yy);
+            gx += (bxn * affine6[0] + byn * affine6[1] + affine6[2]) * wgt;
+            gy += (bxn * affine6[3] + byn * affine6[4] + affine6[5]) * wgt;
+        }
+    };
+    tap(bl.y0, bl.x0, bl.nw);
+    tap(bl.y0, bl.x0 + 1, bl.ne);
+    tap(bl.y0 + 1, bl.x0, bl.sw);
+    tap(bl.y0 + 1, bl.x0 + 1, bl.se);
+    reinterpret_cast<float4*>(out)[idx] = make_float4(gx, gy, 0.f, 0.f);
+}
+
+__global__ void finish_grid_kernel(const float4* __restrict__ coarse, const float4* __restrict__ refine,
+                                   float4* __restrict__ fine, int npix) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix) return;
+    const float4 c = coarse[idx];
+    float gx = c.x, gy = c.y;
+    if (refine != nullptr) {
+        const float4 r = refine[idx];
+        gx = r.x + c.x;
+        gy = r.y + c.y;
+    }
+    fine[idx] = make_float4(fminf(fmaxf(gx, -1.f), 1.f), fminf(fmaxf(gy, -1.f), 1.f), 0.f, 0.f);
+}
+
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+
+__global__ void warp_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ grid,
+                                const float* __restrict__ mask, const float4* __restrict__ s,
+                                float4* __restrict__ xw, float4* __restrict__ cat8, int B, int Hp, int Wp, int HWc,
+                                int clamp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * HWc) return;
+    const int b = idx / HWc, pix = idx - b * HWc;
+    const float4 g = grid[pix];
+    const Bilinear bl = bilinear_setup(g.x, g.y, Wp, Hp);
+    const float4* xb = x + (size_t)b * Hp * Wp;
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    auto tap = [&](int yy, int xx, float wgt) {
+        if ((unsigned)yy < (unsigned)Hp && (unsigned)xx < (unsigned)Wp) {
+            float4 v = xb[yy * Wp + xx];
+            if (clamp) {
+                v.x = clamp01(v.x);
+                v.y = clamp01(v.y);
+                v.z = clamp01(v.z);
+            }
+            r0 += v.x * wgt;
+            r1 += v.y * wgt;
+            r2 += v.z * wgt;
+        }
+    };
+    tap(bl.y0, bl.x0, bl.nw);
+    tap(bl.y0, bl.x0 + 1, bl.ne);
+    tap(bl.y0 + 1, bl.x0, bl.sw);
+    tap(bl.y0 + 1, bl.x0 + 1, bl.se);
+    const float m = (mask != nullptr) ? mask[pix] : 1.f;
+    r0 *= m;
+    r1 *= m;
+    r2 *= m;
+    xw[idx] = make_float4(r0, r1, r2, 0.f);
+    if (cat8 != nullptr) {
+        const float4 sv = s[idx];
+        cat8[2 * (size_t)idx] = make_float4(sv.x, sv.y, sv.z, r0 * sv.x);
+        cat8[2 * (size_t)idx + 1] = make_float4(r1 * sv.y, r2 * sv.z, 0.f, 0.f);
+    }
+}
+
+// Backward w.r.t. the projector image: scatter-add of the four bilinear taps.  The clamp(x,0,1) of the forward
+// passes gradient where 0 <= x <= 1 (ATen clamp_backward).
+__global__ void warp_bwd_kernel(const float4* __restrict__ g_xw, const float4* __restrict__ g_xs,
+                                const float4* __restrict__ x, const float4* __restrict__ grid,
+                                const float* __restrict__ mask, const float4* __restrict__ s, float* __restrict__ g_x,
+                                int B, int Hp, int Wp, int HWc, int clamp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * HWc) return;
+    const int b = idx / HWc, pix = idx - b * HWc;
+    float4 g = g_xw[idx];
+    if (g_xs != nullptr) {
+        const float4 gs = g_xs[idx];
+        const float4 sv = s[idx];
+        g.x += gs.x * sv.x;
+        g.y += gs.y * sv.y;
+        g.z += gs.z * sv.z;
+    }
+    const float m = (mask != nullptr) ? mask[pix] : 1.f;
+    g.x *= m;
+    g.y *= m;
+    g.z *= m;
+    const float4 gr = grid[pix];
+    const Bilinear bl = bilinear_setup(gr.x, gr.y, Wp, Hp);
+    const size_t base = (size_t)b * Hp * Wp;
+    auto tap = [&](int yy, int xx, float wgt) {
+        if ((unsigned)yy < (unsigned)Hp && (unsigned)xx < (unsigned)Wp) {
+            const size_t o = base + (size_t)(yy * Wp + xx);
+            bool p0 = true, p1 = true, p2 = true;
+            if (clamp) {
+                const float4 v = x[o];
+                p0 = (v.x >= 0.f && v.x <= 1.f);
+                p1 = (v.y >= 0.f && v.y <= 1.f);
+                p2 = (v.z >= 0.f && v.z <= 1.f);
+            }
+            float* dst = g_x + 4 * o;
+            if (p0) atomicAdd(dst + 0, g.x * wgt);
+            if (p1) atomicAdd(dst + 1, g.y * wgt);
+            if (p2) atomicAdd(dst + 2, g.z * wgt);
+        }
+    };
+    tap(bl.y0, bl.x0, bl.nw);
+    tap(bl.y0, bl.x0 + 1, bl.ne);
+    tap(bl.y0 + 1, bl.x0, bl.sw);
+    tap(bl.y0 + 1, bl.x0 + 1, bl.se);
+}
+
+__global__ void nchw_to_nhwc4_kernel(const float* __restrict__ src, float4* __restrict__ dst, int B, int HW,
+                                     int clamp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * HW) return;
+    const int b = idx / HW, pix = idx - b * HW;
+    const float* p = src + (size_t)b * 3 * HW + pix;
+    float r = p[0], g = p[HW], bl = p[2 * (size_t)HW];
+    if (clamp) {
+        r = clamp01(r);
+        g = clamp01(g);
+        bl = clamp01(bl);
+    }
+    dst[idx] = make_float4(r, g, bl, 0.f);
+}
+
+__global__ void nhwc4_to_nchw_kernel(const float4* __restrict__ src, float* __restrict__ dst, int B, int HW) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * HW) return;
+    const int b = idx / HW, pix = idx - b * HW;
+    const float4 v = src[idx];
+    float* p = dst + (size_t)b * 3 * HW + pix;
+    p[0] = v.x;
+    p[HW] = v.y;
+    p[2 * (size_t)HW] = v.z;
+}
+
+inline int blocks_for(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
+
+}  // namespace
+
+extern "C" {
+
+int spaa_warp_coarse_grid(const float* affine6, const float* theta, const float* ctrl, int T, int Hin, int Win,
+                          int Hout, int Wout, float* out, spaa_stream_t stream) {
+    if (!affine6 || !theta || !ctrl || !out || T < 1 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(coarse_grid_kernel, dim3(blocks_for((int64_t)Hout * Wout, 256)), dim3(256), 0,
+                       (hipStream_t)stream, affine6, theta, ctrl, T, Hin, Win, Hout, Wout, out);
+    return (int)hipGetLastError();
+}
+
+int spaa_warp_finish_grid(const float* coarse, const float* refine, float* fine, int npix, spaa_stream_t stream) {
+    if (!coarse || !fine || npix < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(finish_grid_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)coarse, (const float4*)refine, (float4*)fine, npix);
+    return (int)hipGetLastError();
+}
+
+int spaa_warp_fwd(const float* x, const float* grid, const float* mask, const float* s, float* xw, float* cat8, int B,
+                  int Hp, int Wp, int Hc, int Wc, int clamp, spaa_stream_t stream) {
+    if (!x || !grid || !xw || (cat8 && !s) || B < 1 || Hp < 1 || Wp < 1 || Hc < 1 || Wc < 1)
+        return hipErrorInvalidValue;
+    if ((int64_t)B * Hc * Wc >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(warp_fwd_kernel, dim3(blocks_for((int64_t)B * Hc * Wc, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)x, (const float4*)grid, mask, (const float4*)s,
+                       (float4*)xw, (float4*)cat8, B, Hp, Wp, Hc * Wc, clamp);
+    return (int)hipGetLastError();
+}
+
+int spaa_warp_bwd(const float* g_xw, const float* g_xs, const float* x, const float* grid, const float* mask,
+                  const float* s, float* g_x, int B, int Hp, int Wp, int Hc, int Wc, int clamp, spaa_stream_t stream) {
+    if (!g_xw || !x || !grid || !g_x || (g_xs && !s) || B < 1 || Hp < 1 || Wp < 1 || Hc < 1 || Wc < 1)
+        return hipErrorInvalidValue;
+    if ((int64_t)B * Hc * Wc >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(warp_bwd_kernel, dim3(blocks_for((int64_t)B * Hc * Wc, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)g_xw, (const float4*)g_xs, (const float4*)x,
+                       (const float4*)grid, mask, (const float4*)s, g_x, B, Hp, Wp, Hc * Wc, clamp);
+    return (int)hipGetLastError();
+}
+
+int spaa_nchw_to_nhwc4(const float* src, float* dst, int B, int H, int W, int clamp, spaa_stream_t stream) {
+    if (!src || !dst || B < 1 || H < 1 || W < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(blocks_for((int64_t)B * H * W, 256)), dim3(256), 0,
+                       (hipStream_t)stream, src, (float4*)dst, B, H * W, clamp);
+    return (int)hipGetLastError();
+}
+
+int spaa_nhwc4_to_nchw(const float* src, float* dst, int B, int H, int W, spaa_stream_t stream) {
+    if (!src || !dst || B < 1 || H < 1 || W < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(nhwc4_to_nchw_kernel, dim3(blocks_for((int64_t)B * H * W, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)src, dst, B, H * W);
+    return (int)hipGetLastError();
+}
+
+int spaa_zero(void* p, int64_t bytes, spaa_stream_t stream) {
+    if (!p || bytes < 0) return hipErrorInvalidValue;
+    return (int)hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+}
+
+const char* spaa_version(void) { return "spaa_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

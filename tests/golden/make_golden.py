@@ -1,0 +1,212 @@
+"""Generates tests/golden/*.npz by running the UNMODIFIED reference (imported via oracle/ref_shims.py)
+on deterministic synthetic inputs.  Runs only in the build container (needs /root/reference);
+the fixtures it writes are data (inputs' seeds + expected outputs), not reference source.
+
+    python tests/golden/make_golden.py [--only NAME ...]
+
+While generating, every case is also run through the oracle restatement (oracle/spaa_oracle.py) and the
+max |difference| is printed and stored (`oracle_maxdiff`), which is how the oracle was pinned.
+"""
+import argparse
+import io
+import contextlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+
+import spaa_oracle as so  # noqa: E402
+import ref_shims  # noqa: E402
+from spaa_amd import synthetic as syn  # noqa: E402
+
+LABELS = {i: f'class{i}' for i in range(1000)}
+GAIN = 20.0
+
+
+def weights_checksum(sd):
+    return np.array([float(sum(v.double().sum() for v in sd.values())),
+                     float(sum(v.double().abs().sum() for v in sd.values()))])
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f'  wrote {name}.npz ({os.path.getsize(path) / 1e6:.2f} MB)')
+
+
+def color_inputs():
+    """Random pairs plus the edge cases of SURVEY §8c(1)."""
+    rng = np.random.default_rng(7)
+    a = rng.random((2, 3, 16, 16)).astype(np.float32)
+    b = rng.random((2, 3, 16, 16)).astype(np.float32)
+    a[0, :, 0, 0:4] = 0.0                      # exactly black (X=Y=Z=0 -> f(0)=0, Q3)
+    b[0, :, 0, 2:6] = 0.0
+    a[0, :, 1, :] = b[0, :, 1, :]              # identical pixels -> dE = 0, zero gradient
+    g = np.linspace(0, 1, 16, dtype=np.float32)
+    a[0, :, 2, :] = g                          # greys: a=b=0 in Lab up to rounding
+    b[0, :, 2, :] = g[::-1]
+    a[0, :, 3, :] = np.array([0.0404, 0.0405, 0.0406, 0.04049999, 0.0405001, 0.03, 0.05, 0.0] * 2, np.float32)
+    b[0, :, 3, :] = 0.3
+    a[0, 0, 4, :], a[0, 1, 4, :], a[0, 2, 4, :] = 1.0, g * 0.2, 0.0      # saturated reds: hue near 0/360 wrap
+    b[0, 0, 4, :], b[0, 1, 4, :], b[0, 2, 4, :] = 1.0, 0.0, g * 0.2
+    a[0, 0, 5, :], a[0, 1, 5, :], a[0, 2, 5, :] = g, 0.0, 1.0            # blue/purple: hue ~ 275 (dRO peak)
+    b[0, 0, 5, :], b[0, 1, 5, :], b[0, 2, 5, :] = g[::-1], 0.1, 0.9
+    a[0, :, 6, :] = 0.002 * g                  # very dark: xyz below 0.008856 (linear branch)
+    b[0, :, 6, :] = 0.003 * g[::-1]
+    a[0, :, 7, :] = 1.0                        # white vs near white
+    b[0, :, 7, :] = 1.0 - 0.01 * g
+    return torch.from_numpy(a), torch.from_numpy(b)
+
+
+def gen_color(ref):
+    a, b = color_inputs()
+    a.requires_grad_(True)
+    lab_a = ref.color.rgb2lab_diff(a, 'cpu')
+    lab_b = ref.color.rgb2lab_diff(b, 'cpu')
+    de = ref.color.ciede2000_diff(lab_a, lab_b, 'cpu')
+    de.sum().backward()
+    ga = a.grad.clone()
+    a2 = a.detach().clone().requires_grad_(True)
+    de_o = so.ciede2000_diff(so.rgb2lab_diff(a2), so.rgb2lab_diff(b))
+    de_o.sum().backward()
+    diff = max((de_o - de).abs().max().item(), (a2.grad - ga).abs().max().item())
+    # Sharma pair: reference constant 39 gives 2.0213, textbook 2.0425
+    l1 = torch.tensor([50., 2.6772, -79.7751]).view(1, 3, 1, 1)
+    l2 = torch.tensor([50., 0., -82.7485]).view(1, 3, 1, 1)
+    sharma = ref.color.ciede2000_diff(l1, l2, 'cpu')
+    print(f'  colour: oracle maxdiff {diff:.3e}; Sharma pair -> {sharma.item():.4f}')
+    save('color_kat', rgb_a=a.detach(), rgb_b=b, lab_a=lab_a.detach(), lab_b=lab_b, de=de.detach(), grad_a=ga,
+         sharma=sharma, oracle_maxdiff=diff)
+
+
+def gen_pcnet(ref, name, prj_sz, cam_sz, mask, seed, bsz=2):
+    sd = syn.pcnet_state_dict(seed, cam_sz=cam_sz, mask=mask)
+    pc = ref_shims.make_reference_pcnet(ref, sd, prj_sz, cam_sz)
+    rng = np.random.default_rng(seed + 100)
+    x = torch.from_numpy(rng.random((bsz, 3, *prj_sz)).astype(np.float32)).requires_grad_(True)
+    s = syn.scenes(seed + 1, bsz, cam_sz)
+    r = torch.from_numpy(rng.standard_normal((bsz, 3, *cam_sz)).astype(np.float32))
+    y = pc(x, s)
+    (y * r).sum().backward()
+    g = x.grad.clone()
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = so.pcnet_forward(sd, x2, s)
+    (y2 * r).sum().backward()
+    diff = max((y2 - y).abs().max().item(), (x2.grad - g).abs().max().item())
+    fine = so.warping_fine_grid(sd, x.shape, cam_sz)
+    print(f'  {name}: oracle maxdiff {diff:.3e}')
+    save(name, seed=seed, prj_sz=prj_sz, cam_sz=cam_sz, mask=mask, x=x.detach(), s=s, r=r, y=y.detach(), grad_x=g,
+         fine_grid=fine, wsum=weights_checksum(sd), oracle_maxdiff=diff)
+
+
+class Recorder:
+    """Wraps the duck-typed classifier to observe the reference's loop without touching it."""
+
+    def __init__(self, clf):
+        self.clf, self.top1, self.p1, self.cam_mean = clf, [], [], []
+
+    def __call__(self, im, cp):
+        raw, p, idx = self.clf(im, cp)
+        self.top1.append(idx[:, 0].copy())
+        self.p1.append(p[:, 0].copy())
+        self.cam_mean.append(im.detach().mean(dim=(1, 2, 3)).numpy().copy())
+        return raw, p, idx
+
+
+def near_targets(clf, scene, cp, n, skip=1):
+    _, _, idx = clf(scene, cp)
+    return [int(i) for i in idx[0, skip:skip + n]]
+
+
+def gen_spaa(ref, name, sz, targeted, targets, d_thr, stealth, seed=0, mask='rect', keep=None, scene_seed=1):
+    t0 = time.time()
+    sd = syn.pcnet_state_dict(seed, cam_sz=sz, mask=mask)
+    pc = ref_shims.make_reference_pcnet(ref, sd, sz, sz)
+    csd = syn.resnet18_state_dict(2, logit_gain=GAIN)
+    in_sz = (224, 224) if sz[0] >= 240 else (sz[0] - 8, sz[1] - 8)
+    cp = (240, 240) if sz[0] >= 240 else (sz[0] - 4, sz[1] - 4)
+    clf = so.OracleClassifier('resnet18', csd, input_sz=in_sz)
+    scene = syn.scenes(scene_seed, 1, sz)
+    if targets == 'true':
+        targets = near_targets(clf, scene, cp, 1, skip=0)
+    elif isinstance(targets, tuple) and targets[0] == 'near':
+        targets = near_targets(clf, scene, cp, targets[1])
+    setup = dict(classifier_crop_sz=cp, prj_brightness=0.5, prj_im_sz=sz)
+    rec = Recorder(clf)
+    with contextlib.redirect_stdout(io.StringIO()):
+        cam_best, prj_best = ref.attack.spaa(pc, rec, LABELS, targets, targeted, scene[0], d_thr, stealth, 'cpu', setup)
+    tr = []
+    cam_o, prj_o = so.spaa(sd, clf, targets, targeted, scene, d_thr, stealth, setup, trace=tr)
+    diff = max((cam_o - cam_best).abs().max().item(), (prj_o - prj_best).abs().max().item())
+    top1 = np.stack(rec.top1)
+    assert (top1 == np.stack([t['top1'] for t in tr])).all()
+    k = slice(None) if keep is None else slice(0, keep)
+    print(f'  {name}: B={len(targets)} oracle maxdiff {diff:.3e}; succ/it {[int(t["succ"].sum()) for t in tr][::7]} '
+          f'best_adv/it {[int(t["best_adv"].sum()) for t in tr][::7]} ({time.time() - t0:.0f}s)')
+    save(name, seed=seed, scene_seed=scene_seed, sz=sz, mask=mask, targeted=targeted, targets=np.array(targets),
+         d_thr=d_thr, stealth=stealth, gain=GAIN, crop=cp, input_sz=in_sz,
+         cam_infer_best=cam_best.detach()[k], prj_adv_best=prj_best.detach()[k],
+         top1=top1, p1=np.stack(rec.p1), cam_mean=np.stack(rec.cam_mean),
+         succ=np.stack([t['succ'] for t in tr]), best_adv=np.stack([t['best_adv'] for t in tr]),
+         best=np.stack([t['best'] for t in tr]), caml2=np.stack([t['caml2'] for t in tr]),
+         camdE=np.stack([t['camdE'] for t in tr]), col_loss=np.stack([t['col_loss'] for t in tr]),
+         prj_adv_it0=tr[0]['prj_adv'][k], prj_adv_it9=tr[9]['prj_adv'][k],
+         wsum=weights_checksum(sd), oracle_maxdiff=diff)
+
+
+def gen_percal(ref, name, sz, targeted, d_thr, confidence):
+    csd = syn.resnet18_state_dict(2, logit_gain=GAIN)
+    cp, in_sz = (sz[0] - 4, sz[1] - 4), (sz[0] - 8, sz[1] - 8)
+    clf = so.OracleClassifier('resnet18', csd, input_sz=in_sz)
+    scene = syn.scenes(1, 1, sz)
+    targets = near_targets(clf, scene, cp, 8) if targeted else near_targets(clf, scene, cp, 1, skip=0) * 8
+    inputs = scene.expand(8, -1, -1, -1).contiguous()
+    labels = torch.tensor(targets)
+    att = ref.perc_al.PerC_AL(device='cpu', max_iterations=50, alpha_l_init=1, alpha_c_init=0.5, confidence=confidence)
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = att.adversary_projector(clf, inputs, labels, LABELS, d_thr, targeted, cp)
+    out_o = so.perc_al_adversary_projector(clf, inputs, labels, d_thr, targeted, cp, 50, 1., 0.5, confidence)
+    diff = (out_o - out).abs().max().item()
+    print(f'  {name}: oracle maxdiff {diff:.3e}; changed px {(out != inputs).float().mean().item():.3f}')
+    save(name, sz=sz, targeted=targeted, targets=np.array(targets), d_thr=d_thr, confidence=confidence, gain=GAIN,
+         crop=cp, input_sz=in_sz, x_adv_best=out.detach(), oracle_maxdiff=diff)
+
+
+CASES = {
+    'color_kat': lambda r: gen_color(r),
+    'pcnet_64': lambda r: gen_pcnet(r, 'pcnet_64', (64, 64), (64, 64), 'rect', 0),
+    'pcnet_nonsq': lambda r: gen_pcnet(r, 'pcnet_nonsq', (64, 64), (48, 80), 'ones', 3),
+    'pcnet_256': lambda r: gen_pcnet(r, 'pcnet_256', (256, 256), (256, 256), 'ones', 0, bsz=1),
+    'spaa_64_untargeted': lambda r: gen_spaa(r, 'spaa_64_untargeted', (64, 64), False, 'true', 5, 'camdE_caml2'),
+    'spaa_64_imagenet10': lambda r: gen_spaa(r, 'spaa_64_imagenet10', (64, 64), True, syn.IMAGENET10_TARGETS, 5,
+                                             'camdE_caml2'),
+    'spaa_64_near': lambda r: gen_spaa(r, 'spaa_64_near', (64, 64), True, ('near', 8), 5, 'camdE_caml2'),
+    'spaa_64_caml2_dthr': lambda r: gen_spaa(r, 'spaa_64_caml2_dthr', (64, 64), True, ('near', 8), 40, 'caml2'),
+    'spaa_64_prjl2': lambda r: gen_spaa(r, 'spaa_64_prjl2', (64, 64), True, ('near', 8), 5, 'camdE_caml2_prjl2'),
+    'spaa_64_camdE': lambda r: gen_spaa(r, 'spaa_64_camdE', (64, 64), False, 'true', 2, 'camdE', mask='ones'),
+    'spaa_256_untargeted': lambda r: gen_spaa(r, 'spaa_256_untargeted', (256, 256), False, 'true', 5, 'camdE_caml2',
+                                              mask='ones'),
+    'spaa_256_near': lambda r: gen_spaa(r, 'spaa_256_near', (256, 256), True, ('near', 8), 5, 'camdE_caml2',
+                                        mask='ones', keep=2),
+    'percal_64_targeted': lambda r: gen_percal(r, 'percal_64_targeted', (64, 64), True, 2, 0),
+    'percal_64_untargeted': lambda r: gen_percal(r, 'percal_64_untargeted', (64, 64), False, 2, 40),
+}
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', nargs='*')
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    ref = ref_shims.load_reference()
+    for nm, fn in CASES.items():
+        if args.only and nm not in args.only:
+            continue
+        print(nm)
+        fn(ref)
