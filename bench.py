@@ -1,0 +1,229 @@
+"""bench.py — attack-iterations/sec of the fused SPAA loop (PCNet + ResNet-18 fwd/bwd + dE2000 loss + PGD step).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Workload = BASELINE.json configs[1]: batch 64 (8 synthetic 256x256 scenes x 8 targets) per GPU, ResNet-18, fp32,
+stealth loss camdE_caml2, d_thr 5, targeted.  A "step" is one pass of the loop body
+(/root/reference/src/python/projector_based_attack.py:264-328) over the batch, inputs resident in HBM.
+N > 1: every rank attacks its own 64 samples (weak scaling, no data-path collective); the only exchange is the final
+result gather, timed separately (`gather_ms`).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def build_attack(rank, batch, size, n_scenes, dev):
+    from spaa_amd import synthetic as syn
+    from spaa_amd.models import PCNet, WarpingNet
+    from spaa_amd.classifier import Classifier
+    from spaa_amd.projector_based_attack import AttackState
+
+    sz = (size, size)
+    sd = syn.pcnet_state_dict(0, cam_sz=sz, mask='ones')
+    pc = PCNet(sd['mask'], WarpingNet(out_size=sz))
+    pc.load_state_dict(sd)
+    pc = pc.to(dev)
+    csd = syn.resnet18_state_dict(2, logit_gain=20.0)
+    clf = Classifier('resnet18', dev, state_dict=csd)
+    per = batch // n_scenes
+    scenes = syn.scenes(1 + 1000 * rank, n_scenes, sz)
+    scene_b = scenes.repeat_interleave(per, dim=0)
+    targets = (syn.IMAGENET10_TARGETS * 8)[:per] * n_scenes
+    crop = (size - 16, size - 16)
+    setup = dict(classifier_crop_sz=crop, prj_brightness=0.5, prj_im_sz=sz)
+    st = AttackState(pc, clf, targets, scene_b, 'camdE_caml2', setup, dev)
+    return st, sd, csd, setup, scenes, targets
+
+
+def usable_cores():
+    """Cores this process may actually use: affinity mask and cgroup CPU quota, not the host's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith('cpu.max'):
+                if parts[0] != 'max':
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as fh2:
+                        n = min(n, max(1, q // int(fh2.read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, 64))
+
+
+def log(msg):
+    print(f'[bench] {msg}', file=sys.stderr, flush=True)
+
+
+def cpu_baseline(sd, csd, setup, scenes, budget_b=4, iters=2):
+    """Oracle (CPU restatement of the reference composition: per-iteration grid rebuild, two backward passes) timed on
+    the host cores on a bounded sample: `budget_b` samples x `iters` iterations of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import spaa_oracle as so
+    from spaa_amd import synthetic as syn
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    clf = so.OracleClassifier('resnet18', csd)
+    tg = syn.IMAGENET10_TARGETS[:budget_b]
+    so.spaa(sd, clf, tg, True, scenes[:1], 5, 'camdE_caml2', setup, iters=1, per_batch_grid=True)  # warm-up
+    t0 = time.time()
+    so.spaa(sd, clf, tg, True, scenes[:1], 5, 'camdE_caml2', setup, iters=iters, per_batch_grid=True)
+    dt = time.time() - t0
+    scene_it_s = budget_b * iters / dt
+    return {'value': scene_it_s / 64.0, 'unit': 'attack-iterations/s (batch-64 equivalent)', 'cores': cores,
+            'kind': 'port', 'scene_iterations_per_s': scene_it_s,
+            'sample': f'{budget_b} samples x {iters} iterations of the same 256x256 ResNet-18 workload on the host '
+                      f'CPU ({dt:.1f} s), scaled by 1/64 to a batch-64 iteration'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-out', default=None, help='write the per-layer tapconv timing table (JSON) here')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: spaa_amd has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = f'cuda:{local_rank}'
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+
+    log('building attack state')
+    st, sd, csd, setup, scenes, targets = build_attack(rank, args.batch, args.size, 8, dev)
+    torch.cuda.synchronize()
+    log('warmup')
+    hp = dict(targeted=True, d_thr=5, adv_lr=2, col_lr=1, p_thresh=0.9)
+
+    for _ in range(args.warmup):
+        st.iteration(**hp)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    log('timed region')
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st.iteration(**hp)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    log(f'{args.steps} steps in {dt:.3f}s')
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    # final result gather (the path's only exchange, once per attack): prj_adv_best + cam_infer_best of every rank
+    gather_ms = None
+    cam, prj = st.results()
+    if dist is not None:
+        torch.cuda.synchronize()
+        dist.barrier()
+        g0 = time.perf_counter()
+        outs = [torch.empty_like(prj) for _ in range(world)]
+        outs2 = [torch.empty_like(cam) for _ in range(world)]
+        dist.all_gather(outs, prj)
+        dist.all_gather(outs2, cam)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    # instrumented pass: HIP events around every tapconv launch (same stream) -> per-kernel roofline
+    from spaa_amd import convplan
+    roof, table = None, {}
+    if rank == 0:
+        convplan.PROFILE = []
+        n_prof = 3
+        for _ in range(n_prof):
+            st.iteration(**hp)
+        torch.cuda.synchronize()
+        per_tile, per_layer = {}, {}
+        for name, tile, flops, e0, e1 in convplan.PROFILE:
+            ms = e0.elapsed_time(e1)
+            a = per_tile.setdefault(tile, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += ms
+            a[2] += 1
+            b = per_layer.setdefault(name, [0.0, 0.0, 0, tile])
+            b[0] += flops
+            b[1] += ms
+            b[2] += 1
+        convplan.PROFILE = None
+        tot_ms = sum(v[1] for v in per_tile.values())
+        dom = max(per_tile, key=lambda k: per_tile[k][1])
+        f, ms, n = per_tile[dom]
+        ach = f / (ms * 1e-3) / 1e12
+        roof = {'kernel': f'tapconv_kernel<{dom}> (fp32 MFMA implicit-GEMM conv/deconv/dgrad)', 'bound': 'mfma',
+                'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                'avg_launch_us': round(ms * 1e3 / n, 2), 'launches_per_step': n // n_prof,
+                'flop_per_launch': f / n, 'share_of_conv_time': round(ms / tot_ms, 3),
+                'all_tapconv_tflops': round(sum(v[0] for v in per_tile.values()) / (tot_ms * 1e-3) / 1e12, 2),
+                'conv_ms_per_step': round(tot_ms / n_prof, 3)}
+        table = {k: {'tile': v[3], 'gflop_per_launch': v[0] / v[2] / 1e9, 'us_per_launch': v[1] * 1e3 / v[2],
+                     'tflops': v[0] / (v[1] * 1e-3) / 1e12} for k, v in per_layer.items()}
+        if args.profile_out:
+            with open(args.profile_out, 'w') as fh:
+                json.dump({'per_tile': {k: {'flop': v[0], 'ms': v[1], 'launches': v[2]} for k, v in per_tile.items()},
+                           'per_layer': table}, fh, indent=1)
+
+    if rank == 0:
+        value = world * args.steps / dt
+        out = {
+            'metric': 'attack-iterations/sec (PCNet+classifier fwd/bwd), 256x256 batch=64',
+            'value': round(value, 3), 'unit': 'attack-iterations/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'configs[1]: batch={args.batch} ({8} scenes x {args.batch // 8} targets) '
+                                   f'{args.size}x{args.size}, ResNet-18, camdE_caml2, per GPU',
+                       'global_batch': args.batch * world, 'parallelism': f'dp{world} (independent shards)'},
+            'scene_iterations_per_s': round(value * args.batch, 1),
+            'roofline': roof,
+        }
+        if gather_ms is not None:
+            out['gather_ms'] = round(gather_ms, 3)
+        if world == 1 and not args.no_cpu_baseline:
+            log(f'cpu baseline on {usable_cores()} cores')
+            out['cpu_baseline'] = cpu_baseline(sd, csd, setup, scenes)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -63,7 +63,11 @@ typedef struct {
     const float* gate;    /* indexed like `out`, or NULL */
     int32_t gate_cstride, gate_coff, gate_mode;
     int32_t act;
-    float* aux_out;       /* optional second output: value BEFORE the clamp of SPAA_ACT_RELU_CLAMP1 (same indexing) */
+    float* aux_out;       /* optional second output (indexed like `out`):
+                             act == SPAA_ACT_RELU_CLAMP1: the value BEFORE the clamp;
+                             otherwise, with gate2: (gate2 > 0) ? out_value : 0  (a second ReLU-backward gate) */
+    const float* gate2;
+    int32_t gate2_cstride, gate2_coff;
     int32_t nclass;
     spaa_tapclass_t cls[SPAA_MAX_CLASSES];
 } spaa_tapconv_t;
@@ -73,7 +77,8 @@ int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream);
 /* ---- layout conversion at the NCHW boundary ---------------------------------------------------------------- */
 /* src [B,3,H,W] -> dst [B,H,W,4] (lane 3 = 0); optional clamp to [0,1] (projector_based_attack.py:265) */
 int spaa_nchw_to_nhwc4(const float* src, float* dst, int B, int H, int W, int clamp01, spaa_stream_t stream);
-int spaa_nhwc4_to_nchw(const float* src, float* dst, int B, int H, int W, spaa_stream_t stream);
+/* dst [B,3,H,W]; optional final clamp to [0,1] (projector_based_attack.py:337) */
+int spaa_nhwc4_to_nchw(const float* src, float* dst, int B, int H, int W, int clamp01, spaa_stream_t stream);
 
 /* ---- WarpingNet (models.py:163-185, pytorch_tps.py:29-106) ----------------------------------------------- */
 /* Coarse grid: F.affine_grid(affine_mat) sampled at tps_grid(theta, ctrl) (models.py:168-172), batch 1.

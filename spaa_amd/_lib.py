@@ -1,0 +1,116 @@
+"""ctypes binding of libspaa_hip.so (include/spaa_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a kernel launch fails, this module
+raises.  PyTorch is used only as plumbing (device memory, current stream).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libspaa_hip.so')
+
+MAX_CLASSES = 4
+MAX_TAPS = 64
+ACT_NONE, ACT_RELU, ACT_RELU_CLAMP1, ACT_LEAKY01 = 0, 1, 2, 3
+GATE_NONE, GATE_POS, GATE_POS_LE1 = 0, 1, 2
+
+
+class TapClass(C.Structure):
+    _fields_ = [('oy0', C.c_int32), ('ox0', C.c_int32), ('ntaps', C.c_int32), ('tap_off', C.c_int32),
+                ('K', C.c_int32), ('Kpad', C.c_int32), ('w_off', C.c_int64)]
+
+
+class TapConv(C.Structure):
+    _fields_ = [
+        ('inp', C.c_void_p), ('Hin', C.c_int32), ('Win', C.c_int32), ('Cin', C.c_int32), ('in_cstride', C.c_int32),
+        ('in_coff', C.c_int32),
+        ('out', C.c_void_p), ('Hout', C.c_int32), ('Wout', C.c_int32), ('Cout', C.c_int32), ('out_cstride', C.c_int32),
+        ('out_coff', C.c_int32),
+        ('B', C.c_int32), ('Hm', C.c_int32), ('Wm', C.c_int32), ('s_in', C.c_int32), ('s_out', C.c_int32),
+        ('weights', C.c_void_p), ('taps', C.c_void_p), ('bias', C.c_void_p),
+        ('add', C.c_void_p), ('add_cstride', C.c_int32), ('add_coff', C.c_int32),
+        ('gate', C.c_void_p), ('gate_cstride', C.c_int32), ('gate_coff', C.c_int32), ('gate_mode', C.c_int32),
+        ('act', C.c_int32),
+        ('aux_out', C.c_void_p),
+        ('gate2', C.c_void_p), ('gate2_cstride', C.c_int32), ('gate2_coff', C.c_int32),
+        ('nclass', C.c_int32),
+        ('cls', TapClass * MAX_CLASSES),
+    ]
+
+
+_i, _f, _p, _l = C.c_int, C.c_float, C.c_void_p, C.c_int64
+
+# name -> argument types (all return int)
+_SIGNATURES = {
+    'spaa_tapconv_f32': [C.POINTER(TapConv), _p],
+    'spaa_nchw_to_nhwc4': [_p, _p, _i, _i, _i, _i, _p],
+    'spaa_nhwc4_to_nchw': [_p, _p, _i, _i, _i, _i, _p],
+    'spaa_warp_coarse_grid': [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
+    'spaa_warp_finish_grid': [_p, _p, _p, _i, _p],
+    'spaa_warp_fwd': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'spaa_warp_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'spaa_rgb2lab': [_p, _p, _i, _p],
+    'spaa_ciede2000': [_p, _p, _p, _i, _p],
+    'spaa_stealth_loss_fwd_bwd': [_p, _p, _p, _f, _f, _f, _p, _p, _i, _i, _p],
+    'spaa_preproc_fwd': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p],
+    'spaa_preproc_bwd': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), _p],
+    'spaa_maxpool3s2_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'spaa_maxpool3s2_bwd': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'spaa_avgpool_fwd': [_p, _p, _i, _i, _i, _p],
+    'spaa_avgpool_bwd': [_p, _p, _p, _i, _i, _i, _p],
+    'spaa_decide': [_p, _i, _p, _i, _p, _i, _i, _p, _f, _f, _f, _f, _f, _f, _p, _p, _p, _i, _p],
+    'spaa_select_grad': [_p, _p, _p, _p, _p, _i, _i, _p],
+    'spaa_prjl2_fwd': [_p, _f, _p, _i, _i, _p],
+    'spaa_grad_sumsq': [_p, _p, _f, _f, _p, _p, _i, _i, _p],
+    'spaa_step_and_track': [_p, _p, _p, _p, _f, _f, _p, _p, _p, _i, _i, _i, _p],
+    'spaa_zero': [_p, _l, _p],
+}
+
+EXPORTS = sorted(list(_SIGNATURES) + ['spaa_version'])
+
+_lib = None
+
+
+def load():
+    """Loads libspaa_hip.so; raises RuntimeError (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                           f'or `make -C spaa_amd/csrc`. spaa_amd has no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.spaa_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def check_dev(*tensors):
+    for t in tensors:
+        if t is not None and (not t.is_cuda or not t.is_contiguous() or t.dtype != torch.float32):
+            raise ValueError('spaa_amd kernels need contiguous float32 tensors on the GPU '
+                             f'(got device={t.device}, dtype={t.dtype}, contiguous={t.is_contiguous()})')
+
+
+def call(name, *args):
+    """Invoke an entry point on torch's current stream; non-zero return -> RuntimeError."""
+    lib = load()
+    rc = getattr(lib, name)(*args, _stream())
+    if rc != 0:
+        raise RuntimeError(f'{name} failed with HIP error {rc}')

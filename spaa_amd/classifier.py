@@ -1,0 +1,268 @@
+"""Frozen ImageNet classifier on HIP kernels behind the reference's `Classifier` contract.
+
+Mirrors /root/reference/src/python/classifier.py:12-75: `Classifier(model_name, device, device_ids, fix_params,
+sort_results)` and `classifier(im, crop_sz) -> (raw_score Tensor[B,1000], p_sorted ndarray, idx ndarray)`.
+The network bodies are torchvision's (third-party, not in the reference tree; pinned torchvision==0.15.1): the
+architecture is restated here as a layer table over the tap-list convolution kernel, with eval-mode BatchNorm
+folded into the convolutions.  Pretrained weights cannot be downloaded in this environment (the reference fetches
+them by URL, classifier.py:24-36): pass `state_dict=` (torchvision key names) or `weights_path=`.
+
+`ClassifierEngine` is what the fused attack loop drives: forward = crop + area-resize + normalise -> net -> logits;
+backward = input gradient only (all parameters frozen, classifier.py:41-44).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from . import convplan as cp
+from .models import to_nhwc4, to_nchw
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+INPUT_SZ = {'resnet18': (224, 224), 'vgg16': (224, 224), 'inception_v3': (299, 299)}
+
+
+def center_crop_origin(h, w, size):
+    """img_proc.py:126-132."""
+    th, tw = size
+    return int(round((h - th) / 2.)), int(round((w - tw) / 2.))
+
+
+def _strip(sd):
+    out = {}
+    for k, v in sd.items():
+        while k.startswith('module.'):
+            k = k[len('module.'):]
+        out[k] = v
+    return out
+
+
+class ResNet18Body:
+    """torchvision.models.resnet18 (eval) forward + input-gradient on tapconv/maxpool/avgpool kernels."""
+
+    def __init__(self, sd, batch, in_hw, dev):
+        sd = _strip(sd)
+        self.B, self.dev = batch, dev
+        h, w = in_hw
+
+        def folded(conv, bn):
+            return cp.fold_bn(sd[conv + '.weight'], sd[bn + '.weight'], sd[bn + '.bias'], sd[bn + '.running_mean'],
+                              sd[bn + '.running_var'])
+
+        def z(*shape):
+            return torch.zeros(*shape, device=dev)
+
+        def osz(n, k, s, p):
+            return (n + 2 * p - k) // s + 1
+
+        wgt, b = folded('conv1', 'bn1')
+        self.stem_f = cp.conv_fwd_plan(wgt, b, 2, 3, dev, 'conv1')
+        self.stem_d = cp.conv_dgrad_plan(wgt, 2, 3, dev, 'conv1_dgrad')
+        self.in_hw = (h, w)
+        h1, w1 = osz(h, 7, 2, 3), osz(w, 7, 2, 3)
+        self.c1 = z(batch, h1, w1, 64)
+        h2, w2 = osz(h1, 3, 2, 1), osz(w1, 3, 2, 1)
+        self.mp = z(batch, h2, w2, 64)
+        self.mp_arg = torch.zeros(batch, h2, w2, 64, dtype=torch.uint8, device=dev)
+        self.blocks = []
+        cin, hh, ww = 64, h2, w2
+        x_buf = self.mp
+        for li, cout in enumerate((64, 128, 256, 512), start=1):
+            for bi in range(2):
+                p = f'layer{li}.{bi}'
+                stride = 2 if (li > 1 and bi == 0) else 1
+                ho, wo = osz(hh, 3, stride, 1), osz(ww, 3, stride, 1)
+                blk = dict(name=p, stride=stride, x=x_buf)
+                w1_, b1_ = folded(p + '.conv1', p + '.bn1')
+                w2_, b2_ = folded(p + '.conv2', p + '.bn2')
+                blk['f1'] = cp.conv_fwd_plan(w1_, b1_, stride, 1, dev, p + '.conv1')
+                blk['d1'] = cp.conv_dgrad_plan(w1_, stride, 1, dev, p + '.conv1_dgrad')
+                blk['f2'] = cp.conv_fwd_plan(w2_, b2_, 1, 1, dev, p + '.conv2')
+                blk['d2'] = cp.conv_dgrad_plan(w2_, 1, 1, dev, p + '.conv2_dgrad')
+                if p + '.downsample.0.weight' in sd:
+                    wd, bd = folded(p + '.downsample.0', p + '.downsample.1')
+                    blk['fd'] = cp.conv_fwd_plan(wd, bd, stride, 0, dev, p + '.downsample')
+                    blk['dd'] = cp.conv_dgrad_plan(wd, stride, 0, dev, p + '.downsample_dgrad')
+                    blk['idt'] = z(batch, ho, wo, cout)
+                    blk['g_t'] = z(batch, hh, ww, cin)
+                blk['o1'] = z(batch, ho, wo, cout)
+                blk['out'] = z(batch, ho, wo, cout)
+                blk['g_o1'] = z(batch, ho, wo, cout)
+                blk['g_x'] = z(batch, hh, ww, cin)
+                self.blocks.append(blk)
+                x_buf, cin, hh, ww = blk['out'], cout, ho, wo
+        self.feat_hw = hh * ww
+        self.feat = z(batch, 1, 1, 512)
+        ncls = sd['fc.weight'].shape[0]
+        self.ncls = ncls
+        self.fc_f = cp.linear_fwd_plan(sd['fc.weight'], sd['fc.bias'], dev, 'fc')
+        self.fc_d = cp.linear_dgrad_plan(sd['fc.weight'], dev, 'fc_dgrad')
+        self.logits = z(batch, 1, 1, ncls)
+        self.g_feat = z(batch, 1, 1, 512)
+        self.g_last = z(batch, hh, ww, 512)
+        self.g_c1 = z(batch, h1, w1, 64)
+        self.g_in = z(batch, h, w, 4)
+
+    def forward(self, x4):
+        R = _lib.ACT_RELU
+        B = self.B
+        self.stem_f.run(x4, self.c1, act=R)
+        _, h1, w1, _ = self.c1.shape
+        _, h2, w2, _ = self.mp.shape
+        _lib.call('spaa_maxpool3s2_fwd', _lib.ptr(self.c1), _lib.ptr(self.mp), _lib.ptr(self.mp_arg), B, h1, w1, 64,
+                  h2, w2)
+        for blk in self.blocks:
+            blk['f1'].run(blk['x'], blk['o1'], act=R)
+            if 'fd' in blk:
+                blk['fd'].run(blk['x'], blk['idt'])
+                idt = blk['idt']
+            else:
+                idt = blk['x']
+            blk['f2'].run(blk['o1'], blk['out'], add=idt, act=R)
+        last = self.blocks[-1]['out']
+        _lib.call('spaa_avgpool_fwd', _lib.ptr(last), _lib.ptr(self.feat), B, self.feat_hw, 512)
+        self.fc_f.run(self.feat, self.logits)
+        return self.logits.view(B, self.ncls)
+
+    def backward(self, g_logits):
+        """g_logits [B,ncls] -> gradient w.r.t. the normalised input [B,h,w,4]."""
+        B = self.B
+        self.fc_d.run(g_logits.view(B, 1, 1, self.ncls), self.g_feat)
+        last = self.blocks[-1]['out']
+        _lib.call('spaa_avgpool_bwd', _lib.ptr(self.g_feat), _lib.ptr(last), _lib.ptr(self.g_last), B, self.feat_hw,
+                  512)
+        gP = self.g_last
+        for i in range(len(self.blocks) - 1, -1, -1):
+            blk = self.blocks[i]
+            blk['d2'].run(gP, blk['g_o1'], gate=blk['o1'])
+            gate_x = blk['x'] if i > 0 else None  # block 0's input is the max-pool output (gated in maxpool_bwd)
+            if 'dd' in blk:
+                blk['dd'].run(gP, blk['g_t'])
+                blk['d1'].run(blk['g_o1'], blk['g_x'], add=blk['g_t'], gate=gate_x)
+            else:
+                blk['d1'].run(blk['g_o1'], blk['g_x'], add=gP, gate=gate_x)
+            gP = blk['g_x']
+        _, h1, w1, _ = self.c1.shape
+        _, h2, w2, _ = self.mp.shape
+        _lib.call('spaa_maxpool3s2_bwd', _lib.ptr(gP), _lib.ptr(self.mp_arg), _lib.ptr(self.c1), _lib.ptr(self.g_c1),
+                  B, h1, w1, 64, h2, w2)
+        self.stem_d.run(self.g_c1, self.g_in)
+        return self.g_in
+
+    def flops_fwd(self):
+        h, w = self.in_hw
+        t = self.stem_f.flops(self.B, *self.c1.shape[1:3])
+        for blk in self.blocks:
+            ho, wo = blk['out'].shape[1:3]
+            t += blk['f1'].flops(self.B, ho, wo) + blk['f2'].flops(self.B, ho, wo)
+            if 'fd' in blk:
+                t += blk['fd'].flops(self.B, ho, wo)
+        return t + self.fc_f.flops(self.B, 1, 1)
+
+
+BODIES = {'resnet18': ResNet18Body}
+
+
+class ClassifierEngine:
+    """crop -> area resize -> normalise -> net, forward and input-gradient, for a fixed batch/geometry."""
+
+    def __init__(self, name, state_dict, batch, im_hw, crop_sz, input_sz=None, device='cuda'):
+        if name not in BODIES:
+            raise NotImplementedError(f'classifier body {name!r} is not implemented on HIP yet (have: {list(BODIES)})')
+        self.name, self.B, self.dev = name, batch, torch.device(device)
+        self.H, self.W = im_hw
+        self.ch, self.cw = crop_sz
+        self.cy0, self.cx0 = center_crop_origin(self.H, self.W, crop_sz)
+        self.oh, self.ow = tuple(input_sz) if input_sz is not None else INPUT_SZ[name]
+        self.body = BODIES[name](state_dict, batch, (self.oh, self.ow), self.dev)
+        self.pre = torch.zeros(batch, self.oh, self.ow, 4, device=self.dev)
+        self.g_y = torch.zeros(batch, self.H, self.W, 4, device=self.dev)
+        import ctypes as C
+        self._mean = (C.c_float * 3)(*IMAGENET_MEAN)
+        self._std = (C.c_float * 3)(*IMAGENET_STD)
+        self.ncls = self.body.ncls
+
+    def forward(self, y4):
+        _lib.check_dev(y4)
+        assert y4.shape == (self.B, self.H, self.W, 4)
+        _lib.call('spaa_preproc_fwd', _lib.ptr(y4), _lib.ptr(self.pre), self.B, self.H, self.W, self.cy0, self.cx0,
+                  self.ch, self.cw, self.oh, self.ow, self._mean, self._std)
+        return self.body.forward(self.pre)
+
+    def backward(self, g_logits):
+        g_pre = self.body.backward(g_logits)
+        _lib.call('spaa_preproc_bwd', _lib.ptr(g_pre), _lib.ptr(self.g_y), self.B, self.H, self.W, self.cy0, self.cx0,
+                  self.ch, self.cw, self.oh, self.ow, self._std)
+        return self.g_y
+
+
+class _ClassifyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, im, clf, crop_sz):
+        b, _, h, w = im.shape
+        eng = clf.engine(b, (h, w), crop_sz)
+        logits = eng.forward(to_nhwc4(im))
+        ctx.eng = eng
+        return logits.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        gy4 = ctx.eng.backward(g.detach().float().contiguous())
+        return to_nchw(gy4), None, None
+
+
+class Classifier(object):
+    """classifier.py:12-75 on HIP.  Extra keyword arguments: `state_dict`/`weights_path` (no download here) and
+    `input_sz` (tests use reduced sizes)."""
+
+    def __init__(self, model_name, device, device_ids=(0,), fix_params=True, sort_results=True, state_dict=None,
+                 weights_path=None, input_sz=None):
+        self.name = model_name
+        self.fix_params = fix_params
+        self.device = torch.device(device)
+        self.sort_results = sort_results
+        if model_name not in INPUT_SZ:
+            raise ValueError(f'unknown classifier {model_name!r}')
+        self.input_sz = tuple(input_sz) if input_sz is not None else INPUT_SZ[model_name]
+        if state_dict is None and weights_path is not None:
+            state_dict = torch.load(weights_path, map_location='cpu')
+        if state_dict is None:
+            raise RuntimeError('no network access: pass state_dict= (torchvision key names) or weights_path= instead of '
+                               'the pretrained-weights URL the reference downloads (classifier.py:24-36)')
+        if not fix_params:
+            raise NotImplementedError('spaa_amd classifiers are frozen (input gradients only)')
+        self.state_dict = {k: v.detach().float().cpu() for k, v in _strip(state_dict).items()}
+        self._engines = {}
+
+    def engine(self, batch, im_hw, crop_sz):
+        key = (batch, tuple(im_hw), tuple(crop_sz))
+        if key not in self._engines:
+            self._engines[key] = ClassifierEngine(self.name, self.state_dict, batch, im_hw, crop_sz, self.input_sz,
+                                                  self.device)
+        return self._engines[key]
+
+    def classify(self, im, crop_sz=(240, 240)):
+        if im.dtype == torch.uint8:
+            im = im.type(torch.float32) / 255
+        while im.ndim < 4:
+            im = im[None]
+        raw_score = _ClassifyFn.apply(im.to(self.device), self, tuple(crop_sz))
+        # Compatibility outputs (classifier.py:64-72).  The fused attack loop does NOT use these: it takes top-1 and
+        # its probability on device (spaa_decide); the full 1000-way sort is only done for API parity here.
+        p = torch.softmax(raw_score.detach(), dim=1).cpu()
+        if self.sort_results:
+            p_sorted, idx = p.sort(descending=True)
+        else:
+            p_sorted, idx = p, torch.arange(p.shape[1]).repeat(p.shape[0], 1)
+        return raw_score, p_sorted.numpy(), idx.numpy()
+
+    def __call__(self, im, crop_sz):
+        return self.classify(im, crop_sz)
+
+
+def load_imagenet_labels(filename):
+    """classifier.py:109-116 (the label file is a Python dict literal)."""
+    import ast
+    with open(filename) as f:
+        labels = ast.literal_eval(f.read())
+    return {k: v.split(',')[0] for k, v in labels.items()}

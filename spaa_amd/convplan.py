@@ -1,0 +1,220 @@
+"""Host-side planning for the tap-list convolution kernel (csrc/tapconv.hip).
+
+Every convolution-like op on the SPAA hot path — nn.Conv2d forward, nn.ConvTranspose2d forward and the
+input-gradient (`aten::convolution_backward`) of both — is expressed as
+
+    out[b, oy0 + s_out*y, ox0 + s_out*x, n] = sum_t sum_c in[b, s_in*y + dy_t, s_in*x + dx_t, c] * W_t[n, c]
+
+so one MFMA kernel serves all of them.  The weights are frozen during an attack
+(/root/reference/src/python/projector_based_attack.py:62-67), so the packing below runs once per model.
+
+This module only rearranges weights (layout plumbing, on the host); the arithmetic happens in the HIP kernel.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+BK = 32
+NPAD = 128
+PROFILE = None  # set to a list by bench.py to time every tapconv launch with HIP events
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+class TapClassSpec:
+    """One output-parity class: output offset and a list of (dy, dx, W[n, c]) taps."""
+
+    def __init__(self, oy0, ox0):
+        self.oy0, self.ox0, self.taps = oy0, ox0, []
+
+    def add(self, dy, dx, w):
+        self.taps.append((int(dy), int(dx), w))
+
+
+class ConvPlan:
+    """Packed weights + launch template for spaa_tapconv_f32."""
+
+    def __init__(self, classes, cin, cout, s_in, s_out, bias=None, device='cuda', name=''):
+        assert 1 <= len(classes) <= _lib.MAX_CLASSES
+        self.name = name
+        self.cin = cin                      # logical input channels (before padding)
+        self.cin_p = _ceil(cin, 4)          # K uses the padded count; pad columns are zero
+        self.cout = cout
+        self.s_in, self.s_out = s_in, s_out
+        npad = _ceil(cout, NPAD)
+        w_chunks, tap_list, self.cls = [], [], []
+        w_off = 0
+        for c in classes:
+            nt = len(c.taps)
+            assert nt <= _lib.MAX_TAPS
+            k = nt * self.cin_p
+            kpad = _ceil(k, BK)
+            wp = torch.zeros(npad, kpad, dtype=torch.float32)
+            for t, (dy, dx, w) in enumerate(c.taps):
+                assert w.shape == (cout, cin), (w.shape, cout, cin)
+                wp[:cout, t * self.cin_p:t * self.cin_p + cin] = w
+            self.cls.append(dict(oy0=c.oy0, ox0=c.ox0, ntaps=nt, tap_off=len(tap_list), K=k, Kpad=kpad, w_off=w_off))
+            tap_list += [(dy, dx) for dy, dx, _ in c.taps]
+            w_chunks.append(wp.reshape(-1))
+            w_off += npad * kpad
+        self.classes_host = classes
+        self.weights = torch.cat(w_chunks).to(device) if w_off > 0 else torch.zeros(4, device=device)
+        taps = torch.tensor(tap_list if tap_list else [(0, 0)], dtype=torch.int32).reshape(-1)
+        self.taps = taps.to(device)
+        self.bias = bias.detach().float().contiguous().to(device) if bias is not None else None
+        # algorithmic FLOPs (2*MAC, logical channels, no padding) per pixel of the class grid
+        self.flops_per_pixel = 2 * sum(c['ntaps'] for c in self.cls) * cin * cout
+        self.tile = '128x128' if cout > 64 else ('256x64' if cout > 32 else '256x32')
+
+    def run(self, inp, out, add=None, gate=None, gate_mode=_lib.GATE_POS, act=_lib.ACT_NONE, aux_out=None,
+            gate2=None, in_coff=0, out_coff=0, add_coff=0, gate_coff=0):
+        """inp: [B,Hin,Win,Cs_in], out: [B,Hout,Wout,Cs_out] NHWC float32 CUDA tensors."""
+        _lib.check_dev(inp, out, add, gate, aux_out, gate2)
+        b, hin, win, cs_in = inp.shape
+        b2, hout, wout, cs_out = out.shape
+        assert b == b2 and cs_in % 4 == 0 and in_coff % 4 == 0 and in_coff + self.cin_p <= cs_in
+        assert out_coff + self.cout <= cs_out
+        d = _lib.TapConv()
+        d.inp, d.Hin, d.Win, d.Cin, d.in_cstride, d.in_coff = inp.data_ptr(), hin, win, self.cin_p, cs_in, in_coff
+        d.out, d.Hout, d.Wout, d.Cout, d.out_cstride, d.out_coff = out.data_ptr(), hout, wout, self.cout, cs_out, out_coff
+        d.B = b
+        if self.s_out == 1:
+            d.Hm, d.Wm = hout, wout
+        else:
+            d.Hm, d.Wm = (hout + self.s_out - 1) // self.s_out, (wout + self.s_out - 1) // self.s_out
+        d.s_in, d.s_out = self.s_in, self.s_out
+        d.weights, d.taps = self.weights.data_ptr(), self.taps.data_ptr()
+        d.bias = self.bias.data_ptr() if self.bias is not None else None
+        if add is not None:
+            assert add.shape[:3] == out.shape[:3] and add_coff + self.cout <= add.shape[3]
+            d.add, d.add_cstride, d.add_coff = add.data_ptr(), add.shape[3], add_coff
+        if gate is not None:
+            assert gate.shape[:3] == out.shape[:3] and gate_coff + self.cout <= gate.shape[3]
+            d.gate, d.gate_cstride, d.gate_coff, d.gate_mode = gate.data_ptr(), gate.shape[3], gate_coff, gate_mode
+        d.act = act
+        if aux_out is not None:
+            assert aux_out.shape == out.shape
+            d.aux_out = aux_out.data_ptr()
+        if gate2 is not None:
+            assert aux_out is not None and gate2.shape[:3] == out.shape[:3] and self.cout <= gate2.shape[3]
+            d.gate2, d.gate2_cstride, d.gate2_coff = gate2.data_ptr(), gate2.shape[3], 0
+        d.nclass = len(self.cls)
+        for i, c in enumerate(self.cls):
+            for k, v in c.items():
+                setattr(d.cls[i], k, v)
+        if PROFILE is None:
+            _lib.call('spaa_tapconv_f32', C.byref(d))
+        else:  # bench.py's instrumented pass: HIP events on the launch stream around this one kernel
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.call('spaa_tapconv_f32', C.byref(d))
+            e1.record()
+            PROFILE.append((self.name, self.tile, self.flops(b, hout, wout), e0, e1))
+        return out
+
+    def flops(self, b, hout, wout):
+        hm = hout if self.s_out == 1 else (hout + 1) // 2
+        wm = wout if self.s_out == 1 else (wout + 1) // 2
+        return b * hm * wm * self.flops_per_pixel
+
+
+def _w2(w):
+    return w.detach().float().cpu()
+
+
+def conv_fwd_plan(weight, bias, stride, pad, device='cuda', name=''):
+    """nn.Conv2d forward. weight [co, ci, kh, kw]."""
+    w = _w2(weight)
+    co, ci, kh, kw = w.shape
+    c = TapClassSpec(0, 0)
+    for ky in range(kh):
+        for kx in range(kw):
+            c.add(ky - pad, kx - pad, w[:, :, ky, kx])
+    return ConvPlan([c], ci, co, stride, 1, bias, device, name)
+
+
+def _fractional_classes(wsel, kh, kw, pad):
+    """Stride-2 transposed structure: output (2y+py, 2x+px) receives taps with (py+pad-ky) even."""
+    classes = []
+    for py in range(2):
+        for px in range(2):
+            c = TapClassSpec(py, px)
+            for ky in range(kh):
+                if (py + pad - ky) % 2:
+                    continue
+                for kx in range(kw):
+                    if (px + pad - kx) % 2:
+                        continue
+                    c.add((py + pad - ky) // 2, (px + pad - kx) // 2, wsel(ky, kx))
+            classes.append(c)
+    return classes
+
+
+def conv_dgrad_plan(weight, stride, pad, device='cuda', name='', in_ch=None):
+    """Input gradient of nn.Conv2d: consumes grad_out [.., co], produces grad_in [.., ci].
+    `in_ch=(lo, hi)` restricts the produced input channels (used for conv1_s, whose first 3 inputs are constant)."""
+    w = _w2(weight)
+    co, ci, kh, kw = w.shape
+    lo, hi = in_ch if in_ch is not None else (0, ci)
+
+    def wsel(ky, kx):
+        return w[:, lo:hi, ky, kx].t().contiguous()
+
+    if stride == 1:
+        c = TapClassSpec(0, 0)
+        for ky in range(kh):
+            for kx in range(kw):
+                c.add(pad - ky, pad - kx, wsel(ky, kx))
+        return ConvPlan([c], co, hi - lo, 1, 1, None, device, name)
+    assert stride == 2
+    return ConvPlan(_fractional_classes(wsel, kh, kw, pad), co, hi - lo, 1, 2, None, device, name)
+
+
+def deconv_fwd_plan(weight, bias, stride, pad, device='cuda', name=''):
+    """nn.ConvTranspose2d forward (stride 2). weight [ci, co, kh, kw]."""
+    assert stride == 2
+    w = _w2(weight)
+    ci, co, kh, kw = w.shape
+
+    def wsel(ky, kx):
+        return w[:, :, ky, kx].t().contiguous()
+
+    return ConvPlan(_fractional_classes(wsel, kh, kw, pad), ci, co, 1, 2, bias, device, name)
+
+
+def deconv_dgrad_plan(weight, stride, pad, device='cuda', name=''):
+    """Input gradient of nn.ConvTranspose2d: a stride-`stride` convolution of grad_out."""
+    w = _w2(weight)
+    ci, co, kh, kw = w.shape
+    c = TapClassSpec(0, 0)
+    for ky in range(kh):
+        for kx in range(kw):
+            c.add(ky - pad, kx - pad, w[:, :, ky, kx].contiguous())
+    return ConvPlan([c], co, ci, stride, 1, None, device, name)
+
+
+def linear_fwd_plan(weight, bias, device='cuda', name=''):
+    """nn.Linear as a 1x1 convolution over a [B,1,1,C] activation."""
+    w = _w2(weight)
+    c = TapClassSpec(0, 0)
+    c.add(0, 0, w)
+    return ConvPlan([c], w.shape[1], w.shape[0], 1, 1, bias, device, name)
+
+
+def linear_dgrad_plan(weight, device='cuda', name=''):
+    w = _w2(weight)
+    c = TapClassSpec(0, 0)
+    c.add(0, 0, w.t().contiguous())
+    return ConvPlan([c], w.shape[0], w.shape[1], 1, 1, None, device, name)
+
+
+def fold_bn(weight, bn_w, bn_b, bn_mean, bn_var, eps=1e-5):
+    """Eval-mode BatchNorm folded into the preceding bias-free convolution."""
+    scale = bn_w.double() / torch.sqrt(bn_var.double() + eps)
+    w = (weight.double() * scale.view(-1, 1, 1, 1)).float()
+    b = (bn_b.double() - bn_mean.double() * scale).float()
+    return w, b

@@ -34,9 +34,11 @@ __device__ __forceinline__ float srgb_lin(float v, float& dv) {
     return 100.f * (v / 12.92f);
 }
 
+// forward-only variant: the SAME arithmetic as srgb_lin, so that Lab(scene) cached by spaa_rgb2lab and Lab(y)
+// recomputed inside the fused loss kernel agree bit-for-bit on identical pixels (dE == 0 exactly, zero gradient).
 __device__ __forceinline__ float srgb_lin_fwd(float v) {
-    if (v > 0.0405f) return 100.f * powf((v + 0.055f) / 1.055f, 2.4f);
-    return 100.f * (v / 12.92f);
+    float d;
+    return srgb_lin(v, d);
 }
 
 __device__ __forceinline__ float lab_f(float t, float& dt) {
@@ -291,7 +293,12 @@ __global__ __launch_bounds__(256) void stealth_loss_kernel(const float4* __restr
             g1 = k * d1;
             g2 = k * d2;
         }
-        if (camdE_w != 0.f) {
+        if (l2 == 0.f) {
+            // identical pixels: the reference's two Lab values are bitwise equal, so res_square == 0 -> dE = 0 with
+            // zero gradient (differential_color_functions.py:174-178); do not depend on Lab(scene) having been
+            // rounded identically by another kernel.
+            de = 0.f;
+        } else if (camdE_w != 0.f) {
             const float4 lv = scene_lab[idx];
             float r0, r1, r2;
             de = de_rgb_grad(yv.x, yv.y, yv.z, lv.x, lv.y, lv.z, r0, r1, r2);

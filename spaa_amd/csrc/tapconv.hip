@@ -218,6 +218,10 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const spaa_tapconv_t p,
                     v = pass ? v : 0.f;
                 }
                 p.out[o * p.out_cstride + p.out_coff + n] = v;
+                if (p.gate2 != nullptr) {
+                    const float g2 = p.gate2[o * p.gate2_cstride + p.gate2_coff + n];
+                    p.aux_out[o * p.out_cstride + p.out_coff + n] = (g2 > 0.f) ? v : 0.f;
+                }
             }
         }
     }
@@ -251,6 +255,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
     if (d.Cin <= 0 || (d.Cin & 3) || (d.in_cstride & 3) || (d.in_coff & 3) || d.in_coff + d.Cin > d.in_cstride)
         return hipErrorInvalidValue;
     if (d.Cout <= 0 || d.out_coff + d.Cout > d.out_cstride) return hipErrorInvalidValue;
+    if (d.gate2 != nullptr && (d.aux_out == nullptr || d.act == SPAA_ACT_RELU_CLAMP1)) return hipErrorInvalidValue;
     if (d.nclass < 1 || d.nclass > SPAA_MAX_CLASSES || d.B <= 0 || d.Hm <= 0 || d.Wm <= 0) return hipErrorInvalidValue;
     if (d.s_in < 1 || d.s_out < 1) return hipErrorInvalidValue;
     for (int c = 0; c < d.nclass; ++c) {

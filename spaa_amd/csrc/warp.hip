@@ -212,11 +212,17 @@ __global__ void nchw_to_nhwc4_kernel(const float* __restrict__ src, float4* __re
     dst[idx] = make_float4(r, g, bl, 0.f);
 }
 
-__global__ void nhwc4_to_nchw_kernel(const float4* __restrict__ src, float* __restrict__ dst, int B, int HW) {
+__global__ void nhwc4_to_nchw_kernel(const float4* __restrict__ src, float* __restrict__ dst, int B, int HW,
+                                     int clamp) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * HW) return;
     const int b = idx / HW, pix = idx - b * HW;
-    const float4 v = src[idx];
+    float4 v = src[idx];
+    if (clamp) {
+        v.x = clamp01(v.x);
+        v.y = clamp01(v.y);
+        v.z = clamp01(v.z);
+    }
     float* p = dst + (size_t)b * 3 * HW + pix;
     p[0] = v.x;
     p[HW] = v.y;
@@ -274,10 +280,10 @@ int spaa_nchw_to_nhwc4(const float* src, float* dst, int B, int H, int W, int cl
     return (int)hipGetLastError();
 }
 
-int spaa_nhwc4_to_nchw(const float* src, float* dst, int B, int H, int W, spaa_stream_t stream) {
+int spaa_nhwc4_to_nchw(const float* src, float* dst, int B, int H, int W, int clamp, spaa_stream_t stream) {
     if (!src || !dst || B < 1 || H < 1 || W < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(nhwc4_to_nchw_kernel, dim3(blocks_for((int64_t)B * H * W, 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const float4*)src, dst, B, H * W);
+                       (hipStream_t)stream, (const float4*)src, dst, B, H * W, clamp);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,431 @@
+"""PCNet (WarpingNet + ShadingNetSPAA) on hand-written HIP kernels, behind the reference's module interface.
+
+Mirrors /root/reference/src/python/models.py:98-185 (WarpingNet), :214-303 (ShadingNetSPAA), :305-346 (PCNet):
+same constructor arguments, parameter/buffer names (state_dict of 44 parameters + `mask`, `warping_net.ctrl_pts`)
+and `forward(x, s)` semantics.  The modules only *hold* parameters; all arithmetic runs in libspaa_hip.so through
+`PCNetEngine` (no PyTorch compute ops on the path, no CPU fallback).
+
+`PCNet.forward(x, s)` is differentiable w.r.t. `x` (torch.autograd.Function around the HIP forward / input-gradient
+passes).  Parameters are treated as frozen, as the attack does (projector_based_attack.py:62-67): no weight
+gradients are produced.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import convplan as cp
+from .synthetic import uniform_ctrl_pts
+
+
+def _strip(sd):
+    out = {}
+    for k, v in sd.items():
+        while k.startswith('module.'):
+            k = k[len('module.'):]
+        out[k] = v
+    return out
+
+
+class _ParamHolder(nn.Module):
+    """nn.Conv2d-like holder: parameters only (names/shapes as torch's), never called."""
+
+    def __init__(self, wshape, bshape):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(*wshape))
+        self.bias = nn.Parameter(torch.zeros(*bshape))
+
+    def forward(self, *a):  # pragma: no cover
+        raise RuntimeError('spaa_amd modules hold parameters only; compute runs in PCNetEngine (HIP)')
+
+
+def _conv(ci, co, k):
+    m = _ParamHolder((co, ci, k, k), (co,))
+    fan_in = ci * k * k
+    nn.init.kaiming_normal_(m.weight)
+    nn.init.uniform_(m.bias, -fan_in ** -0.5, fan_in ** -0.5)
+    return m
+
+
+def _deconv(ci, co, k):
+    m = _ParamHolder((ci, co, k, k), (co,))
+    bound = (co * k * k) ** -0.5
+    nn.init.uniform_(m.weight, -bound, bound)
+    nn.init.uniform_(m.bias, -bound, bound)
+    return m
+
+
+class _Identity(nn.Module):
+    def forward(self, x):  # pragma: no cover
+        return x
+
+
+class WarpingNet(nn.Module):
+    """models.py:98-185.  Parameters: affine_mat [1,2,3], theta [1,38,2], grid_refine_net.{0,2,4,6}."""
+
+    def __init__(self, grid_shape=(6, 6), out_size=(256, 256), with_refine=True):
+        super().__init__()
+        self.grid_shape = grid_shape
+        self.out_size = tuple(out_size)
+        self.with_refine = with_refine
+        self.name = self.__class__.__name__ if with_refine else self.__class__.__name__ + '_without_refine'
+        self.register_buffer('fine_grid', None)
+        self.affine_mat = nn.Parameter(torch.Tensor([1, 0, 0, 0, 1, 0]).view(-1, 2, 3))
+        self.nctrl = grid_shape[0] * grid_shape[1]
+        self.nparam = self.nctrl + 2
+        self.register_buffer('ctrl_pts', uniform_ctrl_pts(grid_shape))
+        self.theta = nn.Parameter(torch.ones(1, self.nparam, 2) * 1e-3)
+        if with_refine:
+            mods = [_conv(2, 32, 3), _Identity(), _conv(32, 64, 3), _Identity(), _deconv(64, 32, 2), _Identity(),
+                    _deconv(32, 2, 2), _Identity()]
+            for i in (0, 2):
+                nn.init.normal_(mods[i].weight, 0, 1e-4)
+            self.grid_refine_net = nn.Sequential(*mods)
+        else:
+            self.grid_refine_net = None
+
+    def set_affine(self, affine_vec):
+        self.affine_mat.data = torch.Tensor(affine_vec).view(-1, 2, 3).to(self.affine_mat.device)
+
+    def build_fine_grid(self, in_size):
+        """The sampling grid [Hout, Wout, 4] = (gx, gy, 0, 0) of models.py:168-178, built once by HIP kernels."""
+        dev = self.affine_mat.device
+        if dev.type != 'cuda':
+            raise RuntimeError('spaa_amd.WarpingNet needs its parameters on the GPU (no CPU fallback)')
+        hi, wi = in_size
+        ho, wo = self.out_size
+        t = self.nctrl
+        assert self.theta.shape[1] == t + 2, 'only the reduced TPS form (T+2 parameters) is used by the reference'
+        coarse = torch.zeros(1, ho, wo, 4, device=dev)
+        aff = self.affine_mat.detach().float().contiguous().view(-1)
+        theta = self.theta.detach().float().contiguous().view(-1)
+        ctrl = self.ctrl_pts.detach().float().contiguous().view(-1)
+        _lib.call('spaa_warp_coarse_grid', _lib.ptr(aff), _lib.ptr(theta), _lib.ptr(ctrl), t, hi, wi, ho, wo,
+                  _lib.ptr(coarse))
+        refine = None
+        if self.with_refine:
+            if ho % 4 or wo % 4:
+                raise ValueError('grid refinement net needs an output size divisible by 4 (as in the reference)')
+            g = self.grid_refine_net
+            p0 = cp.conv_fwd_plan(g[0].weight, g[0].bias, 2, 1, dev, 'refine0')
+            p2 = cp.conv_fwd_plan(g[2].weight, g[2].bias, 2, 1, dev, 'refine2')
+            p4 = cp.deconv_fwd_plan(g[4].weight, g[4].bias, 2, 0, dev, 'refine4')
+            p6 = cp.deconv_fwd_plan(g[6].weight, g[6].bias, 2, 0, dev, 'refine6')
+            r0 = torch.zeros(1, ho // 2, wo // 2, 32, device=dev)
+            r2 = torch.zeros(1, ho // 4, wo // 4, 64, device=dev)
+            r4 = torch.zeros(1, ho // 2, wo // 2, 32, device=dev)
+            refine = torch.zeros(1, ho, wo, 4, device=dev)
+            p0.run(coarse, r0, act=_lib.ACT_RELU)
+            p2.run(r0, r2, act=_lib.ACT_RELU)
+            p4.run(r2, r4, act=_lib.ACT_RELU)
+            p6.run(r4, refine, act=_lib.ACT_LEAKY01)
+        fine = torch.zeros(ho, wo, 4, device=dev)
+        _lib.call('spaa_warp_finish_grid', _lib.ptr(coarse), _lib.ptr(refine), _lib.ptr(fine), ho * wo)
+        return fine
+
+    def simplify(self, x):
+        """models.py:149-161: cache the fine grid (stored [1,H,W,2] like the reference's buffer)."""
+        self.fine_grid = self.build_fine_grid(x.shape[-2:])[None, :, :, :2].contiguous()
+
+    def forward(self, x):
+        """models.py:163-185: warp a [B,3,H,W] image (HIP grid_sample, differentiable w.r.t. x)."""
+        return _WarpFn.apply(x, self)
+
+
+class ShadingNetSPAA(nn.Module):
+    """models.py:214-303 (parameters only; compute in PCNetEngine)."""
+
+    def __init__(self, use_rough=True):
+        super().__init__()
+        self.use_rough = use_rough
+        self.name = self.__class__.__name__ if use_rough else self.__class__.__name__ + '_no_rough'
+        self.conv1 = _conv(3, 32, 3)
+        self.conv2 = _conv(32, 64, 3)
+        self.conv3 = _conv(64, 128, 3)
+        self.conv4 = _conv(128, 256, 3)
+        self.conv5 = _conv(256, 128, 3)
+        nch = 6 if use_rough else 3
+        self.conv1_s = _conv(nch, 32, 3)
+        self.conv2_s = _conv(32, 64, 3)
+        self.conv3_s = _conv(64, 128, 3)
+        self.conv4_s = _conv(128, 256, 3)
+        self.transConv1 = _deconv(128, 64, 3)
+        self.transConv2 = _deconv(64, 32, 2)
+        self.conv6 = _conv(32, 3, 3)
+        self.skipConv1 = nn.Sequential(_conv(3, 3, 1), _Identity(), _conv(3, 3, 3), _Identity(), _conv(3, 3, 3),
+                                       _Identity())
+        self.skipConv2 = _conv(32, 64, 1)
+        self.skipConv3 = _conv(64, 128, 3)
+        for n in ('res1_s', 'res2_s', 'res3_s', 'res4_s'):
+            self.register_buffer(n, None)
+
+
+class PCNet(nn.Module):
+    """models.py:305-346."""
+
+    def __init__(self, mask=None, warping_net=None, shading_net=None, fix_shading_net=False, use_mask=True,
+                 use_rough=True):
+        super().__init__()
+        self.name = self.__class__.__name__
+        self.use_mask = use_mask
+        self.use_rough = use_rough
+        if not use_mask:
+            self.name += '_no_mask'
+        if not use_rough:
+            self.name += '_no_rough'
+        if not use_rough:
+            raise NotImplementedError('spaa_amd implements the SPAA configuration (use_rough=True) only')
+
+        def unwrap(m):
+            return copy.deepcopy(m.module if hasattr(m, 'module') else m)
+
+        if warping_net is None:
+            out_size = tuple(mask.shape[-2:]) if mask is not None else (256, 256)
+            self.warping_net = WarpingNet(out_size=out_size)
+        else:
+            self.warping_net = unwrap(warping_net)
+        self.shading_net = unwrap(shading_net) if shading_net is not None else ShadingNetSPAA()
+        if use_mask:
+            self.register_buffer('mask', mask.clone().float())
+        for p in self.shading_net.parameters():
+            p.requires_grad = not fix_shading_net
+        self._engines = {}
+
+    def load_state_dict(self, state_dict, strict=True):
+        r = super().load_state_dict(_strip(state_dict), strict)
+        self._engines = {}
+        return r
+
+    def engine(self, batch, prj_size):
+        key = (batch, tuple(prj_size), self.mask.device if self.use_mask else None)
+        if key not in self._engines:
+            self._engines[key] = PCNetEngine(self, batch, prj_size)
+        return self._engines[key]
+
+    def invalidate(self):
+        """Call after changing parameters in place (packed weights are cached)."""
+        self._engines = {}
+
+    def forward(self, x, s):
+        return _PCNetFn.apply(x, s, self)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def to_nhwc4(x, clamp01=False):
+    """[B,3,H,W] (any float layout) -> NHWC4 on the GPU."""
+    x = x.detach().float().contiguous()
+    if not x.is_cuda:
+        raise RuntimeError('spaa_amd needs CUDA(HIP) tensors; there is no CPU fallback')
+    b, c, h, w = x.shape
+    assert c == 3
+    out = torch.zeros(b, h, w, 4, device=x.device)
+    _lib.call('spaa_nchw_to_nhwc4', _lib.ptr(x), _lib.ptr(out), b, h, w, int(clamp01))
+    return out
+
+
+def to_nchw(x4, clamp01=False):
+    b, h, w, _ = x4.shape
+    out = torch.empty(b, 3, h, w, device=x4.device)
+    _lib.call('spaa_nhwc4_to_nchw', _lib.ptr(x4), _lib.ptr(out), b, h, w, int(clamp01))
+    return out
+
+
+class PCNetEngine:
+    """Packed weights, sampling grid and workspaces of one PCNet for a fixed batch size; HIP forward and
+    input-gradient passes over NHWC4 tensors."""
+
+    def __init__(self, pcnet, batch, prj_size):
+        wn, sn = pcnet.warping_net, pcnet.shading_net
+        dev = sn.conv1.weight.device
+        if dev.type != 'cuda':
+            raise RuntimeError('PCNetEngine needs the model on the GPU (no CPU fallback)')
+        self.dev, self.B = dev, batch
+        self.Hp, self.Wp = prj_size
+        self.Hc, self.Wc = wn.out_size
+        if self.Hc % 4 or self.Wc % 4:
+            raise ValueError('camera size must be divisible by 4')
+        fg = getattr(wn, 'fine_grid', None)
+        if fg is not None:
+            self.grid = torch.zeros(self.Hc, self.Wc, 4, device=dev)
+            self.grid[..., :2] = fg[0]
+        else:
+            self.grid = wn.build_fine_grid(prj_size)
+        self.mask = pcnet.mask.detach().float().contiguous().view(-1).to(dev) if pcnet.use_mask else None
+        if self.mask is not None:
+            assert self.mask.numel() == self.Hc * self.Wc
+        f, d = {}, {}
+        for nm, st in (('conv1', 2), ('conv2', 2), ('conv3', 1), ('conv4', 1), ('conv5', 1), ('conv1_s', 2),
+                       ('conv2_s', 2), ('conv3_s', 1), ('conv4_s', 1), ('conv6', 1), ('skipConv3', 1)):
+            m = getattr(sn, nm)
+            f[nm] = cp.conv_fwd_plan(m.weight, m.bias, st, 1, dev, nm)
+            d[nm] = cp.conv_dgrad_plan(m.weight, st, 1, dev, nm + '_dgrad', in_ch=(3, 6) if nm == 'conv1_s' else None)
+        f['skipConv2'] = cp.conv_fwd_plan(sn.skipConv2.weight, sn.skipConv2.bias, 1, 0, dev, 'skipConv2')
+        d['skipConv2'] = cp.conv_dgrad_plan(sn.skipConv2.weight, 1, 0, dev, 'skipConv2_dgrad')
+        f['transConv1'] = cp.deconv_fwd_plan(sn.transConv1.weight, sn.transConv1.bias, 2, 1, dev, 'transConv1')
+        d['transConv1'] = cp.deconv_dgrad_plan(sn.transConv1.weight, 2, 1, dev, 'transConv1_dgrad')
+        f['transConv2'] = cp.deconv_fwd_plan(sn.transConv2.weight, sn.transConv2.bias, 2, 0, dev, 'transConv2')
+        d['transConv2'] = cp.deconv_dgrad_plan(sn.transConv2.weight, 2, 0, dev, 'transConv2_dgrad')
+        sk = sn.skipConv1
+        f['skip1a'] = cp.conv_fwd_plan(sk[0].weight, sk[0].bias, 1, 0, dev, 'skipConv1.0')
+        f['skip1b'] = cp.conv_fwd_plan(sk[2].weight, sk[2].bias, 1, 1, dev, 'skipConv1.2')
+        f['skip1c'] = cp.conv_fwd_plan(sk[4].weight, sk[4].bias, 1, 1, dev, 'skipConv1.4')
+        self.f, self.d = f, d
+        B, H, W = batch, self.Hc, self.Wc
+        H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+
+        def z(*shape):
+            return torch.zeros(*shape, device=dev)
+
+        a = {}
+        a['xw'], a['cat8'] = z(B, H, W, 4), z(B, H, W, 8)
+        a['S1'], a['S2'], a['S3'], a['S4'] = z(B, H2, W2, 32), z(B, H4, W4, 64), z(B, H4, W4, 128), z(B, H4, W4, 256)
+        a['X1'], a['R2'], a['X2'], a['R3'] = z(B, H2, W2, 32), z(B, H2, W2, 64), z(B, H4, W4, 64), z(B, H4, W4, 128)
+        a['X3'], a['X4'], a['X5'] = z(B, H4, W4, 128), z(B, H4, W4, 256), z(B, H4, W4, 128)
+        a['X6'], a['X7'] = z(B, H2, W2, 64), z(B, H, W, 32)
+        a['Y'], a['Ypre'], a['R1'] = z(B, H, W, 4), z(B, H, W, 4), z(B, H, W, 4)
+        self.a = a
+        g = {}
+        g['P7'], g['P6'], g['P5'], g['P4'] = z(B, H, W, 32), z(B, H2, W2, 64), z(B, H4, W4, 128), z(B, H4, W4, 256)
+        g['S4'], g['P3'], g['t2'], g['P2'] = z(B, H4, W4, 256), z(B, H4, W4, 128), z(B, H4, W4, 64), z(B, H4, W4, 64)
+        g['t1'], g['P1'] = z(B, H2, W2, 32), z(B, H2, W2, 32)
+        g['S3'], g['S2'], g['S1'] = z(B, H4, W4, 128), z(B, H4, W4, 64), z(B, H2, W2, 32)
+        g['xw'], g['xs'], g['x'] = z(B, H, W, 4), z(B, H, W, 4), z(B, self.Hp, self.Wp, 4)
+        self.g = g
+        self.scene = None
+        self._x = None
+        self._clamp = 1
+
+    # ------------------------------------------------------------------------------------------------------
+    def set_scene(self, scene4):
+        """scene4: [B,Hc,Wc,4] camera-captured scene(s); precomputes the loop-invariant skipConv1(s) (models.py:291)."""
+        assert scene4.shape == (self.B, self.Hc, self.Wc, 4)
+        self.scene = scene4
+        t0, t1 = torch.zeros_like(scene4), torch.zeros_like(scene4)
+        self.f['skip1a'].run(scene4, t0, act=_lib.ACT_RELU)
+        self.f['skip1b'].run(t0, t1, act=_lib.ACT_RELU)
+        self.f['skip1c'].run(t1, self.a['R1'], act=_lib.ACT_RELU)
+
+    def warp(self, x4, clamp01=True):
+        a = self.a
+        _lib.check_dev(x4)
+        assert x4.shape == (self.B, self.Hp, self.Wp, 4)
+        _lib.call('spaa_warp_fwd', _lib.ptr(x4), _lib.ptr(self.grid), _lib.ptr(self.mask), _lib.ptr(self.scene),
+                  _lib.ptr(a['xw']), _lib.ptr(a['cat8']) if self.scene is not None else None, self.B, self.Hp,
+                  self.Wp, self.Hc, self.Wc, int(clamp01))
+        self._x, self._clamp = x4, int(clamp01)
+        return a['xw']
+
+    def forward(self, x4, clamp01=True):
+        """PCNet.forward on NHWC4 input [B,Hp,Wp,4]; returns cam_infer [B,Hc,Wc,4] (a workspace view)."""
+        if self.scene is None:
+            raise RuntimeError('call set_scene() first')
+        a, f = self.a, self.f
+        R, N = _lib.ACT_RELU, _lib.ACT_NONE
+        self.warp(x4, clamp01)
+        f['conv1_s'].run(a['cat8'], a['S1'], act=R)
+        f['conv2_s'].run(a['S1'], a['S2'], act=R)
+        f['conv3_s'].run(a['S2'], a['S3'], act=R)
+        f['conv4_s'].run(a['S3'], a['S4'], act=R)
+        f['conv1'].run(a['xw'], a['X1'], add=a['S1'], act=R)
+        f['skipConv2'].run(a['X1'], a['R2'], act=N)
+        f['conv2'].run(a['X1'], a['X2'], add=a['S2'], act=R)
+        f['skipConv3'].run(a['X2'], a['R3'], act=N)
+        f['conv3'].run(a['X2'], a['X3'], add=a['S3'], act=R)
+        f['conv4'].run(a['X3'], a['X4'], add=a['S4'], act=R)
+        f['conv5'].run(a['X4'], a['X5'], add=a['R3'], act=R)
+        f['transConv1'].run(a['X5'], a['X6'], add=a['R2'], act=R)
+        f['transConv2'].run(a['X6'], a['X7'], act=R)
+        f['conv6'].run(a['X7'], a['Y'], add=a['R1'], act=_lib.ACT_RELU_CLAMP1, aux_out=a['Ypre'])
+        return a['Y']
+
+    def backward(self, gP):
+        """gP: gradient w.r.t. conv6's pre-activation (already gated by 0 < Ypre <= 1), [B,Hc,Wc,4].
+        Returns the gradient w.r.t. the projector image x4 [B,Hp,Wp,4] (workspace)."""
+        a, g, d = self.a, self.g, self.d
+        d['conv6'].run(gP, g['P7'], gate=a['X7'])
+        d['transConv2'].run(g['P7'], g['P6'], gate=a['X6'])
+        d['transConv1'].run(g['P6'], g['P5'], gate=a['X5'])
+        d['conv5'].run(g['P5'], g['P4'], gate=a['X4'], aux_out=g['S4'], gate2=a['S4'])
+        d['conv4'].run(g['P4'], g['P3'], gate=a['X3'])
+        d['skipConv3'].run(g['P5'], g['t2'])
+        d['conv3'].run(g['P3'], g['P2'], add=g['t2'], gate=a['X2'])
+        d['skipConv2'].run(g['P6'], g['t1'])
+        d['conv2'].run(g['P2'], g['P1'], add=g['t1'], gate=a['X1'])
+        d['conv1'].run(g['P1'], g['xw'])
+        # surface branch (depends on x through the rough input x*s)
+        d['conv4_s'].run(g['S4'], g['S3'], add=g['P3'], gate=a['S3'])
+        d['conv3_s'].run(g['S3'], g['S2'], add=g['P2'], gate=a['S2'])
+        d['conv2_s'].run(g['S2'], g['S1'], add=g['P1'], gate=a['S1'])
+        d['conv1_s'].run(g['S1'], g['xs'])
+        return self.warp_backward(g['xw'], g['xs'])
+
+    def warp_backward(self, g_xw, g_xs=None):
+        g = self.g
+        _lib.call('spaa_zero', _lib.ptr(g['x']), g['x'].numel() * 4)
+        _lib.call('spaa_warp_bwd', _lib.ptr(g_xw), _lib.ptr(g_xs), _lib.ptr(self._x), _lib.ptr(self.grid),
+                  _lib.ptr(self.mask), _lib.ptr(self.scene) if g_xs is not None else None, _lib.ptr(g['x']), self.B,
+                  self.Hp, self.Wp, self.Hc, self.Wc, self._clamp)
+        return g['x']
+
+    def flops_fwd(self):
+        B, H, W = self.B, self.Hc, self.Wc
+        sizes = {'conv1_s': (H // 2, W // 2), 'conv2_s': (H // 4, W // 4), 'conv3_s': (H // 4, W // 4),
+                 'conv4_s': (H // 4, W // 4), 'conv1': (H // 2, W // 2), 'skipConv2': (H // 2, W // 2),
+                 'conv2': (H // 4, W // 4), 'skipConv3': (H // 4, W // 4), 'conv3': (H // 4, W // 4),
+                 'conv4': (H // 4, W // 4), 'conv5': (H // 4, W // 4), 'transConv1': (H // 2, W // 2),
+                 'transConv2': (H, W), 'conv6': (H, W)}
+        return sum(self.f[k].flops(B, *v) for k, v in sizes.items())
+
+
+class _PCNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s, pcnet):
+        b = x.shape[0]
+        eng = pcnet.engine(b, x.shape[-2:])
+        s4 = to_nhwc4(s.expand(b, -1, -1, -1) if s.shape[0] != b else s)
+        eng.set_scene(s4)
+        x4 = to_nhwc4(x)
+        y4 = eng.forward(x4, clamp01=False)
+        ctx.eng = eng
+        return to_nchw(y4)
+
+    @staticmethod
+    def backward(ctx, gy):
+        eng = ctx.eng
+        g4 = to_nhwc4(gy)
+        gP = torch.zeros_like(g4)
+        state = torch.ones(eng.B, 4, dtype=torch.int32, device=g4.device)  # best_adv=1 -> take the 2nd argument
+        _lib.call('spaa_select_grad', _lib.ptr(g4), _lib.ptr(g4), _lib.ptr(state), _lib.ptr(eng.a['Ypre']),
+                  _lib.ptr(gP), eng.B, eng.Hc * eng.Wc)
+        gx4 = eng.backward(gP)
+        return to_nchw(gx4), None, None
+
+
+class _WarpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wn):
+        b = x.shape[0]
+        holder = type('H', (), {})()
+        x4 = to_nhwc4(x)
+        grid = wn.build_fine_grid(x.shape[-2:]) if wn.fine_grid is None else None
+        if grid is None:
+            grid = torch.zeros(*wn.out_size, 4, device=x.device)
+            grid[..., :2] = wn.fine_grid[0]
+        hc, wc = wn.out_size
+        xw = torch.zeros(b, hc, wc, 4, device=x.device)
+        _lib.call('spaa_warp_fwd', _lib.ptr(x4), _lib.ptr(grid), None, None, _lib.ptr(xw), None, b, x.shape[-2],
+                  x.shape[-1], hc, wc, 0)
+        holder.x4, holder.grid = x4, grid
+        ctx.h = holder
+        return to_nchw(xw)
+
+    @staticmethod
+    def backward(ctx, gy):
+        h = ctx.h
+        g4 = to_nhwc4(gy)
+        b, hp, wp, _ = h.x4.shape
+        gx = torch.zeros_like(h.x4)
+        _lib.call('spaa_warp_bwd', _lib.ptr(g4), None, _lib.ptr(h.x4), _lib.ptr(h.grid), None, None, _lib.ptr(gx), b,
+                  hp, wp, g4.shape[1], g4.shape[2], 0)
+        return to_nchw(gx), None

@@ -1,0 +1,73 @@
+"""CPU checks of the conv -> tap-list lowering (spaa_amd/convplan.py) against torch's own conv ops and autograd."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from spaa_amd import convplan as cp
+from tapconv_emu import emulate, nhwc, nchw
+
+torch.manual_seed(0)
+
+
+@pytest.mark.parametrize('ci,co,k,s,p,h,w', [(3, 8, 3, 1, 1, 9, 11), (6, 5, 3, 2, 1, 12, 10), (4, 7, 1, 1, 0, 6, 5),
+                                             (3, 4, 7, 2, 3, 20, 18), (5, 6, 1, 2, 0, 8, 8), (2, 3, 3, 2, 1, 9, 7)])
+def test_conv_fwd_and_dgrad(ci, co, k, s, p, h, w):
+    x = torch.randn(2, ci, h, w, requires_grad=True)
+    wt = torch.randn(co, ci, k, k)
+    b = torch.randn(co)
+    y = F.conv2d(x, wt, b, s, p)
+    plan = cp.conv_fwd_plan(wt, b, s, p, device='cpu')
+    y2 = emulate(plan, nhwc(x.detach(), plan.cin_p), y.shape[2], y.shape[3])
+    assert torch.allclose(nchw(y2), y, atol=1e-4)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    dplan = cp.conv_dgrad_plan(wt, s, p, device='cpu')
+    gx = emulate(dplan, nhwc(gy, dplan.cin_p), h, w)
+    assert torch.allclose(nchw(gx), x.grad, atol=1e-4)
+
+
+def test_conv_dgrad_channel_subset():
+    x = torch.randn(1, 6, 8, 8, requires_grad=True)
+    wt = torch.randn(5, 6, 3, 3)
+    y = F.conv2d(x, wt, None, 2, 1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    dplan = cp.conv_dgrad_plan(wt, 2, 1, device='cpu', in_ch=(3, 6))
+    gx = emulate(dplan, nhwc(gy, dplan.cin_p), 8, 8)
+    assert torch.allclose(nchw(gx), x.grad[:, 3:6], atol=1e-4)
+
+
+@pytest.mark.parametrize('ci,co,k,p,op,h,w', [(6, 4, 3, 1, 1, 5, 7), (5, 3, 2, 0, 0, 6, 4)])
+def test_deconv_fwd_and_dgrad(ci, co, k, p, op, h, w):
+    x = torch.randn(2, ci, h, w, requires_grad=True)
+    wt = torch.randn(ci, co, k, k)
+    b = torch.randn(co)
+    y = F.conv_transpose2d(x, wt, b, 2, p, op)
+    plan = cp.deconv_fwd_plan(wt, b, 2, p, device='cpu')
+    y2 = emulate(plan, nhwc(x.detach(), plan.cin_p), y.shape[2], y.shape[3])
+    assert torch.allclose(nchw(y2), y, atol=1e-4)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    dplan = cp.deconv_dgrad_plan(wt, 2, p, device='cpu')
+    gx = emulate(dplan, nhwc(gy, dplan.cin_p), h, w)
+    assert torch.allclose(nchw(gx), x.grad, atol=1e-4)
+
+
+def test_linear_and_bn_fold():
+    x = torch.randn(3, 10, requires_grad=True)
+    w, b = torch.randn(7, 10), torch.randn(7)
+    y = F.linear(x, w, b)
+    plan = cp.linear_fwd_plan(w, b, device='cpu')
+    y2 = emulate(plan, F.pad(x.detach(), (0, 2)).view(3, 1, 1, 12), 1, 1)
+    assert torch.allclose(y2.view(3, 7), y, atol=1e-5)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    dplan = cp.linear_dgrad_plan(w, device='cpu')
+    gx = emulate(dplan, F.pad(gy, (0, 1)).view(3, 1, 1, 8), 1, 1)
+    assert torch.allclose(gx.view(3, 10), x.grad, atol=1e-5)
+    cw = torch.randn(4, 3, 3, 3)
+    g, bb, m, v = torch.rand(4) + 0.5, torch.randn(4), torch.randn(4), torch.rand(4) + 0.5
+    xi = torch.randn(1, 3, 6, 6)
+    ref = F.batch_norm(F.conv2d(xi, cw, None, 1, 1), m, v, g, bb, False, 0.0, 1e-5)
+    fw, fb = cp.fold_bn(cw, g, bb, m, v)
+    assert torch.allclose(F.conv2d(xi, fw, fb, 1, 1), ref, atol=1e-5)
