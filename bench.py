@@ -74,7 +74,7 @@ def log(msg):
     print(f'[bench] {msg}', file=sys.stderr, flush=True)
 
 
-def cpu_baseline(sd, csd, setup, scenes, budget_b=4, iters=2):
+def cpu_baseline(sd, csd, setup, scenes, budget_b=16, iters=8):
     """Oracle (CPU restatement of the reference composition: per-iteration grid rebuild, two backward passes) timed on
     the host cores on a bounded sample: `budget_b` samples x `iters` iterations of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -83,7 +83,7 @@ def cpu_baseline(sd, csd, setup, scenes, budget_b=4, iters=2):
     cores = usable_cores()
     torch.set_num_threads(cores)
     clf = so.OracleClassifier('resnet18', csd)
-    tg = syn.IMAGENET10_TARGETS[:budget_b]
+    tg = (syn.IMAGENET10_TARGETS * 2)[:budget_b]
     so.spaa(sd, clf, tg, True, scenes[:1], 5, 'camdE_caml2', setup, iters=1, per_batch_grid=True)  # warm-up
     t0 = time.time()
     so.spaa(sd, clf, tg, True, scenes[:1], 5, 'camdE_caml2', setup, iters=iters, per_batch_grid=True)

@@ -381,6 +381,7 @@ def spaa(pcnet_sd, classifier, target_idx, targeted, cam_scene, d_thr, stealth_l
         prj_adv.grad.zero_()
         prj_adv.data[mask_best_adv] -= col_lr * (col_grad.permute(1, 2, 3, 0) / torch.norm(
             col_grad.view(col_grad.shape[0], -1), dim=1)).permute(3, 0, 1, 2)[mask_best_adv]
+        col_loss_best_before = col_loss_best.clone().numpy()
         mask_best_color = (col_loss_batch < col_loss_best).detach().cpu().numpy()
         mask_best = mask_best_color * mask_best_adv
         col_loss_best[mask_best] = col_loss_batch.data[mask_best].clone()
@@ -393,7 +394,8 @@ def spaa(pcnet_sd, classifier, target_idx, targeted, cam_scene, d_thr, stealth_l
                               top1=idx[:, 0].copy(), p1=p[:, 0].copy(), caml2=caml2.detach().numpy().copy(),
                               camdE=camdE.detach().numpy().copy(), prjl2=prjl2.detach().numpy().copy(),
                               col_loss=col_loss_batch.detach().numpy().copy(), adv_loss=float(adv_loss.detach()),
-                              prj_adv=prj_adv.detach().clone().numpy()))
+                              prj_adv=prj_adv.detach().clone().numpy(), col_loss_best_before=col_loss_best_before,
+                              target_logit=sel.detach().numpy().copy(), cam_infer=cam_infer.detach().numpy().copy()))
     prj_adv_best = torch.clamp(prj_adv_best, 0, 1)
     return cam_infer_best.detach(), prj_adv_best.detach()
 
