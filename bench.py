@@ -170,8 +170,9 @@ def main():
             st.iteration(**hp)
         torch.cuda.synchronize()
         per_tile, per_layer = {}, {}
-        for name, tile, flops, e0, e1 in convplan.PROFILE:
+        for name, key, flops, e0, e1, tile_id in convplan.PROFILE:
             ms = e0.elapsed_time(e1)
+            tile = convplan.TILE_NAMES.get(tile_id, 'auto')
             a = per_tile.setdefault(tile, [0.0, 0.0, 0])
             a[0] += flops
             a[1] += ms

@@ -63,6 +63,7 @@ typedef struct {
     const float* gate;    /* indexed like `out`, or NULL */
     int32_t gate_cstride, gate_coff, gate_mode;
     int32_t act;
+    int32_t tile;         /* 0 = auto; 1..8 = explicit workgroup tile (tuning; see tapconv.hip) */
     float* aux_out;       /* optional second output (indexed like `out`):
                              act == SPAA_ACT_RELU_CLAMP1: the value BEFORE the clamp;
                              otherwise, with gate2: (gate2 > 0) ? out_value : 0  (a second ReLU-backward gate) */

@@ -32,7 +32,7 @@ class TapConv(C.Structure):
         ('weights', C.c_void_p), ('taps', C.c_void_p), ('bias', C.c_void_p),
         ('add', C.c_void_p), ('add_cstride', C.c_int32), ('add_coff', C.c_int32),
         ('gate', C.c_void_p), ('gate_cstride', C.c_int32), ('gate_coff', C.c_int32), ('gate_mode', C.c_int32),
-        ('act', C.c_int32),
+        ('act', C.c_int32), ('tile', C.c_int32),
         ('aux_out', C.c_void_p),
         ('gate2', C.c_void_p), ('gate2_cstride', C.c_int32), ('gate2_coff', C.c_int32),
         ('nclass', C.c_int32),

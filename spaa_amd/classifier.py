@@ -56,8 +56,8 @@ class ResNet18Body:
             return (n + 2 * p - k) // s + 1
 
         wgt, b = folded('conv1', 'bn1')
-        self.stem_f = cp.conv_fwd_plan(wgt, b, 2, 3, dev, 'conv1')
-        self.stem_d = cp.conv_dgrad_plan(wgt, 2, 3, dev, 'conv1_dgrad')
+        self.stem_f = cp.conv_fwd_plan(wgt, b, 2, 3, dev, 'stem')
+        self.stem_d = cp.conv_dgrad_plan(wgt, 2, 3, dev, 'stem_dgrad')
         self.in_hw = (h, w)
         h1, w1 = osz(h, 7, 2, 3), osz(w, 7, 2, 3)
         self.c1 = z(batch, h1, w1, 64)

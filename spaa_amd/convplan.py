@@ -19,6 +19,21 @@ from . import _lib
 BK = 32
 NPAD = 128
 PROFILE = None  # set to a list by bench.py to time every tapconv launch with HIP events
+FORCE_TILE = 0  # tools/autotune.py: force one workgroup tile for every launch
+TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32', 6: '64x64', 7: '64x128', 8: '128x64b'}
+
+
+def _load_tune():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tapconv_tune.json')
+    if os.path.exists(path):
+        with open(path) as fh:
+            return {k: int(v) for k, v in json.load(fh).items()}
+    return {}
+
+
+TUNE = _load_tune()  # shape key -> tile id, measured on MI355X by tools/autotune.py (absent key = heuristic)
 
 
 def _ceil(a, b):
@@ -68,7 +83,7 @@ class ConvPlan:
         self.bias = bias.detach().float().contiguous().to(device) if bias is not None else None
         # algorithmic FLOPs (2*MAC, logical channels, no padding) per pixel of the class grid
         self.flops_per_pixel = 2 * sum(c['ntaps'] for c in self.cls) * cin * cout
-        self.tile = '128x128' if cout > 64 else ('256x64' if cout > 32 else '256x32')
+        self.ntaps_total = sum(c['ntaps'] for c in self.cls)
 
     def run(self, inp, out, add=None, gate=None, gate_mode=_lib.GATE_POS, act=_lib.ACT_NONE, aux_out=None,
             gate2=None, in_coff=0, out_coff=0, add_coff=0, gate_coff=0):
@@ -102,6 +117,8 @@ class ConvPlan:
         if gate2 is not None:
             assert aux_out is not None and gate2.shape[:3] == out.shape[:3] and self.cout <= gate2.shape[3]
             d.gate2, d.gate2_cstride, d.gate2_coff = gate2.data_ptr(), gate2.shape[3], 0
+        key = f'{self.cin_p}_{self.cout}_{self.ntaps_total}_{self.s_in}_{self.s_out}_{b * d.Hm * d.Wm}'
+        d.tile = FORCE_TILE if FORCE_TILE else TUNE.get(key, 0)
         d.nclass = len(self.cls)
         for i, c in enumerate(self.cls):
             for k, v in c.items():
@@ -113,7 +130,7 @@ class ConvPlan:
             e0.record()
             _lib.call('spaa_tapconv_f32', C.byref(d))
             e1.record()
-            PROFILE.append((self.name, self.tile, self.flops(b, hout, wout), e0, e1))
+            PROFILE.append((self.name, key, self.flops(b, hout, wout), e0, e1, d.tile))
         return out
 
     def flops(self, b, hout, wout):

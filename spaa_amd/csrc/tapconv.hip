@@ -18,12 +18,13 @@
 #include "../../include/spaa_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int BK = 32;
 constexpr int LDK = 36;           // LDS row stride in floats (BK + 4): 144 B rows, 16-B aligned
-constexpr int TAP_SMEM_FLOATS = 2 * SPAA_MAX_TAPS;
+constexpr int TAP_SMEM_FLOATS = 4 * (SPAA_MAX_TAPS + 4);
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void tapconv_kernel(const spaa_tapconv_t p, const int m_tiles,
@@ -31,11 +32,12 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const spaa_tapconv_t p,
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int A_LD = BM * 8 / 256;
-    constexpr int B_LD = (BN * 8 + 255) / 256;
+    constexpr int B_LD = BN * 8 / 256;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    static_assert(B_LD >= 1, "BN >= 32");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    int2* s_taps = reinterpret_cast<int2*>(smem);
+    int4* s_taps = reinterpret_cast<int4*>(smem);  // (dy, dx, dy*Win + dx, 0) per tap; entry ntaps = invalid
     float* As = smem + TAP_SMEM_FLOATS;
     float* Bs = As + 2 * BM * LDK;
 
@@ -56,16 +58,21 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const spaa_tapconv_t p,
     const int n_blk = (tile % n_tiles) * BN;
     const int m_blk = (tile / n_tiles) * BM;
 
-    for (int i = tid; i < cl.ntaps; i += 256) {
-        s_taps[i] = make_int2(p.taps[2 * (cl.tap_off + i)], p.taps[2 * (cl.tap_off + i) + 1]);
+    for (int i = tid; i <= cl.ntaps; i += 256) {
+        if (i < cl.ntaps) {
+            const int dy = p.taps[2 * (cl.tap_off + i)], dx = p.taps[2 * (cl.tap_off + i) + 1];
+            s_taps[i] = make_int4(dy, dx, dy * p.Win + dx, 0);
+        } else {
+            s_taps[i] = make_int4(-(1 << 28), 0, 0, 0);  // k >= K: always out of bounds
+        }
     }
 
     const int HWm = p.Hm * p.Wm;
     const int M = p.B * HWm;
     const int kq = tid & 7;
 
-    int a_iy[A_LD], a_ix[A_LD];
-    uint32_t a_base[A_LD];
+    // per-thread im2col rows: input coordinates of the centre tap and its pixel index
+    int a_iy[A_LD], a_ix[A_LD], a_pix[A_LD];
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
         const int m = m_blk + (tid >> 3) + 32 * i;
@@ -77,59 +84,65 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const spaa_tapconv_t p,
         const int x = r - y * p.Wm;
         a_iy[i] = ok ? y * p.s_in : -(1 << 28);
         a_ix[i] = x * p.s_in;
-        a_base[i] = (uint32_t)b * (uint32_t)(p.Hin * p.Win);
+        a_pix[i] = (b * p.Hin + y * p.s_in) * p.Win + x * p.s_in;
     }
-    const float* wrow[B_LD];
+    // hardware-bounds-checked buffer loads: an out-of-image tap gets an offset past num_records and reads 0
+    const uint32_t in_bytes = (uint32_t)p.B * (uint32_t)(p.Hin * p.Win) * (uint32_t)p.in_cstride * 4u;
+    // descriptor inputs forced wave-uniform (readfirstlane) so hipcc keeps the SRD in SGPRs instead of wrapping
+    // every buffer_load in a waterfall loop
+    const uint64_t in_addr = reinterpret_cast<uint64_t>(p.in);
+    const uint32_t in_lo = __builtin_amdgcn_readfirstlane((uint32_t)in_addr);
+    const uint32_t in_hi = __builtin_amdgcn_readfirstlane((uint32_t)(in_addr >> 32));
+    float* in_uniform = reinterpret_cast<float*>(((uint64_t)in_hi << 32) | in_lo);
+    const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+        in_uniform, 0, (int)__builtin_amdgcn_readfirstlane(in_bytes), 0x00020000);
+    const int npad = (p.Cout + 127) & ~127;
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.weights + cl.w_off), 0,
+                                                           npad * cl.Kpad * 4, 0x00020000);
+    int w_off[B_LD];
 #pragma unroll
-    for (int i = 0; i < B_LD; ++i) {
-        const int n = n_blk + (tid >> 3) + 32 * i;
-        wrow[i] = p.weights + cl.w_off + (int64_t)n * cl.Kpad + 4 * kq;
-    }
-    constexpr bool B_ALL = (BN * 8 >= 256);  // BN >= 32: every thread loads
-    const bool b_active = B_ALL || (tid >> 3) < BN;
+    for (int i = 0; i < B_LD; ++i) w_off[i] = ((n_blk + (tid >> 3) + 32 * i) * cl.Kpad + 4 * kq) * 4;
 
-    float4 ra[A_LD], rb[B_LD];
-    const int nk = cl.Kpad / BK;
+    // (tap, channel) of this thread's 4-wide K slice, advanced incrementally by BK per K-step (no division)
     const int Cin = p.Cin;
+    const int adv_tap = BK / Cin, adv_c = BK - adv_tap * Cin;
+    int k_tap = (4 * kq) / Cin;
+    int k_c = 4 * kq - k_tap * Cin;
+
+    f4 ra[A_LD], rb[B_LD];
+    const int nk = cl.Kpad / BK;
 
     __syncthreads();  // taps visible
 
-    auto load_tile = [&](int ks) {
-        const int k = ks * BK + 4 * kq;
-        const bool kval = k < cl.K;
-        const int tap = kval ? k / Cin : 0;
-        const int c = k - tap * Cin;
-        const int2 d = s_taps[tap];
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int iy = a_iy[i] + d.x;
-            const int ix = a_ix[i] + d.y;
-            const bool v = kval && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-            if (v) {
-                const size_t off = (size_t)(a_base[i] + (uint32_t)(iy * p.Win + ix)) * (size_t)p.in_cstride +
-                                   (size_t)(p.in_coff + c);
-                ra[i] = *reinterpret_cast<const float4*>(p.in + off);
-            } else {
-                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            if (b_active) rb[i] = *reinterpret_cast<const float4*>(wrow[i] + ks * BK);
-        }
-    };
-    auto store_tile = [&](int stage) {
-        float* as = As + stage * BM * LDK;
-        float* bs = Bs + stage * BN * LDK;
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            *reinterpret_cast<float4*>(as + ((tid >> 3) + 32 * i) * LDK + 4 * kq) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            if (b_active) *reinterpret_cast<float4*>(bs + ((tid >> 3) + 32 * i) * LDK + 4 * kq) = rb[i];
-        }
-    };
+#define TAPCONV_LOAD_TILE(ks)                                                                             \
+    {                                                                                                     \
+        const int4 d = s_taps[min(k_tap, cl.ntaps)];                                                      \
+        const int cbyte = (p.in_coff + k_c) * 4;                                                          \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                                \
+            const int iy = a_iy[i] + d.x, ix = a_ix[i] + d.y;                                             \
+            const bool v = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;              \
+            const int off = (a_pix[i] + d.z) * (p.in_cstride * 4) + cbyte;                                \
+            ra[i] = __builtin_bit_cast(                                                                   \
+                f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, v ? off : (int)0x80000000, 0, 0));     \
+        }                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < B_LD; ++i) {                                                \
+            rb[i] = __builtin_bit_cast(                                                                   \
+                f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off[i], (ks) * (BK * 4), 0));         \
+        }                                                                                                 \
+        k_tap += adv_tap;                                                                                 \
+        k_c += adv_c;                                                                                     \
+        if (k_c >= Cin) {                                                                                 \
+            k_c -= Cin;                                                                                   \
+            k_tap += 1;                                                                                   \
+        }                                                                                                 \
+    }
+#define TAPCONV_STORE_TILE(stage)                                                                         \
+    {                                                                                                     \
+        float* as_ = As + (stage) * BM * LDK + (tid >> 3) * LDK + 4 * kq;                                 \
+        float* bs_ = Bs + (stage) * BN * LDK + (tid >> 3) * LDK + 4 * kq;                                 \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i) *reinterpret_cast<f4*>(as_ + 32 * i * LDK) = ra[i]; \
+        _Pragma("unroll") for (int i = 0; i < B_LD; ++i) *reinterpret_cast<f4*>(bs_ + 32 * i * LDK) = rb[i]; \
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -144,36 +157,46 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const spaa_tapconv_t p,
     const int frag_off = (lane & 31) * LDK + 4 * (lane >> 5);
 
     if (nk > 0) {
-        load_tile(0);
-        store_tile(0);
+        TAPCONV_LOAD_TILE(0)
+        TAPCONV_STORE_TILE(0)
     }
     __syncthreads();
 
     for (int ks = 0; ks < nk; ++ks) {
         const int stage = ks & 1;
-        if (ks + 1 < nk) load_tile(ks + 1);
+        const bool more = ks + 1 < nk;
         const float* as = As + stage * BM * LDK + wm0 * LDK + frag_off;
         const float* bs = Bs + stage * BN * LDK + wn0 * LDK + frag_off;
+        f4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f4*>(as + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f4*>(bs + j * 32 * LDK);
+        if (more) TAPCONV_LOAD_TILE(ks + 1)
 #pragma unroll
         for (int kb = 0; kb < BK / 8; ++kb) {
-            float4 af[TM], bf[TN];
+            const int cur = kb & 1, nxt = cur ^ 1;
+            if (kb + 1 < BK / 8) {  // prefetch the next 8-deep fragment pair while this one feeds the matrix core
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDK + kb * 8);
+                for (int i = 0; i < TM; ++i)
+                    af[nxt][i] = *reinterpret_cast<const f4*>(as + i * 32 * LDK + (kb + 1) * 8);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDK + kb * 8);
+                for (int j = 0; j < TN; ++j)
+                    bf[nxt][j] = *reinterpret_cast<const f4*>(bs + j * 32 * LDK + (kb + 1) * 8);
+            }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bf[cur][j][e], acc[i][j], 0, 0, 0);
         }
-        if (ks + 1 < nk) store_tile(stage ^ 1);
+        if (more) TAPCONV_STORE_TILE(stage ^ 1)
         __syncthreads();
     }
+#undef TAPCONV_LOAD_TILE
+#undef TAPCONV_STORE_TILE
 
     // ---- epilogue: C/D map of the 32x32 accumulator: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool linear = (p.s_out == 1) && (cl.oy0 == 0) && (cl.ox0 == 0) && (p.Hm == p.Hout) && (p.Wm == p.Wout);
@@ -263,8 +286,26 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         if (cl.ntaps < 0 || cl.ntaps > SPAA_MAX_TAPS || cl.K != cl.ntaps * d.Cin || (cl.Kpad % BK) || cl.Kpad < cl.K)
             return hipErrorInvalidValue;
     }
-    if ((int64_t)d.B * d.Hin * d.Win * d.in_cstride >= (int64_t)1 << 32) return hipErrorInvalidValue;
-    if (d.Cout > 64) return launch<128, 128, 64, 64>(d, stream);
-    if (d.Cout > 32) return launch<256, 64, 64, 64>(d, stream);
-    return launch<256, 32, 64, 32>(d, stream);
+    // buffer loads use 32-bit byte offsets; 0x80000000 is the out-of-bounds sentinel
+    if ((int64_t)d.B * d.Hin * d.Win * d.in_cstride * 4 >= (int64_t)1 << 31) return hipErrorInvalidValue;
+    for (int c = 0; c < d.nclass; ++c)
+        if ((int64_t)((d.Cout + 127) & ~127) * d.cls[c].Kpad * 4 >= (int64_t)1 << 31) return hipErrorInvalidValue;
+    int tile = d.tile;
+    if (tile == 0) {  // heuristic: widest N tile that fits Cout; shrink M when the grid would not fill 256 CUs twice
+        const int64_t M = (int64_t)d.B * d.Hm * d.Wm * d.nclass;
+        if (d.Cout > 64) tile = (M / 128) * ((d.Cout + 127) / 128) >= 512 ? 1 : 6;
+        else if (d.Cout > 32) tile = (M / 128) >= 512 ? 4 : 6;
+        else tile = 5;
+    }
+    switch (tile) {
+        case 1: return launch<128, 128, 64, 64>(d, stream);
+        case 2: return launch<256, 64, 64, 64>(d, stream);
+        case 3: return launch<256, 32, 64, 32>(d, stream);
+        case 4: return launch<128, 64, 64, 32>(d, stream);
+        case 5: return launch<128, 32, 32, 32>(d, stream);
+        case 6: return launch<64, 64, 32, 32>(d, stream);
+        case 7: return launch<64, 128, 32, 64>(d, stream);
+        case 8: return launch<128, 64, 32, 64>(d, stream);
+        default: return hipErrorInvalidValue;
+    }
 }

@@ -1,0 +1,57 @@
+"""Measures every tapconv launch of one SPAA iteration (bench workload) under each workgroup tile and writes the
+fastest tile per layer shape to spaa_amd/tapconv_tune.json.  Run on the GPU box: python tools/autotune.py"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from spaa_amd import convplan  # noqa: E402
+
+
+def main():
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    st, *_ = bench.build_attack(0, batch, 256, 8, 'cuda:0')
+    hp = dict(targeted=True, d_thr=5, adv_lr=2, col_lr=1, p_thresh=0.9)
+    st.iteration(**hp)
+    torch.cuda.synchronize()
+    res = {}
+    names = {}
+    for tile in range(1, 9):
+        convplan.FORCE_TILE = tile
+        st.iteration(**hp)  # warm (sets the LDS attribute of a new instantiation)
+        convplan.PROFILE = []
+        for _ in range(2):
+            st.iteration(**hp)
+        torch.cuda.synchronize()
+        for name, key, flops, e0, e1, _ in convplan.PROFILE:
+            res.setdefault(key, {}).setdefault(tile, []).append(e0.elapsed_time(e1))
+            names.setdefault(key, set()).add(name)
+        convplan.PROFILE = None
+        print('tile', tile, 'done', flush=True)
+    convplan.FORCE_TILE = 0
+    tune, total_best, total_t1 = {}, 0.0, 0.0
+    rows = []
+    for key, per in res.items():
+        # a key may be launched several times per iteration; compare mean time per launch
+        avg = {t: sum(v) / len(v) for t, v in per.items()}
+        best = min(avg, key=avg.get)
+        tune[key] = best
+        n = len(per[best]) / 2
+        total_best += avg[best] * n
+        rows.append((avg[best] * n, key, sorted(names[key])[:3], best, {t: round(a * 1e3) for t, a in avg.items()}))
+    for r in sorted(rows, reverse=True)[:40]:
+        print(f'{r[0]*1e3:8.0f} us/iter  {r[1]:32s} best={r[3]} {r[4]} {r[2]}')
+    print(f'sum of best per-launch times: {total_best:.2f} ms/iteration')
+    out = os.path.join(ROOT, 'gpurun_out', 'tapconv_tune.json')
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    with open(out, 'w') as fh:
+        json.dump(tune, fh, indent=0, sort_keys=True)
+    print('wrote', out)
+
+
+if __name__ == '__main__':
+    main()
