@@ -20,7 +20,8 @@ BK = 32
 NPAD = 128
 PROFILE = None  # set to a list by bench.py to time every tapconv launch with HIP events
 FORCE_TILE = 0  # tools/autotune.py: force one workgroup tile for every launch
-TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32', 6: '64x64', 7: '64x128', 8: '128x64b'}
+TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32', 6: '64x64', 7: '64x128', 8: '128x64b',
+              9: 'direct4', 10: 'direct32'}
 
 
 def _load_tune():
@@ -118,7 +119,12 @@ class ConvPlan:
             assert aux_out is not None and gate2.shape[:3] == out.shape[:3] and self.cout <= gate2.shape[3]
             d.gate2, d.gate2_cstride, d.gate2_coff = gate2.data_ptr(), gate2.shape[3], 0
         key = f'{self.cin_p}_{self.cout}_{self.ntaps_total}_{self.s_in}_{self.s_out}_{b * d.Hm * d.Wm}'
-        d.tile = FORCE_TILE if FORCE_TILE else TUNE.get(key, 0)
+        forced = FORCE_TILE
+        if forced == 9 and self.cout > 4:
+            forced = 0
+        if forced == 10 and (self.cout > 32 or self.ntaps_total * self.cin_p > 512):
+            forced = 0
+        d.tile = forced if forced else TUNE.get(key, 0)
         d.nclass = len(self.cls)
         for i, c in enumerate(self.cls):
             for k, v in c.items():

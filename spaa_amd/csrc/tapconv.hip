@@ -250,6 +250,102 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const spaa_tapconv_t p,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Direct (VALU) variant of the same tap-list convolution for THIN layers, where a 32-wide MFMA tile would be >= 90 %
+// padding: few output channels (conv6 32->3, the input-gradients of conv1 / conv1_s / the ResNet stem: N = 3) or few
+// input channels (input-gradient of conv6, conv1, conv1_s: K <= 72).  One lane = one output pixel with all NOUT
+// accumulators in registers; the weights of a (tap, channel-quad) are wave-uniform and come through the scalar cache
+// (s_load), the im2col row through bounds-checked buffer loads.  HBM/L1-bound instead of MFMA-bound.
+template <int NOUT>
+__global__ __launch_bounds__(256) void directconv_kernel(const spaa_tapconv_t p) {
+    const spaa_tapclass_t cl = p.cls[blockIdx.y];
+    const int HWm = p.Hm * p.Wm;
+    const int M = p.B * HWm;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = m < M;
+    const int mm = ok ? m : 0;
+    const int b = mm / HWm;
+    const int r = mm - b * HWm;
+    const int y = r / p.Wm;
+    const int x = r - y * p.Wm;
+
+    const uint32_t in_bytes = (uint32_t)p.B * (uint32_t)(p.Hin * p.Win) * (uint32_t)p.in_cstride * 4u;
+    const uint64_t in_addr = reinterpret_cast<uint64_t>(p.in);
+    const uint32_t in_lo = __builtin_amdgcn_readfirstlane((uint32_t)in_addr);
+    const uint32_t in_hi = __builtin_amdgcn_readfirstlane((uint32_t)(in_addr >> 32));
+    const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)in_hi << 32) | in_lo), 0,
+                                                            (int)__builtin_amdgcn_readfirstlane(in_bytes), 0x00020000);
+    const float* __restrict__ W = p.weights + cl.w_off;  // [Npad][Kpad], K contiguous
+    const int Kpad = cl.Kpad;
+    const int Cin = p.Cin;
+
+    float acc[NOUT];
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) acc[n] = 0.f;
+
+    // few output channels: K is long -> keep several channel-quads in flight per tap;
+    // few input channels: a tap is one or two quads -> keep several taps in flight
+#pragma unroll(NOUT <= 4 ? 1 : 3)
+    for (int t = 0; t < cl.ntaps; ++t) {
+        const int dy = p.taps[2 * (cl.tap_off + t)], dx = p.taps[2 * (cl.tap_off + t) + 1];
+        const int iy = y * p.s_in + dy, ix = x * p.s_in + dx;
+        const bool v = ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+        const int off = (((b * p.Hin + iy) * p.Win + ix) * p.in_cstride + p.in_coff) * 4;
+        const int voff = v ? off : (int)0x80000000;
+        const float* __restrict__ wt = W + t * Cin;
+#pragma unroll(NOUT <= 4 ? 8 : 1)
+        for (int c = 0; c < Cin; c += 4) {
+            const f4 a = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, voff + c * 4, 0, 0));
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n) {
+                const f4 w = *reinterpret_cast<const f4*>(wt + (size_t)n * Kpad + c);
+                acc[n] = fmaf(a.x, w.x, acc[n]);
+                acc[n] = fmaf(a.y, w.y, acc[n]);
+                acc[n] = fmaf(a.z, w.z, acc[n]);
+                acc[n] = fmaf(a.w, w.w, acc[n]);
+            }
+        }
+    }
+    if (!ok) return;
+    const int oy = cl.oy0 + y * p.s_out, ox = cl.ox0 + x * p.s_out;
+    if (oy >= p.Hout || ox >= p.Wout) return;
+    const size_t o = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) {
+        if (n >= p.Cout) break;
+        float v = acc[n] + (p.bias != nullptr ? p.bias[n] : 0.f);
+        if (p.add != nullptr) v += p.add[o * p.add_cstride + p.add_coff + n];
+        if (p.act == SPAA_ACT_RELU) {
+            v = fmaxf(v, 0.f);
+        } else if (p.act == SPAA_ACT_RELU_CLAMP1) {
+            v = fmaxf(v, 0.f);
+            if (p.aux_out != nullptr) p.aux_out[o * p.out_cstride + p.out_coff + n] = v;
+            v = fminf(v, 1.f);
+        } else if (p.act == SPAA_ACT_LEAKY01) {
+            v = v > 0.f ? v : 0.1f * v;
+        }
+        if (p.gate != nullptr) {
+            const float g = p.gate[o * p.gate_cstride + p.gate_coff + n];
+            const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (g > 0.f && g <= 1.f) : (g > 0.f);
+            v = pass ? v : 0.f;
+        }
+        p.out[o * p.out_cstride + p.out_coff + n] = v;
+        if (p.gate2 != nullptr) {
+            const float g2 = p.gate2[o * p.gate2_cstride + p.gate2_coff + n];
+            p.aux_out[o * p.out_cstride + p.out_coff + n] = (g2 > 0.f) ? v : 0.f;
+        }
+    }
+}
+
+template <int NOUT>
+int launch_direct(const spaa_tapconv_t& d, hipStream_t stream) {
+    if (d.Cout > NOUT) return hipErrorInvalidValue;
+    const int64_t M = (int64_t)d.B * d.Hm * d.Wm;
+    dim3 grid((unsigned)((M + 255) / 256), d.nclass, 1);
+    hipLaunchKernelGGL((directconv_kernel<NOUT>), grid, dim3(256), 0, stream, d);
+    return (int)hipGetLastError();
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch(const spaa_tapconv_t& d, hipStream_t stream) {
     const int64_t M = (int64_t)d.B * d.Hm * d.Wm;
@@ -306,6 +402,8 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         case 6: return launch<64, 64, 32, 32>(d, stream);
         case 7: return launch<64, 128, 32, 64>(d, stream);
         case 8: return launch<128, 64, 32, 64>(d, stream);
+        case 9: return launch_direct<4>(d, stream);
+        case 10: return launch_direct<32>(d, stream);
         default: return hipErrorInvalidValue;
     }
 }

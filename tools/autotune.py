@@ -20,14 +20,16 @@ def main():
     torch.cuda.synchronize()
     res = {}
     names = {}
-    for tile in range(1, 9):
+    for tile in range(1, 11):
         convplan.FORCE_TILE = tile
         st.iteration(**hp)  # warm (sets the LDS attribute of a new instantiation)
         convplan.PROFILE = []
         for _ in range(2):
             st.iteration(**hp)
         torch.cuda.synchronize()
-        for name, key, flops, e0, e1, _ in convplan.PROFILE:
+        for name, key, flops, e0, e1, used in convplan.PROFILE:
+            if used != tile:
+                continue  # this tile is not valid for the layer (ConvPlan.run fell back)
             res.setdefault(key, {}).setdefault(tile, []).append(e0.elapsed_time(e1))
             names.setdefault(key, set()).add(name)
         convplan.PROFILE = None
