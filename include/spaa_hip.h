@@ -109,10 +109,10 @@ int spaa_ciede2000(const float* lab1, const float* lab2, float* de, int npix, sp
 /* Fused camera-side stealth loss + gradient (one launch replaces ~600 ATen ops):
  *   caml2_px = ||scene - y||_2 over rgb ; camdE_px = dE00(lab(y), scene_lab)
  *   g_y      = gscale * (caml2_w * d caml2_px/dy + camdE_w * d camdE_px/dy)      gscale = 1/(B*H*W)
- * y, scene, scene_lab, g_y: [B,HW,4]; partial: [B][nblk][2] block partial sums (caml2, camdE) with
- * nblk = ceil(HW/256), reduced in fixed order by spaa_decide. */
+ * y, scene, scene_lab, g_y: [B,HW,4]; de_map: optional [B,HW] per-pixel dE; partial: [B][nblk][3] block partial
+ * sums (caml2, camdE, camdE^2) with nblk = ceil(HW/256), reduced in fixed order by spaa_decide / spaa_scale_by_map. */
 int spaa_stealth_loss_fwd_bwd(const float* y, const float* scene, const float* scene_lab, float caml2_w,
-                              float camdE_w, float gscale, float* g_y, float* partial, int B, int HW,
+                              float camdE_w, float gscale, float* g_y, float* de_map, float* partial, int B, int HW,
                               spaa_stream_t stream);
 
 /* ---- classifier pre/post-processing (classifier.py:55-72, img_proc.py:117-132) --------------------------- */
@@ -159,6 +159,31 @@ int spaa_grad_sumsq(float* g, const float* x, float gray, float prjl2_scale, con
 int spaa_step_and_track(float* x, const float* g, const float* partial, const int32_t* state, float adv_lr,
                         float col_lr, float* x_best, const float* cam, float* cam_best, int B, int HWp, int HWc,
                         spaa_stream_t stream);
+
+/* ---- PerC_AL.adversary_projector (perc_al/__init__.py:133-256) ------------------------------------------ */
+/* x = a + b (inputs + delta), NHWC4 */
+int spaa_add_nhwc4(const float* a, const float* b, float* x, int npix, spaa_stream_t stream);
+/* g_logits = mult * d CrossEntropy_sum / d logits = mult * (softmax - onehot)  (:186-187) */
+int spaa_ce_grad(const float* logits, int ncls, const int32_t* label, float mult, float* g_logits, int B,
+                 spaa_stream_t stream);
+/* x_b += step * g_b/||g_b||_2 where (state[b][col] != 0) == want; partial from spaa_grad_sumsq  (:193-195,204-209) */
+int spaa_masked_step(float* x, const float* g, const float* partial, const int32_t* state, int col, int want,
+                     float step, int B, int HW, spaa_stream_t stream);
+/* g_px *= dE_px / ||dE_b||_2 (gradient of color_dis = ||d_map||_2, :198-200), color_dis_b out; partial3 from
+ * spaa_stealth_loss_fwd_bwd */
+int spaa_scale_by_map(float* g, const float* de_map, const float* partial3, float* color_dis, int B, int HW,
+                      spaa_stream_t stream);
+/* delta = clamp(inputs+delta,0,1) - inputs; x_round = round((inputs+delta)*255)/255 (:211-212,15-18); partial
+ * [B][nblk] = block sums of ||delta_px||_2 (:215) */
+int spaa_perc_clamp_quant(const float* inputs, float* delta, float* x_round, float* partial, int B, int HW,
+                          spaa_stream_t stream);
+/* masks on the quantised image (:216-243). mode 0 targeted, 1 untargeted, 2 untargeted with Carlini margin.
+ * state [B][4]: isadv, best_adv, best, top1; stats [B][8]: p1, caml2, margin, color_dis, -, bound_best(in/out) */
+int spaa_perc_decide(const float* logits, int ncls, const int32_t* label, int mode, float confidence,
+                     const float* partial, int nblk, int HW, const float* color_dis, float d_thr, float p_thresh,
+                     int32_t* state, float* stats, int B, spaa_stream_t stream);
+/* dst_b = src_b where state[b][0] != 0 (:244-245) */
+int spaa_track_where(const float* src, float* dst, const int32_t* state, int B, int HW, spaa_stream_t stream);
 
 /* misc */
 int spaa_zero(void* p, int64_t bytes, spaa_stream_t stream);

@@ -408,7 +408,8 @@ def quantization(x):
 
 
 def perc_al_adversary_projector(classifier, inputs, labels, d_thr, targeted=True, cp_sz=(240, 240), max_iterations=50,
-                                alpha_l_init=1., alpha_c_init=0.5, confidence=0, p_thresh=0.9):
+                                alpha_l_init=1., alpha_c_init=0.5, confidence=0, p_thresh=0.9, stop_after=None,
+                                trace=None):
     if inputs.min() < 0 or inputs.max() > 1:
         raise ValueError('Input values should be in the [0, 1] range.')
     alpha_l_min = alpha_l_init / 100
@@ -426,6 +427,8 @@ def perc_al_adversary_projector(classifier, inputs, labels, d_thr, targeted=True
         print('Only support setting confidence in untargeted case!')
         return None
     for i in range(max_iterations):
+        if stop_after is not None and i >= stop_after:
+            break
         raw_score, p, idx = classifier(inputs + delta, cp_sz)
         alpha_c = alpha_c_min + 0.5 * (alpha_c_init - alpha_c_min) * (1 + math.cos(i / max_iterations * math.pi))
         alpha_l = alpha_l_min + 0.5 * (alpha_l_init - alpha_l_min) * (1 + math.cos(i / max_iterations * math.pi))
@@ -463,4 +466,8 @@ def perc_al_adversary_projector(classifier, inputs, labels, d_thr, targeted=True
         bound_best[mask_best] = color_dis.data[mask_best].clone()
         x_best[mask_isadv] = x_round[mask_isadv].clone()
         x_best[mask_best] = x_round[mask_best].clone()
+        if trace is not None:
+            trace.append(dict(delta=delta.detach().clone(), isadv=mask_isadv.clone(), best_adv=mask_best_adv.clone(),
+                              color_dis=color_dis.detach().clone(), caml2=caml2.clone(), p1=p[:, 0].copy(),
+                              top1=idx[:, 0].copy(), x_round=x_round.clone()))
     return x_best

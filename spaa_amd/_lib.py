@@ -53,7 +53,14 @@ _SIGNATURES = {
     'spaa_warp_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'spaa_rgb2lab': [_p, _p, _i, _p],
     'spaa_ciede2000': [_p, _p, _p, _i, _p],
-    'spaa_stealth_loss_fwd_bwd': [_p, _p, _p, _f, _f, _f, _p, _p, _i, _i, _p],
+    'spaa_stealth_loss_fwd_bwd': [_p, _p, _p, _f, _f, _f, _p, _p, _p, _i, _i, _p],
+    'spaa_add_nhwc4': [_p, _p, _p, _i, _p],
+    'spaa_ce_grad': [_p, _i, _p, _f, _p, _i, _p],
+    'spaa_masked_step': [_p, _p, _p, _p, _i, _i, _f, _i, _i, _p],
+    'spaa_scale_by_map': [_p, _p, _p, _p, _i, _i, _p],
+    'spaa_perc_clamp_quant': [_p, _p, _p, _p, _i, _i, _p],
+    'spaa_perc_decide': [_p, _i, _p, _i, _f, _p, _i, _i, _p, _f, _f, _p, _p, _i, _p],
+    'spaa_track_where': [_p, _p, _p, _i, _i, _p],
     'spaa_preproc_fwd': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p],
     'spaa_preproc_bwd': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), _p],
     'spaa_maxpool3s2_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

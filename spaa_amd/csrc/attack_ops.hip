@@ -83,10 +83,10 @@ __global__ __launch_bounds__(256) void decide_kernel(const float* __restrict__ l
     const float p1 = 1.f / se;
     // loss sums (fixed order)
     float a = 0.f, d = 0.f;
-    const float* pp = partial + 2 * (size_t)b * nblk;
+    const float* pp = partial + 3 * (size_t)b * nblk;
     for (int i = threadIdx.x; i < nblk; i += 256) {
-        a += pp[2 * i];
-        d += pp[2 * i + 1];
+        a += pp[3 * i];
+        d += pp[3 * i + 1];
     }
     a = block_sum(a, red);
     d = block_sum(d, red);

@@ -274,7 +274,8 @@ __global__ __launch_bounds__(256) void stealth_loss_kernel(const float4* __restr
                                                            const float4* __restrict__ scene,
                                                            const float4* __restrict__ scene_lab, float caml2_w,
                                                            float camdE_w, float gscale, float4* __restrict__ g_y,
-                                                           float* __restrict__ partial, int HW) {
+                                                           float* __restrict__ de_map, float* __restrict__ partial,
+                                                           int HW) {
     __shared__ float red[4];
     const int b = blockIdx.y;
     const int pix = blockIdx.x * 256 + threadIdx.x;
@@ -312,13 +313,16 @@ __global__ __launch_bounds__(256) void stealth_loss_kernel(const float4* __restr
             de = ciede2000<false>(L, A, Bv, lv.x, lv.y, lv.z).de;
         }
         g_y[idx] = make_float4(g0 * gscale, g1 * gscale, g2 * gscale, 0.f);
+        if (de_map != nullptr) de_map[idx] = de;
     }
     const float s_l2 = block_sum_256(l2, red);
     const float s_de = block_sum_256(de, red);
+    const float s_de2 = block_sum_256(de * de, red);
     if (threadIdx.x == 0) {
-        float* p = partial + 2 * ((size_t)b * gridDim.x + blockIdx.x);
+        float* p = partial + 3 * ((size_t)b * gridDim.x + blockIdx.x);
         p[0] = s_l2;
         p[1] = s_de;
+        p[2] = s_de2;
     }
 }
 
@@ -345,13 +349,13 @@ int spaa_ciede2000(const float* lab1, const float* lab2, float* de, int npix, sp
 }
 
 int spaa_stealth_loss_fwd_bwd(const float* y, const float* scene, const float* scene_lab, float caml2_w,
-                              float camdE_w, float gscale, float* g_y, float* partial, int B, int HW,
+                              float camdE_w, float gscale, float* g_y, float* de_map, float* partial, int B, int HW,
                               spaa_stream_t stream) {
     if (!y || !scene || !scene_lab || !g_y || !partial || B < 1 || HW < 1) return hipErrorInvalidValue;
     dim3 grid((HW + 255) / 256, B);
     hipLaunchKernelGGL(stealth_loss_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)y,
                        (const float4*)scene, (const float4*)scene_lab, caml2_w, camdE_w, gscale, (float4*)g_y,
-                       partial, HW);
+                       de_map, partial, HW);
     return (int)hipGetLastError();
 }
 

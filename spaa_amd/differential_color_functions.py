@@ -42,9 +42,9 @@ def stealth_loss_with_grad(cam_infer, cam_scene, caml2_w=1.0, camdE_w=1.0):
     lab = torch.zeros_like(s4)
     _lib.call('spaa_rgb2lab', _lib.ptr(s4), _lib.ptr(lab), b * h * w)
     nblk = (h * w + 255) // 256
-    part = torch.zeros(b, nblk, 2, device=y4.device)
+    part = torch.zeros(b, nblk, 3, device=y4.device)
     g = torch.zeros_like(y4)
     _lib.call('spaa_stealth_loss_fwd_bwd', _lib.ptr(y4), _lib.ptr(s4), _lib.ptr(lab), float(caml2_w), float(camdE_w),
-              1.0 / (h * w), _lib.ptr(g), _lib.ptr(part), b, h * w)
+              1.0 / (h * w), _lib.ptr(g), None, _lib.ptr(part), b, h * w)
     sums = part.sum(dim=1) / (h * w)
     return sums[:, 0], sums[:, 1], to_nchw(g)

@@ -62,7 +62,7 @@ class AttackState:
         self.stats[:, 5] = 1e6
         self.nblk_c = (self.HWc + 255) // 256
         self.nblk_p = (self.HWp + 255) // 256
-        self.partial_loss = torch.zeros(B, self.nblk_c, 2, device=dev)
+        self.partial_loss = torch.zeros(B, self.nblk_c, 3, device=dev)
         self.partial_ss = torch.zeros(B, self.nblk_p, device=dev)
         self.g_col = torch.zeros(B, Hc, Wc, 4, device=dev)
         self.gP = torch.zeros(B, Hc, Wc, 4, device=dev)
@@ -81,7 +81,7 @@ class AttackState:
         if self.prjl2_w:
             _lib.call('spaa_prjl2_fwd', p(self.x), self.gray, p(self.prjl2), B, self.HWp)    # :275
         _lib.call('spaa_stealth_loss_fwd_bwd', p(y), p(self.scene4), p(self.scene_lab), self.caml2_w, self.camdE_w,
-                  1.0 / (B * self.HWc), p(self.g_col), p(self.partial_loss), B, self.HWc)    # :279-287 + backward
+                  1.0 / (B * self.HWc), p(self.g_col), None, p(self.partial_loss), B, self.HWc)    # :279-287 + backward
         _lib.call('spaa_decide', p(logits), self.clf.ncls, p(self.target), int(bool(targeted)), p(self.partial_loss),
                   self.nblk_c, self.HWc, p(self.prjl2) if self.prjl2_w else None, self.prjl2_w, self.caml2_w,
                   self.camdE_w, float(d_thr), float(p_thresh), adv_w / B, p(self.state), p(self.stats),
