@@ -133,6 +133,24 @@ int spaa_avgpool_fwd(const float* in, float* out, int B, int HW, int C, spaa_str
 int spaa_avgpool_bwd(const float* g_out, const float* act, float* g_in, int B, int HW, int C,
                      spaa_stream_t stream);
 
+/* Generic NHWC pooling of the VGG-16 / Inception-v3 bodies (C % 4 == 0); `*_cstride/_coff` address a channel window
+ * of a concatenated buffer; backward passes are deterministic gathers with an optional ReLU gate of the input. */
+int spaa_maxpool_fwd(const float* in, float* out, uint8_t* argmax, int B, int Hin, int Win, int C, int Hout, int Wout,
+                     int k, int s, int p, int out_cstride, int out_coff, spaa_stream_t stream);
+int spaa_maxpool_bwd(const float* g_out, const uint8_t* argmax, const float* gate_in, float* g_in, int B, int Hin,
+                     int Win, int C, int Hout, int Wout, int k, int s, int p, int gout_cstride, int gout_coff,
+                     spaa_stream_t stream);
+/* avg_pool2d(k, s, p), count_include_pad=True */
+int spaa_avgpool2d_fwd(const float* in, float* out, int B, int Hin, int Win, int C, int Hout, int Wout, int k, int s,
+                       int p, int out_cstride, int out_coff, spaa_stream_t stream);
+int spaa_avgpool2d_bwd(const float* g_out, float* g_in, int B, int Hin, int Win, int C, int Hout, int Wout, int k,
+                       int s, int p, int gout_cstride, int gout_coff, spaa_stream_t stream);
+/* adaptive_avg_pool2d((Hout, Wout)) */
+int spaa_adaptive_avgpool_fwd(const float* in, float* out, int B, int Hin, int Win, int C, int Hout, int Wout,
+                              spaa_stream_t stream);
+int spaa_adaptive_avgpool_bwd(const float* g_out, const float* gate_in, float* g_in, int B, int Hin, int Win, int C,
+                              int Hout, int Wout, spaa_stream_t stream);
+
 /* ---- SPAA Algorithm 1 control on device (projector_based_attack.py:269-328) ------------------------------ */
 /* Per-sample decision, one workgroup per sample: softmax top-1 / argmax of logits (classifier.py:64-68), loss
  * reduction, masks (:290-299), best bookkeeping (:318-320), and the seed of the adversarial backward pass

@@ -306,6 +306,92 @@ def resnet18_forward(sd, x):
     return F.linear(x, sd['fc.weight'], sd['fc.bias'])
 
 
+def vgg16_forward(sd, x):
+    """torchvision.models.vgg16 (eval), v0.15.1 architecture (configuration 'D', no batch norm)."""
+    idx = 0
+    for v in [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']:
+        if v == 'M':
+            x = F.max_pool2d(x, 2, 2)
+            idx += 1
+        else:
+            x = F.relu(F.conv2d(x, sd[f'features.{idx}.weight'], sd[f'features.{idx}.bias'], 1, 1))
+            idx += 2
+    x = F.adaptive_avg_pool2d(x, (7, 7)).flatten(1)
+    x = F.relu(F.linear(x, sd['classifier.0.weight'], sd['classifier.0.bias']))
+    x = F.relu(F.linear(x, sd['classifier.3.weight'], sd['classifier.3.bias']))
+    return F.linear(x, sd['classifier.6.weight'], sd['classifier.6.bias'])
+
+
+def inception_v3_forward(sd, x):
+    """torchvision.models.inception_v3(transform_input=True) in eval mode (aux head unused), v0.15.1 architecture."""
+    def bc(name, t, stride=1, padding=0):
+        t = F.conv2d(t, sd[name + '.conv.weight'], None, stride, padding)
+        t = F.batch_norm(t, sd[name + '.bn.running_mean'], sd[name + '.bn.running_var'], sd[name + '.bn.weight'],
+                         sd[name + '.bn.bias'], False, 0.0, 0.001)
+        return F.relu(t)
+
+    x = torch.cat((x[:, 0:1] * (0.229 / 0.5) + (0.485 - 0.5) / 0.5, x[:, 1:2] * (0.224 / 0.5) + (0.456 - 0.5) / 0.5,
+                   x[:, 2:3] * (0.225 / 0.5) + (0.406 - 0.5) / 0.5), 1)
+    x = bc('Conv2d_1a_3x3', x, 2)
+    x = bc('Conv2d_2a_3x3', x)
+    x = bc('Conv2d_2b_3x3', x, 1, 1)
+    x = F.max_pool2d(x, 3, 2)
+    x = bc('Conv2d_3b_1x1', x)
+    x = bc('Conv2d_4a_3x3', x)
+    x = F.max_pool2d(x, 3, 2)
+
+    def inc_a(n, t):
+        b1 = bc(n + '.branch1x1', t)
+        b5 = bc(n + '.branch5x5_2', bc(n + '.branch5x5_1', t), 1, 2)
+        b3 = bc(n + '.branch3x3dbl_3', bc(n + '.branch3x3dbl_2', bc(n + '.branch3x3dbl_1', t), 1, 1), 1, 1)
+        bp = bc(n + '.branch_pool', F.avg_pool2d(t, 3, 1, 1))
+        return torch.cat([b1, b5, b3, bp], 1)
+
+    def inc_b(n, t):
+        b3 = bc(n + '.branch3x3', t, 2)
+        bd = bc(n + '.branch3x3dbl_3', bc(n + '.branch3x3dbl_2', bc(n + '.branch3x3dbl_1', t), 1, 1), 2)
+        return torch.cat([b3, bd, F.max_pool2d(t, 3, 2)], 1)
+
+    def inc_c(n, t):
+        b1 = bc(n + '.branch1x1', t)
+        b7 = bc(n + '.branch7x7_3', bc(n + '.branch7x7_2', bc(n + '.branch7x7_1', t), 1, (0, 3)), 1, (3, 0))
+        bd = bc(n + '.branch7x7dbl_1', t)
+        bd = bc(n + '.branch7x7dbl_2', bd, 1, (3, 0))
+        bd = bc(n + '.branch7x7dbl_3', bd, 1, (0, 3))
+        bd = bc(n + '.branch7x7dbl_4', bd, 1, (3, 0))
+        bd = bc(n + '.branch7x7dbl_5', bd, 1, (0, 3))
+        bp = bc(n + '.branch_pool', F.avg_pool2d(t, 3, 1, 1))
+        return torch.cat([b1, b7, bd, bp], 1)
+
+    def inc_d(n, t):
+        b3 = bc(n + '.branch3x3_2', bc(n + '.branch3x3_1', t), 2)
+        b7 = bc(n + '.branch7x7x3_1', t)
+        b7 = bc(n + '.branch7x7x3_2', b7, 1, (0, 3))
+        b7 = bc(n + '.branch7x7x3_3', b7, 1, (3, 0))
+        b7 = bc(n + '.branch7x7x3_4', b7, 2)
+        return torch.cat([b3, b7, F.max_pool2d(t, 3, 2)], 1)
+
+    def inc_e(n, t):
+        b1 = bc(n + '.branch1x1', t)
+        b3 = bc(n + '.branch3x3_1', t)
+        b3 = torch.cat([bc(n + '.branch3x3_2a', b3, 1, (0, 1)), bc(n + '.branch3x3_2b', b3, 1, (1, 0))], 1)
+        bd = bc(n + '.branch3x3dbl_2', bc(n + '.branch3x3dbl_1', t), 1, 1)
+        bd = torch.cat([bc(n + '.branch3x3dbl_3a', bd, 1, (0, 1)), bc(n + '.branch3x3dbl_3b', bd, 1, (1, 0))], 1)
+        bp = bc(n + '.branch_pool', F.avg_pool2d(t, 3, 1, 1))
+        return torch.cat([b1, b3, bd, bp], 1)
+
+    for n in ('Mixed_5b', 'Mixed_5c', 'Mixed_5d'):
+        x = inc_a(n, x)
+    x = inc_b('Mixed_6a', x)
+    for n in ('Mixed_6b', 'Mixed_6c', 'Mixed_6d', 'Mixed_6e'):
+        x = inc_c(n, x)
+    x = inc_d('Mixed_7a', x)
+    x = inc_e('Mixed_7b', x)
+    x = inc_e('Mixed_7c', x)
+    x = F.adaptive_avg_pool2d(x, 1).flatten(1)
+    return F.linear(x, sd['fc.weight'], sd['fc.bias'])
+
+
 class OracleClassifier:
     """Duck-typed stand-in for classifier.Classifier: same call contract (classifier.py:55-75)."""
     INPUT_SZ = {'resnet18': (224, 224), 'vgg16': (224, 224), 'inception_v3': (299, 299)}
@@ -315,7 +401,8 @@ class OracleClassifier:
         self.sd = state_dict
         self.input_sz = tuple(input_sz) if input_sz is not None else self.INPUT_SZ[name]
         self.sort_results = sort_results
-        self.body = {'resnet18': resnet18_forward}[name]
+        self.body = {'resnet18': resnet18_forward, 'vgg16': vgg16_forward,
+                     'inception_v3': globals().get('inception_v3_forward')}[name]
 
     def __call__(self, im, crop_sz=(240, 240)):
         if im.dtype == torch.uint8:

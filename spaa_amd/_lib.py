@@ -65,6 +65,12 @@ _SIGNATURES = {
     'spaa_preproc_bwd': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), _p],
     'spaa_maxpool3s2_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'spaa_maxpool3s2_bwd': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'spaa_maxpool_fwd': [_p, _p, _p] + [_i] * 11 + [_p],
+    'spaa_maxpool_bwd': [_p, _p, _p, _p] + [_i] * 11 + [_p],
+    'spaa_avgpool2d_fwd': [_p, _p] + [_i] * 11 + [_p],
+    'spaa_avgpool2d_bwd': [_p, _p] + [_i] * 11 + [_p],
+    'spaa_adaptive_avgpool_fwd': [_p, _p] + [_i] * 6 + [_p],
+    'spaa_adaptive_avgpool_bwd': [_p, _p, _p] + [_i] * 6 + [_p],
     'spaa_avgpool_fwd': [_p, _p, _i, _i, _i, _p],
     'spaa_avgpool_bwd': [_p, _p, _p, _i, _i, _i, _p],
     'spaa_decide': [_p, _i, _p, _i, _p, _i, _i, _p, _f, _f, _f, _f, _f, _f, _p, _p, _p, _i, _p],

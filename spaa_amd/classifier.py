@@ -160,7 +160,115 @@ class ResNet18Body:
         return t + self.fc_f.flops(self.B, 1, 1)
 
 
-BODIES = {'resnet18': ResNet18Body}
+VGG16_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
+
+
+class VGG16Body:
+    """torchvision.models.vgg16 (eval: dropout is the identity) forward + input-gradient."""
+
+    def __init__(self, sd, batch, in_hw, dev):
+        sd = _strip(sd)
+        self.B, self.dev = batch, dev
+        h, w = in_hw
+        self.in_hw = (h, w)
+
+        def z(*shape):
+            return torch.zeros(*shape, device=dev)
+
+        self.ops = []
+        cin, idx = 3, 0
+        for v in VGG16_CFG:
+            if v == 'M':
+                ho, wo = h // 2, w // 2
+                self.ops.append(dict(kind='pool', hin=h, win=w, c=cin, out=z(batch, ho, wo, cin),
+                                     arg=torch.zeros(batch, ho, wo, cin, dtype=torch.uint8, device=dev),
+                                     g=z(batch, h, w, cin)))
+                h, w = ho, wo
+                idx += 1
+            else:
+                wt, bs = sd[f'features.{idx}.weight'], sd[f'features.{idx}.bias']
+                self.ops.append(dict(kind='conv', f=cp.conv_fwd_plan(wt, bs, 1, 1, dev, f'features.{idx}'),
+                                     d=cp.conv_dgrad_plan(wt, 1, 1, dev, f'features.{idx}_dgrad'),
+                                     out=z(batch, h, w, v), g=z(batch, h, w, 4 if cin == 3 else cin)))
+                cin = v
+                idx += 2
+        self.feat_hw = (h, w)
+        self.pool7 = z(batch, 7, 7, 512)
+        self.g_pool7 = z(batch, 7, 7, 512)
+        self.g_feat = z(batch, h, w, 512)
+        w1 = sd['classifier.0.weight']
+        w1p = w1.view(w1.shape[0], 512, 49).permute(0, 2, 1).reshape(w1.shape[0], 49 * 512)  # NCHW flatten -> NHWC
+        self.fc = [(cp.linear_fwd_plan(w1p, sd['classifier.0.bias'], dev, 'classifier.0'),
+                    cp.linear_dgrad_plan(w1p, dev, 'classifier.0_dgrad')),
+                   (cp.linear_fwd_plan(sd['classifier.3.weight'], sd['classifier.3.bias'], dev, 'classifier.3'),
+                    cp.linear_dgrad_plan(sd['classifier.3.weight'], dev, 'classifier.3_dgrad')),
+                   (cp.linear_fwd_plan(sd['classifier.6.weight'], sd['classifier.6.bias'], dev, 'classifier.6'),
+                    cp.linear_dgrad_plan(sd['classifier.6.weight'], dev, 'classifier.6_dgrad'))]
+        self.ncls = sd['classifier.6.weight'].shape[0]
+        fcw = sd['classifier.0.weight'].shape[0]
+        self.h1, self.h2 = z(batch, 1, 1, fcw), z(batch, 1, 1, fcw)
+        self.logits = z(batch, 1, 1, self.ncls)
+        self.g_h1, self.g_h2 = z(batch, 1, 1, fcw), z(batch, 1, 1, fcw)
+
+    def forward(self, x4):
+        B, R = self.B, _lib.ACT_RELU
+        t = x4
+        for op in self.ops:
+            if op['kind'] == 'conv':
+                op['f'].run(t, op['out'], act=R)
+            else:
+                _lib.call('spaa_maxpool_fwd', _lib.ptr(t), _lib.ptr(op['out']), _lib.ptr(op['arg']), B, op['hin'],
+                          op['win'], op['c'], op['hin'] // 2, op['win'] // 2, 2, 2, 0, op['c'], 0)
+            op['inp'] = t
+            t = op['out']
+        fh, fw = self.feat_hw
+        if (fh, fw) != (7, 7):
+            _lib.call('spaa_adaptive_avgpool_fwd', _lib.ptr(t), _lib.ptr(self.pool7), B, fh, fw, 512, 7, 7)
+            t = self.pool7
+        flat = t.view(B, 1, 1, 49 * 512)
+        self.fc[0][0].run(flat, self.h1, act=R)
+        self.fc[1][0].run(self.h1, self.h2, act=R)
+        self.fc[2][0].run(self.h2, self.logits)
+        return self.logits.view(B, self.ncls)
+
+    def backward(self, g_logits):
+        B = self.B
+        self.fc[2][1].run(g_logits.view(B, 1, 1, self.ncls), self.g_h2, gate=self.h2)
+        self.fc[1][1].run(self.g_h2, self.g_h1, gate=self.h1)
+        self.fc[0][1].run(self.g_h1, self.g_pool7.view(B, 1, 1, 49 * 512))
+        fh, fw = self.feat_hw
+        g = self.g_pool7
+        if (fh, fw) != (7, 7):
+            _lib.call('spaa_adaptive_avgpool_bwd', _lib.ptr(g), None, _lib.ptr(self.g_feat), B, fh, fw, 512, 7, 7)
+            g = self.g_feat
+        # g is the gradient w.r.t. the last pool's output
+        for i in range(len(self.ops) - 1, -1, -1):
+            op = self.ops[i]
+            if op['kind'] == 'pool':
+                # input of a pool is a conv+ReLU output: gather + ReLU gate -> gradient w.r.t. that conv's pre-activation
+                _lib.call('spaa_maxpool_bwd', _lib.ptr(g), _lib.ptr(op['arg']), _lib.ptr(op['inp']), _lib.ptr(op['g']),
+                          B, op['hin'], op['win'], op['c'], op['hin'] // 2, op['win'] // 2, 2, 2, 0, op['c'], 0)
+            else:
+                prev = self.ops[i - 1] if i > 0 else None
+                gate = op['inp'] if (prev is not None and prev['kind'] == 'conv') else None
+                op['d'].run(g, op['g'], gate=gate)
+            g = op['g']
+        return g
+
+    def flops_fwd(self):
+        t = 0
+        for op in self.ops:
+            if op['kind'] == 'conv':
+                t += op['f'].flops(self.B, *op['out'].shape[1:3])
+        return t + sum(f.flops(self.B, 1, 1) for f, _ in self.fc)
+
+
+def _inception_body(sd, batch, in_hw, dev):
+    from .inception import InceptionV3Body
+    return InceptionV3Body(sd, batch, in_hw, dev)
+
+
+BODIES = {'resnet18': ResNet18Body, 'vgg16': VGG16Body, 'inception_v3': _inception_body}
 
 
 class ClassifierEngine:

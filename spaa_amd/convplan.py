@@ -153,26 +153,32 @@ def conv_fwd_plan(weight, bias, stride, pad, device='cuda', name=''):
     """nn.Conv2d forward. weight [co, ci, kh, kw]."""
     w = _w2(weight)
     co, ci, kh, kw = w.shape
+    ph, pw = _pair(pad)
     c = TapClassSpec(0, 0)
     for ky in range(kh):
         for kx in range(kw):
-            c.add(ky - pad, kx - pad, w[:, :, ky, kx])
+            c.add(ky - ph, kx - pw, w[:, :, ky, kx])
     return ConvPlan([c], ci, co, stride, 1, bias, device, name)
+
+
+def _pair(p):
+    return (p, p) if isinstance(p, int) else (int(p[0]), int(p[1]))
 
 
 def _fractional_classes(wsel, kh, kw, pad):
     """Stride-2 transposed structure: output (2y+py, 2x+px) receives taps with (py+pad-ky) even."""
+    ph, pw = _pair(pad)
     classes = []
     for py in range(2):
         for px in range(2):
             c = TapClassSpec(py, px)
             for ky in range(kh):
-                if (py + pad - ky) % 2:
+                if (py + ph - ky) % 2:
                     continue
                 for kx in range(kw):
-                    if (px + pad - kx) % 2:
+                    if (px + pw - kx) % 2:
                         continue
-                    c.add((py + pad - ky) // 2, (px + pad - kx) // 2, wsel(ky, kx))
+                    c.add((py + ph - ky) // 2, (px + pw - kx) // 2, wsel(ky, kx))
             classes.append(c)
     return classes
 
@@ -188,10 +194,11 @@ def conv_dgrad_plan(weight, stride, pad, device='cuda', name='', in_ch=None):
         return w[:, lo:hi, ky, kx].t().contiguous()
 
     if stride == 1:
+        ph, pw = _pair(pad)
         c = TapClassSpec(0, 0)
         for ky in range(kh):
             for kx in range(kw):
-                c.add(pad - ky, pad - kx, wsel(ky, kx))
+                c.add(ph - ky, pw - kx, wsel(ky, kx))
         return ConvPlan([c], co, hi - lo, 1, 1, None, device, name)
     assert stride == 2
     return ConvPlan(_fractional_classes(wsel, kh, kw, pad), co, hi - lo, 1, 2, None, device, name)

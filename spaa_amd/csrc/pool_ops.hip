@@ -1,0 +1,280 @@
+// pool_ops.hip — generic NHWC pooling layers of the torchvision classifier bodies (VGG-16, Inception-v3), forward and
+// input-gradient.  Backward passes are gathers (each input element sums the windows that cover it): deterministic,
+// no atomics.  Replaces max_pool2d / avg_pool2d / adaptive_avg_pool2d behind classifier.py:60 and their autograd.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/spaa_hip.h"
+
+namespace {
+
+__device__ __forceinline__ int a_start(int i, int out, int in) { return (int)floorf((float)(i * in) / (float)out); }
+__device__ __forceinline__ int a_end(int i, int out, int in) { return (int)ceilf((float)((i + 1) * in) / (float)out); }
+
+struct Geo {
+    int B, Hin, Win, C4, Hout, Wout, k, s, p;
+};
+
+// max_pool2d(k, s, p), first maximum in row-major window order wins (ATen CPU rule); 4 channels per thread
+__global__ void maxpool_fwd_kernel(const float4* __restrict__ in, float4* __restrict__ out,
+                                   uchar4* __restrict__ argmax, Geo g, int out_c4stride, int out_c4off) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.B * g.Hout * g.Wout * g.C4) return;
+    const int c = idx % g.C4;
+    int r = idx / g.C4;
+    const int ox = r % g.Wout;
+    r /= g.Wout;
+    const int oy = r % g.Hout;
+    const int b = r / g.Hout;
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    uchar4 am = make_uchar4(0, 0, 0, 0);
+    for (int ky = 0; ky < g.k; ++ky) {
+        const int iy = oy * g.s - g.p + ky;
+        if ((unsigned)iy >= (unsigned)g.Hin) continue;
+        for (int kx = 0; kx < g.k; ++kx) {
+            const int ix = ox * g.s - g.p + kx;
+            if ((unsigned)ix >= (unsigned)g.Win) continue;
+            const float4 v = in[(((size_t)b * g.Hin + iy) * g.Win + ix) * g.C4 + c];
+            const unsigned char kk = (unsigned char)(ky * g.k + kx);
+            if (v.x > best.x || v.x != v.x) { best.x = v.x; am.x = kk; }
+            if (v.y > best.y || v.y != v.y) { best.y = v.y; am.y = kk; }
+            if (v.z > best.z || v.z != v.z) { best.z = v.z; am.z = kk; }
+            if (v.w > best.w || v.w != v.w) { best.w = v.w; am.w = kk; }
+        }
+    }
+    out[(((size_t)b * g.Hout + oy) * g.Wout + ox) * out_c4stride + out_c4off + c] = best;
+    argmax[idx] = am;
+}
+
+__global__ void maxpool_bwd_kernel(const float4* __restrict__ g_out, const uchar4* __restrict__ argmax,
+                                   const float4* __restrict__ gate_in, float4* __restrict__ g_in, Geo g,
+                                   int gout_c4stride, int gout_c4off) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.B * g.Hin * g.Win * g.C4) return;
+    const int c = idx % g.C4;
+    int r = idx / g.C4;
+    const int ix = r % g.Win;
+    r /= g.Win;
+    const int iy = r % g.Hin;
+    const int b = r / g.Hin;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ky = 0; ky < g.k; ++ky) {
+        const int t = iy + g.p - ky;
+        if (t < 0 || (t % g.s)) continue;
+        const int oy = t / g.s;
+        if (oy >= g.Hout) continue;
+        for (int kx = 0; kx < g.k; ++kx) {
+            const int u = ix + g.p - kx;
+            if (u < 0 || (u % g.s)) continue;
+            const int ox = u / g.s;
+            if (ox >= g.Wout) continue;
+            const size_t opix = ((size_t)b * g.Hout + oy) * g.Wout + ox;
+            const uchar4 am = argmax[opix * g.C4 + c];
+            const float4 go = g_out[opix * gout_c4stride + gout_c4off + c];
+            const unsigned char kk = (unsigned char)(ky * g.k + kx);
+            if (am.x == kk) acc.x += go.x;
+            if (am.y == kk) acc.y += go.y;
+            if (am.z == kk) acc.z += go.z;
+            if (am.w == kk) acc.w += go.w;
+        }
+    }
+    if (gate_in != nullptr) {
+        const float4 a = gate_in[idx];
+        acc.x = a.x > 0.f ? acc.x : 0.f;
+        acc.y = a.y > 0.f ? acc.y : 0.f;
+        acc.z = a.z > 0.f ? acc.z : 0.f;
+        acc.w = a.w > 0.f ? acc.w : 0.f;
+    }
+    g_in[idx] = acc;
+}
+
+// avg_pool2d(k, s, p), count_include_pad=True (divisor k*k), optional output channel window of a concat buffer
+__global__ void avgpool_fwd_kernel(const float4* __restrict__ in, float4* __restrict__ out, Geo g, int out_c4stride,
+                                   int out_c4off) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.B * g.Hout * g.Wout * g.C4) return;
+    const int c = idx % g.C4;
+    int r = idx / g.C4;
+    const int ox = r % g.Wout;
+    r /= g.Wout;
+    const int oy = r % g.Hout;
+    const int b = r / g.Hout;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ky = 0; ky < g.k; ++ky) {
+        const int iy = oy * g.s - g.p + ky;
+        if ((unsigned)iy >= (unsigned)g.Hin) continue;
+        for (int kx = 0; kx < g.k; ++kx) {
+            const int ix = ox * g.s - g.p + kx;
+            if ((unsigned)ix >= (unsigned)g.Win) continue;
+            const float4 v = in[(((size_t)b * g.Hin + iy) * g.Win + ix) * g.C4 + c];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    const float d = (float)(g.k * g.k);
+    out[(((size_t)b * g.Hout + oy) * g.Wout + ox) * out_c4stride + out_c4off + c] =
+        make_float4(a.x / d, a.y / d, a.z / d, a.w / d);
+}
+
+__global__ void avgpool_bwd_kernel(const float4* __restrict__ g_out, float4* __restrict__ g_in, Geo g,
+                                   int gout_c4stride, int gout_c4off) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.B * g.Hin * g.Win * g.C4) return;
+    const int c = idx % g.C4;
+    int r = idx / g.C4;
+    const int ix = r % g.Win;
+    r /= g.Win;
+    const int iy = r % g.Hin;
+    const int b = r / g.Hin;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ky = 0; ky < g.k; ++ky) {
+        const int t = iy + g.p - ky;
+        if (t < 0 || (t % g.s)) continue;
+        const int oy = t / g.s;
+        if (oy >= g.Hout) continue;
+        for (int kx = 0; kx < g.k; ++kx) {
+            const int u = ix + g.p - kx;
+            if (u < 0 || (u % g.s)) continue;
+            const int ox = u / g.s;
+            if (ox >= g.Wout) continue;
+            const float4 go = g_out[(((size_t)b * g.Hout + oy) * g.Wout + ox) * gout_c4stride + gout_c4off + c];
+            acc.x += go.x; acc.y += go.y; acc.z += go.z; acc.w += go.w;
+        }
+    }
+    const float d = (float)(g.k * g.k);
+    g_in[idx] = make_float4(acc.x / d, acc.y / d, acc.z / d, acc.w / d);
+}
+
+// adaptive_avg_pool2d to (Hout, Wout) with ATen's window rule
+__global__ void adaptive_fwd_kernel(const float4* __restrict__ in, float4* __restrict__ out, Geo g) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.B * g.Hout * g.Wout * g.C4) return;
+    const int c = idx % g.C4;
+    int r = idx / g.C4;
+    const int ox = r % g.Wout;
+    r /= g.Wout;
+    const int oy = r % g.Hout;
+    const int b = r / g.Hout;
+    const int ys = a_start(oy, g.Hout, g.Hin), ye = a_end(oy, g.Hout, g.Hin);
+    const int xs = a_start(ox, g.Wout, g.Win), xe = a_end(ox, g.Wout, g.Win);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int iy = ys; iy < ye; ++iy)
+        for (int ix = xs; ix < xe; ++ix) {
+            const float4 v = in[(((size_t)b * g.Hin + iy) * g.Win + ix) * g.C4 + c];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    const float d = (float)((ye - ys) * (xe - xs));
+    out[idx] = make_float4(a.x / d, a.y / d, a.z / d, a.w / d);
+}
+
+__global__ void adaptive_bwd_kernel(const float4* __restrict__ g_out, const float4* __restrict__ gate_in,
+                                    float4* __restrict__ g_in, Geo g) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.B * g.Hin * g.Win * g.C4) return;
+    const int c = idx % g.C4;
+    int r = idx / g.C4;
+    const int ix = r % g.Win;
+    r /= g.Win;
+    const int iy = r % g.Hin;
+    const int b = r / g.Hin;
+    const int oy_lo = max(0, (iy * g.Hout) / g.Hin - 1), oy_hi = min(g.Hout - 1, ((iy + 1) * g.Hout + g.Hin - 1) / g.Hin + 1);
+    const int ox_lo = max(0, (ix * g.Wout) / g.Win - 1), ox_hi = min(g.Wout - 1, ((ix + 1) * g.Wout + g.Win - 1) / g.Win + 1);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        const int ys = a_start(oy, g.Hout, g.Hin), ye = a_end(oy, g.Hout, g.Hin);
+        if (iy < ys || iy >= ye) continue;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            const int xs = a_start(ox, g.Wout, g.Win), xe = a_end(ox, g.Wout, g.Win);
+            if (ix < xs || ix >= xe) continue;
+            const float inv = 1.f / (float)((ye - ys) * (xe - xs));
+            const float4 go = g_out[(((size_t)b * g.Hout + oy) * g.Wout + ox) * g.C4 + c];
+            acc.x += go.x * inv; acc.y += go.y * inv; acc.z += go.z * inv; acc.w += go.w * inv;
+        }
+    }
+    if (gate_in != nullptr) {
+        const float4 a = gate_in[idx];
+        acc.x = a.x > 0.f ? acc.x : 0.f;
+        acc.y = a.y > 0.f ? acc.y : 0.f;
+        acc.z = a.z > 0.f ? acc.z : 0.f;
+        acc.w = a.w > 0.f ? acc.w : 0.f;
+    }
+    g_in[idx] = acc;
+}
+
+inline int nb(int64_t n) { return (int)((n + 255) / 256); }
+
+inline bool geo_ok(int B, int Hin, int Win, int C, int Hout, int Wout, int k, int s, int p) {
+    return B > 0 && Hin > 0 && Win > 0 && C > 0 && !(C & 3) && k > 0 && k <= 15 && s > 0 && p >= 0 && 2 * p <= k &&
+           Hout == (Hin + 2 * p - k) / s + 1 && Wout == (Win + 2 * p - k) / s + 1 &&
+           (int64_t)B * Hin * Win * C < ((int64_t)1 << 31);
+}
+
+}  // namespace
+
+extern "C" {
+
+int spaa_maxpool_fwd(const float* in, float* out, uint8_t* argmax, int B, int Hin, int Win, int C, int Hout, int Wout,
+                     int k, int s, int p, int out_cstride, int out_coff, spaa_stream_t stream) {
+    if (!in || !out || !argmax || !geo_ok(B, Hin, Win, C, Hout, Wout, k, s, p) || (out_cstride & 3) || (out_coff & 3) ||
+        out_coff + C > out_cstride)
+        return hipErrorInvalidValue;
+    Geo g{B, Hin, Win, C / 4, Hout, Wout, k, s, p};
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nb((int64_t)B * Hout * Wout * g.C4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)in, (float4*)out, (uchar4*)argmax, g, out_cstride / 4, out_coff / 4);
+    return (int)hipGetLastError();
+}
+
+int spaa_maxpool_bwd(const float* g_out, const uint8_t* argmax, const float* gate_in, float* g_in, int B, int Hin,
+                     int Win, int C, int Hout, int Wout, int k, int s, int p, int gout_cstride, int gout_coff,
+                     spaa_stream_t stream) {
+    if (!g_out || !argmax || !g_in || !geo_ok(B, Hin, Win, C, Hout, Wout, k, s, p) || (gout_cstride & 3) ||
+        (gout_coff & 3) || gout_coff + C > gout_cstride)
+        return hipErrorInvalidValue;
+    Geo g{B, Hin, Win, C / 4, Hout, Wout, k, s, p};
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nb((int64_t)B * Hin * Win * g.C4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)g_out, (const uchar4*)argmax, (const float4*)gate_in, (float4*)g_in, g,
+                       gout_cstride / 4, gout_coff / 4);
+    return (int)hipGetLastError();
+}
+
+int spaa_avgpool2d_fwd(const float* in, float* out, int B, int Hin, int Win, int C, int Hout, int Wout, int k, int s,
+                       int p, int out_cstride, int out_coff, spaa_stream_t stream) {
+    if (!in || !out || !geo_ok(B, Hin, Win, C, Hout, Wout, k, s, p) || (out_cstride & 3) || (out_coff & 3) ||
+        out_coff + C > out_cstride)
+        return hipErrorInvalidValue;
+    Geo g{B, Hin, Win, C / 4, Hout, Wout, k, s, p};
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(nb((int64_t)B * Hout * Wout * g.C4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)in, (float4*)out, g, out_cstride / 4, out_coff / 4);
+    return (int)hipGetLastError();
+}
+
+int spaa_avgpool2d_bwd(const float* g_out, float* g_in, int B, int Hin, int Win, int C, int Hout, int Wout, int k,
+                       int s, int p, int gout_cstride, int gout_coff, spaa_stream_t stream) {
+    if (!g_out || !g_in || !geo_ok(B, Hin, Win, C, Hout, Wout, k, s, p) || (gout_cstride & 3) || (gout_coff & 3) ||
+        gout_coff + C > gout_cstride)
+        return hipErrorInvalidValue;
+    Geo g{B, Hin, Win, C / 4, Hout, Wout, k, s, p};
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(nb((int64_t)B * Hin * Win * g.C4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)g_out, (float4*)g_in, g, gout_cstride / 4, gout_coff / 4);
+    return (int)hipGetLastError();
+}
+
+int spaa_adaptive_avgpool_fwd(const float* in, float* out, int B, int Hin, int Win, int C, int Hout, int Wout,
+                              spaa_stream_t stream) {
+    if (!in || !out || B < 1 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1 || C < 1 || (C & 3))
+        return hipErrorInvalidValue;
+    Geo g{B, Hin, Win, C / 4, Hout, Wout, 0, 0, 0};
+    hipLaunchKernelGGL(adaptive_fwd_kernel, dim3(nb((int64_t)B * Hout * Wout * g.C4)), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)in, (float4*)out, g);
+    return (int)hipGetLastError();
+}
+
+int spaa_adaptive_avgpool_bwd(const float* g_out, const float* gate_in, float* g_in, int B, int Hin, int Win, int C,
+                              int Hout, int Wout, spaa_stream_t stream) {
+    if (!g_out || !g_in || B < 1 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1 || C < 1 || (C & 3))
+        return hipErrorInvalidValue;
+    Geo g{B, Hin, Win, C / 4, Hout, Wout, 0, 0, 0};
+    hipLaunchKernelGGL(adaptive_bwd_kernel, dim3(nb((int64_t)B * Hin * Win * g.C4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)g_out, (const float4*)gate_in, (float4*)g_in, g);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,271 @@
+"""Inception-v3 (torchvision.models.inception_v3, eval, transform_input=True, aux head unused) as a small op graph over
+the tap-list convolution kernel and the generic pooling kernels: forward and input-gradient.
+
+The reference builds it with `models.inception_v3(init_weights=False, transform_input=True)` and feeds 299x299 crops
+(/root/reference/src/python/classifier.py:29-33).  The architecture is third-party (torchvision==0.15.1); it is
+restated here from its published definition.  BasicConv2d = conv(bias=False) + BatchNorm(eps=1e-3) + ReLU, with the
+BatchNorm folded into the convolution; concatenations are channel windows of one NHWC buffer (no copy).
+"""
+import torch
+
+from . import _lib
+from . import convplan as cp
+
+# layer table: name -> builder spec.  conv spec = (name, cout, (kh, kw), stride, (ph, pw))
+A_ = lambda pf: dict(kind='A', pf=pf)  # noqa: E731
+STEM = [('Conv2d_1a_3x3', 32, (3, 3), 2, (0, 0)), ('Conv2d_2a_3x3', 32, (3, 3), 1, (0, 0)),
+        ('Conv2d_2b_3x3', 64, (3, 3), 1, (1, 1)), 'maxpool', ('Conv2d_3b_1x1', 80, (1, 1), 1, (0, 0)),
+        ('Conv2d_4a_3x3', 192, (3, 3), 1, (0, 0)), 'maxpool']
+BLOCKS = [('Mixed_5b', 'A', 32), ('Mixed_5c', 'A', 64), ('Mixed_5d', 'A', 64), ('Mixed_6a', 'B', None),
+          ('Mixed_6b', 'C', 128), ('Mixed_6c', 'C', 160), ('Mixed_6d', 'C', 160), ('Mixed_6e', 'C', 192),
+          ('Mixed_7a', 'D', None), ('Mixed_7b', 'E', None), ('Mixed_7c', 'E', None)]
+
+
+def block_spec(kind, arg):
+    """Branches of an Inception block: list of (branch ops, concat?) in torchvision's concatenation order.
+    op = ('conv', suffix, cout, (kh,kw), stride, (ph,pw)) | ('avg',) | ('max',) | ('split', [ops_a], [ops_b])."""
+    c = lambda s, co, k=(1, 1), st=1, p=(0, 0): ('conv', s, co, k, st, p)  # noqa: E731
+    if kind == 'A':
+        return [[c('branch1x1', 64)],
+                [c('branch5x5_1', 48), c('branch5x5_2', 64, (5, 5), 1, (2, 2))],
+                [c('branch3x3dbl_1', 64), c('branch3x3dbl_2', 96, (3, 3), 1, (1, 1)),
+                 c('branch3x3dbl_3', 96, (3, 3), 1, (1, 1))],
+                [('avg',), c('branch_pool', arg)]]
+    if kind == 'B':
+        return [[c('branch3x3', 384, (3, 3), 2)],
+                [c('branch3x3dbl_1', 64), c('branch3x3dbl_2', 96, (3, 3), 1, (1, 1)), c('branch3x3dbl_3', 96, (3, 3), 2)],
+                [('max',)]]
+    if kind == 'C':
+        c7 = arg
+        return [[c('branch1x1', 192)],
+                [c('branch7x7_1', c7), c('branch7x7_2', c7, (1, 7), 1, (0, 3)), c('branch7x7_3', 192, (7, 1), 1, (3, 0))],
+                [c('branch7x7dbl_1', c7), c('branch7x7dbl_2', c7, (7, 1), 1, (3, 0)),
+                 c('branch7x7dbl_3', c7, (1, 7), 1, (0, 3)), c('branch7x7dbl_4', c7, (7, 1), 1, (3, 0)),
+                 c('branch7x7dbl_5', 192, (1, 7), 1, (0, 3))],
+                [('avg',), c('branch_pool', 192)]]
+    if kind == 'D':
+        return [[c('branch3x3_1', 192), c('branch3x3_2', 320, (3, 3), 2)],
+                [c('branch7x7x3_1', 192), c('branch7x7x3_2', 192, (1, 7), 1, (0, 3)),
+                 c('branch7x7x3_3', 192, (7, 1), 1, (3, 0)), c('branch7x7x3_4', 192, (3, 3), 2)],
+                [('max',)]]
+    if kind == 'E':
+        return [[c('branch1x1', 320)],
+                [c('branch3x3_1', 384), ('split', [c('branch3x3_2a', 384, (1, 3), 1, (0, 1))],
+                                         [c('branch3x3_2b', 384, (3, 1), 1, (1, 0))])],
+                [c('branch3x3dbl_1', 448), c('branch3x3dbl_2', 384, (3, 3), 1, (1, 1)),
+                 ('split', [c('branch3x3dbl_3a', 384, (1, 3), 1, (0, 1))], [c('branch3x3dbl_3b', 384, (3, 1), 1, (1, 0))])],
+                [('avg',), c('branch_pool', 192)]]
+    raise ValueError(kind)
+
+
+class Ten:
+    """A channel window [coff, coff+C) of an NHWC buffer, plus its gradient buffer of identical layout."""
+
+    def __init__(self, buf, coff, c, gbuf=None, kind='act'):
+        self.buf, self.coff, self.c, self.gbuf, self.kind = buf, coff, c, gbuf, kind
+        self.consumers = []
+        self.g_written = False
+
+    @property
+    def hw(self):
+        return self.buf.shape[1], self.buf.shape[2]
+
+    def whole(self):
+        return self.coff == 0 and self.c == self.buf.shape[3]
+
+
+def _osz(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+class InceptionV3Body:
+    def __init__(self, sd, batch, in_hw, dev):
+        from .classifier import _strip
+        sd = _strip(sd)
+        self.B, self.dev, self.sd = batch, dev, sd
+        self.ops = []
+        h, w = in_hw
+        self.in_hw = (h, w)
+
+        def z(*shape):
+            return torch.zeros(*shape, device=dev)
+
+        self.z = z
+        # transform_input=True (torchvision): per-channel affine on the already-normalised image, folded into the
+        # first convolution:  x' = a_c * x + b_c  =>  W' = W * a_c, bias' += sum_taps W * b_c  -- valid only where no
+        # zero padding is involved: Conv2d_1a has padding 0, so the folding is exact.
+        self.x_in = Ten(z(batch, h, w, 4), 0, 3, z(batch, h, w, 4), kind='input')
+        t = self.x_in
+        first = True
+        for item in STEM:
+            if item == 'maxpool':
+                t = self.add_pool('max', t, 3, 2, 0)
+            else:
+                name, co, k, st, p = item
+                t = self.add_conv(name, t, co, k, st, p, fold_input_affine=first)
+                first = False
+        for name, kind, arg in BLOCKS:
+            t = self.add_block(name, kind, arg, t)
+        self.feat = t
+        fh, fw = t.hw
+        self.feat_hw = fh * fw
+        self.pooled = z(batch, 1, 1, 2048)
+        self.g_pooled = z(batch, 1, 1, 2048)
+        self.ncls = sd['fc.weight'].shape[0]
+        self.fc_f = cp.linear_fwd_plan(sd['fc.weight'], sd['fc.bias'], dev, 'fc')
+        self.fc_d = cp.linear_dgrad_plan(sd['fc.weight'], dev, 'fc_dgrad')
+        self.logits = z(batch, 1, 1, self.ncls)
+
+    # ---- graph construction ------------------------------------------------------------------------------------
+    def folded(self, name, fold_input_affine=False):
+        sd = self.sd
+        wgt, b = cp.fold_bn(sd[name + '.conv.weight'], sd[name + '.bn.weight'], sd[name + '.bn.bias'],
+                            sd[name + '.bn.running_mean'], sd[name + '.bn.running_var'], eps=1e-3)
+        if fold_input_affine:
+            a = torch.tensor([0.229 / 0.5, 0.224 / 0.5, 0.225 / 0.5], dtype=torch.float64)
+            c = torch.tensor([(0.485 - 0.5) / 0.5, (0.456 - 0.5) / 0.5, (0.406 - 0.5) / 0.5], dtype=torch.float64)
+            wd = wgt.double()
+            b = (b.double() + (wd * c.view(1, 3, 1, 1)).sum(dim=(1, 2, 3))).float()
+            wgt = (wd * a.view(1, 3, 1, 1)).float()
+        return wgt, b
+
+    def add_conv(self, name, inp, cout, k, stride, pad, out=None, fold_input_affine=False):
+        hin, win = inp.hw
+        ho, wo = _osz(hin, k[0], stride, pad[0]), _osz(win, k[1], stride, pad[1])
+        if out is None:
+            out = Ten(self.z(self.B, ho, wo, cout), 0, cout, self.z(self.B, ho, wo, cout))
+        assert out.hw == (ho, wo) and out.c == cout
+        wgt, b = self.folded(name, fold_input_affine)
+        op = dict(kind='conv', name=name, inp=inp, out=out,
+                  f=cp.conv_fwd_plan(wgt, b, stride, pad, self.dev, name),
+                  d=cp.conv_dgrad_plan(wgt, stride, pad, self.dev, name + '_dgrad'))
+        inp.consumers.append(op)
+        self.ops.append(op)
+        return out
+
+    def add_pool(self, mode, inp, k, s, p, out=None):
+        assert inp.whole(), 'pool inputs are whole buffers'
+        hin, win = inp.hw
+        ho, wo = _osz(hin, k, s, p), _osz(win, k, s, p)
+        if out is None:
+            out = Ten(self.z(self.B, ho, wo, inp.c), 0, inp.c, self.z(self.B, ho, wo, inp.c), kind='pool')
+        op = dict(kind=mode, inp=inp, out=out, k=k, s=s, p=p)
+        if mode == 'max':
+            op['arg'] = torch.zeros(self.B, ho, wo, inp.c, dtype=torch.uint8, device=self.dev)
+        inp.consumers.append(op)
+        self.ops.append(op)
+        return out
+
+    def add_block(self, name, kind, arg, inp):
+        spec = block_spec(kind, arg)
+        hin, win = inp.hw
+
+        def out_channels(ops):
+            last = ops[-1]
+            if last[0] == 'conv':
+                return last[2]
+            if last[0] == 'split':
+                return out_channels(last[1]) + out_channels(last[2])
+            return inp.c  # max-pool branch passes the input channels through
+
+        def spatial(ops, h, w):
+            for o in ops:
+                if o[0] == 'conv':
+                    h, w = _osz(h, o[3][0], o[4], o[5][0]), _osz(w, o[3][1], o[4], o[5][1])
+                elif o[0] == 'max':
+                    h, w = _osz(h, 3, 2, 0), _osz(w, 3, 2, 0)
+                elif o[0] == 'split':
+                    h, w = spatial(o[1], h, w)
+            return h, w
+
+        ctot = sum(out_channels(b) for b in spec)
+        ho, wo = spatial(spec[0], hin, win)
+        cat = self.z(self.B, ho, wo, ctot)
+        gcat = self.z(self.B, ho, wo, ctot)
+
+        def run_chain(ops, t, coff):
+            """Builds ops; the LAST op of the chain writes into the concat window starting at coff."""
+            for i, o in enumerate(ops):
+                is_last = i == len(ops) - 1
+                if o[0] == 'conv':
+                    dst = Ten(cat, coff, o[2], gcat) if is_last else None
+                    t = self.add_conv(f'{name}.{o[1]}', t, o[2], o[3], o[4], o[5], out=dst)
+                elif o[0] == 'avg':
+                    t = self.add_pool('avg', t, 3, 1, 1)
+                elif o[0] == 'max':
+                    dst = Ten(cat, coff, t.c, gcat, kind='pool') if is_last else None
+                    t = self.add_pool('max', t, 3, 2, 0, out=dst)
+                elif o[0] == 'split':
+                    assert is_last
+                    ca = out_channels(o[1])
+                    run_chain(o[1], t, coff)
+                    run_chain(o[2], t, coff + ca)
+            return t
+
+        coff = 0
+        for br in spec:
+            run_chain(br, inp, coff)
+            coff += out_channels(br)
+        return Ten(cat, 0, ctot, gcat)
+
+    # ---- execution ---------------------------------------------------------------------------------------------
+    def forward(self, x4):
+        B = self.B
+        self.x_in.buf = x4
+        for op in self.ops:
+            i, o = op['inp'], op['out']
+            if op['kind'] == 'conv':
+                if i is self.x_in:
+                    i.buf = x4
+                op['f'].run(i.buf, o.buf, act=_lib.ACT_RELU, in_coff=i.coff, out_coff=o.coff)
+            elif op['kind'] == 'max':
+                hin, win = i.hw
+                ho, wo = o.hw
+                _lib.call('spaa_maxpool_fwd', _lib.ptr(i.buf), _lib.ptr(o.buf), _lib.ptr(op['arg']), B, hin, win, i.c, ho,
+                          wo, op['k'], op['s'], op['p'], o.buf.shape[3], o.coff)
+            else:
+                hin, win = i.hw
+                ho, wo = o.hw
+                _lib.call('spaa_avgpool2d_fwd', _lib.ptr(i.buf), _lib.ptr(o.buf), B, hin, win, i.c, ho, wo, op['k'],
+                          op['s'], op['p'], o.buf.shape[3], o.coff)
+        _lib.call('spaa_avgpool_fwd', _lib.ptr(self.feat.buf), _lib.ptr(self.pooled), B, self.feat_hw, 2048)
+        self.fc_f.run(self.pooled, self.logits)
+        return self.logits.view(B, self.ncls)
+
+    def backward(self, g_logits):
+        B = self.B
+        self.fc_d.run(g_logits.view(B, 1, 1, self.ncls), self.g_pooled)
+        # gradient w.r.t. the pre-activations of the last concat (all four slices are ReLU outputs)
+        _lib.call('spaa_avgpool_bwd', _lib.ptr(self.g_pooled), _lib.ptr(self.feat.buf), _lib.ptr(self.feat.gbuf), B,
+                  self.feat_hw, 2048)
+        written = set()
+        for op in reversed(self.ops):
+            i, o = op['inp'], op['out']
+            key = (id(i.gbuf), i.coff)
+            last = i.consumers[0] is op          # processed last in reverse order -> applies the ReLU gate of `i`
+            gate = i.buf if (last and i.kind != 'input') else None
+            if op['kind'] == 'conv':
+                add = i.gbuf if key in written else None
+                op['d'].run(o.gbuf, i.gbuf, add=add, gate=gate, in_coff=o.coff, out_coff=i.coff, add_coff=i.coff,
+                            gate_coff=i.coff)
+            else:
+                assert key not in written, 'pool branches must be the first gradient contribution of their input'
+                hin, win = i.hw
+                ho, wo = o.hw
+                if op['kind'] == 'max':
+                    _lib.call('spaa_maxpool_bwd', _lib.ptr(o.gbuf), _lib.ptr(op['arg']),
+                              _lib.ptr(gate) if gate is not None else None, _lib.ptr(i.gbuf), B, hin, win, i.c, ho, wo,
+                              op['k'], op['s'], op['p'], o.gbuf.shape[3], o.coff)
+                else:
+                    assert gate is None, 'avg-pool is never the only consumer in Inception-v3'
+                    _lib.call('spaa_avgpool2d_bwd', _lib.ptr(o.gbuf), _lib.ptr(i.gbuf), B, hin, win, i.c, ho, wo, op['k'],
+                              op['s'], op['p'], o.gbuf.shape[3], o.coff)
+            written.add(key)
+        return self.x_in.gbuf
+
+    def flops_fwd(self):
+        t = 0
+        for op in self.ops:
+            if op['kind'] == 'conv':
+                t += op['f'].flops(self.B, *op['out'].hw)
+        return t + self.fc_f.flops(self.B, 1, 1)

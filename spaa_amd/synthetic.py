@@ -150,6 +150,98 @@ def resnet18_state_dict(seed=2, num_classes=1000, logit_gain=1.0):
     return sd
 
 
+def vgg16_state_dict(seed=3, num_classes=1000, logit_gain=1.0, fc_width=4096):
+    """Random-init VGG-16 (torchvision key names: features.N / classifier.N).  `fc_width` < 4096 gives a small
+    test-sized head (the architecture code reads the widths from the tensors)."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    cin, idx = 3, 0
+    for v in [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']:
+        if v == 'M':
+            idx += 1
+            continue
+        fan_out = v * 9  # torchvision: kaiming_normal_(mode='fan_out', nonlinearity='relu'), bias 0
+        sd[f'features.{idx}.weight'] = _t(rng.standard_normal((v, cin, 3, 3)) * math.sqrt(2.0 / fan_out))
+        sd[f'features.{idx}.bias'] = _t(rng.uniform(-0.05, 0.05, (v,)))
+        cin = v
+        idx += 2
+    dims = [(fc_width, 512 * 49), (fc_width, fc_width), (num_classes, fc_width)]
+    for i, (o, n) in zip((0, 3, 6), dims):
+        g = logit_gain if i == 6 else 1.0
+        sd[f'classifier.{i}.weight'] = _t(rng.standard_normal((o, n)) * math.sqrt(2.0 / n) * g)
+        sd[f'classifier.{i}.bias'] = _t(rng.uniform(-0.05, 0.05, (o,)) * g)
+    return sd
+
+
+def inception_v3_state_dict(seed=4, num_classes=1000, logit_gain=1.0):
+    """Random-init Inception-v3 (torchvision key names; AuxLogits omitted: unused in eval)."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+
+    def bc(name, cin, cout, k):
+        kh, kw = k
+        sd[name + '.conv.weight'] = _t(rng.standard_normal((cout, cin, kh, kw)) * math.sqrt(2.0 / (cin * kh * kw)))
+        _bn(rng, cout, sd, name + '.bn')
+        return cout
+
+    c = bc('Conv2d_1a_3x3', 3, 32, (3, 3))
+    c = bc('Conv2d_2a_3x3', c, 32, (3, 3))
+    c = bc('Conv2d_2b_3x3', c, 64, (3, 3))
+    c = bc('Conv2d_3b_1x1', c, 80, (1, 1))
+    c = bc('Conv2d_4a_3x3', c, 192, (3, 3))
+
+    def inc_a(n, cin, pf):
+        bc(n + '.branch1x1', cin, 64, (1, 1))
+        bc(n + '.branch5x5_1', cin, 48, (1, 1)); bc(n + '.branch5x5_2', 48, 64, (5, 5))
+        bc(n + '.branch3x3dbl_1', cin, 64, (1, 1)); bc(n + '.branch3x3dbl_2', 64, 96, (3, 3))
+        bc(n + '.branch3x3dbl_3', 96, 96, (3, 3))
+        bc(n + '.branch_pool', cin, pf, (1, 1))
+        return 64 + 64 + 96 + pf
+
+    def inc_b(n, cin):
+        bc(n + '.branch3x3', cin, 384, (3, 3))
+        bc(n + '.branch3x3dbl_1', cin, 64, (1, 1)); bc(n + '.branch3x3dbl_2', 64, 96, (3, 3))
+        bc(n + '.branch3x3dbl_3', 96, 96, (3, 3))
+        return 384 + 96 + cin
+
+    def inc_c(n, cin, c7):
+        bc(n + '.branch1x1', cin, 192, (1, 1))
+        bc(n + '.branch7x7_1', cin, c7, (1, 1)); bc(n + '.branch7x7_2', c7, c7, (1, 7)); bc(n + '.branch7x7_3', c7, 192, (7, 1))
+        bc(n + '.branch7x7dbl_1', cin, c7, (1, 1)); bc(n + '.branch7x7dbl_2', c7, c7, (7, 1))
+        bc(n + '.branch7x7dbl_3', c7, c7, (1, 7)); bc(n + '.branch7x7dbl_4', c7, c7, (7, 1))
+        bc(n + '.branch7x7dbl_5', c7, 192, (1, 7))
+        bc(n + '.branch_pool', cin, 192, (1, 1))
+        return 768
+
+    def inc_d(n, cin):
+        bc(n + '.branch3x3_1', cin, 192, (1, 1)); bc(n + '.branch3x3_2', 192, 320, (3, 3))
+        bc(n + '.branch7x7x3_1', cin, 192, (1, 1)); bc(n + '.branch7x7x3_2', 192, 192, (1, 7))
+        bc(n + '.branch7x7x3_3', 192, 192, (7, 1)); bc(n + '.branch7x7x3_4', 192, 192, (3, 3))
+        return 320 + 192 + cin
+
+    def inc_e(n, cin):
+        bc(n + '.branch1x1', cin, 320, (1, 1))
+        bc(n + '.branch3x3_1', cin, 384, (1, 1)); bc(n + '.branch3x3_2a', 384, 384, (1, 3)); bc(n + '.branch3x3_2b', 384, 384, (3, 1))
+        bc(n + '.branch3x3dbl_1', cin, 448, (1, 1)); bc(n + '.branch3x3dbl_2', 448, 384, (3, 3))
+        bc(n + '.branch3x3dbl_3a', 384, 384, (1, 3)); bc(n + '.branch3x3dbl_3b', 384, 384, (3, 1))
+        bc(n + '.branch_pool', cin, 192, (1, 1))
+        return 2048
+
+    c = inc_a('Mixed_5b', c, 32)
+    c = inc_a('Mixed_5c', c, 64)
+    c = inc_a('Mixed_5d', c, 64)
+    c = inc_b('Mixed_6a', c)
+    for n, c7 in (('Mixed_6b', 128), ('Mixed_6c', 160), ('Mixed_6d', 160), ('Mixed_6e', 192)):
+        c = inc_c(n, c, c7)
+    c = inc_d('Mixed_7a', c)
+    c = inc_e('Mixed_7b', c)
+    c = inc_e('Mixed_7c', c)
+    bound = 1.0 / math.sqrt(2048)
+    sd['fc.weight'] = _t(rng.uniform(-bound, bound, (num_classes, 2048)) * logit_gain)
+    sd['fc.bias'] = _t(rng.uniform(-bound, bound, (num_classes,)) * logit_gain)
+    return sd
+
+
 def scenes(seed=1, n=1, sz=(256, 256), box=8, lo=0.05, hi=0.95):
     """`n` smooth random camera scenes in [lo,hi]: U[0,1) low-pass filtered by a box x box mean."""
     rng = np.random.default_rng(seed)

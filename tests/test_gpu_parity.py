@@ -459,3 +459,40 @@ def test_perc_al_adversary_projector(hip, golden_dir, targeted, confidence):
     # (the 50-iteration result itself is chaotic, like spaa(): see test_reference_sensitivity_envelope)
     ref = torch.from_numpy(z['x_adv_best'])
     assert ref.shape == out.shape
+
+
+def test_vgg16_classifier_vs_oracle(hip):
+    """VGG-16 body (config 5 of BASELINE.json) on tapconv + generic pooling vs the oracle restatement."""
+    csd = syn.vgg16_state_dict(3, logit_gain=5.0, fc_width=512)
+    for (h, crop, insz, b) in [(64, (60, 60), (48, 48), 2), (256, (240, 240), (224, 224), 1)]:
+        torch.manual_seed(2)
+        im = torch.rand(b, 3, h, h, requires_grad=True)
+        raw, p, idx = so.OracleClassifier('vgg16', csd, input_sz=insz)(im, crop)
+        r = torch.randn(b, 1000)
+        (raw * r).sum().backward()
+        clf = hip['clf'].Classifier('vgg16', DEV, state_dict=csd, input_sz=insz)
+        im2 = im.detach().clone().to(DEV).requires_grad_(True)
+        raw2, p2, idx2 = clf(im2, crop)
+        (raw2 * r.to(DEV)).sum().backward()
+        assert rel_inf(raw2, raw) < 1e-5
+        # 13 ReLU convs + 5 max-pools without skip connections: a gate / arg-max flip reaches the whole image
+        assert rel_l2(im2.grad, im.grad) < 5e-3 and outlier_fraction(im2.grad, im.grad, 1e-3) < 5e-2
+        assert (idx2[:, 0] == idx[:, 0]).all()
+
+
+def test_inception_v3_classifier_vs_oracle(hip):
+    """Inception-v3 body (config 3 of BASELINE.json: 299x299 area-resized crop, transform_input=True) vs the oracle."""
+    csd = syn.inception_v3_state_dict(4, logit_gain=20.0)
+    for (h, crop, insz, b) in [(128, (120, 120), (107, 107), 2), (256, (240, 240), (299, 299), 1)]:
+        torch.manual_seed(5)
+        im = torch.rand(b, 3, h, h, requires_grad=True)
+        raw, p, idx = so.OracleClassifier('inception_v3', csd, input_sz=insz)(im, crop)
+        r = torch.randn(b, 1000)
+        (raw * r).sum().backward()
+        clf = hip['clf'].Classifier('inception_v3', DEV, state_dict=csd, input_sz=insz)
+        im2 = im.detach().clone().to(DEV).requires_grad_(True)
+        raw2, p2, idx2 = clf(im2, crop)
+        (raw2 * r.to(DEV)).sum().backward()
+        assert rel_inf(raw2, raw) < 2e-5
+        assert rel_l2(im2.grad, im.grad) < 5e-3 and outlier_fraction(im2.grad, im.grad, 1e-3) < 5e-2
+        assert (idx2[:, 0] == idx[:, 0]).all()
