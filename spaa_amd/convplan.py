@@ -21,7 +21,7 @@ NPAD = 128
 PROFILE = None  # set to a list by bench.py to time every tapconv launch with HIP events
 FORCE_TILE = 0  # tools/autotune.py: force one workgroup tile for every launch
 TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32', 6: '64x64', 7: '64x128', 8: '128x64b',
-              9: 'direct4', 10: 'direct32'}
+              9: 'direct4', 10: 'direct32', 11: 'thin4'}
 
 
 def _load_tune():
@@ -123,6 +123,8 @@ class ConvPlan:
         if forced == 9 and self.cout > 4:
             forced = 0
         if forced == 10 and (self.cout > 32 or self.ntaps_total * self.cin_p > 512):
+            forced = 0
+        if forced == 11 and (self.cout > 4 or self.cin_p > 256 or (self.cin_p & (self.cin_p - 1))):
             forced = 0
         d.tile = forced if forced else TUNE.get(key, 0)
         d.nclass = len(self.cls)

@@ -160,11 +160,17 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const spaa_tapconv_t p,
         TAPCONV_LOAD_TILE(0)
         TAPCONV_STORE_TILE(0)
     }
+    if (nk > 1) TAPCONV_LOAD_TILE(1)
     __syncthreads();
 
+    // Step ks: tile ks is in LDS stage ks&1; the registers hold tile ks+1 (loads issued one step ago).  Its LDS store
+    // and the global loads of tile ks+2 are issued BEFORE the MFMAs of step ks, so their latency hides under the matrix
+    // work and the barrier at the end of the step finds every wave's writes long done.  (Stage (ks+1)&1 was last read
+    // in step ks-1, which every wave has left through the previous barrier.)
     for (int ks = 0; ks < nk; ++ks) {
         const int stage = ks & 1;
-        const bool more = ks + 1 < nk;
+        if (ks + 1 < nk) TAPCONV_STORE_TILE(stage ^ 1)
+        if (ks + 2 < nk) TAPCONV_LOAD_TILE(ks + 2)
         const float* as = As + stage * BM * LDK + wm0 * LDK + frag_off;
         const float* bs = Bs + stage * BN * LDK + wn0 * LDK + frag_off;
         f4 af[2][TM], bf[2][TN];
@@ -172,7 +178,6 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const spaa_tapconv_t p,
         for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f4*>(as + i * 32 * LDK);
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f4*>(bs + j * 32 * LDK);
-        if (more) TAPCONV_LOAD_TILE(ks + 1)
 #pragma unroll
         for (int kb = 0; kb < BK / 8; ++kb) {
             const int cur = kb & 1, nxt = cur ^ 1;
@@ -192,7 +197,6 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const spaa_tapconv_t p,
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bf[cur][j][e], acc[i][j], 0, 0, 0);
         }
-        if (more) TAPCONV_STORE_TILE(stage ^ 1)
         __syncthreads();
     }
 #undef TAPCONV_LOAD_TILE
@@ -346,6 +350,154 @@ int launch_direct(const spaa_tapconv_t& d, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Coalesced thin-N variant (Cout <= 4, Cin a power of two in 4..256): conv6 (32->3), the input-gradients of conv1 /
+// conv1_s (32->3) and of the ResNet stem (64->3).  The L = Cin/4 lanes of a pixel each own one channel quad, so a
+// wave reads whole 128-B lines (64/L neighbouring pixels per load instruction); every lane carries P pixels so that a
+// tap's weights (three ds_read_b128 from LDS, broadcast across the pixels of the wave) feed P*12 FMAs; the L partial
+// sums of a pixel are combined with xor-shuffles.  HBM/L1-bound: reads the input once, writes 16 B per pixel.
+template <int P>
+__global__ __launch_bounds__(256) void thinconv_kernel(const spaa_tapconv_t p) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];  // [ntaps][4][Cin] weights, then int2 taps
+    const spaa_tapclass_t cl = p.cls[blockIdx.y];
+    const int Cin = p.Cin;
+    const int L = Cin >> 2;
+    const int tid = threadIdx.x;
+    const float* __restrict__ W = p.weights + cl.w_off;
+    for (int i = tid; i < cl.ntaps * 4 * Cin; i += 256) {
+        const int c = i % Cin;
+        const int r = i / Cin;
+        s_w[i] = W[(size_t)(r & 3) * cl.Kpad + (r >> 2) * Cin + c];
+    }
+    int2* s_t = reinterpret_cast<int2*>(s_w + cl.ntaps * 4 * Cin);
+    for (int i = tid; i < cl.ntaps; i += 256)
+        s_t[i] = make_int2(p.taps[2 * (cl.tap_off + i)], p.taps[2 * (cl.tap_off + i) + 1]);
+    __syncthreads();
+
+    const int cq = tid & (L - 1);
+    const int ps = tid / L;
+    const int PB = 256 / L;
+    const int HWm = p.Hm * p.Wm;
+    const int M = p.B * HWm;
+
+    const uint32_t in_bytes = (uint32_t)p.B * (uint32_t)(p.Hin * p.Win) * (uint32_t)p.in_cstride * 4u;
+    const uint64_t in_addr = reinterpret_cast<uint64_t>(p.in);
+    const uint32_t in_lo = __builtin_amdgcn_readfirstlane((uint32_t)in_addr);
+    const uint32_t in_hi = __builtin_amdgcn_readfirstlane((uint32_t)(in_addr >> 32));
+    const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)in_hi << 32) | in_lo), 0,
+                                                            (int)__builtin_amdgcn_readfirstlane(in_bytes), 0x00020000);
+    // XCD-aware order: the workgroups of one XCD (blockIdx.x % 8) take a contiguous range of pixel blocks, so the rows
+    // above / below a block (the other taps) are served by that XCD's L2 instead of being fetched 3x from HBM
+    int blk;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    int iy0[P], ix0[P], pix0[P], mm[P];
+    float acc[P][4];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int m = (blk * P + j) * PB + ps;
+        mm[j] = m;
+        const bool ok = m < M;
+        const int q = ok ? m : 0;
+        const int b = q / HWm;
+        const int r = q - b * HWm;
+        const int y = r / p.Wm;
+        const int x = r - y * p.Wm;
+        iy0[j] = ok ? y * p.s_in : -(1 << 28);
+        ix0[j] = x * p.s_in;
+        pix0[j] = (b * p.Hin + y * p.s_in) * p.Win + x * p.s_in;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[j][n] = 0.f;
+    }
+    const int cbyte = (p.in_coff + 4 * cq) * 4;
+    for (int t = 0; t < cl.ntaps; ++t) {
+        const int2 d = s_t[t];
+        const int doff = d.x * p.Win + d.y;
+        const float* wp = s_w + (size_t)t * 4 * Cin + 4 * cq;
+        const f4 w0 = *reinterpret_cast<const f4*>(wp);
+        const f4 w1 = *reinterpret_cast<const f4*>(wp + Cin);
+        const f4 w2 = *reinterpret_cast<const f4*>(wp + 2 * Cin);
+        const f4 w3 = *reinterpret_cast<const f4*>(wp + 3 * Cin);
+        f4 a[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int iy = iy0[j] + d.x, ix = ix0[j] + d.y;
+            const bool v = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            const int off = (pix0[j] + doff) * (p.in_cstride * 4) + cbyte;
+            a[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, v ? off : (int)0x80000000, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            acc[j][0] = fmaf(a[j].x, w0.x, fmaf(a[j].y, w0.y, fmaf(a[j].z, w0.z, fmaf(a[j].w, w0.w, acc[j][0]))));
+            acc[j][1] = fmaf(a[j].x, w1.x, fmaf(a[j].y, w1.y, fmaf(a[j].z, w1.z, fmaf(a[j].w, w1.w, acc[j][1]))));
+            acc[j][2] = fmaf(a[j].x, w2.x, fmaf(a[j].y, w2.y, fmaf(a[j].z, w2.z, fmaf(a[j].w, w2.w, acc[j][2]))));
+            acc[j][3] = fmaf(a[j].x, w3.x, fmaf(a[j].y, w3.y, fmaf(a[j].z, w3.z, fmaf(a[j].w, w3.w, acc[j][3]))));
+        }
+    }
+    // combine the L channel-quad partial sums of each pixel (lanes of one pixel are contiguous, L is a power of two)
+    for (int off = L >> 1; off > 0; off >>= 1) {
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[j][n] += __shfl_xor(acc[j][n], off, 64);
+    }
+    // after the butterfly every lane of a pixel holds the full sums: lane cq finishes channel cq (cq + L, ...), so the
+    // L lanes of a pixel write neighbouring floats instead of one lane writing them all
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int m = mm[j];
+        if (m >= M) continue;
+        const int b = m / HWm;
+        const int r = m - b * HWm;
+        const int y = r / p.Wm;
+        const int x = r - y * p.Wm;
+        const int oy = cl.oy0 + y * p.s_out, ox = cl.ox0 + x * p.s_out;
+        if (oy >= p.Hout || ox >= p.Wout) continue;
+        const size_t o = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+        for (int n = cq; n < p.Cout; n += L) {
+            float v = (n == 0 ? acc[j][0] : n == 1 ? acc[j][1] : n == 2 ? acc[j][2] : acc[j][3]) +
+                      (p.bias != nullptr ? p.bias[n] : 0.f);
+            if (p.add != nullptr) v += p.add[o * p.add_cstride + p.add_coff + n];
+            if (p.act == SPAA_ACT_RELU) {
+                v = fmaxf(v, 0.f);
+            } else if (p.act == SPAA_ACT_RELU_CLAMP1) {
+                v = fmaxf(v, 0.f);
+                if (p.aux_out != nullptr) p.aux_out[o * p.out_cstride + p.out_coff + n] = v;
+                v = fminf(v, 1.f);
+            } else if (p.act == SPAA_ACT_LEAKY01) {
+                v = v > 0.f ? v : 0.1f * v;
+            }
+            if (p.gate != nullptr) {
+                const float g = p.gate[o * p.gate_cstride + p.gate_coff + n];
+                const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (g > 0.f && g <= 1.f) : (g > 0.f);
+                v = pass ? v : 0.f;
+            }
+            p.out[o * p.out_cstride + p.out_coff + n] = v;
+            if (p.gate2 != nullptr) {
+                const float g2 = p.gate2[o * p.gate2_cstride + p.gate2_coff + n];
+                p.aux_out[o * p.out_cstride + p.out_coff + n] = (g2 > 0.f) ? v : 0.f;
+            }
+        }
+    }
+}
+
+int launch_thin(const spaa_tapconv_t& d, hipStream_t stream) {
+    constexpr int P = 4;
+    if (d.Cout > 4 || d.Cin < 4 || d.Cin > 256 || (d.Cin & (d.Cin - 1))) return hipErrorInvalidValue;
+    int maxtaps = 0;
+    for (int c = 0; c < d.nclass; ++c) maxtaps = d.cls[c].ntaps > maxtaps ? d.cls[c].ntaps : maxtaps;
+    const size_t smem = (size_t)maxtaps * (4 * d.Cin * sizeof(float) + sizeof(int2)) + 16;
+    if (smem > 64 * 1024) return hipErrorInvalidValue;
+    const int L = d.Cin / 4, PB = 256 / L;
+    const int64_t M = (int64_t)d.B * d.Hm * d.Wm;
+    dim3 grid((unsigned)((M + (int64_t)PB * P - 1) / ((int64_t)PB * P)), d.nclass, 1);
+    hipLaunchKernelGGL((thinconv_kernel<P>), grid, dim3(256), smem, stream, d);
+    return (int)hipGetLastError();
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch(const spaa_tapconv_t& d, hipStream_t stream) {
     const int64_t M = (int64_t)d.B * d.Hm * d.Wm;
@@ -404,6 +556,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         case 8: return launch<128, 64, 32, 64>(d, stream);
         case 9: return launch_direct<4>(d, stream);
         case 10: return launch_direct<32>(d, stream);
+        case 11: return launch_thin(d, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -20,7 +20,7 @@ def main():
     torch.cuda.synchronize()
     res = {}
     names = {}
-    for tile in range(1, 11):
+    for tile in range(1, 12):
         convplan.FORCE_TILE = tile
         st.iteration(**hp)  # warm (sets the LDS attribute of a new instantiation)
         convplan.PROFILE = []
