@@ -56,6 +56,9 @@ typedef struct {
     int32_t Hout, Wout, Cout, out_cstride, out_coff;
     int32_t B, Hm, Wm, s_in, s_out;
     const float* weights; /* packed, see spaa_tapclass_t.w_off; rows padded to a multiple of 128 */
+    const uint16_t* w_split; /* optional: the same weights as three bf16 planes per class, [3][Npad][Kpad] with
+                                w == h + m + l exactly (tiles 12-14: fp32 emulated on the bf16 matrix cores); class c
+                                starts at element 3 * cls[c].w_off */
     const int32_t* taps;  /* device array of (dy, dx) pairs */
     const float* bias;    /* [Cout] or NULL */
     const float* add;     /* residual, indexed like `out`, or NULL */

@@ -29,7 +29,7 @@ class TapConv(C.Structure):
         ('out', C.c_void_p), ('Hout', C.c_int32), ('Wout', C.c_int32), ('Cout', C.c_int32), ('out_cstride', C.c_int32),
         ('out_coff', C.c_int32),
         ('B', C.c_int32), ('Hm', C.c_int32), ('Wm', C.c_int32), ('s_in', C.c_int32), ('s_out', C.c_int32),
-        ('weights', C.c_void_p), ('taps', C.c_void_p), ('bias', C.c_void_p),
+        ('weights', C.c_void_p), ('w_split', C.c_void_p), ('taps', C.c_void_p), ('bias', C.c_void_p),
         ('add', C.c_void_p), ('add_cstride', C.c_int32), ('add_coff', C.c_int32),
         ('gate', C.c_void_p), ('gate_cstride', C.c_int32), ('gate_coff', C.c_int32), ('gate_mode', C.c_int32),
         ('act', C.c_int32), ('tile', C.c_int32),

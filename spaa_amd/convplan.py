@@ -21,7 +21,10 @@ NPAD = 128
 PROFILE = None  # set to a list by bench.py to time every tapconv launch with HIP events
 FORCE_TILE = 0  # tools/autotune.py: force one workgroup tile for every launch
 TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32', 6: '64x64', 7: '64x128', 8: '128x64b',
-              9: 'direct4', 10: 'direct32', 11: 'thin4'}
+              9: 'direct4', 10: 'direct32', 11: 'thin4', 12: 'x6_64x64', 13: 'x6_128x32', 14: 'x6_32x128',
+              15: 'x6v2_128x64g3', 16: 'x6v2_128x64g2', 17: 'x6v2_128x128g1', 18: 'x6v2_64x64g3', 19: 'x6v2_64x128g2',
+              20: 'x6v3_128x64g3', 21: 'x6v3_128x64g2', 22: 'x6v3_64x64g3', 23: 'x6v3_128x128g1', 24: 'x6v3_64x128g2'}
+ENABLE_X6 = True  # build the split-bf16 weight planes (needed by tiles 12-14)
 
 
 def _load_tune():
@@ -79,6 +82,17 @@ class ConvPlan:
             w_off += npad * kpad
         self.classes_host = classes
         self.weights = torch.cat(w_chunks).to(device) if w_off > 0 else torch.zeros(4, device=device)
+        # the same weights as three bf16 planes with w == h + m + l exactly (tapconv_x6.hip)
+        self.w_split = None
+        if ENABLE_X6 and w_off > 0:
+            parts = []
+            for wp in w_chunks:
+                h = wp.to(torch.bfloat16)
+                r1 = wp - h.float()
+                m = r1.to(torch.bfloat16)
+                lo = (r1 - m.float()).to(torch.bfloat16)
+                parts.append(torch.stack([h, m, lo]).view(torch.int16).reshape(-1))
+            self.w_split = torch.cat(parts).to(device)
         taps = torch.tensor(tap_list if tap_list else [(0, 0)], dtype=torch.int32).reshape(-1)
         self.taps = taps.to(device)
         self.bias = bias.detach().float().contiguous().to(device) if bias is not None else None
@@ -104,6 +118,7 @@ class ConvPlan:
             d.Hm, d.Wm = (hout + self.s_out - 1) // self.s_out, (wout + self.s_out - 1) // self.s_out
         d.s_in, d.s_out = self.s_in, self.s_out
         d.weights, d.taps = self.weights.data_ptr(), self.taps.data_ptr()
+        d.w_split = self.w_split.data_ptr() if self.w_split is not None else None
         d.bias = self.bias.data_ptr() if self.bias is not None else None
         if add is not None:
             assert add.shape[:3] == out.shape[:3] and add_coff + self.cout <= add.shape[3]

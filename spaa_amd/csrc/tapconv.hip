@@ -17,6 +17,8 @@
 #include <stdint.h>
 #include "../../include/spaa_hip.h"
 
+int spaa_launch_tapconv_x6(const spaa_tapconv_t& d, int tile, hipStream_t stream);  // tapconv_x6.hip
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -557,6 +559,19 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         case 9: return launch_direct<4>(d, stream);
         case 10: return launch_direct<32>(d, stream);
         case 11: return launch_thin(d, stream);
+        case 12:
+        case 13:
+        case 14:
+        case 15:
+        case 16:
+        case 17:
+        case 18:
+        case 19:
+        case 20:
+        case 21:
+        case 22:
+        case 23:
+        case 24: return spaa_launch_tapconv_x6(d, tile, stream);
         default: return hipErrorInvalidValue;
     }
 }

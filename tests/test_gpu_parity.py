@@ -139,6 +139,40 @@ def test_directconv_thin_layers(hip, tile):
         cp.FORCE_TILE = 0
 
 
+@pytest.mark.parametrize('tile', [12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
+def test_tapconv_x6_is_fp32_accurate(hip, tile):
+    """fp32 emulated on the bf16 matrix cores (exact 3-way operand split, 6 of 9 partial products, separate
+    accumulators): the error against an fp64 reference must not exceed that of the exact-fp32 MFMA kernel."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(21)
+    try:
+        for ci, co, k, s, p, h, w, b in [(128, 256, 3, 1, 1, 16, 16, 3), (64, 96, 3, 2, 1, 17, 19, 2), (32, 64, 1, 1, 0, 24, 24, 2),
+                                         (6, 32, 3, 2, 1, 16, 24, 2), (256, 128, 3, 1, 1, 9, 17, 2), (3, 64, 7, 2, 3, 40, 40, 2)]:
+            x = torch.relu(torch.randn(b, ci, h, w)) * (1 + 3 * torch.rand(b, ci, 1, 1))   # activation-like, wide range
+            wt = torch.randn(co, ci, k, k) / (ci * k * k) ** 0.5
+            bias = torch.randn(co)
+            truth = F.conv2d(x.double(), wt.double(), bias.double(), s, p)
+            gy = torch.randn(b, co, truth.shape[2], truth.shape[3])
+            g_truth = torch.nn.grad.conv2d_input(x.shape, wt.double(), gy.double(), s, p)
+            fplan, dplan = cp.conv_fwd_plan(wt, bias, s, p, DEV), cp.conv_dgrad_plan(wt, s, p, DEV)
+            errs = {}
+            for t in (6, tile):
+                out = torch.zeros(b, truth.shape[2], truth.shape[3], (co + 3) // 4 * 4, device=DEV)
+                gx = torch.zeros(b, h, w, (ci + 3) // 4 * 4, device=DEV)
+                cp.FORCE_TILE = t
+                fplan.run(nhwc(x, fplan.cin_p).to(DEV), out)
+                dplan.run(nhwc(gy, dplan.cin_p).to(DEV), gx)
+                cp.FORCE_TILE = 0
+                e_f = (nchw(out.cpu(), co).double() - truth).abs().max().item() / truth.abs().max().item()
+                e_d = (nchw(gx.cpu(), ci).double() - g_truth).abs().max().item() / g_truth.abs().max().item()
+                errs[t] = (e_f, e_d)
+            print(f'ci={ci} co={co} k={k} s={s}: rel err vs fp64  fp32-MFMA fwd {errs[6][0]:.1e} dgrad {errs[6][1]:.1e} | '
+                  f'bf16x6 fwd {errs[tile][0]:.1e} dgrad {errs[tile][1]:.1e}')
+            assert errs[tile][0] < max(2 * errs[6][0], 3e-7) and errs[tile][1] < max(2 * errs[6][1], 3e-7)
+    finally:
+        cp.FORCE_TILE = 0
+
+
 def test_tapconv_epilogues(hip):
     cp, lib = hip['cp'], hip['lib']
     torch.manual_seed(3)
