@@ -104,6 +104,16 @@ int spaa_warp_bwd(const float* g_xw, const float* g_xs, const float* x, const fl
                   const float* s, float* g_x, int B, int Hp, int Wp, int Hc, int Wc, int clamp01,
                   spaa_stream_t stream);
 
+/* Deterministic form of the same backward: the grid is constant during an attack, so the scatter is transposed once.
+ * spaa_warp_taps: per (camera pixel, tap) the projector pixel index (0x7fffffff = outside) and bilinear weight,
+ * src/wgt: [Hc*Wc*4].  The host sorts the entries by source pixel (stable) into `order` (entry ids) and `off`
+ * ([Hp*Wp+1] list boundaries); spaa_warp_bwd_gather then sums each projector pixel's list in fixed order (no atomics,
+ * no zeroing, run-to-run reproducible). */
+int spaa_warp_taps(const float* grid, int Hp, int Wp, int Hc, int Wc, int32_t* src, float* wgt, spaa_stream_t stream);
+int spaa_warp_bwd_gather(const float* g_xw, const float* g_xs, const float* x, const float* mask, const float* s,
+                         const int32_t* off, const int32_t* order, const float* wgt, float* g_x, int B, int Hp, int Wp,
+                         int Hc, int Wc, int clamp01, spaa_stream_t stream);
+
 /* ---- stealthiness losses (projector_based_attack.py:275-287; perc_al/differential_color_functions.py) ----- */
 /* rgb [B,H,W,4] -> lab [B,H,W,4]  (rgb2lab_diff :39-64) */
 int spaa_rgb2lab(const float* rgb, float* lab, int npix, spaa_stream_t stream);

@@ -51,6 +51,8 @@ _SIGNATURES = {
     'spaa_warp_finish_grid': [_p, _p, _p, _i, _p],
     'spaa_warp_fwd': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'spaa_warp_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'spaa_warp_taps': [_p, _i, _i, _i, _i, _p, _p, _p],
+    'spaa_warp_bwd_gather': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'spaa_rgb2lab': [_p, _p, _i, _p],
     'spaa_ciede2000': [_p, _p, _p, _i, _p],
     'spaa_stealth_loss_fwd_bwd': [_p, _p, _p, _f, _f, _f, _p, _p, _p, _i, _i, _p],

@@ -197,6 +197,64 @@ __global__ void warp_bwd_kernel(const float4* __restrict__ g_xw, const float4* _
     tap(bl.y0 + 1, bl.x0 + 1, bl.se);
 }
 
+// Per (camera pixel, bilinear tap): the projector pixel it reads (or -1) and its weight.  The grid is constant during an
+// attack, so the transposed (projector pixel -> list of contributions) structure is built ONCE from this table
+// (stable sort by source index; spaa_amd/models.py) and the backward pass becomes a deterministic gather.
+__global__ void warp_taps_kernel(const float4* __restrict__ grid, int Hp, int Wp, int HWc, int32_t* __restrict__ src,
+                                 float* __restrict__ wgt) {
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= HWc) return;
+    const float4 g = grid[pix];
+    const Bilinear bl = bilinear_setup(g.x, g.y, Wp, Hp);
+    const int ys[4] = {bl.y0, bl.y0, bl.y0 + 1, bl.y0 + 1};
+    const int xs[4] = {bl.x0, bl.x0 + 1, bl.x0, bl.x0 + 1};
+    const float ws[4] = {bl.nw, bl.ne, bl.sw, bl.se};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const bool ok = (unsigned)ys[t] < (unsigned)Hp && (unsigned)xs[t] < (unsigned)Wp;
+        src[4 * pix + t] = ok ? ys[t] * Wp + xs[t] : 0x7fffffff;
+        wgt[4 * pix + t] = ok ? ws[t] : 0.f;
+    }
+}
+
+// g_x[b, s] = clampgate(x) * sum_{e in list(s)} w_e * ((g_xw + g_xs * scene) * mask)[b, campix_e]
+// order[e] = 4*campix + tap (entries sorted by source pixel, ties in camera-pixel order), off[s]..off[s+1] the list of s.
+__global__ void warp_bwd_gather_kernel(const float4* __restrict__ g_xw, const float4* __restrict__ g_xs,
+                                       const float4* __restrict__ x, const float* __restrict__ mask,
+                                       const float4* __restrict__ s, const int32_t* __restrict__ off,
+                                       const int32_t* __restrict__ order, const float* __restrict__ wgt,
+                                       float4* __restrict__ g_x, int B, int HWp, int HWc, int clamp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * HWp) return;
+    const int b = idx / HWp, sp = idx - b * HWp;
+    const int e0 = off[sp], e1 = off[sp + 1];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int e = e0; e < e1; ++e) {
+        const int ent = order[e];
+        const int cp = ent >> 2;
+        const size_t ci = (size_t)b * HWc + cp;
+        float4 g = g_xw[ci];
+        if (g_xs != nullptr) {
+            const float4 gs = g_xs[ci];
+            const float4 sv = s[ci];
+            g.x += gs.x * sv.x;
+            g.y += gs.y * sv.y;
+            g.z += gs.z * sv.z;
+        }
+        const float w = wgt[ent] * ((mask != nullptr) ? mask[cp] : 1.f);
+        a0 += g.x * w;
+        a1 += g.y * w;
+        a2 += g.z * w;
+    }
+    if (clamp) {
+        const float4 v = x[idx];
+        a0 = (v.x >= 0.f && v.x <= 1.f) ? a0 : 0.f;
+        a1 = (v.y >= 0.f && v.y <= 1.f) ? a1 : 0.f;
+        a2 = (v.z >= 0.f && v.z <= 1.f) ? a2 : 0.f;
+    }
+    g_x[idx] = make_float4(a0, a1, a2, 0.f);
+}
+
 __global__ void nchw_to_nhwc4_kernel(const float* __restrict__ src, float4* __restrict__ dst, int B, int HW,
                                      int clamp) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -270,6 +328,26 @@ int spaa_warp_bwd(const float* g_xw, const float* g_xs, const float* x, const fl
     hipLaunchKernelGGL(warp_bwd_kernel, dim3(blocks_for((int64_t)B * Hc * Wc, 256)), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)g_xw, (const float4*)g_xs, (const float4*)x,
                        (const float4*)grid, mask, (const float4*)s, g_x, B, Hp, Wp, Hc * Wc, clamp);
+    return (int)hipGetLastError();
+}
+
+int spaa_warp_taps(const float* grid, int Hp, int Wp, int Hc, int Wc, int32_t* src, float* wgt, spaa_stream_t stream) {
+    if (!grid || !src || !wgt || Hp < 1 || Wp < 1 || Hc < 1 || Wc < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(warp_taps_kernel, dim3(blocks_for((int64_t)Hc * Wc, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)grid, Hp, Wp, Hc * Wc, src, wgt);
+    return (int)hipGetLastError();
+}
+
+int spaa_warp_bwd_gather(const float* g_xw, const float* g_xs, const float* x, const float* mask, const float* s,
+                         const int32_t* off, const int32_t* order, const float* wgt, float* g_x, int B, int Hp, int Wp,
+                         int Hc, int Wc, int clamp, spaa_stream_t stream) {
+    if (!g_xw || !x || !off || !order || !wgt || !g_x || (g_xs && !s) || B < 1 || Hp < 1 || Wp < 1 || Hc < 1 || Wc < 1)
+        return hipErrorInvalidValue;
+    if ((int64_t)B * Hp * Wp >= ((int64_t)1 << 31) || (int64_t)B * Hc * Wc >= ((int64_t)1 << 31))
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(warp_bwd_gather_kernel, dim3(blocks_for((int64_t)B * Hp * Wp, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)g_xw, (const float4*)g_xs, (const float4*)x, mask,
+                       (const float4*)s, off, order, wgt, (float4*)g_x, B, Hp * Wp, Hc * Wc, clamp);
     return (int)hipGetLastError();
 }
 

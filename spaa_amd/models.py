@@ -19,6 +19,12 @@ from . import convplan as cp
 from .synthetic import uniform_ctrl_pts
 
 
+def C_ptr(t):
+    """Raw device pointer of a non-float tensor (index arrays)."""
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
 def _strip(sd):
     out = {}
     for k, v in sd.items():
@@ -254,6 +260,17 @@ class PCNetEngine:
         self.mask = pcnet.mask.detach().float().contiguous().view(-1).to(dev) if pcnet.use_mask else None
         if self.mask is not None:
             assert self.mask.numel() == self.Hc * self.Wc
+        # transposed sampling structure for the deterministic backward of grid_sample (index plumbing, once per model)
+        hwc, hwp = self.Hc * self.Wc, self.Hp * self.Wp
+        tap_src = torch.zeros(hwc * 4, dtype=torch.int32, device=dev)
+        self.tap_w = torch.zeros(hwc * 4, device=dev)
+        _lib.call('spaa_warp_taps', _lib.ptr(self.grid), self.Hp, self.Wp, self.Hc, self.Wc,
+                  C_ptr(tap_src), _lib.ptr(self.tap_w))
+        order = torch.argsort(tap_src, stable=True)
+        bounds = torch.searchsorted(tap_src[order].to(torch.int64),
+                                    torch.arange(hwp + 1, dtype=torch.int64, device=dev))
+        self.tap_order = order.to(torch.int32).contiguous()
+        self.tap_off = bounds.to(torch.int32).contiguous()
         f, d = {}, {}
         for nm, st in (('conv1', 2), ('conv2', 2), ('conv3', 1), ('conv4', 1), ('conv5', 1), ('conv1_s', 2),
                        ('conv2_s', 2), ('conv3_s', 1), ('conv4_s', 1), ('conv6', 1), ('skipConv3', 1)):
@@ -362,10 +379,9 @@ class PCNetEngine:
 
     def warp_backward(self, g_xw, g_xs=None):
         g = self.g
-        _lib.call('spaa_zero', _lib.ptr(g['x']), g['x'].numel() * 4)
-        _lib.call('spaa_warp_bwd', _lib.ptr(g_xw), _lib.ptr(g_xs), _lib.ptr(self._x), _lib.ptr(self.grid),
-                  _lib.ptr(self.mask), _lib.ptr(self.scene) if g_xs is not None else None, _lib.ptr(g['x']), self.B,
-                  self.Hp, self.Wp, self.Hc, self.Wc, self._clamp)
+        _lib.call('spaa_warp_bwd_gather', _lib.ptr(g_xw), _lib.ptr(g_xs), _lib.ptr(self._x), _lib.ptr(self.mask),
+                  _lib.ptr(self.scene) if g_xs is not None else None, C_ptr(self.tap_off), C_ptr(self.tap_order),
+                  _lib.ptr(self.tap_w), _lib.ptr(g['x']), self.B, self.Hp, self.Wp, self.Hc, self.Wc, self._clamp)
         return g['x']
 
     def flops_fwd(self):
