@@ -145,6 +145,37 @@ def shading_net(sd, x, s_list, return_all=False):
     return y
 
 
+def compennet_forward(sd, x, s, prefix='compen_net.'):
+    """CompenNet.forward (models.py:74-94)."""
+    p = _sd(sd, prefix)
+
+    def conv(name, t, stride=1, pad=1):
+        return F.conv2d(t, p[name + '.weight'], p[name + '.bias'], stride, pad)
+
+    res1_s = F.relu(conv('conv1_s', s, 2))
+    res2_s = F.relu(conv('conv2_s', res1_s, 2))
+    res3_s = F.relu(conv('conv3_s', res2_s))
+    res4_s = F.relu(conv('conv4_s', res3_s))
+    r = F.relu(conv('skipConv1.0', x))
+    r = F.relu(conv('skipConv1.2', r))
+    res1 = F.relu(conv('skipConv1.4', r))
+    x = F.relu(conv('conv1', x, 2) + res1_s)
+    res2 = conv('skipConv2', x, 1, 0)
+    x = F.relu(conv('conv2', x, 2) + res2_s)
+    res3 = conv('skipConv3', x, 1, 0)
+    x = F.relu(conv('conv3', x) + res3_s)
+    x = F.relu(conv('conv4', x) + res4_s)
+    x = F.relu(conv('conv5', x) + res3)
+    x = F.relu(F.conv_transpose2d(x, p['transConv1.weight'], p['transConv1.bias'], 2, 0) + res2)
+    x = F.relu(F.conv_transpose2d(x, p['transConv2.weight'], p['transConv2.bias'], 2, 0))
+    return torch.clamp(F.relu(conv('conv6', x) + res1), max=1)
+
+
+def compennet_pp_forward(sd, x, s, out_size):
+    """CompenNetPlusplus.forward (models.py:204-212): warp x and s, then CompenNet."""
+    return compennet_forward(sd, warp(sd, x, out_size), warp(sd, s, out_size))
+
+
 def pcnet_forward(sd, x, s, per_batch_grid=False):
     """PCNet.forward (models.py:335-346), use_mask=True, use_rough=True."""
     full = _sd(sd, '')

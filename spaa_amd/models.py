@@ -445,3 +445,116 @@ class _WarpFn(torch.autograd.Function):
         _lib.call('spaa_warp_bwd', _lib.ptr(g4), None, _lib.ptr(h.x4), _lib.ptr(h.grid), None, None, _lib.ptr(gx), b,
                   hp, wp, g4.shape[1], g4.shape[2], 0)
         return to_nchw(gx), None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CompenNet / CompenNet++ (models.py:11-94, :188-212): forward only — used once, after the PerC-AL loop, to turn the
+# adversarial camera image into a projector image (projector_based_attack.py:357).
+class CompenNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.name = 'CompenNet'
+        self.conv1, self.conv2, self.conv3 = _conv(3, 32, 3), _conv(32, 64, 3), _conv(64, 128, 3)
+        self.conv4, self.conv5 = _conv(128, 256, 3), _conv(256, 128, 3)
+        self.conv1_s, self.conv2_s, self.conv3_s = _conv(3, 32, 3), _conv(32, 64, 3), _conv(64, 128, 3)
+        self.conv4_s = _conv(128, 256, 3)
+        self.transConv1, self.transConv2 = _deconv(128, 64, 2), _deconv(64, 32, 2)
+        self.conv6 = _conv(32, 3, 3)
+        self.skipConv1 = nn.Sequential(_conv(3, 3, 3), _Identity(), _conv(3, 3, 3), _Identity(), _conv(3, 3, 3),
+                                       _Identity())
+        self.skipConv2 = _conv(32, 64, 1)
+        self.skipConv3 = _conv(64, 128, 1)
+        for n in ('res1_s', 'res2_s', 'res3_s', 'res4_s'):
+            self.register_buffer(n, None)
+        self._plans = None
+
+    def plans(self):
+        dev = self.conv1.weight.device
+        if self._plans is None or self._plans[0] != dev:
+            f = {}
+            for nm, st, pad in (('conv1', 2, 1), ('conv2', 2, 1), ('conv3', 1, 1), ('conv4', 1, 1), ('conv5', 1, 1),
+                                ('conv1_s', 2, 1), ('conv2_s', 2, 1), ('conv3_s', 1, 1), ('conv4_s', 1, 1),
+                                ('conv6', 1, 1), ('skipConv2', 1, 0), ('skipConv3', 1, 0)):
+                m = getattr(self, nm)
+                f[nm] = cp.conv_fwd_plan(m.weight, m.bias, st, pad, dev, 'compen.' + nm)
+            for i, nm in ((0, 'skip1a'), (2, 'skip1b'), (4, 'skip1c')):
+                f[nm] = cp.conv_fwd_plan(self.skipConv1[i].weight, self.skipConv1[i].bias, 1, 1, dev, 'compen.' + nm)
+            f['transConv1'] = cp.deconv_fwd_plan(self.transConv1.weight, self.transConv1.bias, 2, 0, dev, 'compen.tc1')
+            f['transConv2'] = cp.deconv_fwd_plan(self.transConv2.weight, self.transConv2.bias, 2, 0, dev, 'compen.tc2')
+            self._plans = (dev, f)
+        return self._plans[1]
+
+    def forward_nhwc4(self, x4, s4):
+        """models.py:74-94 on NHWC4 tensors [B,H,W,4] (H, W divisible by 4)."""
+        f = self.plans()
+        b, h, w, _ = x4.shape
+        dev = x4.device
+        R, N = _lib.ACT_RELU, _lib.ACT_NONE
+
+        def z(*shape):
+            return torch.zeros(*shape, device=dev)
+
+        s1, s2 = z(b, h // 2, w // 2, 32), z(b, h // 4, w // 4, 64)
+        s3, s4_ = z(b, h // 4, w // 4, 128), z(b, h // 4, w // 4, 256)
+        f['conv1_s'].run(s4, s1, act=R)
+        f['conv2_s'].run(s1, s2, act=R)
+        f['conv3_s'].run(s2, s3, act=R)
+        f['conv4_s'].run(s3, s4_, act=R)
+        t0, t1, r1 = z(b, h, w, 4), z(b, h, w, 4), z(b, h, w, 4)
+        f['skip1a'].run(x4, t0, act=R)
+        f['skip1b'].run(t0, t1, act=R)
+        f['skip1c'].run(t1, r1, act=R)
+        x1, r2, x2, r3 = z(b, h // 2, w // 2, 32), z(b, h // 2, w // 2, 64), z(b, h // 4, w // 4, 64), z(b, h // 4, w // 4, 128)
+        f['conv1'].run(x4, x1, add=s1, act=R)
+        f['skipConv2'].run(x1, r2, act=N)
+        f['conv2'].run(x1, x2, add=s2, act=R)
+        f['skipConv3'].run(x2, r3, act=N)
+        x3, x4_, x5 = z(b, h // 4, w // 4, 128), z(b, h // 4, w // 4, 256), z(b, h // 4, w // 4, 128)
+        f['conv3'].run(x2, x3, add=s3, act=R)
+        f['conv4'].run(x3, x4_, add=s4_, act=R)
+        f['conv5'].run(x4_, x5, add=r3, act=R)
+        x6, x7, y = z(b, h // 2, w // 2, 64), z(b, h, w, 32), z(b, h, w, 4)
+        f['transConv1'].run(x5, x6, add=r2, act=R)
+        f['transConv2'].run(x6, x7, act=R)
+        f['conv6'].run(x7, y, add=r1, act=_lib.ACT_RELU_CLAMP1)
+        return y
+
+    def forward(self, x, s):
+        b = x.shape[0]
+        return to_nchw(self.forward_nhwc4(to_nhwc4(x), to_nhwc4(s.expand(b, -1, -1, -1) if s.shape[0] != b else s)))
+
+
+class CompenNetPlusplus(nn.Module):
+    """models.py:188-212: warp both the image and the surface with WarpingNet, then CompenNet."""
+
+    def __init__(self, warping_net=None, compen_net=None):
+        super().__init__()
+        self.name = 'CompenNet++'
+
+        def unwrap(m):
+            return copy.deepcopy(m.module if hasattr(m, 'module') else m)
+
+        self.warping_net = unwrap(warping_net) if warping_net is not None else WarpingNet()
+        self.compen_net = unwrap(compen_net) if compen_net is not None else CompenNet()
+        self._grid = None
+
+    def load_state_dict(self, state_dict, strict=True):
+        self._grid = None
+        self.compen_net._plans = None
+        return super().load_state_dict(_strip(state_dict), strict)
+
+    def forward(self, x, s):
+        wn = self.warping_net
+        b = x.shape[0]
+        x4 = to_nhwc4(x)
+        s4 = to_nhwc4(s.expand(b, -1, -1, -1) if s.shape[0] != b else s)
+        if self._grid is None or self._grid[0] != tuple(x.shape[-2:]):
+            self._grid = (tuple(x.shape[-2:]), wn.build_fine_grid(x.shape[-2:]))
+        grid = self._grid[1]
+        ho, wo = wn.out_size
+        hi, wi = x.shape[-2:]
+        xw = torch.zeros(b, ho, wo, 4, device=x4.device)
+        sw = torch.zeros(b, ho, wo, 4, device=x4.device)
+        for src, dst in ((x4, xw), (s4, sw)):
+            _lib.call('spaa_warp_fwd', _lib.ptr(src), _lib.ptr(grid), None, None, _lib.ptr(dst), None, b, hi, wi, ho, wo, 0)
+        return to_nchw(self.compen_net.forward_nhwc4(xw, sw))

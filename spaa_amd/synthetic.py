@@ -113,6 +113,26 @@ def pcnet_state_dict(seed=0, cam_sz=(256, 256), mask='ones', affine=(0.9, 0.02, 
     return sd
 
 
+def compennet_pp_state_dict(seed=5, out_size=(256, 256)):
+    """Random-init CompenNet++ (warping_net.* as in PCNet, compen_net.* per models.py:11-59)."""
+    rng = np.random.default_rng(seed)
+    base = pcnet_state_dict(seed, cam_sz=out_size)
+    sd = {k: v for k, v in base.items() if k.startswith('warping_net.')}
+    cn = 'compen_net.'
+    for name, (cout, cin, k) in {
+        'conv1': (32, 3, 3), 'conv2': (64, 32, 3), 'conv3': (128, 64, 3), 'conv4': (256, 128, 3), 'conv5': (128, 256, 3),
+        'conv1_s': (32, 3, 3), 'conv2_s': (64, 32, 3), 'conv3_s': (128, 64, 3), 'conv4_s': (256, 128, 3),
+        'conv6': (3, 32, 3), 'skipConv1.0': (3, 3, 3), 'skipConv1.2': (3, 3, 3), 'skipConv1.4': (3, 3, 3),
+        'skipConv2': (64, 32, 1), 'skipConv3': (128, 64, 1),
+    }.items():
+        wgt, b = _conv_w(rng, cout, cin, k)
+        sd[cn + name + '.weight'], sd[cn + name + '.bias'] = wgt, b
+    for name, (cin, cout, k) in {'transConv1': (128, 64, 2), 'transConv2': (64, 32, 2)}.items():
+        wgt, b = _deconv_w(rng, cin, cout, k)
+        sd[cn + name + '.weight'], sd[cn + name + '.bias'] = wgt, b
+    return sd
+
+
 def _bn(rng, c, sd, prefix):
     sd[prefix + '.weight'] = _t(rng.uniform(0.5, 1.5, (c,)))
     sd[prefix + '.bias'] = _t(rng.uniform(-0.2, 0.2, (c,)))

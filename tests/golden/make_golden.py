@@ -8,6 +8,7 @@ While generating, every case is also run through the oracle restatement (oracle/
 max |difference| is printed and stored (`oracle_maxdiff`), which is how the oracle was pinned.
 """
 import argparse
+import types
 import io
 import contextlib
 import os
@@ -106,6 +107,23 @@ def gen_pcnet(ref, name, prj_sz, cam_sz, mask, seed, bsz=2):
          fine_grid=fine, wsum=weights_checksum(sd), oracle_maxdiff=diff)
 
 
+def gen_compennet_pp(ref, name, sz, seed):
+    sd = syn.compennet_pp_state_dict(seed, out_size=sz)
+    holder = types.SimpleNamespace
+    net = ref.models.CompenNetPlusplus(holder(module=ref.models.WarpingNet(out_size=tuple(sz))),
+                                       holder(module=ref.models.CompenNet()))
+    net.load_state_dict(sd)
+    net.eval()
+    x = syn.scenes(seed + 20, 2, sz)
+    s = syn.scenes(seed + 21, 1, sz).expand(2, -1, -1, -1).contiguous()
+    with torch.no_grad():
+        y = net(x, s)
+        y2 = so.compennet_pp_forward(sd, x, s, sz)
+    diff = (y2 - y).abs().max().item()
+    print(f'  {name}: oracle maxdiff {diff:.3e}')
+    save(name, seed=seed, sz=sz, x=x, s=s, y=y, wsum=weights_checksum(sd), oracle_maxdiff=diff)
+
+
 class Recorder:
     """Wraps the duck-typed classifier to observe the reference's loop without touching it."""
 
@@ -195,6 +213,7 @@ CASES = {
                                               mask='ones'),
     'spaa_256_near': lambda r: gen_spaa(r, 'spaa_256_near', (256, 256), True, ('near', 8), 5, 'camdE_caml2',
                                         mask='ones', keep=2),
+    'compennet_pp_64': lambda r: gen_compennet_pp(r, 'compennet_pp_64', (64, 64), 5),
     'percal_64_targeted': lambda r: gen_percal(r, 'percal_64_targeted', (64, 64), True, 2, 0),
     'percal_64_untargeted': lambda r: gen_percal(r, 'percal_64_untargeted', (64, 64), False, 2, 40),
 }

@@ -534,3 +534,28 @@ def test_inception_v3_classifier_vs_oracle(hip):
         assert rel_inf(raw2, raw) < 2e-5
         assert rel_l2(im2.grad, im.grad) < 5e-3 and outlier_fraction(im2.grad, im.grad, 1e-3) < 5e-2
         assert (idx2[:, 0] == idx[:, 0]).all()
+
+
+def test_compennet_pp_forward_and_perc_al_glue(hip, golden_dir):
+    """Next-row components: CompenNet++ forward on HIP vs the oracle, and perc_al_compennet_pp glue."""
+    from spaa_amd.models import CompenNetPlusplus, WarpingNet
+    from spaa_amd.perc_al import perc_al_compennet_pp
+    sz = (64, 64)
+    sd = syn.compennet_pp_state_dict(5, out_size=sz)
+    net = CompenNetPlusplus(WarpingNet(out_size=sz))
+    net.load_state_dict(sd)
+    net = net.to(DEV)
+    torch.manual_seed(9)
+    x = syn.scenes(21, 3, sz)
+    s = syn.scenes(22, 1, sz)
+    ref = so.compennet_pp_forward(sd, x, s.expand(3, -1, -1, -1), sz)
+    out = net(x.to(DEV), s.to(DEV))
+    assert rel_inf(out, ref) < 1e-5
+    z = load(golden_dir, 'compennet_pp_64')  # the reference's own output
+    out = net(torch.from_numpy(z['x']).to(DEV), torch.from_numpy(z['s']).to(DEV))
+    assert np.abs(out.cpu().numpy() - z['y']).max() < 1e-5
+    csd = syn.resnet18_state_dict(2, logit_gain=20.0)
+    clf = hip['clf'].Classifier('resnet18', DEV, state_dict=csd, input_sz=(56, 56))
+    setup = dict(classifier_crop_sz=(60, 60), prj_brightness=0.5, prj_im_sz=sz)
+    cam, prj = perc_al_compennet_pp(net, clf, None, [204, 291], True, s[0], 2, DEV, setup)
+    assert cam.shape == (2, 3, 64, 64) and prj.shape == (2, 3, 64, 64) and torch.isfinite(prj).all()

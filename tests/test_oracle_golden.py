@@ -103,3 +103,13 @@ def test_perc_al_first_iterations(golden_dir):
     out = so.perc_al_adversary_projector(clf, scene, torch.tensor(z['targets']), float(z['d_thr']), True,
                                          tuple(int(v) for v in z['crop']), max_iterations=2)
     assert out.shape == scene.shape and out.min() >= 0 and out.max() <= 1
+
+
+def test_compennet_pp_forward(golden_dir):
+    """CompenNet++ (models.py:11-94, :188-212): the oracle against the reference's own output."""
+    z = load(golden_dir, 'compennet_pp_64')
+    sz = tuple(int(v) for v in z['sz'])
+    sd = syn.compennet_pp_state_dict(int(z['seed']), out_size=sz)
+    assert np.allclose(checksum(sd), z['wsum'], rtol=1e-9)
+    y = so.compennet_pp_forward(sd, torch.from_numpy(z['x']), torch.from_numpy(z['s']), sz)
+    assert np.abs(y.numpy() - z['y']).max() <= 1e-6
