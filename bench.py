@@ -11,6 +11,7 @@ result gather, timed separately (`gather_ms`).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -96,6 +97,21 @@ def cpu_baseline(sd, csd, setup, scenes, budget_b=16, iters=8):
                       f'CPU ({dt:.1f} s), scaled by 1/64 to a batch-64 iteration'}
 
 
+def pmc_traffic(tile):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+    m = re.match(r'(x6v\d|x6)_(\d+)x(\d+)(?:g(\d))?', tile)
+    if not os.path.exists(path) or not m:
+        return None
+    fam, bm, bn, g = m.groups()
+    want = f'tapconv_{fam}_kernel<{bm}, {bn}' + (f', {g}>' if g else '>')
+    with open(path) as fh:
+        for k, e in json.load(fh)['kernels'].items():
+            if k.startswith(want):
+                return round(e['hbm_bytes_per_launch'])
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -171,13 +187,14 @@ def main():
             st.iteration(**hp)
         torch.cuda.synchronize()
         per_tile, per_layer = {}, {}
-        for name, key, flops, e0, e1, tile_id in convplan.PROFILE:
+        for name, key, flops, e0, e1, tile_id, nbytes in convplan.PROFILE:
             ms = e0.elapsed_time(e1)
             tile = convplan.TILE_NAMES.get(tile_id, 'auto')
-            a = per_tile.setdefault(tile, [0.0, 0.0, 0])
+            a = per_tile.setdefault(tile, [0.0, 0.0, 0, 0.0])
             a[0] += flops
             a[1] += ms
             a[2] += 1
+            a[3] += nbytes
             b = per_layer.setdefault(name, [0.0, 0.0, 0, tile])
             b[0] += flops
             b[1] += ms
@@ -185,7 +202,7 @@ def main():
         convplan.PROFILE = None
         tot_ms = sum(v[1] for v in per_tile.values())
         dom = max(per_tile, key=lambda k: per_tile[k][1])
-        f, ms, n = per_tile[dom]
+        f, ms, n, nb = per_tile[dom]
         ach = f / (ms * 1e-3) / 1e12
         if dom.startswith('x6'):
             # fp32 emulated with six bf16 MFMAs per product group: the matrix-core ceiling for algorithmic fp32 FLOPs
@@ -195,7 +212,10 @@ def main():
             peak, kname = PEAK_F32_MFMA_TFLOPS, f'tapconv_kernel<{dom}> (fp32 MFMA implicit-GEMM conv/deconv/dgrad)'
         roof = {'kernel': kname, 'bound': 'mfma',
                 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                'frac': round(ach / peak, 4), 'traffic': None,
+                'frac': round(ach / peak, 4), 'traffic': pmc_traffic(dom), 'traffic_unit': 'bytes/launch',
+                'traffic_source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate '
+                                  'passes over this same command; bench.py cannot collect PMC itself)',
+                'algorithmic_bytes_per_launch': round(nb / n),
                 'peak_note': 'algorithmic fp32 FLOP/s; dense bf16 MFMA peak 2516 TF / 6 partial products for the x6 kernels, '
                              '157.3 TF for the fp32-MFMA kernels',
                 'avg_launch_us': round(ms * 1e3 / n, 2), 'launches_per_step': n // n_prof,
@@ -206,7 +226,8 @@ def main():
                      'tflops': v[0] / (v[1] * 1e-3) / 1e12} for k, v in per_layer.items()}
         if args.profile_out:
             with open(args.profile_out, 'w') as fh:
-                json.dump({'per_tile': {k: {'flop': v[0], 'ms': v[1], 'launches': v[2]} for k, v in per_tile.items()},
+                json.dump({'per_tile': {k: {'flop': v[0], 'ms': v[1], 'launches': v[2], 'algorithmic_bytes': v[3]}
+                                        for k, v in per_tile.items()},
                            'per_layer': table}, fh, indent=1)
 
     if rank == 0:

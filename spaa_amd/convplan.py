@@ -153,7 +153,12 @@ class ConvPlan:
             e0.record()
             _lib.call('spaa_tapconv_f32', C.byref(d))
             e1.record()
-            PROFILE.append((self.name, key, self.flops(b, hout, wout), e0, e1, d.tile))
+            # algorithmic bytes: every operand read / result written once (logical channels, fp32)
+            npx = b * hout * wout
+            nbytes = 4 * (b * hin * win * self.cin_p + npx * self.cout * (1 + (add is not None) + (gate is not None)
+                                                                         + (aux_out is not None) + (gate2 is not None))
+                          + self.ntaps_total * self.cin_p * self.cout)
+            PROFILE.append((self.name, key, self.flops(b, hout, wout), e0, e1, d.tile, nbytes))
         return out
 
     def flops(self, b, hout, wout):
