@@ -66,12 +66,13 @@ typedef struct {
     const float* gate;    /* indexed like `out`, or NULL */
     int32_t gate_cstride, gate_coff, gate_mode;
     int32_t act;
-    int32_t tile;         /* 0 = auto; 1..8 = explicit workgroup tile (tuning; see tapconv.hip) */
+    int32_t tile;         /* 0 = auto; 1..28 = explicit kernel / workgroup tile (tuning; see tapconv.hip) */
     float* aux_out;       /* optional second output (indexed like `out`):
                              act == SPAA_ACT_RELU_CLAMP1: the value BEFORE the clamp;
                              otherwise, with gate2: (gate2 > 0) ? out_value : 0  (a second ReLU-backward gate) */
     const float* gate2;
     int32_t gate2_cstride, gate2_coff;
+    int32_t tap_range[4]; /* (dy_min, dy_max, dx_min, dx_max) over the taps of all classes: patch-staged kernels */
     int32_t nclass;
     spaa_tapclass_t cls[SPAA_MAX_CLASSES];
 } spaa_tapconv_t;

@@ -35,6 +35,7 @@ class TapConv(C.Structure):
         ('act', C.c_int32), ('tile', C.c_int32),
         ('aux_out', C.c_void_p),
         ('gate2', C.c_void_p), ('gate2_cstride', C.c_int32), ('gate2_coff', C.c_int32),
+        ('tap_range', C.c_int32 * 4),
         ('nclass', C.c_int32),
         ('cls', TapClass * MAX_CLASSES),
     ]

@@ -23,7 +23,8 @@ FORCE_TILE = 0  # tools/autotune.py: force one workgroup tile for every launch
 TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32', 6: '64x64', 7: '64x128', 8: '128x64b',
               9: 'direct4', 10: 'direct32', 11: 'thin4', 12: 'x6_64x64', 13: 'x6_128x32', 14: 'x6_32x128',
               15: 'x6v2_128x64g3', 16: 'x6v2_128x64g2', 17: 'x6v2_128x128g1', 18: 'x6v2_64x64g3', 19: 'x6v2_64x128g2',
-              20: 'x6v3_128x64g3', 21: 'x6v3_128x64g2', 22: 'x6v3_64x64g3', 23: 'x6v3_128x128g1', 24: 'x6v3_64x128g2'}
+              20: 'x6v3_128x64g3', 21: 'x6v3_128x64g2', 22: 'x6v3_64x64g3', 23: 'x6v3_128x128g1', 24: 'x6v3_64x128g2',
+              25: 'x6d_128x128', 26: 'x6d_256x128', 27: 'x6d_128x64', 28: 'thinpatch32', 29: 'thinpatch16'}
 ENABLE_X6 = True  # build the split-bf16 weight planes (needed by tiles 12-14)
 
 
@@ -93,7 +94,9 @@ class ConvPlan:
                 lo = (r1 - m.float()).to(torch.bfloat16)
                 parts.append(torch.stack([h, m, lo]).view(torch.int16).reshape(-1))
             self.w_split = torch.cat(parts).to(device)
-        taps = torch.tensor(tap_list if tap_list else [(0, 0)], dtype=torch.int32).reshape(-1)
+        tl = tap_list if tap_list else [(0, 0)]
+        self.tap_range = (min(t[0] for t in tl), max(t[0] for t in tl), min(t[1] for t in tl), max(t[1] for t in tl))
+        taps = torch.tensor(tl, dtype=torch.int32).reshape(-1)
         self.taps = taps.to(device)
         self.bias = bias.detach().float().contiguous().to(device) if bias is not None else None
         # algorithmic FLOPs (2*MAC, logical channels, no padding) per pixel of the class grid
@@ -141,8 +144,13 @@ class ConvPlan:
             forced = 0
         if forced == 11 and (self.cout > 4 or self.cin_p > 256 or (self.cin_p & (self.cin_p - 1))):
             forced = 0
+        if forced in (28, 29) and (self.cout > 4 or self.s_in != 1 or self.cin_p % (32 if forced == 28 else 16)):
+            forced = 0
+        if 25 <= forced <= 27 and (self.cin_p % 32 or any(c['Kpad'] != c['K'] for c in self.cls)):
+            forced = 0
         d.tile = forced if forced else TUNE.get(key, 0)
         d.nclass = len(self.cls)
+        d.tap_range[:] = self.tap_range
         for i, c in enumerate(self.cls):
             for k, v in c.items():
                 setattr(d.cls[i], k, v)

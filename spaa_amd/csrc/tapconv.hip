@@ -17,7 +17,9 @@
 #include <stdint.h>
 #include "../../include/spaa_hip.h"
 
-int spaa_launch_tapconv_x6(const spaa_tapconv_t& d, int tile, hipStream_t stream);  // tapconv_x6.hip
+int spaa_launch_tapconv_x6(const spaa_tapconv_t& d, int tile, hipStream_t stream);   // tapconv_x6.hip
+int spaa_launch_tapconv_x6d(const spaa_tapconv_t& d, int tile, hipStream_t stream);  // tapconv_x6d.hip
+int spaa_launch_thinpatch(const spaa_tapconv_t& d, hipStream_t stream);               // thinpatch.hip
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -572,6 +574,11 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         case 22:
         case 23:
         case 24: return spaa_launch_tapconv_x6(d, tile, stream);
+        case 25:
+        case 26:
+        case 27: return spaa_launch_tapconv_x6d(d, tile, stream);
+        case 28:
+        case 29: return spaa_launch_thinpatch(d, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -1,0 +1,398 @@
+// tapconv_x6d.hip — bf16x6 tap-list convolution (see tapconv_x6.hip for the arithmetic) with LDS-DMA staging.
+//
+// The v2/v3 kernels move every operand global -> VGPR -> (split) -> ds_write -> LDS; PMC shows their matrix cores busy
+// 49 % of the time with the two co-resident workgroups convoying through load / split / LDS-store phases.  Here NO
+// operand passes through registers on its way to LDS:
+//   * activations: `buffer_load_dwordx4 ... lds` gathers the im2col rows as fp32 (128-B rows, 16-B chunks XOR-swizzled
+//     on the SOURCE side: the LDS image of an LDS-DMA is lane-linear); out-of-image taps use the out-of-range offset
+//     0x80000000, for which the DMA writes zeros (checked on gfx950: tools/micro/dma_oob.hip);
+//   * weights: the host's pre-split bf16 planes are DMA'd as they are (64-B rows, swizzled the same way);
+//   * each wave owns 32 pixels x BN output channels: it reads its pixels' 8 fp32 per lane (2 x ds_read_b128), splits
+//     them into the three bf16 fragments in registers (no redundancy between waves) and reads the weight fragments
+//     (ds_read_b128, conflict-free); 6 MFMAs per (32 channels x 16 k).
+// Two LDS stages; one __syncthreads() per 32-deep K-step; the DMA of step t+1 is issued right after the barrier of
+// step t and lands during its MFMAs.  Needs Cin % 32 == 0 (a K-step lies inside one tap: the tap is wave-uniform).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/spaa_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK = 32;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ unsigned int cvt2(float a, float b) {
+    f2 v = {a, b};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float lo_f(unsigned int p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float hi_f(unsigned int p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// One LDS-DMA piece: 64 lanes x 16 bytes, global (buffer, per-lane byte offset `voff` + uniform `soff`) -> LDS at the
+// wave-uniform address `dst` + 16 * lane.  An out-of-range offset writes zeros.  (A __device__ helper: the builtin has no
+// host-side meaning and would silently drop the kernel's host stub if it sat in the kernel template itself.)
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rsrc, unsigned char* dst, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)dst, 16, voff, soff, 0, 0);
+}
+
+// 8 fp32 -> three bf16x8 with x == h + m + l exactly
+__device__ __forceinline__ void split8(const f4 x0, const f4 x1, bf16x8& h, bf16x8& m, bf16x8& l) {
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    u4 hh, mm, ll;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned int ph = cvt2(x[2 * i], x[2 * i + 1]);
+        const float r0 = x[2 * i] - lo_f(ph), r1 = x[2 * i + 1] - hi_f(ph);
+        const unsigned int pm = cvt2(r0, r1);
+        const float s0 = r0 - lo_f(pm), s1 = r1 - hi_f(pm);
+        hh[i] = ph;
+        mm[i] = pm;
+        ll[i] = cvt2(s0, s1);
+    }
+    h = __builtin_bit_cast(bf16x8, hh);
+    m = __builtin_bit_cast(bf16x8, mm);
+    l = __builtin_bit_cast(bf16x8, ll);
+}
+
+template <int NW, int BN>
+__global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapconv_t p, const int m_tiles,
+                                                                 const int n_tiles) {
+    constexpr int BM = 32 * NW;
+    constexpr int TN = BN / 32;
+    constexpr int A_BYTES = BM * 128;               // fp32 pixels: [BM][32] floats
+    constexpr int W_PLANE = BN * 64;                // one bf16 plane: [BN][32] bf16
+    constexpr int STAGE = A_BYTES + 3 * W_PLANE;
+    constexpr int W_PIECES = 3 * BN / 16;           // 1-KiB pieces (16 rows of one plane)
+    static_assert(W_PIECES % NW == 0, "weight pieces must divide among the waves");
+    constexpr int WPW = W_PIECES / NW;              // weight pieces per wave per K-step
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const spaa_tapclass_t cl = p.cls[blockIdx.y];
+
+    const int nwg = m_tiles * n_tiles;
+    int tile;
+    {
+        const int orig = blockIdx.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int n_blk = (tile % n_tiles) * BN;
+    const int m_blk = (tile / n_tiles) * BM;
+
+    const int HWm = p.Hm * p.Wm;
+    const int M = p.B * HWm;
+    const int row_bytes = p.in_cstride * 4;
+    const int* __restrict__ taps = p.taps + 2 * cl.tap_off;
+
+    // ---- activation staging: this wave's 32 pixels = 4 pieces of 8 rows; lane -> (row, physical chunk)
+    int a_off[4];
+    uint32_t a_mlo[4], a_mhi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 32 * wave + 8 * j + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);  // logical 16-byte chunk held at this lane's LDS slot
+        const int m = m_blk + r;
+        const bool ok = m < M;
+        const int mm = ok ? m : 0;
+        const int b = mm / HWm;
+        const int rr = mm - b * HWm;
+        const int y = rr / p.Wm;
+        const int x = rr - y * p.Wm;
+        const int iy0 = y * p.s_in, ix0 = x * p.s_in;
+        a_off[j] = ((b * p.Hin + iy0) * p.Win + ix0) * row_bytes + p.in_coff * 4 + c * 16;
+        uint32_t lo = 0, hi = 0;
+        for (int t = 0; t < cl.ntaps; ++t) {
+            const int dy = taps[2 * t], dx = taps[2 * t + 1];
+            const bool v = ok && (unsigned)(iy0 + dy) < (unsigned)p.Hin && (unsigned)(ix0 + dx) < (unsigned)p.Win;
+            if (t < 32) lo |= (v ? 1u : 0u) << t;
+            else hi |= (v ? 1u : 0u) << (t - 32);
+        }
+        a_mlo[j] = lo;
+        a_mhi[j] = hi;
+    }
+    const uint32_t in_bytes = (uint32_t)p.B * (uint32_t)(p.Hin * p.Win) * (uint32_t)row_bytes;
+    const uint64_t in_addr = reinterpret_cast<uint64_t>(p.in);
+    const uint32_t in_lo = __builtin_amdgcn_readfirstlane((uint32_t)in_addr);
+    const uint32_t in_hi = __builtin_amdgcn_readfirstlane((uint32_t)(in_addr >> 32));
+    const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)in_hi << 32) | in_lo), 0,
+                                                            (int)__builtin_amdgcn_readfirstlane(in_bytes), 0x00020000);
+    // ---- weight staging: piece q = wave * WPW + i -> (plane, 16-row block); lane -> (row, physical chunk)
+    const int npad = (p.Cout + 127) & ~127;
+    const int plane_bytes = npad * cl.Kpad * 2;
+    const uint64_t w_addr = reinterpret_cast<uint64_t>(p.w_split) + (uint64_t)cl.w_off * 6u;
+    const uint32_t w_lo = __builtin_amdgcn_readfirstlane((uint32_t)w_addr);
+    const uint32_t w_hi = __builtin_amdgcn_readfirstlane((uint32_t)(w_addr >> 32));
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)w_hi << 32) | w_lo), 0,
+                                                           (int)__builtin_amdgcn_readfirstlane(3u * (uint32_t)plane_bytes),
+                                                           0x00020000);
+    int w_goff[WPW];
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        const int q = wave * WPW + i;
+        const int pl = q / (BN / 16), rb = q % (BN / 16);
+        const int n = 16 * rb + (lane >> 2);
+        const int c = (lane & 3) ^ ((n >> 2) & 3);
+        w_goff[i] = pl * plane_bytes + (n_blk + n) * cl.Kpad * 2 + c * 16;
+    }
+
+    // ---- fragment read addresses (bytes inside a stage)
+    const int prow = 32 * wave + (lane & 31);
+    const int pswz = (prow >> 1) & 7;
+    int p_addr[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) p_addr[kk][h] = prow * 128 + (((kk * 4 + (lane >> 5) * 2 + h) ^ pswz) * 16);
+    int w_addr_l[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int n = lane & 31;
+        w_addr_l[kk] = A_BYTES + n * 64 + (((2 * kk + (lane >> 5)) ^ ((n >> 2) & 3)) * 16);
+    }
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int nk = cl.Kpad / BK;
+    const int Cin = p.Cin;
+    // wave-uniform state of the K-step being STAGED (one ahead of the one being multiplied); the tap offsets come through
+    // scalar loads issued one K-step before they are used
+    typedef const __attribute__((address_space(4))) int* cint_ptr;
+    cint_ptr ctaps = (cint_ptr)(uintptr_t)taps;
+    int s_tap = 0, s_kc = 0;
+    int n_dy = ctaps[0], n_dx = ctaps[1];
+    int voff[4];
+
+#define X6D_PREP(more, ks_next)                                                                                    \
+    {                                                                                                              \
+        const int tapoff = (n_dy * p.Win + n_dx) * row_bytes + s_kc * 4;                                           \
+        const uint32_t bit = (more) ? 1u << (s_tap & 31) : 0u;                                                     \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                            \
+            const uint32_t mw = s_tap < 32 ? a_mlo[j] : a_mhi[j];                                                  \
+            voff[j] = (mw & bit) ? a_off[j] + tapoff : (int)0x80000000;                                            \
+        }                                                                                                          \
+        s_kc += BK;                                                                                                \
+        if (s_kc >= Cin) {                                                                                         \
+            s_kc = 0;                                                                                              \
+            s_tap += 1;                                                                                            \
+        }                                                                                                          \
+        const int tn = min(s_tap, cl.ntaps - 1);                                                                   \
+        n_dy = ctaps[2 * tn];                                                                                      \
+        n_dx = ctaps[2 * tn + 1];                                                                                  \
+    }
+#define X6D_DMA_A(sbase, j)                                                                                        \
+    dma16(rsrc_in, (sbase) + (4 * wave + (j)) * 1024, voff[j], 0);
+#define X6D_DMA_W(sbase, i, soff)                                                                                  \
+    dma16(rsrc_w, (sbase) + A_BYTES + (wave * WPW + (i)) * 1024, w_goff[i], (soff));
+#define X6D_LDW(dst, sbase, kk, j)                                                                                 \
+    {                                                                                                              \
+        const unsigned char* wb_ = (sbase) + w_addr_l[kk] + (j) * 2048;                                            \
+        dst[0] = *reinterpret_cast<const bf16x8*>(wb_);                                                            \
+        dst[1] = *reinterpret_cast<const bf16x8*>(wb_ + W_PLANE);                                                  \
+        dst[2] = *reinterpret_cast<const bf16x8*>(wb_ + 2 * W_PLANE);                                              \
+    }
+
+    if (nk > 0) {
+        X6D_PREP(true, 0)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) X6D_DMA_A(smem, j)
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) X6D_DMA_W(smem, i, 0)
+    }
+
+    constexpr int NB = 2 * TN;  // MFMA blocks (6 MFMAs each) per K-step
+    for (int ks = 0; ks < nk; ++ks) {
+        // own DMAs of step ks have landed (vmcnt) and everybody's have (barrier); every wave is also past its reads
+        // of the other stage, which is overwritten during this step
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = ks & 1;
+        const unsigned char* sb = smem + cur * STAGE;
+        unsigned char* sn = smem + (cur ^ 1) * STAGE;
+        const bool more = ks + 1 < nk;
+        const int soff = min(ks + 1, nk - 1) * (BK * 2);
+
+        bf16x8 wf[2][3], pf[2][3];
+        f4 x0 = *reinterpret_cast<const f4*>(sb + p_addr[0][0]);
+        f4 x1 = *reinterpret_cast<const f4*>(sb + p_addr[0][1]);
+        X6D_LDW(wf[0], sb, 0, 0)
+        const f4 y0 = *reinterpret_cast<const f4*>(sb + p_addr[1][0]);
+        const f4 y1 = *reinterpret_cast<const f4*>(sb + p_addr[1][1]);
+        X6D_PREP(more, ks + 1)
+        split8(x0, x1, pf[0][0], pf[0][1], pf[0][2]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int kk = b / TN, j = b % TN;
+            if (b + 1 < NB) X6D_LDW(wf[(b + 1) & 1], sb, (b + 1) / TN, (b + 1) % TN)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q % NB == b) X6D_DMA_A(sn, q)
+#pragma unroll
+            for (int q = 0; q < WPW; ++q)
+                if (q % NB == b) X6D_DMA_W(sn, q, soff)
+            // weights = A operand (rows = output channels), pixels = B operand (columns); small terms first
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[b & 1][2], pf[kk][0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[b & 1][0], pf[kk][2], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[b & 1][1], pf[kk][1], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[b & 1][1], pf[kk][0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[b & 1][0], pf[kk][1], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[b & 1][0], pf[kk][0], acc[j], 0, 0, 0);
+            if (b == 0) split8(y0, y1, pf[1][0], pf[1][1], pf[1][2]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last step's (all-zero) prefetch must not outlive the wave
+#undef X6D_PREP
+#undef X6D_DMA_A
+#undef X6D_DMA_W
+#undef X6D_LDW
+
+    // ---- epilogue.  D layout of a 32x32 tile: column (lane & 31) = pixel, row (r&3) + 8*(r>>2) + 4*(lane>>5) = output
+    // channel: registers 4g..4g+3 of a lane are 4 consecutive channels of its pixel.
+    const int m = m_blk + prow;
+    if (m >= M) return;
+    size_t o;
+    if ((p.s_out == 1) && (cl.oy0 == 0) && (cl.ox0 == 0) && (p.Hm == p.Hout) && (p.Wm == p.Wout)) {
+        o = (size_t)m;
+    } else {
+        const int b = m / HWm;
+        const int rr = m - b * HWm;
+        const int y = rr / p.Wm;
+        const int x = rr - y * p.Wm;
+        const int oy = cl.oy0 + y * p.s_out;
+        const int ox = cl.ox0 + x * p.s_out;
+        if (oy >= p.Hout || ox >= p.Wout) return;
+        o = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+    }
+    const bool vec = !((p.Cout | p.out_cstride | p.out_coff) & 3) &&
+                     (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
+                     (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
+                     (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n0 = n_blk + 32 * j + 8 * g + 4 * (lane >> 5);
+            if (n0 >= p.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[j][4 * g + e];
+            if (vec) {
+                if (p.bias != nullptr) {
+                    const f4 bb = *reinterpret_cast<const f4*>(p.bias + n0);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (p.add != nullptr) {
+                    const f4 aa = *reinterpret_cast<const f4*>(p.add + o * p.add_cstride + p.add_coff + n0);
+                    v[0] += aa.x; v[1] += aa.y; v[2] += aa.z; v[3] += aa.w;
+                }
+                float* outp = p.out + o * p.out_cstride + p.out_coff + n0;
+                if (p.act == SPAA_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (p.act == SPAA_ACT_RELU_CLAMP1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    if (p.aux_out != nullptr)
+                        *reinterpret_cast<f4*>(p.aux_out + o * p.out_cstride + p.out_coff + n0) = f4{v[0], v[1], v[2], v[3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fminf(v[e], 1.f);
+                } else if (p.act == SPAA_ACT_LEAKY01) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.1f * v[e];
+                }
+                if (p.gate != nullptr) {
+                    const f4 gg = *reinterpret_cast<const f4*>(p.gate + o * p.gate_cstride + p.gate_coff + n0);
+                    const float ga[4] = {gg.x, gg.y, gg.z, gg.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (ga[e] > 0.f && ga[e] <= 1.f) : (ga[e] > 0.f);
+                        v[e] = pass ? v[e] : 0.f;
+                    }
+                }
+                *reinterpret_cast<f4*>(outp) = f4{v[0], v[1], v[2], v[3]};
+                if (p.gate2 != nullptr) {
+                    const f4 gg = *reinterpret_cast<const f4*>(p.gate2 + o * p.gate2_cstride + p.gate2_coff + n0);
+                    *reinterpret_cast<f4*>(p.aux_out + o * p.out_cstride + p.out_coff + n0) =
+                        f4{gg.x > 0.f ? v[0] : 0.f, gg.y > 0.f ? v[1] : 0.f, gg.z > 0.f ? v[2] : 0.f, gg.w > 0.f ? v[3] : 0.f};
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + e;
+                    if (n >= p.Cout) continue;
+                    float t = v[e] + (p.bias != nullptr ? p.bias[n] : 0.f);
+                    if (p.add != nullptr) t += p.add[o * p.add_cstride + p.add_coff + n];
+                    if (p.act == SPAA_ACT_RELU) {
+                        t = fmaxf(t, 0.f);
+                    } else if (p.act == SPAA_ACT_RELU_CLAMP1) {
+                        t = fmaxf(t, 0.f);
+                        if (p.aux_out != nullptr) p.aux_out[o * p.out_cstride + p.out_coff + n] = t;
+                        t = fminf(t, 1.f);
+                    } else if (p.act == SPAA_ACT_LEAKY01) {
+                        t = t > 0.f ? t : 0.1f * t;
+                    }
+                    if (p.gate != nullptr) {
+                        const float gv = p.gate[o * p.gate_cstride + p.gate_coff + n];
+                        const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (gv > 0.f && gv <= 1.f) : (gv > 0.f);
+                        t = pass ? t : 0.f;
+                    }
+                    p.out[o * p.out_cstride + p.out_coff + n] = t;
+                    if (p.gate2 != nullptr) {
+                        const float g2 = p.gate2[o * p.gate2_cstride + p.gate2_coff + n];
+                        p.aux_out[o * p.out_cstride + p.out_coff + n] = (g2 > 0.f) ? t : 0.f;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NW, int BN>
+int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream) {
+    constexpr int BM = 32 * NW;
+    const int64_t M = (int64_t)d.B * d.Hm * d.Wm;
+    const int m_tiles = (int)((M + BM - 1) / BM);
+    const int n_tiles = (d.Cout + BN - 1) / BN;
+    const size_t smem = 2 * (size_t)(BM * 128 + 3 * BN * 64);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_x6d_kernel<NW, BN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid(m_tiles * n_tiles, d.nclass, 1);
+    hipLaunchKernelGGL((tapconv_x6d_kernel<NW, BN>), grid, dim3(64 * NW), smem, stream, d, m_tiles, n_tiles);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// called by spaa_tapconv_f32 (tapconv.hip) for tiles 25.. after the common shape checks
+int spaa_launch_tapconv_x6d(const spaa_tapconv_t& d, int tile, hipStream_t stream) {
+    if (d.w_split == nullptr || (d.Cin % BK) != 0) return hipErrorInvalidValue;
+    for (int c = 0; c < d.nclass; ++c) {
+        if ((int64_t)((d.Cout + 127) & ~127) * d.cls[c].Kpad * 6 >= (int64_t)1 << 31) return hipErrorInvalidValue;
+        if (d.cls[c].Kpad != d.cls[c].K) return hipErrorInvalidValue;
+    }
+    switch (tile) {
+        case 25: return launch_x6d<4, 128>(d, stream);
+        case 26: return launch_x6d<8, 128>(d, stream);
+        case 27: return launch_x6d<4, 64>(d, stream);
+        default: return hipErrorInvalidValue;
+    }
+}

@@ -107,15 +107,16 @@ def test_tapconv_deconv_forward_and_dgrad(hip, ci, co, k, p, op, h, w):
     assert rel_inf(nchw(gx.cpu(), ci), x.grad) < 1e-5
 
 
-@pytest.mark.parametrize('tile', [9, 10, 11])
+@pytest.mark.parametrize('tile', [9, 10, 11, 28, 29])
 def test_directconv_thin_layers(hip, tile):
     """The VALU variants for thin layers (few output or few input channels) compute the same tap-list convolution."""
     cp, lib = hip['cp'], hip['lib']
     torch.manual_seed(11)
     cases = [(32, 3, 3, 1, 1, 20, 24), (64, 3, 7, 2, 3, 28, 28), (6, 32, 3, 2, 1, 16, 16)] if tile == 9 else \
         [(3, 32, 3, 1, 1, 20, 24), (3, 32, 3, 2, 1, 16, 16), (6, 32, 3, 2, 1, 12, 20)]
-    if tile == 11:  # (the dgrad of ci=3 layers has 32/64 gradient channels in and 3 out: the thin-N case)
-        cases = [(32, 3, 3, 1, 1, 21, 24), (64, 3, 7, 2, 3, 28, 30), (3, 32, 3, 2, 1, 16, 18), (3, 64, 7, 2, 3, 30, 28)]
+    if tile in (11, 28, 29):  # (the dgrad of ci=3 layers has 32/64 gradient channels in and 3 out: the thin-N case)
+        cases = [(32, 3, 3, 1, 1, 21, 24), (64, 3, 7, 2, 3, 28, 30), (3, 32, 3, 2, 1, 16, 18), (3, 64, 7, 2, 3, 30, 28),
+                 (32, 4, 3, 1, 1, 37, 70), (64, 2, 3, 1, 1, 9, 33)]
     try:
         for ci, co, k, s, p, h, w in cases:
             x = torch.randn(2, ci, h, w, requires_grad=True)
@@ -139,7 +140,7 @@ def test_directconv_thin_layers(hip, tile):
         cp.FORCE_TILE = 0
 
 
-@pytest.mark.parametrize('tile', [12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
+@pytest.mark.parametrize('tile', [12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27])
 def test_tapconv_x6_is_fp32_accurate(hip, tile):
     """fp32 emulated on the bf16 matrix cores (exact 3-way operand split, 6 of 9 partial products, separate
     accumulators): the error against an fp64 reference must not exceed that of the exact-fp32 MFMA kernel."""

@@ -20,7 +20,7 @@ def main():
     torch.cuda.synchronize()
     res = {}
     names = {}
-    tiles = [int(t) for t in os.environ.get('SPAA_TUNE_TILES', '').split(',') if t] or list(range(1, 25))
+    tiles = [int(t) for t in os.environ.get('SPAA_TUNE_TILES', '').split(',') if t] or list(range(1, 30))
     for tile in tiles:
         convplan.FORCE_TILE = tile
         st.iteration(**hp)  # warm (sets the LDS attribute of a new instantiation)
@@ -28,7 +28,7 @@ def main():
         for _ in range(2):
             st.iteration(**hp)
         torch.cuda.synchronize()
-        for name, key, flops, e0, e1, used in convplan.PROFILE:
+        for name, key, flops, e0, e1, used, _nbytes in convplan.PROFILE:
             if used != tile:
                 continue  # this tile is not valid for the layer (ConvPlan.run fell back)
             res.setdefault(key, {}).setdefault(tile, []).append(e0.elapsed_time(e1))
