@@ -24,7 +24,9 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               9: 'direct4', 10: 'direct32', 11: 'thin4', 12: 'x6_64x64', 13: 'x6_128x32', 14: 'x6_32x128',
               15: 'x6v2_128x64g3', 16: 'x6v2_128x64g2', 17: 'x6v2_128x128g1', 18: 'x6v2_64x64g3', 19: 'x6v2_64x128g2',
               20: 'x6v3_128x64g3', 21: 'x6v3_128x64g2', 22: 'x6v3_64x64g3', 23: 'x6v3_128x128g1', 24: 'x6v3_64x128g2',
-              25: 'x6d_128x128', 26: 'x6d_256x128', 27: 'x6d_128x64', 28: 'thinpatch32', 29: 'thinpatch16'}
+              25: 'x6d_128x128', 26: 'x6d_256x128', 27: 'x6d_128x64', 28: 'thinpatch32', 29: 'thinpatch16',
+              30: 'x6d_128x32', 31: 'x6d_64x64', 32: 'x6d_64x128', 33: 'x6d_256x64',
+              34: 'x6d16_128x128', 35: 'x6d16_256x128', 36: 'x6d16_128x64', 37: 'x6d16_128x32'}
 ENABLE_X6 = True  # build the split-bf16 weight planes (needed by tiles 12-14)
 
 
@@ -146,7 +148,7 @@ class ConvPlan:
             forced = 0
         if forced in (28, 29) and (self.cout > 4 or self.s_in != 1 or self.cin_p % (32 if forced == 28 else 16)):
             forced = 0
-        if 25 <= forced <= 27 and (self.cin_p % 32 or any(c['Kpad'] != c['K'] for c in self.cls)):
+        if (25 <= forced <= 27 or 30 <= forced <= 37) and (self.cin_p % 32 or any(c['Kpad'] != c['K'] for c in self.cls)):
             forced = 0
         d.tile = forced if forced else TUNE.get(key, 0)
         d.nclass = len(self.cls)

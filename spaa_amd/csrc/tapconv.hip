@@ -579,6 +579,14 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         case 27: return spaa_launch_tapconv_x6d(d, tile, stream);
         case 28:
         case 29: return spaa_launch_thinpatch(d, stream);
+        case 30:
+        case 31:
+        case 32:
+        case 33:
+        case 34:
+        case 35:
+        case 36:
+        case 37: return spaa_launch_tapconv_x6d(d, tile, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -22,6 +22,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -61,7 +62,113 @@ __device__ __forceinline__ void split8(const f4 x0, const f4 x1, bf16x8& h, bf16
     l = __builtin_bit_cast(bf16x8, ll);
 }
 
-template <int NW, int BN>
+// LDS chunk swizzles.  A b128 LDS read is served in groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...); the
+// 16 lanes of a group must hit 16 different 16-byte bank groups.  With 32x32x16 fragments (SH = 32) a group holds 16
+// consecutive rows at ONE k-chunk; with 16x16x32 fragments (SH = 16) it holds rows {0-3,12-15} at chunk c and rows
+// {4-11} at chunk c+1 (weights) / c+2 (pixels), which needs the second form below.
+template <int SH>
+__device__ __forceinline__ int swz_pix(int r) {  // 128-byte rows, 8 chunks
+    if (SH == 32) return (r >> 1) & 7;
+    const int v = (r >> 1) & 1, u = (r >> 2) & 3;
+    return (((u ^ (u >> 1)) & 1)) | (v << 1) | ((u >> 1) << 2);
+}
+template <int SH>
+__device__ __forceinline__ int swz_w(int n) {  // 64-byte rows, 4 chunks
+    return SH == 32 ? (n >> 2) & 3 : ((n >> 3) & 1) << 1;
+}
+
+// fused epilogue for 4 consecutive output channels n0..n0+3 of output pixel o
+__device__ __forceinline__ void store4(const spaa_tapconv_t& p, const size_t o, const int n0, float (&v)[4], const bool vec) {
+    if (n0 >= p.Cout) return;
+    if (vec) {
+        if (p.bias != nullptr) {
+            const f4 bb = *reinterpret_cast<const f4*>(p.bias + n0);
+            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        }
+        if (p.add != nullptr) {
+            const f4 aa = *reinterpret_cast<const f4*>(p.add + o * p.add_cstride + p.add_coff + n0);
+            v[0] += aa.x; v[1] += aa.y; v[2] += aa.z; v[3] += aa.w;
+        }
+        float* outp = p.out + o * p.out_cstride + p.out_coff + n0;
+        if (p.act == SPAA_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (p.act == SPAA_ACT_RELU_CLAMP1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            if (p.aux_out != nullptr)
+                *reinterpret_cast<f4*>(p.aux_out + o * p.out_cstride + p.out_coff + n0) = f4{v[0], v[1], v[2], v[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fminf(v[e], 1.f);
+        } else if (p.act == SPAA_ACT_LEAKY01) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.1f * v[e];
+        }
+        if (p.gate != nullptr) {
+            const f4 gg = *reinterpret_cast<const f4*>(p.gate + o * p.gate_cstride + p.gate_coff + n0);
+            const float ga[4] = {gg.x, gg.y, gg.z, gg.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (ga[e] > 0.f && ga[e] <= 1.f) : (ga[e] > 0.f);
+                v[e] = pass ? v[e] : 0.f;
+            }
+        }
+        *reinterpret_cast<f4*>(outp) = f4{v[0], v[1], v[2], v[3]};
+        if (p.gate2 != nullptr) {
+            const f4 gg = *reinterpret_cast<const f4*>(p.gate2 + o * p.gate2_cstride + p.gate2_coff + n0);
+            *reinterpret_cast<f4*>(p.aux_out + o * p.out_cstride + p.out_coff + n0) =
+                f4{gg.x > 0.f ? v[0] : 0.f, gg.y > 0.f ? v[1] : 0.f, gg.z > 0.f ? v[2] : 0.f, gg.w > 0.f ? v[3] : 0.f};
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + e;
+            if (n >= p.Cout) continue;
+            float t = v[e] + (p.bias != nullptr ? p.bias[n] : 0.f);
+            if (p.add != nullptr) t += p.add[o * p.add_cstride + p.add_coff + n];
+            if (p.act == SPAA_ACT_RELU) {
+                t = fmaxf(t, 0.f);
+            } else if (p.act == SPAA_ACT_RELU_CLAMP1) {
+                t = fmaxf(t, 0.f);
+                if (p.aux_out != nullptr) p.aux_out[o * p.out_cstride + p.out_coff + n] = t;
+                t = fminf(t, 1.f);
+            } else if (p.act == SPAA_ACT_LEAKY01) {
+                t = t > 0.f ? t : 0.1f * t;
+            }
+            if (p.gate != nullptr) {
+                const float gv = p.gate[o * p.gate_cstride + p.gate_coff + n];
+                const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (gv > 0.f && gv <= 1.f) : (gv > 0.f);
+                t = pass ? t : 0.f;
+            }
+            p.out[o * p.out_cstride + p.out_coff + n] = t;
+            if (p.gate2 != nullptr) {
+                const float g2 = p.gate2[o * p.gate2_cstride + p.gate2_coff + n];
+                p.aux_out[o * p.out_cstride + p.out_coff + n] = (g2 > 0.f) ? t : 0.f;
+            }
+        }
+    }
+}
+
+// output pixel index of tile row m (class grid -> output grid); false when the pixel does not exist
+__device__ __forceinline__ bool out_pixel(const spaa_tapconv_t& p, const spaa_tapclass_t& cl, const int m, const int M,
+                                          const int HWm, size_t& o) {
+    if (m >= M) return false;
+    if ((p.s_out == 1) && (cl.oy0 == 0) && (cl.ox0 == 0) && (p.Hm == p.Hout) && (p.Wm == p.Wout)) {
+        o = (size_t)m;
+        return true;
+    }
+    const int b = m / HWm;
+    const int rr = m - b * HWm;
+    const int y = rr / p.Wm;
+    const int x = rr - y * p.Wm;
+    const int oy = cl.oy0 + y * p.s_out;
+    const int ox = cl.ox0 + x * p.s_out;
+    if (oy >= p.Hout || ox >= p.Wout) return false;
+    o = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+    return true;
+}
+
+template <int NW, int BN, int SH>
 __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapconv_t p, const int m_tiles,
                                                                  const int n_tiles) {
     constexpr int BM = 32 * NW;
@@ -70,8 +177,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
     constexpr int W_PLANE = BN * 64;                // one bf16 plane: [BN][32] bf16
     constexpr int STAGE = A_BYTES + 3 * W_PLANE;
     constexpr int W_PIECES = 3 * BN / 16;           // 1-KiB pieces (16 rows of one plane)
-    static_assert(W_PIECES % NW == 0, "weight pieces must divide among the waves");
-    constexpr int WPW = W_PIECES / NW;              // weight pieces per wave per K-step
+    constexpr int WPW = (W_PIECES + NW - 1) / NW;   // weight pieces per wave per K-step (piece q -> wave q % NW)
 
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
@@ -101,7 +207,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = 32 * wave + 8 * j + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);  // logical 16-byte chunk held at this lane's LDS slot
+        const int c = (lane & 7) ^ swz_pix<SH>(r);  // logical 16-byte chunk held at this lane's LDS slot
         const int m = m_blk + r;
         const bool ok = m < M;
         const int mm = ok ? m : 0;
@@ -139,33 +245,12 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
     int w_goff[WPW];
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
-        const int q = wave * WPW + i;
+        const int q = wave + NW * i;  // (q >= W_PIECES: no such piece, never issued)
         const int pl = q / (BN / 16), rb = q % (BN / 16);
         const int n = 16 * rb + (lane >> 2);
-        const int c = (lane & 3) ^ ((n >> 2) & 3);
+        const int c = (lane & 3) ^ swz_w<SH>(n);
         w_goff[i] = pl * plane_bytes + (n_blk + n) * cl.Kpad * 2 + c * 16;
     }
-
-    // ---- fragment read addresses (bytes inside a stage)
-    const int prow = 32 * wave + (lane & 31);
-    const int pswz = (prow >> 1) & 7;
-    int p_addr[2][2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) p_addr[kk][h] = prow * 128 + (((kk * 4 + (lane >> 5) * 2 + h) ^ pswz) * 16);
-    int w_addr_l[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        const int n = lane & 31;
-        w_addr_l[kk] = A_BYTES + n * 64 + (((2 * kk + (lane >> 5)) ^ ((n >> 2) & 3)) * 16);
-    }
-
-    f32x16 acc[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     const int nk = cl.Kpad / BK;
     const int Cin = p.Cin;
@@ -194,30 +279,110 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
         n_dy = ctaps[2 * tn];                                                                                      \
         n_dx = ctaps[2 * tn + 1];                                                                                  \
     }
-#define X6D_DMA_A(sbase, j)                                                                                        \
-    dma16(rsrc_in, (sbase) + (4 * wave + (j)) * 1024, voff[j], 0);
+#define X6D_DMA_A(sbase, j) dma16(rsrc_in, (sbase) + (4 * wave + (j)) * 1024, voff[j], 0);
 #define X6D_DMA_W(sbase, i, soff)                                                                                  \
-    dma16(rsrc_w, (sbase) + A_BYTES + (wave * WPW + (i)) * 1024, w_goff[i], (soff));
-#define X6D_LDW(dst, sbase, kk, j)                                                                                 \
+    if (W_PIECES % NW == 0 || wave + NW * (i) < W_PIECES)                                                          \
+        dma16(rsrc_w, (sbase) + A_BYTES + (wave + NW * (i)) * 1024, w_goff[i], (soff));
+#define X6D_LDW(dst, ptr)                                                                                          \
     {                                                                                                              \
-        const unsigned char* wb_ = (sbase) + w_addr_l[kk] + (j) * 2048;                                            \
+        const unsigned char* wb_ = (ptr);                                                                          \
         dst[0] = *reinterpret_cast<const bf16x8*>(wb_);                                                            \
         dst[1] = *reinterpret_cast<const bf16x8*>(wb_ + W_PLANE);                                                  \
         dst[2] = *reinterpret_cast<const bf16x8*>(wb_ + 2 * W_PLANE);                                              \
     }
+// weights = A operand (rows = output channels), pixels = B operand (columns); small terms first
+#define X6D_MFMA6(MF, accv, wf, pf)                                                                                \
+    accv = MF(wf[2], pf[0], accv, 0, 0, 0);                                                                        \
+    accv = MF(wf[0], pf[2], accv, 0, 0, 0);                                                                        \
+    accv = MF(wf[1], pf[1], accv, 0, 0, 0);                                                                        \
+    accv = MF(wf[1], pf[0], accv, 0, 0, 0);                                                                        \
+    accv = MF(wf[0], pf[1], accv, 0, 0, 0);                                                                        \
+    accv = MF(wf[0], pf[0], accv, 0, 0, 0);
 
+    // DMA issue order inside a K-step: the 4 pixel pieces first, then the weight pieces, spread over the MFMA blocks;
+    // piece s of NP goes to block s * NBLK / NP.  A wave reads back only ITS OWN pixel rows, so the pixel fragments of
+    // step t+1 are read and split at the end of step t, behind a counted vmcnt that covers the pixel pieces (no barrier
+    // needed for own DMA data); the barrier at the top of a step then only orders the weight planes.
+    constexpr int NP = 4 + WPW;
+    constexpr int W_MIN = W_PIECES / NW;  // weight pieces every wave issues after its last pixel piece
+#define X6D_ISSUE(blk, NBLK, sn, soff)                                                                             \
+    {                                                                                                              \
+        _Pragma("unroll") for (int s_ = 0; s_ < NP; ++s_)                                                          \
+            if (s_ * (NBLK) / NP == (blk)) {                                                                       \
+                if (s_ < 4) { X6D_DMA_A(sn, s_) } else { X6D_DMA_W(sn, s_ - 4, soff) }                             \
+            }                                                                                                      \
+    }
+
+    const bool vec = !((p.Cout | p.out_cstride | p.out_coff) & 3) &&
+                     (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
+                     (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
+                     (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
+
+    // fragment read addresses (bytes inside a stage).  Pixels: a lane holds 2 x 8 fp32 of its pixel(s) per K-step.
+    int p_addr[2][2];
+    int w_addr_l[2];
+    if constexpr (SH == 32) {
+        // 32x32x16: pixel (lane & 31); half-step kk covers k-chunks 4 kk + 2 (lane >> 5) + {0, 1}
+        const int prow = 32 * wave + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                p_addr[kk][h] = prow * 128 + (((kk * 4 + (lane >> 5) * 2 + h) ^ swz_pix<SH>(prow)) * 16);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int n = lane & 31;
+            w_addr_l[kk] = A_BYTES + n * 64 + (((2 * kk + (lane >> 5)) ^ swz_w<SH>(n)) * 16);
+        }
+    } else {
+        // 16x16x32: pixel (lane & 15) of each of the wave's two 16-pixel blocks; k-chunks 2 (lane >> 4) + {0, 1}
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            const int r = 32 * wave + 16 * ib + (lane & 15);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) p_addr[ib][h] = r * 128 + ((((lane >> 4) * 2 + h) ^ swz_pix<SH>(r)) * 16);
+        }
+        w_addr_l[0] = A_BYTES + (lane & 15) * 64 + (((lane >> 4) ^ swz_w<SH>(lane & 15)) * 16);
+        w_addr_l[1] = 0;
+    }
+#define X6D_LDP(pf, sbase)                                                                                         \
+    {                                                                                                              \
+        const f4 x0_ = *reinterpret_cast<const f4*>((sbase) + p_addr[0][0]);                                       \
+        const f4 x1_ = *reinterpret_cast<const f4*>((sbase) + p_addr[0][1]);                                       \
+        const f4 y0_ = *reinterpret_cast<const f4*>((sbase) + p_addr[1][0]);                                       \
+        const f4 y1_ = *reinterpret_cast<const f4*>((sbase) + p_addr[1][1]);                                       \
+        split8(x0_, x1_, pf[0][0], pf[0][1], pf[0][2]);                                                            \
+        split8(y0_, y1_, pf[1][0], pf[1][1], pf[1][2]);                                                            \
+    }
+
+    constexpr int TJ = BN / 16;
+    constexpr int NACC = SH == 32 ? TN : 1;
+    f32x16 acc32[NACC];
+    f32x4 acc16[2][SH == 16 ? TJ : 1];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[j][r] = 0.f;
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int j = 0; j < (SH == 16 ? TJ : 1); ++j) acc16[ib][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 pfc[2][3];  // pixel fragments of the current K-step (h / m / l planes of the two halves or pixel blocks)
     if (nk > 0) {
         X6D_PREP(true, 0)
 #pragma unroll
         for (int j = 0; j < 4; ++j) X6D_DMA_A(smem, j)
 #pragma unroll
         for (int i = 0; i < WPW; ++i) X6D_DMA_W(smem, i, 0)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_MIN) : "memory");
+        X6D_LDP(pfc, smem)
     }
 
-    constexpr int NB = 2 * TN;  // MFMA blocks (6 MFMAs each) per K-step
+    constexpr int NBLK = SH == 32 ? 2 * TN : TJ;  // MFMA blocks per K-step (6 resp. 12 MFMAs each)
     for (int ks = 0; ks < nk; ++ks) {
-        // own DMAs of step ks have landed (vmcnt) and everybody's have (barrier); every wave is also past its reads
-        // of the other stage, which is overwritten during this step
+        // own weight DMAs of step ks have landed (vmcnt) and everybody's have (barrier); every wave is also past its
+        // reads of the other stage's weight planes, which are overwritten during this step
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int cur = ks & 1;
@@ -226,142 +391,76 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
         const bool more = ks + 1 < nk;
         const int soff = min(ks + 1, nk - 1) * (BK * 2);
 
-        bf16x8 wf[2][3], pf[2][3];
-        f4 x0 = *reinterpret_cast<const f4*>(sb + p_addr[0][0]);
-        f4 x1 = *reinterpret_cast<const f4*>(sb + p_addr[0][1]);
-        X6D_LDW(wf[0], sb, 0, 0)
-        const f4 y0 = *reinterpret_cast<const f4*>(sb + p_addr[1][0]);
-        const f4 y1 = *reinterpret_cast<const f4*>(sb + p_addr[1][1]);
+        bf16x8 wf[2][3], pfn[2][3];
+        X6D_LDW(wf[0], sb + w_addr_l[0])
         X6D_PREP(more, ks + 1)
-        split8(x0, x1, pf[0][0], pf[0][1], pf[0][2]);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int kk = b / TN, j = b % TN;
-            if (b + 1 < NB) X6D_LDW(wf[(b + 1) & 1], sb, (b + 1) / TN, (b + 1) % TN)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (q % NB == b) X6D_DMA_A(sn, q)
-#pragma unroll
-            for (int q = 0; q < WPW; ++q)
-                if (q % NB == b) X6D_DMA_W(sn, q, soff)
-            // weights = A operand (rows = output channels), pixels = B operand (columns); small terms first
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[b & 1][2], pf[kk][0], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[b & 1][0], pf[kk][2], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[b & 1][1], pf[kk][1], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[b & 1][1], pf[kk][0], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[b & 1][0], pf[kk][1], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[b & 1][0], pf[kk][0], acc[j], 0, 0, 0);
-            if (b == 0) split8(y0, y1, pf[1][0], pf[1][1], pf[1][2]);
+        for (int b = 0; b < NBLK; ++b) {
+            if (b + 1 < NBLK) {
+                if constexpr (SH == 32) {
+                    X6D_LDW(wf[(b + 1) & 1], sb + w_addr_l[(b + 1) / TN] + ((b + 1) % TN) * 2048)
+                } else {
+                    X6D_LDW(wf[(b + 1) & 1], sb + w_addr_l[0] + (b + 1) * 1024)
+                }
+            }
+            X6D_ISSUE(b, NBLK, sn, soff)
+            if (b == NBLK - 1) {
+                // the pixel pieces of step ks+1 (this wave's own rows) have landed: fetch and split them now, under
+                // the last block's MFMAs
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_MIN) : "memory");
+                X6D_LDP(pfn, sn)
+            }
+            if constexpr (SH == 32) {
+                X6D_MFMA6(__builtin_amdgcn_mfma_f32_32x32x16_bf16, acc32[b % TN], wf[b & 1], pfc[b / TN])
+            } else {
+                X6D_MFMA6(__builtin_amdgcn_mfma_f32_16x16x32_bf16, acc16[0][b], wf[b & 1], pfc[0])
+                X6D_MFMA6(__builtin_amdgcn_mfma_f32_16x16x32_bf16, acc16[1][b], wf[b & 1], pfc[1])
+            }
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) pfc[i][pl] = pfn[i][pl];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last step's (all-zero) prefetch must not outlive the wave
+
+    if constexpr (SH == 32) {
+        // D layout of a 32x32 tile: column (lane & 31) = pixel, row (r&3) + 8*(r>>2) + 4*(lane>>5) = output channel:
+        // registers 4g..4g+3 of a lane are 4 consecutive channels of its pixel.
+        size_t o;
+        if (!out_pixel(p, cl, m_blk + 32 * wave + (lane & 31), M, HWm, o)) return;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc32[j][4 * g + e];
+                store4(p, o, n_blk + 32 * j + 8 * g + 4 * (lane >> 5), v, vec);
+            }
+    } else {
+        // D layout of a 16x16 tile: column (lane & 15) = pixel, rows 4*(lane>>4) + i = 4 consecutive output channels
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            size_t o;
+            if (!out_pixel(p, cl, m_blk + 32 * wave + 16 * ib + (lane & 15), M, HWm, o)) continue;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                float v[4] = {acc16[ib][j][0], acc16[ib][j][1], acc16[ib][j][2], acc16[ib][j][3]};
+                store4(p, o, n_blk + 16 * j + 4 * (lane >> 4), v, vec);
+            }
+        }
+    }
+#undef X6D_ISSUE
+#undef X6D_LDP
 #undef X6D_PREP
 #undef X6D_DMA_A
 #undef X6D_DMA_W
 #undef X6D_LDW
-
-    // ---- epilogue.  D layout of a 32x32 tile: column (lane & 31) = pixel, row (r&3) + 8*(r>>2) + 4*(lane>>5) = output
-    // channel: registers 4g..4g+3 of a lane are 4 consecutive channels of its pixel.
-    const int m = m_blk + prow;
-    if (m >= M) return;
-    size_t o;
-    if ((p.s_out == 1) && (cl.oy0 == 0) && (cl.ox0 == 0) && (p.Hm == p.Hout) && (p.Wm == p.Wout)) {
-        o = (size_t)m;
-    } else {
-        const int b = m / HWm;
-        const int rr = m - b * HWm;
-        const int y = rr / p.Wm;
-        const int x = rr - y * p.Wm;
-        const int oy = cl.oy0 + y * p.s_out;
-        const int ox = cl.ox0 + x * p.s_out;
-        if (oy >= p.Hout || ox >= p.Wout) return;
-        o = ((size_t)b * p.Hout + oy) * p.Wout + ox;
-    }
-    const bool vec = !((p.Cout | p.out_cstride | p.out_coff) & 3) &&
-                     (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
-                     (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
-                     (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n0 = n_blk + 32 * j + 8 * g + 4 * (lane >> 5);
-            if (n0 >= p.Cout) continue;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[j][4 * g + e];
-            if (vec) {
-                if (p.bias != nullptr) {
-                    const f4 bb = *reinterpret_cast<const f4*>(p.bias + n0);
-                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                }
-                if (p.add != nullptr) {
-                    const f4 aa = *reinterpret_cast<const f4*>(p.add + o * p.add_cstride + p.add_coff + n0);
-                    v[0] += aa.x; v[1] += aa.y; v[2] += aa.z; v[3] += aa.w;
-                }
-                float* outp = p.out + o * p.out_cstride + p.out_coff + n0;
-                if (p.act == SPAA_ACT_RELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                } else if (p.act == SPAA_ACT_RELU_CLAMP1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    if (p.aux_out != nullptr)
-                        *reinterpret_cast<f4*>(p.aux_out + o * p.out_cstride + p.out_coff + n0) = f4{v[0], v[1], v[2], v[3]};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fminf(v[e], 1.f);
-                } else if (p.act == SPAA_ACT_LEAKY01) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.1f * v[e];
-                }
-                if (p.gate != nullptr) {
-                    const f4 gg = *reinterpret_cast<const f4*>(p.gate + o * p.gate_cstride + p.gate_coff + n0);
-                    const float ga[4] = {gg.x, gg.y, gg.z, gg.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (ga[e] > 0.f && ga[e] <= 1.f) : (ga[e] > 0.f);
-                        v[e] = pass ? v[e] : 0.f;
-                    }
-                }
-                *reinterpret_cast<f4*>(outp) = f4{v[0], v[1], v[2], v[3]};
-                if (p.gate2 != nullptr) {
-                    const f4 gg = *reinterpret_cast<const f4*>(p.gate2 + o * p.gate2_cstride + p.gate2_coff + n0);
-                    *reinterpret_cast<f4*>(p.aux_out + o * p.out_cstride + p.out_coff + n0) =
-                        f4{gg.x > 0.f ? v[0] : 0.f, gg.y > 0.f ? v[1] : 0.f, gg.z > 0.f ? v[2] : 0.f, gg.w > 0.f ? v[3] : 0.f};
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int n = n0 + e;
-                    if (n >= p.Cout) continue;
-                    float t = v[e] + (p.bias != nullptr ? p.bias[n] : 0.f);
-                    if (p.add != nullptr) t += p.add[o * p.add_cstride + p.add_coff + n];
-                    if (p.act == SPAA_ACT_RELU) {
-                        t = fmaxf(t, 0.f);
-                    } else if (p.act == SPAA_ACT_RELU_CLAMP1) {
-                        t = fmaxf(t, 0.f);
-                        if (p.aux_out != nullptr) p.aux_out[o * p.out_cstride + p.out_coff + n] = t;
-                        t = fminf(t, 1.f);
-                    } else if (p.act == SPAA_ACT_LEAKY01) {
-                        t = t > 0.f ? t : 0.1f * t;
-                    }
-                    if (p.gate != nullptr) {
-                        const float gv = p.gate[o * p.gate_cstride + p.gate_coff + n];
-                        const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (gv > 0.f && gv <= 1.f) : (gv > 0.f);
-                        t = pass ? t : 0.f;
-                    }
-                    p.out[o * p.out_cstride + p.out_coff + n] = t;
-                    if (p.gate2 != nullptr) {
-                        const float g2 = p.gate2[o * p.gate2_cstride + p.gate2_coff + n];
-                        p.aux_out[o * p.out_cstride + p.out_coff + n] = (g2 > 0.f) ? t : 0.f;
-                    }
-                }
-            }
-        }
-    }
+#undef X6D_MFMA6
 }
 
-template <int NW, int BN>
+template <int NW, int BN, int SH = 32>
 int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream) {
     constexpr int BM = 32 * NW;
     const int64_t M = (int64_t)d.B * d.Hm * d.Wm;
@@ -370,13 +469,13 @@ int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream) {
     const size_t smem = 2 * (size_t)(BM * 128 + 3 * BN * 64);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_x6d_kernel<NW, BN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_x6d_kernel<NW, BN, SH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid(m_tiles * n_tiles, d.nclass, 1);
-    hipLaunchKernelGGL((tapconv_x6d_kernel<NW, BN>), grid, dim3(64 * NW), smem, stream, d, m_tiles, n_tiles);
+    hipLaunchKernelGGL((tapconv_x6d_kernel<NW, BN, SH>), grid, dim3(64 * NW), smem, stream, d, m_tiles, n_tiles);
     return (int)hipGetLastError();
 }
 
@@ -393,6 +492,14 @@ int spaa_launch_tapconv_x6d(const spaa_tapconv_t& d, int tile, hipStream_t strea
         case 25: return launch_x6d<4, 128>(d, stream);
         case 26: return launch_x6d<8, 128>(d, stream);
         case 27: return launch_x6d<4, 64>(d, stream);
+        case 30: return launch_x6d<4, 32>(d, stream);
+        case 31: return launch_x6d<2, 64>(d, stream);
+        case 32: return launch_x6d<2, 128>(d, stream);
+        case 33: return launch_x6d<8, 64>(d, stream);
+        case 34: return launch_x6d<4, 128, 16>(d, stream);
+        case 35: return launch_x6d<8, 128, 16>(d, stream);
+        case 36: return launch_x6d<4, 64, 16>(d, stream);
+        case 37: return launch_x6d<4, 32, 16>(d, stream);
         default: return hipErrorInvalidValue;
     }
 }
