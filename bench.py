@@ -100,11 +100,16 @@ def cpu_baseline(sd, csd, setup, scenes, budget_b=16, iters=8):
 def pmc_traffic(tile):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py), or None."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
-    m = re.match(r'(x6v\d|x6)_(\d+)x(\d+)(?:g(\d))?', tile)
-    if not os.path.exists(path) or not m:
+    if not os.path.exists(path):
+        return None
+    m = re.match(r'(x6d16|x6d|x6v\d|x6)_(\d+)x(\d+)(?:g(\d))?', tile)
+    if not m:
         return None
     fam, bm, bn, g = m.groups()
-    want = f'tapconv_{fam}_kernel<{bm}, {bn}' + (f', {g}>' if g else '>')
+    if fam.startswith('x6d'):
+        want = f'tapconv_x6d_kernel<{int(bm) // 32}, {bn}, {16 if fam == "x6d16" else 32}>'
+    else:
+        want = f'tapconv_{fam}_kernel<{bm}, {bn}' + (f', {g}>' if g else '>')
     with open(path) as fh:
         for k, e in json.load(fh)['kernels'].items():
             if k.startswith(want):
@@ -189,7 +194,7 @@ def main():
         per_tile, per_layer = {}, {}
         for name, key, flops, e0, e1, tile_id, nbytes in convplan.PROFILE:
             ms = e0.elapsed_time(e1)
-            tile = convplan.TILE_NAMES.get(tile_id, 'auto')
+            tile = convplan.TILE_NAMES.get(tile_id % 100, 'auto') + (f'_splitk{tile_id // 100}' if tile_id >= 100 else '')
             a = per_tile.setdefault(tile, [0.0, 0.0, 0, 0.0])
             a[0] += flops
             a[1] += ms

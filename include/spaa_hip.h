@@ -73,6 +73,10 @@ typedef struct {
     const float* gate2;
     int32_t gate2_cstride, gate2_coff;
     int32_t tap_range[4]; /* (dy_min, dy_max, dx_min, dx_max) over the taps of all classes: patch-staged kernels */
+    float* splitk_ws;     /* split-K workspace, ksplit * B*Hm*Wm * Npad floats (Npad = Cout rounded up to 128), or NULL */
+    int32_t ksplit;       /* <= 1: off.  > 1 (tiles 25.., one class): K is cut into `ksplit` ranges computed by separate
+                             workgroups into splitk_ws; a second kernel adds them in fixed order and applies the epilogue
+                             (layers with few output pixels and long K, e.g. ResNet layer4: fills the chip) */
     int32_t nclass;
     spaa_tapclass_t cls[SPAA_MAX_CLASSES];
 } spaa_tapconv_t;

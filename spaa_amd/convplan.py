@@ -104,6 +104,7 @@ class ConvPlan:
         # algorithmic FLOPs (2*MAC, logical channels, no padding) per pixel of the class grid
         self.flops_per_pixel = 2 * sum(c['ntaps'] for c in self.cls) * cin * cout
         self.ntaps_total = sum(c['ntaps'] for c in self.cls)
+        self._ws = None  # split-K workspace, allocated on first use
 
     def run(self, inp, out, add=None, gate=None, gate_mode=_lib.GATE_POS, act=_lib.ACT_NONE, aux_out=None,
             gate2=None, in_coff=0, out_coff=0, add_coff=0, gate_coff=0):
@@ -150,7 +151,19 @@ class ConvPlan:
             forced = 0
         if (25 <= forced <= 27 or 30 <= forced <= 37) and (self.cin_p % 32 or any(c['Kpad'] != c['K'] for c in self.cls)):
             forced = 0
-        d.tile = forced if forced else TUNE.get(key, 0)
+        tile = forced if forced else TUNE.get(key, 0)
+        # tune values >= 100 encode split-K: tile + 100 * ksplit (x6d tiles, one class, enough K-steps per split)
+        ksplit, tile = (tile // 100, tile % 100) if tile >= 100 else (1, tile)
+        if ksplit > 1:
+            nk = self.cls[0]['Kpad'] // BK
+            if len(self.cls) != 1 or nk < 2 * ksplit or not (25 <= tile <= 27 or 30 <= tile <= 37) or self.cin_p % 32:
+                ksplit, tile = 1, (0 if forced else tile)
+        if ksplit > 1:
+            need = ksplit * b * d.Hm * d.Wm * ((self.cout + 127) // 128 * 128)
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, device=inp.device, dtype=torch.float32)
+            d.splitk_ws, d.ksplit = self._ws.data_ptr(), ksplit
+        d.tile = tile
         d.nclass = len(self.cls)
         d.tap_range[:] = self.tap_range
         for i, c in enumerate(self.cls):
@@ -168,7 +181,7 @@ class ConvPlan:
             nbytes = 4 * (b * hin * win * self.cin_p + npx * self.cout * (1 + (add is not None) + (gate is not None)
                                                                          + (aux_out is not None) + (gate2 is not None))
                           + self.ntaps_total * self.cin_p * self.cout)
-            PROFILE.append((self.name, key, self.flops(b, hout, wout), e0, e1, d.tile, nbytes))
+            PROFILE.append((self.name, key, self.flops(b, hout, wout), e0, e1, d.tile + 100 * (d.ksplit if d.ksplit > 1 else 0), nbytes))
         return out
 
     def flops(self, b, hout, wout):

@@ -252,14 +252,19 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
         w_goff[i] = pl * plane_bytes + (n_blk + n) * cl.Kpad * 2 + c * 16;
     }
 
-    const int nk = cl.Kpad / BK;
+    const int nk_all = cl.Kpad / BK;
     const int Cin = p.Cin;
+    // split-K: this workgroup multiplies K-steps [ks_begin, ks_end) only
+    const int nsplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int ks_begin = (int)((int64_t)blockIdx.z * nk_all / nsplit);
+    const int ks_end = (int)((int64_t)(blockIdx.z + 1) * nk_all / nsplit);
+    const int nk = ks_end - ks_begin;
     // wave-uniform state of the K-step being STAGED (one ahead of the one being multiplied); the tap offsets come through
     // scalar loads issued one K-step before they are used
     typedef const __attribute__((address_space(4))) int* cint_ptr;
     cint_ptr ctaps = (cint_ptr)(uintptr_t)taps;
-    int s_tap = 0, s_kc = 0;
-    int n_dy = ctaps[0], n_dx = ctaps[1];
+    int s_tap = (ks_begin * BK) / Cin, s_kc = (ks_begin * BK) % Cin;
+    int n_dy = ctaps[2 * min(s_tap, cl.ntaps - 1)], n_dx = ctaps[2 * min(s_tap, cl.ntaps - 1) + 1];
     int voff[4];
 
 #define X6D_PREP(more, ks_next)                                                                                    \
@@ -374,22 +379,22 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
 #pragma unroll
         for (int j = 0; j < 4; ++j) X6D_DMA_A(smem, j)
 #pragma unroll
-        for (int i = 0; i < WPW; ++i) X6D_DMA_W(smem, i, 0)
+        for (int i = 0; i < WPW; ++i) X6D_DMA_W(smem, i, ks_begin * (BK * 2))
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_MIN) : "memory");
         X6D_LDP(pfc, smem)
     }
 
     constexpr int NBLK = SH == 32 ? 2 * TN : TJ;  // MFMA blocks per K-step (6 resp. 12 MFMAs each)
-    for (int ks = 0; ks < nk; ++ks) {
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
         // own weight DMAs of step ks have landed (vmcnt) and everybody's have (barrier); every wave is also past its
         // reads of the other stage's weight planes, which are overwritten during this step
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int cur = ks & 1;
+        const int cur = (ks - ks_begin) & 1;
         const unsigned char* sb = smem + cur * STAGE;
         unsigned char* sn = smem + (cur ^ 1) * STAGE;
-        const bool more = ks + 1 < nk;
-        const int soff = min(ks + 1, nk - 1) * (BK * 2);
+        const bool more = ks + 1 < ks_end;
+        const int soff = min(ks + 1, ks_end - 1) * (BK * 2);
 
         bf16x8 wf[2][3], pfn[2][3];
         X6D_LDW(wf[0], sb + w_addr_l[0])
@@ -424,6 +429,31 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last step's (all-zero) prefetch must not outlive the wave
 
+    if (p.ksplit > 1) {
+        // split-K: raw partial sums to the workspace [split][M][Npad]; splitk_reduce_kernel finishes the layer
+        float* ws = p.splitk_ws + (size_t)blockIdx.z * M * npad;
+        if constexpr (SH == 32) {
+            const int m = m_blk + 32 * wave + (lane & 31);
+            if (m < M) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<f4*>(ws + (size_t)m * npad + n_blk + 32 * j + 8 * g + 4 * (lane >> 5)) =
+                            f4{acc32[j][4 * g], acc32[j][4 * g + 1], acc32[j][4 * g + 2], acc32[j][4 * g + 3]};
+            }
+        } else {
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                const int m = m_blk + 32 * wave + 16 * ib + (lane & 15);
+                if (m >= M) continue;
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    *reinterpret_cast<f4*>(ws + (size_t)m * npad + n_blk + 16 * j + 4 * (lane >> 4)) = acc16[ib][j];
+            }
+        }
+        return;
+    }
     if constexpr (SH == 32) {
         // D layout of a 32x32 tile: column (lane & 31) = pixel, row (r&3) + 8*(r>>2) + 4*(lane>>5) = output channel:
         // registers 4g..4g+3 of a lane are 4 consecutive channels of its pixel.
@@ -460,6 +490,25 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
 #undef X6D_MFMA6
 }
 
+// second pass of split-K: out = epilogue( sum over splits, in fixed order ), 4 channels per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const spaa_tapconv_t p, const int M, const int npad) {
+    const int nq = (p.Cout + 3) >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * nq) return;
+    const int m = (int)(idx / nq), n0 = (int)(idx - (int64_t)m * nq) * 4;
+    const spaa_tapclass_t cl = p.cls[0];
+    f4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.ksplit; ++s) sum += *reinterpret_cast<const f4*>(p.splitk_ws + ((size_t)s * M + m) * npad + n0);
+    size_t o;
+    if (!out_pixel(p, cl, m, M, p.Hm * p.Wm, o)) return;
+    const bool vec = !((p.Cout | p.out_cstride | p.out_coff) & 3) &&
+                     (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
+                     (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
+                     (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
+    float v[4] = {sum.x, sum.y, sum.z, sum.w};
+    store4(p, o, n0, v, vec);
+}
+
 template <int NW, int BN, int SH = 32>
 int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream) {
     constexpr int BM = 32 * NW;
@@ -474,8 +523,15 @@ int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid(m_tiles * n_tiles, d.nclass, 1);
+    const int ksplit = d.ksplit > 1 ? d.ksplit : 1;
+    if (ksplit > 1 && (d.nclass != 1 || d.splitk_ws == nullptr || d.cls[0].Kpad / BK < 2 * ksplit)) return hipErrorInvalidValue;
+    dim3 grid(m_tiles * n_tiles, d.nclass, ksplit);
     hipLaunchKernelGGL((tapconv_x6d_kernel<NW, BN, SH>), grid, dim3(64 * NW), smem, stream, d, m_tiles, n_tiles);
+    if (ksplit > 1) {
+        const int npad = (d.Cout + 127) & ~127;
+        const int64_t nthr = M * ((d.Cout + 3) >> 2);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, d, (int)M, npad);
+    }
     return (int)hipGetLastError();
 }
 

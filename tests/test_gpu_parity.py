@@ -140,7 +140,7 @@ def test_directconv_thin_layers(hip, tile):
         cp.FORCE_TILE = 0
 
 
-@pytest.mark.parametrize('tile', [12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 30, 31, 32, 33, 34, 35, 36, 37])
+@pytest.mark.parametrize('tile', [12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 30, 31, 32, 33, 34, 35, 36, 37, 225, 431, 234, 436])
 def test_tapconv_x6_is_fp32_accurate(hip, tile):
     """fp32 emulated on the bf16 matrix cores (exact 3-way operand split, 6 of 9 partial products, separate
     accumulators): the error against an fp64 reference must not exceed that of the exact-fp32 MFMA kernel."""
