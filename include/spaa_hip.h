@@ -77,6 +77,11 @@ typedef struct {
     int32_t ksplit;       /* <= 1: off.  > 1 (tiles 25.., one class): K is cut into `ksplit` ranges computed by separate
                              workgroups into splitk_ws; a second kernel adds them in fixed order and applies the epilogue
                              (layers with few output pixels and long K, e.g. ResNet layer4: fills the chip) */
+    int32_t nfold;        /* <= 1: off.  4 (tiles 25.., one class, s_out == 2, Cout % 4 == 0): the four output-parity classes of
+                             a kernel-2 stride-2 ConvTranspose2d share their single tap, so they are folded into the GEMM N
+                             dimension: weight rows [nfold*Cout], row c*Cout + n -> output pixel (2y + c/2, 2x + c%2),
+                             channel n.  The input is read once instead of once per class. */
+    int32_t reserved0;
     int32_t nclass;
     spaa_tapclass_t cls[SPAA_MAX_CLASSES];
 } spaa_tapconv_t;

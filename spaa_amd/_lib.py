@@ -36,7 +36,7 @@ class TapConv(C.Structure):
         ('aux_out', C.c_void_p),
         ('gate2', C.c_void_p), ('gate2_cstride', C.c_int32), ('gate2_coff', C.c_int32),
         ('tap_range', C.c_int32 * 4),
-        ('splitk_ws', C.c_void_p), ('ksplit', C.c_int32),
+        ('splitk_ws', C.c_void_p), ('ksplit', C.c_int32), ('nfold', C.c_int32), ('reserved0', C.c_int32),
         ('nclass', C.c_int32),
         ('cls', TapClass * MAX_CLASSES),
     ]

@@ -27,6 +27,7 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               25: 'x6d_128x128', 26: 'x6d_256x128', 27: 'x6d_128x64', 28: 'thinpatch32', 29: 'thinpatch16',
               30: 'x6d_128x32', 31: 'x6d_64x64', 32: 'x6d_64x128', 33: 'x6d_256x64',
               34: 'x6d16_128x128', 35: 'x6d16_256x128', 36: 'x6d16_128x64', 37: 'x6d16_128x32'}
+FOLD_DECONV = True  # k2/s2 transposed convs: parity classes folded into GEMM rows (one read of the input)
 ENABLE_X6 = True  # build the split-bf16 weight planes (needed by tiles 12-14)
 
 
@@ -60,14 +61,17 @@ class TapClassSpec:
 class ConvPlan:
     """Packed weights + launch template for spaa_tapconv_f32."""
 
-    def __init__(self, classes, cin, cout, s_in, s_out, bias=None, device='cuda', name=''):
+    def __init__(self, classes, cin, cout, s_in, s_out, bias=None, device='cuda', name='', nfold=1):
         assert 1 <= len(classes) <= _lib.MAX_CLASSES
+        assert nfold == 1 or (nfold == 4 and len(classes) == 1 and s_out == 2 and cout % 4 == 0 and cin % 32 == 0)
+        self.nfold = nfold                  # 4: the parity classes of a k2/s2 deconv folded into GEMM rows
         self.name = name
         self.cin = cin                      # logical input channels (before padding)
         self.cin_p = _ceil(cin, 4)          # K uses the padded count; pad columns are zero
         self.cout = cout
         self.s_in, self.s_out = s_in, s_out
-        npad = _ceil(cout, NPAD)
+        ngemm = cout * nfold
+        npad = _ceil(ngemm, NPAD)
         w_chunks, tap_list, self.cls = [], [], []
         w_off = 0
         for c in classes:
@@ -77,8 +81,8 @@ class ConvPlan:
             kpad = _ceil(k, BK)
             wp = torch.zeros(npad, kpad, dtype=torch.float32)
             for t, (dy, dx, w) in enumerate(c.taps):
-                assert w.shape == (cout, cin), (w.shape, cout, cin)
-                wp[:cout, t * self.cin_p:t * self.cin_p + cin] = w
+                assert w.shape == (ngemm, cin), (w.shape, ngemm, cin)
+                wp[:ngemm, t * self.cin_p:t * self.cin_p + cin] = w
             self.cls.append(dict(oy0=c.oy0, ox0=c.ox0, ntaps=nt, tap_off=len(tap_list), K=k, Kpad=kpad, w_off=w_off))
             tap_list += [(dy, dx) for dy, dx, _ in c.taps]
             w_chunks.append(wp.reshape(-1))
@@ -102,7 +106,7 @@ class ConvPlan:
         self.taps = taps.to(device)
         self.bias = bias.detach().float().contiguous().to(device) if bias is not None else None
         # algorithmic FLOPs (2*MAC, logical channels, no padding) per pixel of the class grid
-        self.flops_per_pixel = 2 * sum(c['ntaps'] for c in self.cls) * cin * cout
+        self.flops_per_pixel = 2 * sum(c['ntaps'] for c in self.cls) * cin * ngemm
         self.ntaps_total = sum(c['ntaps'] for c in self.cls)
         self._ws = None  # split-K workspace, allocated on first use
 
@@ -139,7 +143,7 @@ class ConvPlan:
         if gate2 is not None:
             assert aux_out is not None and gate2.shape[:3] == out.shape[:3] and self.cout <= gate2.shape[3]
             d.gate2, d.gate2_cstride, d.gate2_coff = gate2.data_ptr(), gate2.shape[3], 0
-        key = f'{self.cin_p}_{self.cout}_{self.ntaps_total}_{self.s_in}_{self.s_out}_{b * d.Hm * d.Wm}'
+        key = f'{self.cin_p}_{self.cout}_{self.ntaps_total}_{self.s_in}_{self.s_out}_{b * d.Hm * d.Wm}' + ('_fold' if self.nfold > 1 else '')
         forced = FORCE_TILE
         if forced == 9 and self.cout > 4:
             forced = 0
@@ -154,6 +158,11 @@ class ConvPlan:
         tile = forced if forced else TUNE.get(key, 0)
         # tune values >= 100 encode split-K: tile + 100 * ksplit (x6d tiles, one class, enough K-steps per split)
         ksplit, tile = (tile // 100, tile % 100) if tile >= 100 else (1, tile)
+        if self.nfold > 1:  # only the DMA-staged kernels know the folded epilogue
+            ksplit = 1
+            if not (25 <= tile <= 27 or 30 <= tile <= 37):
+                tile = 34
+            d.nfold = self.nfold
         if ksplit > 1:
             nk = self.cls[0]['Kpad'] // BK
             if len(self.cls) != 1 or nk < 2 * ksplit or not (25 <= tile <= 27 or 30 <= tile <= 37) or self.cin_p % 32:
@@ -258,6 +267,11 @@ def deconv_fwd_plan(weight, bias, stride, pad, device='cuda', name=''):
     def wsel(ky, kx):
         return w[:, :, ky, kx].t().contiguous()
 
+    if FOLD_DECONV and kh == 2 and kw == 2 and pad == 0 and ci % 32 == 0 and co % 4 == 0 and ENABLE_X6:
+        # the four output-parity classes share the tap (0, 0): fold them into the GEMM rows (row c*co + n, c = 2 dy + dx)
+        c = TapClassSpec(0, 0)
+        c.add(0, 0, torch.cat([wsel(dy, dx) for dy in (0, 1) for dx in (0, 1)], 0))
+        return ConvPlan([c], ci, co, 1, 2, bias, device, name, nfold=4)
     return ConvPlan(_fractional_classes(wsel, kh, kw, pad), ci, co, 1, 2, bias, device, name)
 
 

@@ -168,6 +168,21 @@ __device__ __forceinline__ bool out_pixel(const spaa_tapconv_t& p, const spaa_ta
     return true;
 }
 
+// N-folded stride-2 transposed convolution: GEMM row group n0 -> (parity class c, channel n) and the class's pixel
+__device__ __forceinline__ void store4_fold(const spaa_tapconv_t& p, const int m, const int M, const int HWm, const int n0,
+                                            float (&v)[4], const bool vec) {
+    if (m >= M) return;
+    const int c = n0 / p.Cout;
+    if (c >= p.nfold) return;
+    const int b = m / HWm;
+    const int rr = m - b * HWm;
+    const int y = rr / p.Wm;
+    const int x = rr - y * p.Wm;
+    const int oy = 2 * y + (c >> 1), ox = 2 * x + (c & 1);
+    if (oy >= p.Hout || ox >= p.Wout) return;
+    store4(p, ((size_t)b * p.Hout + oy) * p.Wout + ox, n0 - c * p.Cout, v, vec);
+}
+
 template <int NW, int BN, int SH>
 __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapconv_t p, const int m_tiles,
                                                                  const int n_tiles) {
@@ -234,7 +249,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
     const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)in_hi << 32) | in_lo), 0,
                                                             (int)__builtin_amdgcn_readfirstlane(in_bytes), 0x00020000);
     // ---- weight staging: piece q = wave * WPW + i -> (plane, 16-row block); lane -> (row, physical chunk)
-    const int npad = (p.Cout + 127) & ~127;
+    const int npad = (p.Cout * (p.nfold > 1 ? p.nfold : 1) + 127) & ~127;
     const int plane_bytes = npad * cl.Kpad * 2;
     const uint64_t w_addr = reinterpret_cast<uint64_t>(p.w_split) + (uint64_t)cl.w_off * 6u;
     const uint32_t w_lo = __builtin_amdgcn_readfirstlane((uint32_t)w_addr);
@@ -454,6 +469,28 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
         }
         return;
     }
+    if (p.nfold > 1) {
+        if constexpr (SH == 32) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc32[j][4 * g + e];
+                    store4_fold(p, m_blk + 32 * wave + (lane & 31), M, HWm, n_blk + 32 * j + 8 * g + 4 * (lane >> 5), v, vec);
+                }
+        } else {
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    float v[4] = {acc16[ib][j][0], acc16[ib][j][1], acc16[ib][j][2], acc16[ib][j][3]};
+                    store4_fold(p, m_blk + 32 * wave + 16 * ib + (lane & 15), M, HWm, n_blk + 16 * j + 4 * (lane >> 4), v, vec);
+                }
+        }
+        return;
+    }
     if constexpr (SH == 32) {
         // D layout of a 32x32 tile: column (lane & 31) = pixel, row (r&3) + 8*(r>>2) + 4*(lane>>5) = output channel:
         // registers 4g..4g+3 of a lane are 4 consecutive channels of its pixel.
@@ -514,7 +551,9 @@ int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream) {
     constexpr int BM = 32 * NW;
     const int64_t M = (int64_t)d.B * d.Hm * d.Wm;
     const int m_tiles = (int)((M + BM - 1) / BM);
-    const int n_tiles = (d.Cout + BN - 1) / BN;
+    const int nfold = d.nfold > 1 ? d.nfold : 1;
+    if (nfold > 1 && (nfold != 4 || d.nclass != 1 || d.s_out != 2 || (d.Cout & 3) || d.ksplit > 1)) return hipErrorInvalidValue;
+    const int n_tiles = (d.Cout * nfold + BN - 1) / BN;
     const size_t smem = 2 * (size_t)(BM * 128 + 3 * BN * 64);
     static bool attr_set = false;
     if (!attr_set) {
@@ -541,7 +580,8 @@ int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream) {
 int spaa_launch_tapconv_x6d(const spaa_tapconv_t& d, int tile, hipStream_t stream) {
     if (d.w_split == nullptr || (d.Cin % BK) != 0) return hipErrorInvalidValue;
     for (int c = 0; c < d.nclass; ++c) {
-        if ((int64_t)((d.Cout + 127) & ~127) * d.cls[c].Kpad * 6 >= (int64_t)1 << 31) return hipErrorInvalidValue;
+        if ((int64_t)((d.Cout * (d.nfold > 1 ? d.nfold : 1) + 127) & ~127) * d.cls[c].Kpad * 6 >= (int64_t)1 << 31)
+            return hipErrorInvalidValue;
         if (d.cls[c].Kpad != d.cls[c].K) return hipErrorInvalidValue;
     }
     switch (tile) {

@@ -9,6 +9,16 @@ def emulate(plan, inp, hout, wout):
     b, hin, win, _ = inp.shape
     cin = plan.cin
     out = torch.zeros(b, hout, wout, plan.cout)
+    if getattr(plan, 'nfold', 1) > 1:
+        # spaa_tapconv_t.nfold: GEMM row c*Cout + n -> output pixel (2y + c//2, 2x + c%2), channel n
+        (dy, dx, w), = plan.classes_host[0].taps
+        assert (dy, dx) == (0, 0) and plan.s_in == 1 and plan.s_out == 2
+        acc = inp[..., :cin] @ w.t()                      # [b, hin, win, 4*cout]
+        for c in range(4):
+            oy, ox = 2 * torch.arange(hin) + c // 2, 2 * torch.arange(win) + c % 2
+            ky, kx = oy < hout, ox < wout
+            out[:, oy[ky][:, None], ox[kx][None, :]] = acc[:, ky][:, :, kx][..., c * plan.cout:(c + 1) * plan.cout]
+        return out + plan.bias.cpu() if plan.bias is not None else out
     for c in plan.classes_host:
         if plan.s_out == 1:
             hm, wm = hout, wout

@@ -37,13 +37,14 @@ def test_conv_dgrad_channel_subset():
     assert torch.allclose(nchw(gx), x.grad[:, 3:6], atol=1e-4)
 
 
-@pytest.mark.parametrize('ci,co,k,p,op,h,w', [(6, 4, 3, 1, 1, 5, 7), (5, 3, 2, 0, 0, 6, 4)])
+@pytest.mark.parametrize('ci,co,k,p,op,h,w', [(6, 4, 3, 1, 1, 5, 7), (5, 3, 2, 0, 0, 6, 4), (32, 8, 2, 0, 0, 5, 3)])
 def test_deconv_fwd_and_dgrad(ci, co, k, p, op, h, w):
     x = torch.randn(2, ci, h, w, requires_grad=True)
     wt = torch.randn(ci, co, k, k)
     b = torch.randn(co)
     y = F.conv_transpose2d(x, wt, b, 2, p, op)
     plan = cp.deconv_fwd_plan(wt, b, 2, p, device='cpu')
+    assert plan.nfold == (4 if (k == 2 and ci % 32 == 0) else 1)
     y2 = emulate(plan, nhwc(x.detach(), plan.cin_p), y.shape[2], y.shape[3])
     assert torch.allclose(nchw(y2), y, atol=1e-4)
     gy = torch.randn_like(y)

@@ -560,3 +560,25 @@ def test_compennet_pp_forward_and_perc_al_glue(hip, golden_dir):
     setup = dict(classifier_crop_sz=(60, 60), prj_brightness=0.5, prj_im_sz=sz)
     cam, prj = perc_al_compennet_pp(net, clf, None, [204, 291], True, s[0], 2, DEV, setup)
     assert cam.shape == (2, 3, 64, 64) and prj.shape == (2, 3, 64, 64) and torch.isfinite(prj).all()
+
+
+@pytest.mark.parametrize('tile', [0, 25, 27, 30, 34, 36, 37])
+def test_folded_deconv_with_epilogue(hip, tile):
+    """Kernel-2 stride-2 ConvTranspose2d with the four parity classes folded into the GEMM rows (spaa_tapconv_t.nfold),
+    fused residual + ReLU, against torch; every DMA-staged tile shape."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(17)
+    for ci, co, h, w in [(64, 32, 9, 7), (32, 8, 16, 16), (96, 36, 5, 6)]:
+        x = torch.randn(2, ci, h, w)
+        wt = torch.randn(ci, co, 2, 2) / (ci * 4) ** 0.5
+        bias, add = torch.randn(co), torch.randn(2, co, 2 * h, 2 * w)
+        y = F.relu(F.conv_transpose2d(x, wt, bias, 2, 0) + add)
+        plan = cp.deconv_fwd_plan(wt, bias, 2, 0, DEV)
+        assert plan.nfold == 4
+        out = torch.zeros(2, 2 * h, 2 * w, co, device=DEV)
+        try:
+            cp.FORCE_TILE = tile
+            plan.run(nhwc(x, ci).to(DEV), out, add=nhwc(add).to(DEV), act=lib.ACT_RELU)
+        finally:
+            cp.FORCE_TILE = 0
+        assert rel_inf(nchw(out.cpu(), co), y) < 1e-5
