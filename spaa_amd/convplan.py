@@ -26,7 +26,7 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               20: 'x6v3_128x64g3', 21: 'x6v3_128x64g2', 22: 'x6v3_64x64g3', 23: 'x6v3_128x128g1', 24: 'x6v3_64x128g2',
               25: 'x6d_128x128', 26: 'x6d_256x128', 27: 'x6d_128x64', 28: 'thinpatch32', 29: 'thinpatch16',
               30: 'x6d_128x32', 31: 'x6d_64x64', 32: 'x6d_64x128', 33: 'x6d_256x64',
-              34: 'x6d16_128x128', 35: 'x6d16_256x128', 36: 'x6d16_128x64', 37: 'x6d16_128x32'}
+              34: 'x6d16_128x128', 35: 'x6d16_256x128', 36: 'x6d16_128x64', 37: 'x6d16_128x32', 38: 'smallcin'}
 FOLD_DECONV = True  # k2/s2 transposed convs: parity classes folded into GEMM rows (one read of the input)
 ENABLE_X6 = True  # build the split-bf16 weight planes (needed by tiles 12-14)
 
@@ -150,6 +150,9 @@ class ConvPlan:
         if forced == 10 and (self.cout > 32 or self.ntaps_total * self.cin_p > 512):
             forced = 0
         if forced == 11 and (self.cout > 4 or self.cin_p > 256 or (self.cin_p & (self.cin_p - 1))):
+            forced = 0
+        if forced == 38 and (len(self.cls) != 1 or self.cout > 32 or self.cin_p not in (4, 8) or self.ntaps_total > 9
+                             or self.s_in > 2):
             forced = 0
         if forced in (28, 29) and (self.cout > 4 or self.s_in != 1 or self.cin_p % (32 if forced == 28 else 16)):
             forced = 0

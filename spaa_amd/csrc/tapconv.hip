@@ -20,6 +20,7 @@
 int spaa_launch_tapconv_x6(const spaa_tapconv_t& d, int tile, hipStream_t stream);   // tapconv_x6.hip
 int spaa_launch_tapconv_x6d(const spaa_tapconv_t& d, int tile, hipStream_t stream);  // tapconv_x6d.hip
 int spaa_launch_thinpatch(const spaa_tapconv_t& d, hipStream_t stream);               // thinpatch.hip
+int spaa_launch_smallcin(const spaa_tapconv_t& d, hipStream_t stream);                // smallcin.hip
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -588,6 +589,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         case 35:
         case 36:
         case 37: return spaa_launch_tapconv_x6d(d, tile, stream);
+        case 38: return spaa_launch_smallcin(d, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -107,7 +107,7 @@ def test_tapconv_deconv_forward_and_dgrad(hip, ci, co, k, p, op, h, w):
     assert rel_inf(nchw(gx.cpu(), ci), x.grad) < 1e-5
 
 
-@pytest.mark.parametrize('tile', [9, 10, 11, 28, 29])
+@pytest.mark.parametrize('tile', [9, 10, 11, 28, 29, 38])
 def test_directconv_thin_layers(hip, tile):
     """The VALU variants for thin layers (few output or few input channels) compute the same tap-list convolution."""
     cp, lib = hip['cp'], hip['lib']
