@@ -92,7 +92,7 @@ __device__ __forceinline__ void store4_fold(const spaa_tapconv_t& p, const int m
     store4(p, ((size_t)b * p.Hout + oy) * p.Wout + ox, n0 - c * p.Cout, v, vec);
 }
 
-template <int NW, int BN, int SH>
+template <int NW, int BN, int SH, bool CO>
 __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapconv_t p, const int m_tiles,
                                                                  const int n_tiles) {
     constexpr int BM = 32 * NW;
@@ -378,6 +378,59 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
         }
         return;
     }
+    if constexpr (CO) {
+        // ---- coalesced epilogue (memory-heavy layers): the result tile goes through LDS (the stage buffers are free
+        // now) so that a store instruction writes whole channel rows of a few pixels, and the residual / gate loads read
+        // whole rows, instead of 16-byte pieces of 16 different rows.
+        static_assert(SH == 16, "coalesced epilogue: 16x16x32 variant only");
+        constexpr int PITCH = BN + 4;  // floats: a 16-B bank group apart per row -> conflict-free b128 writes
+        static_assert(BM * PITCH * 4 <= 2 * STAGE, "result tile must fit in the stage buffers");
+        if (vec) {
+            __syncthreads();  // every wave is past its last reads of the stages
+            float* slab = reinterpret_cast<float*>(smem) + (32 * wave) * PITCH;  // this wave's 32 rows
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    *reinterpret_cast<f32x4*>(slab + (16 * ib + (lane & 15)) * PITCH + 16 * j + 4 * (lane >> 4)) = acc16[ib][j];
+            constexpr int LPR = BN / 4;    // lanes per row (4 channels each)
+            constexpr int RPI = 64 / LPR;  // rows per store instruction
+            const int n0 = n_blk + 4 * (lane % LPR);
+            const int cfold = p.nfold > 1 ? n0 / p.Cout : 0;
+            const bool linear = p.nfold <= 1 && (p.s_out == 1) && (cl.oy0 == 0) && (cl.ox0 == 0) && (p.Hm == p.Hout) &&
+                                (p.Wm == p.Wout);
+            int m = m_blk + 32 * wave + lane / LPR;
+            int pb = m / HWm, py = (m - pb * HWm) / p.Wm, px = m - pb * HWm - py * p.Wm;
+#pragma unroll
+            for (int i = 0; i < 32 / RPI; ++i) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(slab + (i * RPI + lane / LPR) * PITCH + 4 * (lane % LPR));
+                if (m < M) {
+                    float v[4] = {t[0], t[1], t[2], t[3]};
+                    if (p.nfold > 1) {
+                        const int oy = 2 * py + (cfold >> 1), ox = 2 * px + (cfold & 1);
+                        if (cfold < p.nfold && oy < p.Hout && ox < p.Wout)
+                            store4(p, ((size_t)pb * p.Hout + oy) * p.Wout + ox, n0 - cfold * p.Cout, v, vec);
+                    } else if (linear) {
+                        store4(p, (size_t)m, n0, v, vec);
+                    } else {
+                        const int oy = cl.oy0 + py * p.s_out, ox = cl.ox0 + px * p.s_out;
+                        if (oy < p.Hout && ox < p.Wout) store4(p, ((size_t)pb * p.Hout + oy) * p.Wout + ox, n0, v, vec);
+                    }
+                }
+                m += RPI;
+                px += RPI;
+                while (px >= p.Wm) {
+                    px -= p.Wm;
+                    py += 1;
+                }
+                while (py >= p.Hm) {
+                    py -= p.Hm;
+                    pb += 1;
+                }
+            }
+            return;
+        }
+    }
     if (p.nfold > 1) {
         if constexpr (SH == 32) {
 #pragma unroll
@@ -455,7 +508,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const spaa_tapconv_t
     store4(p, o, n0, v, vec);
 }
 
-template <int NW, int BN, int SH = 32>
+template <int NW, int BN, int SH = 32, bool CO = false>
 int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream) {
     constexpr int BM = 32 * NW;
     const int64_t M = (int64_t)d.B * d.Hm * d.Wm;
@@ -466,7 +519,7 @@ int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream) {
     const size_t smem = 2 * (size_t)(BM * 128 + 3 * BN * 64);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_x6d_kernel<NW, BN, SH>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_x6d_kernel<NW, BN, SH, CO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -474,7 +527,7 @@ int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream) {
     const int ksplit = d.ksplit > 1 ? d.ksplit : 1;
     if (ksplit > 1 && (d.nclass != 1 || d.splitk_ws == nullptr || d.cls[0].Kpad / BK < 2 * ksplit)) return hipErrorInvalidValue;
     dim3 grid(m_tiles * n_tiles, d.nclass, ksplit);
-    hipLaunchKernelGGL((tapconv_x6d_kernel<NW, BN, SH>), grid, dim3(64 * NW), smem, stream, d, m_tiles, n_tiles);
+    hipLaunchKernelGGL((tapconv_x6d_kernel<NW, BN, SH, CO>), grid, dim3(64 * NW), smem, stream, d, m_tiles, n_tiles);
     if (ksplit > 1) {
         const int npad = (d.Cout + 127) & ~127;
         const int64_t nthr = M * ((d.Cout + 3) >> 2);
@@ -505,6 +558,9 @@ int spaa_launch_tapconv_x6d(const spaa_tapconv_t& d, int tile, hipStream_t strea
         case 35: return launch_x6d<8, 128, 16>(d, stream);
         case 36: return launch_x6d<4, 64, 16>(d, stream);
         case 37: return launch_x6d<4, 32, 16>(d, stream);
+        case 39: return launch_x6d<4, 128, 16, true>(d, stream);
+        case 40: return launch_x6d<4, 64, 16, true>(d, stream);
+        case 41: return launch_x6d<4, 32, 16, true>(d, stream);
         default: return hipErrorInvalidValue;
     }
 }

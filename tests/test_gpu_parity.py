@@ -140,7 +140,7 @@ def test_directconv_thin_layers(hip, tile):
         cp.FORCE_TILE = 0
 
 
-@pytest.mark.parametrize('tile', [12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 30, 31, 32, 33, 34, 35, 36, 37, 225, 431, 234, 436])
+@pytest.mark.parametrize('tile', [12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 30, 31, 32, 33, 34, 35, 36, 37, 225, 431, 234, 436, 39, 40, 41])
 def test_tapconv_x6_is_fp32_accurate(hip, tile):
     """fp32 emulated on the bf16 matrix cores (exact 3-way operand split, 6 of 9 partial products, separate
     accumulators): the error against an fp64 reference must not exceed that of the exact-fp32 MFMA kernel."""
@@ -174,8 +174,10 @@ def test_tapconv_x6_is_fp32_accurate(hip, tile):
         cp.FORCE_TILE = 0
 
 
-def test_tapconv_epilogues(hip):
+@pytest.mark.parametrize('tile', [0, 6, 18, 34, 36, 39, 40, 41])
+def test_tapconv_epilogues(hip, tile):
     cp, lib = hip['cp'], hip['lib']
+    cp.FORCE_TILE = tile
     torch.manual_seed(3)
     x, wt, bias = torch.randn(2, 32, 12, 12), torch.randn(64, 32, 3, 3) / 17, torch.randn(64)
     add, gate, gate2 = torch.randn(2, 64, 12, 12), torch.randn(2, 64, 12, 12), torch.randn(2, 64, 12, 12)
@@ -191,6 +193,14 @@ def test_tapconv_epilogues(hip):
     assert rel_inf(nchw(out.cpu()), pre.clamp(max=1)) < 1e-5 and rel_inf(nchw(aux.cpu()), pre) < 1e-5
     plan.run(nhwc(x).to(DEV), out, act=lib.ACT_LEAKY01)
     assert rel_inf(nchw(out.cpu()), F.leaky_relu(F.conv2d(x, wt, bias, 1, 1), 0.1)) < 1e-5
+    # strided output classes (3x3 stride-2 transposed conv) with a residual, non-square, ragged against the tile
+    xt, wtt = torch.randn(2, 32, 9, 11), torch.randn(32, 64, 3, 3) / 17
+    addt = torch.randn(2, 64, 18, 22)
+    tplan = cp.deconv_fwd_plan(wtt, bias, 2, 1, DEV)
+    outt = torch.zeros(2, 18, 22, 64, device=DEV)
+    tplan.run(nhwc(xt).to(DEV), outt, add=nhwc(addt).to(DEV), act=lib.ACT_RELU)
+    assert rel_inf(nchw(outt.cpu()), F.relu(F.conv_transpose2d(xt, wtt, bias, 2, 1, 1) + addt)) < 1e-5
+    cp.FORCE_TILE = 0
     with pytest.raises(AssertionError):  # shape mismatch is caught on the host, before any launch
         plan.run(nhwc(x).to(DEV), torch.zeros(2, 12, 12, 32, device=DEV))
 
@@ -562,7 +572,7 @@ def test_compennet_pp_forward_and_perc_al_glue(hip, golden_dir):
     assert cam.shape == (2, 3, 64, 64) and prj.shape == (2, 3, 64, 64) and torch.isfinite(prj).all()
 
 
-@pytest.mark.parametrize('tile', [0, 25, 27, 30, 34, 36, 37])
+@pytest.mark.parametrize('tile', [0, 25, 27, 30, 34, 36, 37, 39, 40, 41])
 def test_folded_deconv_with_epilogue(hip, tile):
     """Kernel-2 stride-2 ConvTranspose2d with the four parity classes folded into the GEMM rows (spaa_tapconv_t.nfold),
     fused residual + ReLU, against torch; every DMA-staged tile shape."""
