@@ -11,6 +11,8 @@ torch.manual_seed(0)
 wt = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
 plan = cp.conv_fwd_plan(wt, torch.randn(cout), s, k // 2, 'cuda')
 x = torch.randn(B, H, W, (cin + 3) // 4 * 4, device='cuda')
+if os.environ.get('PROF_ZERO_INPUT'):
+    x.zero_()  # same instruction stream, no operand toggling: separates clock/power effects from cycle counts
 ho, wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
 out = torch.zeros(B, ho, wo, (cout + 3) // 4 * 4, device='cuda')
 cp.FORCE_TILE = tile
