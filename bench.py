@@ -102,12 +102,13 @@ def pmc_traffic(tile):
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
     if not os.path.exists(path):
         return None
-    m = re.match(r'(x6d16|x6d|x6v\d|x6)_(\d+)x(\d+)(?:g(\d))?', tile)
+    m = re.match(r'(x6d16co|x6d16|x6d|x6v\d|x6)_(\d+)x(\d+)(?:g(\d))?', tile)
     if not m:
         return None
     fam, bm, bn, g = m.groups()
     if fam.startswith('x6d'):
-        want = f'tapconv_x6d_kernel<{int(bm) // 32}, {bn}, {16 if fam == "x6d16" else 32}>'
+        want = (f'tapconv_x6d_kernel<{int(bm) // 32}, {bn}, {16 if fam.startswith("x6d16") else 32}, '
+                f'{"true" if fam.endswith("co") else "false"}>')
     else:
         want = f'tapconv_{fam}_kernel<{bm}, {bn}' + (f', {g}>' if g else '>')
     with open(path) as fh:
@@ -194,8 +195,10 @@ def main():
         per_tile, per_layer = {}, {}
         for name, key, flops, e0, e1, tile_id, nbytes in convplan.PROFILE:
             ms = e0.elapsed_time(e1)
-            tile = convplan.TILE_NAMES.get(tile_id % 100, 'auto') + (f'_splitk{tile_id // 100}' if tile_id >= 100 else '')
-            a = per_tile.setdefault(tile, [0.0, 0.0, 0, 0.0])
+            # roofline groups = kernel instantiations (as rocprofv3 reports them): split-K launches of a tile belong to it
+            base = convplan.TILE_NAMES.get(tile_id % 100, 'auto')
+            tile = base + (f'_splitk{tile_id // 100}' if tile_id >= 100 else '')
+            a = per_tile.setdefault(base, [0.0, 0.0, 0, 0.0])
             a[0] += flops
             a[1] += ms
             a[2] += 1
