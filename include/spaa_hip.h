@@ -138,6 +138,17 @@ int spaa_stealth_loss_fwd_bwd(const float* y, const float* scene, const float* s
                               float camdE_w, float gscale, float* g_y, float* de_map, float* partial, int B, int HW,
                               spaa_stream_t stream);
 
+/* calc_img_dists (utils.py:420-491), NHWC4 images x, y of `npix` = B*H*W pixels: per-pixel terms of PSNR/RMSE (sum of
+ * squared differences), mean L2 (:460-471), mean L_inf (:475-486) and mean dE2000 (differential_color_functions.py:183-190)
+ * reduced per 256-pixel block in fixed order: partial[(npix+255)/256][4] = (sum d^2, sum ||d||_2, sum max|d|, sum dE). */
+int spaa_img_dists(const float* x, const float* y, float* partial, int npix, spaa_stream_t stream);
+
+/* SSIM map sum (pytorch_ssim/__init__.py:26-58: 11x11 Gaussian `window` [121] as create_window builds it, replicate
+ * padding, C1 = 0.01^2, C2 = 0.03^2, per channel): partial[B][ceil(H/16)][ceil(W/16)] = sum over the tile's pixels and
+ * 3 channels; the mean is the sum of all partials / (B*3*H*W). */
+int spaa_ssim(const float* x, const float* y, const float* window, float* partial, int B, int H, int W,
+              spaa_stream_t stream);
+
 /* ---- classifier pre/post-processing (classifier.py:55-72, img_proc.py:117-132) --------------------------- */
 /* center_crop + F.interpolate(mode='area') + Normalize, NHWC4 in -> NHWC4 out; mean3/std3 are HOST pointers */
 int spaa_preproc_fwd(const float* y, float* out, int B, int H, int W, int cy0, int cx0, int ch, int cw, int oh,

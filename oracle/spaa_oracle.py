@@ -589,3 +589,37 @@ def perc_al_adversary_projector(classifier, inputs, labels, d_thr, targeted=True
                               color_dis=color_dis.detach().clone(), caml2=caml2.clone(), p1=p[:, 0].copy(),
                               top1=idx[:, 0].copy(), x_round=x_round.clone()))
     return x_best
+
+
+# --------------------------------------------------------------------------------------
+# utils.py:420-491 (calc_img_dists) and pytorch_ssim/__init__.py:9-58
+# --------------------------------------------------------------------------------------
+def ssim_window(window_size=11, sigma=1.5, channel=3):
+    g = torch.Tensor([math.exp(-(i - window_size // 2) ** 2 / float(2 * sigma ** 2)) for i in range(window_size)])
+    g = (g / g.sum()).unsqueeze(1)
+    return g.mm(g.t()).float()[None, None].expand(channel, 1, window_size, window_size).contiguous()
+
+
+def ssim(x, y, window_size=11):
+    """pytorch_ssim.ssim (:98-107) -> _ssim (:26-58): replicate padding, grouped 11x11 Gaussian, mean of the map."""
+    c = x.shape[1]
+    w = ssim_window(window_size, 1.5, c)
+    pad = window_size // 2
+    x, y = F.pad(x, (pad,) * 4, mode='replicate'), F.pad(y, (pad,) * 4, mode='replicate')
+    mu1, mu2 = F.conv2d(x, w, groups=c), F.conv2d(y, w, groups=c)
+    mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s1 = F.conv2d(x * x, w, groups=c) - mu1_sq
+    s2 = F.conv2d(y * y, w, groups=c) - mu2_sq
+    s12 = F.conv2d(x * y, w, groups=c) - mu12
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu12 + c1) * (2 * s12 + c2)) / ((mu1_sq + mu2_sq + c1) * (s1 + s2 + c2))).mean().item()
+
+
+def calc_img_dists(x, y):
+    """utils.py:420-491: (PSNR, RMSE, SSIM, mean L2 * 255, mean L_inf * 255, mean dE2000)."""
+    x, y = expand_4d(x), expand_4d(y)
+    mse = F.mse_loss(x, y)
+    d = x - y
+    de = ciede2000_diff(rgb2lab_diff(x), rgb2lab_diff(y)).mean().item()
+    return (10 * math.log10(1 / mse), math.sqrt(mse.item() * 3), ssim(x, y), torch.norm(d, p=2, dim=1).mean().item() * 255,
+            torch.norm(d, p=float('inf'), dim=1).mean().item() * 255, de)

@@ -58,6 +58,8 @@ _SIGNATURES = {
     'spaa_rgb2lab': [_p, _p, _i, _p],
     'spaa_ciede2000': [_p, _p, _p, _i, _p],
     'spaa_stealth_loss_fwd_bwd': [_p, _p, _p, _f, _f, _f, _p, _p, _p, _i, _i, _p],
+    'spaa_img_dists': [_p, _p, _p, _i, _p],
+    'spaa_ssim': [_p, _p, _p, _p, _i, _i, _i, _p],
     'spaa_add_nhwc4': [_p, _p, _p, _i, _p],
     'spaa_ce_grad': [_p, _i, _p, _f, _p, _i, _p],
     'spaa_masked_step': [_p, _p, _p, _p, _i, _i, _f, _i, _i, _p],

@@ -330,9 +330,102 @@ __global__ __launch_bounds__(256) void stealth_loss_kernel(const float4* __restr
 // dE(inputs_LAB, lab(x)) with the *second* argument variable (perc_al/__init__.py:197): provided by the
 // symmetric kernel below (argument order swapped inside ciede2000 is NOT equivalent, so it has its own adjoint).
 
+// ---------------------------------------------------------------------------------------------------------------
+// calc_img_dists (utils.py:420-491): per-pixel terms of MSE / mean-L2 / mean-L_inf / mean dE2000 in one pass.
+// partial[block][4] = (sum d^2 over 3 channels, sum ||d||_2, sum max|d|, sum dE); the host adds the blocks in order.
+__global__ __launch_bounds__(256) void img_dists_kernel(const float4* __restrict__ x, const float4* __restrict__ y,
+                                                        float* __restrict__ partial, int npix) {
+    __shared__ float red[4];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    float sq = 0.f, l2 = 0.f, li = 0.f, de = 0.f;
+    if (idx < npix) {
+        const float4 a = x[idx], b = y[idx];
+        const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+        sq = dx * dx + dy * dy + dz * dz;
+        l2 = sqrtf(sq);
+        li = fmaxf(fabsf(dx), fmaxf(fabsf(dy), fabsf(dz)));
+        float L1, A1, B1, L2, A2, B2;
+        rgb_to_lab(a.x, a.y, a.z, L1, A1, B1);
+        rgb_to_lab(b.x, b.y, b.z, L2, A2, B2);
+        de = ciede2000<false>(L1, A1, B1, L2, A2, B2).de;
+    }
+    const float s0 = block_sum_256(sq, red), s1 = block_sum_256(l2, red), s2 = block_sum_256(li, red),
+                s3 = block_sum_256(de, red);
+    if (threadIdx.x == 0) {
+        partial[4 * blockIdx.x + 0] = s0;
+        partial[4 * blockIdx.x + 1] = s1;
+        partial[4 * blockIdx.x + 2] = s2;
+        partial[4 * blockIdx.x + 3] = s3;
+    }
+}
+
+// SSIM (pytorch_ssim/__init__.py:26-58): 11x11 Gaussian window (sigma 1.5, passed in as the reference builds it),
+// replicate padding, per channel; partial[block] = sum of the SSIM map over the block's 16x16 pixels x 3 channels.
+constexpr int SS_T = 16, SS_R = 5, SS_P = SS_T + 2 * SS_R;
+__global__ __launch_bounds__(256) void ssim_kernel(const float4* __restrict__ x, const float4* __restrict__ y,
+                                                   const float* __restrict__ window, float* __restrict__ partial, int H,
+                                                   int W) {
+    __shared__ float4 sx[SS_P * SS_P], sy[SS_P * SS_P];
+    __shared__ float sw[121];
+    __shared__ float red[4];
+    const int b = blockIdx.z, y0 = blockIdx.y * SS_T, x0 = blockIdx.x * SS_T;
+    const size_t base = (size_t)b * H * W;
+    for (int i = threadIdx.x; i < SS_P * SS_P; i += 256) {
+        const int py = i / SS_P, px = i - py * SS_P;
+        const int iy = min(max(y0 + py - SS_R, 0), H - 1), ix = min(max(x0 + px - SS_R, 0), W - 1);  // replicate
+        sx[i] = x[base + (size_t)iy * W + ix];
+        sy[i] = y[base + (size_t)iy * W + ix];
+    }
+    if (threadIdx.x < 121) sw[threadIdx.x] = window[threadIdx.x];
+    __syncthreads();
+    const int ly = threadIdx.x / SS_T, lx = threadIdx.x - ly * SS_T;
+    float mu1[3] = {0, 0, 0}, mu2[3] = {0, 0, 0}, s11[3] = {0, 0, 0}, s22[3] = {0, 0, 0}, s12[3] = {0, 0, 0};
+    for (int ky = 0; ky < 11; ++ky)
+        for (int kx = 0; kx < 11; ++kx) {
+            const float w = sw[ky * 11 + kx];
+            const float4 a = sx[(ly + ky) * SS_P + lx + kx], c = sy[(ly + ky) * SS_P + lx + kx];
+            const float av[3] = {a.x, a.y, a.z}, cv[3] = {c.x, c.y, c.z};
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                mu1[ch] = fmaf(w, av[ch], mu1[ch]);
+                mu2[ch] = fmaf(w, cv[ch], mu2[ch]);
+                s11[ch] = fmaf(w, av[ch] * av[ch], s11[ch]);
+                s22[ch] = fmaf(w, cv[ch] * cv[ch], s22[ch]);
+                s12[ch] = fmaf(w, av[ch] * cv[ch], s12[ch]);
+            }
+        }
+    float v = 0.f;
+    if (y0 + ly < H && x0 + lx < W) {
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float m11 = mu1[ch] * mu1[ch], m22 = mu2[ch] * mu2[ch], m12 = mu1[ch] * mu2[ch];
+            v += ((2.f * m12 + C1) * (2.f * (s12[ch] - m12) + C2)) /
+                 ((m11 + m22 + C1) * ((s11[ch] - m11) + (s22[ch] - m22) + C2));
+        }
+    }
+    const float s = block_sum_256(v, red);
+    if (threadIdx.x == 0) partial[((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+}
+
 }  // namespace
 
 extern "C" {
+
+int spaa_img_dists(const float* x, const float* y, float* partial, int npix, spaa_stream_t stream) {
+    if (!x || !y || !partial || npix < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(img_dists_kernel, dim3((npix + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                       (const float4*)y, partial, npix);
+    return (int)hipGetLastError();
+}
+
+int spaa_ssim(const float* x, const float* y, const float* window, float* partial, int B, int H, int W,
+              spaa_stream_t stream) {
+    if (!x || !y || !window || !partial || B < 1 || H < 1 || W < 1 || B > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ssim_kernel, dim3((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, B), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)x, (const float4*)y, window, partial, H, W);
+    return (int)hipGetLastError();
+}
 
 int spaa_rgb2lab(const float* rgb, float* lab, int npix, spaa_stream_t stream) {
     if (!rgb || !lab || npix < 1) return hipErrorInvalidValue;

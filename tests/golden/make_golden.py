@@ -124,6 +124,35 @@ def gen_compennet_pp(ref, name, sz, seed):
     save(name, seed=seed, sz=sz, x=x, s=s, y=y, wsum=weights_checksum(sd), oracle_maxdiff=diff)
 
 
+def gen_metrics(ref, name):
+    """calc_img_dists (utils.py:420-491).  utils.py itself cannot be imported (visdom / Qt at import time), so its four
+    small metric functions are exec'd from their source text; SSIM and deltaE are the reference's own modules."""
+    import ast
+    import importlib.util
+    import math
+    import torch.nn as nn
+    ref_root = ref_shims.REF_ROOT
+    spec = importlib.util.spec_from_file_location('ref_pytorch_ssim', os.path.join(ref_root, 'pytorch_ssim', '__init__.py'))
+    ref_ssim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_ssim)
+    src = open(os.path.join(ref_root, 'utils.py')).read()
+    ns = dict(torch=torch, nn=nn, math=math)
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name in ('psnr', 'rmse', 'l2_norm', 'linf_norm'):
+            exec(compile(ast.Module([node], []), 'utils.py', 'exec'), ns)
+    x = syn.scenes(31, 3, (48, 72))
+    rng = np.random.default_rng(5)
+    y = (x + torch.from_numpy(rng.normal(0, 0.03, x.shape).astype(np.float32))).clamp(0, 1)
+    y[0, :, :8] = x[0, :, :8]  # identical region (dE shortcut, SSIM = 1 there)
+    with torch.no_grad():
+        want = np.array([ns['psnr'](x, y), ns['rmse'](x, y), ref_ssim.ssim(x, y).item(), ns['l2_norm'](x, y),
+                         ns['linf_norm'](x, y), ref.color.deltaE(x, y)])
+    got = np.array(so.calc_img_dists(x, y))
+    diff = float(np.abs(got - want).max())
+    print(f'  {name}: reference {want}, oracle maxdiff {diff:.3e}')
+    save(name, x=x, y=y, dists=want, oracle_maxdiff=diff)
+
+
 class Recorder:
     """Wraps the duck-typed classifier to observe the reference's loop without touching it."""
 
@@ -214,6 +243,7 @@ CASES = {
     'spaa_256_near': lambda r: gen_spaa(r, 'spaa_256_near', (256, 256), True, ('near', 8), 5, 'camdE_caml2',
                                         mask='ones', keep=2),
     'compennet_pp_64': lambda r: gen_compennet_pp(r, 'compennet_pp_64', (64, 64), 5),
+    'img_dists': lambda r: gen_metrics(r, 'img_dists'),
     'percal_64_targeted': lambda r: gen_percal(r, 'percal_64_targeted', (64, 64), True, 2, 0),
     'percal_64_untargeted': lambda r: gen_percal(r, 'percal_64_untargeted', (64, 64), False, 2, 40),
 }

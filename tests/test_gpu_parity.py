@@ -592,3 +592,24 @@ def test_folded_deconv_with_epilogue(hip, tile):
         finally:
             cp.FORCE_TILE = 0
         assert rel_inf(nchw(out.cpu(), co), y) < 1e-5
+
+
+def test_img_dists_metrics(hip, golden_dir):
+    """Next-row component: calc_img_dists on HIP vs the reference's values and vs the oracle on other sizes."""
+    from spaa_amd import metrics
+    z = load(golden_dir, 'img_dists')
+    x, y = torch.from_numpy(z['x']), torch.from_numpy(z['y'])
+    got = np.array(metrics.calc_img_dists(x.to(DEV), y))          # mixed devices, as the reference tolerates
+    assert np.abs(got / z['dists'] - 1).max() < 2e-5, (got, z['dists'])
+    torch.manual_seed(4)
+    for shape in [(3, 37, 53), (2, 3, 256, 256), (1, 3, 16, 16)]:   # ragged tiles, full size, one tile; 3-D input
+        a = torch.rand(*shape)
+        b = (a + 0.05 * torch.randn(*shape)).clamp(0, 1)
+        want = np.array(so.calc_img_dists(a, b))
+        got = np.array(metrics.calc_img_dists(a, b))
+        assert np.abs(got / want - 1).max() < 2e-5, (shape, got, want)
+        single = np.array([metrics.psnr(a, b), metrics.rmse(a, b), metrics.ssim(a, b), metrics.l2_norm(a, b),
+                           metrics.linf_norm(a, b), metrics.deltaE(a, b)])
+        assert np.array_equal(single, got)
+    with pytest.raises(ValueError):
+        metrics.calc_img_dists(torch.rand(3, 8, 8), torch.rand(3, 8, 9))

@@ -113,3 +113,10 @@ def test_compennet_pp_forward(golden_dir):
     assert np.allclose(checksum(sd), z['wsum'], rtol=1e-9)
     y = so.compennet_pp_forward(sd, torch.from_numpy(z['x']), torch.from_numpy(z['s']), sz)
     assert np.abs(y.numpy() - z['y']).max() <= 1e-6
+
+
+def test_img_dists_metrics(golden_dir):
+    """calc_img_dists (utils.py:420-491): PSNR, RMSE, SSIM, mean L2, mean L_inf, mean dE against the reference's values."""
+    z = load(golden_dir, 'img_dists')
+    got = np.array(so.calc_img_dists(torch.from_numpy(z['x']), torch.from_numpy(z['y'])))
+    assert np.abs(got - z['dists']).max() <= 1e-6 * np.abs(z['dists']).max()
