@@ -21,4 +21,16 @@ def __getattr__(name):
     if name in ('rgb2lab_diff', 'ciede2000_diff', 'deltaE', 'stealth_loss_with_grad'):
         from . import differential_color_functions
         return getattr(differential_color_functions, name)
+    if name in ('CompenNet', 'CompenNetPlusplus'):
+        from . import models
+        return getattr(models, name)
+    if name in ('PerC_AL', 'perc_al_compennet_pp'):
+        from . import perc_al
+        return getattr(perc_al, name)
+    if name == 'calc_img_dists':
+        from . import metrics
+        return metrics.calc_img_dists
+    if name in ('torch_imread', 'torch_imread_mt', 'save_imgs', 'load_setup_info', 'save_checkpoint'):
+        from . import io
+        return getattr(io, name)
     raise AttributeError(name)
