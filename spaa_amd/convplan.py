@@ -11,6 +11,7 @@ so one MFMA kernel serves all of them.  The weights are frozen during an attack
 This module only rearranges weights (layout plumbing, on the host); the arithmetic happens in the HIP kernel.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -28,6 +29,7 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               30: 'x6d_128x32', 31: 'x6d_64x64', 32: 'x6d_64x128', 33: 'x6d_256x64',
               34: 'x6d16_128x128', 35: 'x6d16_256x128', 36: 'x6d16_128x64', 37: 'x6d16_128x32', 38: 'smallcin',
               39: 'x6d16co_128x128', 40: 'x6d16co_128x64', 41: 'x6d16co_128x32'}
+DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
 FOLD_DECONV = True  # k2/s2 transposed convs: parity classes folded into GEMM rows (one read of the input)
 ENABLE_X6 = True  # build the split-bf16 weight planes (needed by tiles 12-14)
 
@@ -159,7 +161,9 @@ class ConvPlan:
             forced = 0
         if (25 <= forced <= 27 or 30 <= forced <= 37 or 39 <= forced <= 41) and (self.cin_p % 32 or any(c['Kpad'] != c['K'] for c in self.cls)):
             forced = 0
-        tile = forced if forced else TUNE.get(key, 0)
+        tile = forced if forced else TUNE.get(key, -1)
+        if tile < 0:
+            tile = self._default_tile(b * d.Hm * d.Wm)
         # tune values >= 100 encode split-K: tile + 100 * ksplit (x6d tiles, one class, enough K-steps per split)
         ksplit, tile = (tile // 100, tile % 100) if tile >= 100 else (1, tile)
         if self.nfold > 1:  # only the DMA-staged kernels know the folded epilogue
@@ -196,6 +200,27 @@ class ConvPlan:
                           + self.ntaps_total * self.cin_p * self.cout)
             PROFILE.append((self.name, key, self.flops(b, hout, wout), e0, e1, d.tile + 100 * (d.ksplit if d.ksplit > 1 else 0), nbytes))
         return out
+
+    def _default_tile(self, m):
+        """Kernel choice for a layer shape that tools/autotune.py has not measured: the family that wins for the
+        measured shapes of the same kind."""
+        one = len(self.cls) == 1
+        off = DEFAULT_DISABLE  # debugging aid: families to leave out of the default choice
+        if 'thin' not in off and self.cout <= 4 and self.s_in == 1 and self.cin_p % 16 == 0:
+            return 29                                                   # thin output: patch-staged VALU kernel
+        if 'smallcin' not in off and one and self.cin_p in (4, 8) and self.cout <= 32 and self.ntaps_total <= 9 and self.s_in <= 2:
+            return 38                                                   # few input channels: fp32 MFMA from an LDS patch
+        if self.w_split is None:
+            return 0
+        if 'x6d' not in off and self.cin_p % 32 == 0:                   # DMA-staged bf16x6 kernels
+            ngemm = self.cout * self.nfold
+            tile = 34 if ngemm > 64 else (36 if ngemm > 32 else 37)
+            nk = self.cls[0]['Kpad'] // BK
+            wgs = (m + 127) // 128 * ((ngemm + 127) // 128 if tile == 34 else 1)
+            if 'splitk' not in off and one and self.nfold == 1 and wgs < 256 and nk >= 16:      # few pixels, long K: split K to fill the chip
+                tile += 100 * (4 if wgs < 128 and nk >= 32 else 2)
+            return tile
+        return 18 if self.cout > 32 else 16                             # register-staged bf16x6 kernels
 
     def flops(self, b, hout, wout):
         hm = hout if self.s_out == 1 else (hout + 1) // 2

@@ -304,7 +304,13 @@ def test_resnet18_classifier_vs_oracle(hip):
         raw2, p2, idx2 = clf(im2, crop)
         (raw2 * r.to(DEV)).sum().backward()
         assert rel_inf(raw2, raw) < 1e-5
-        assert rel_l2(im2.grad, im.grad) < 1e-4 and outlier_fraction(im2.grad, im.grad, 1e-3) < 1e-3
+        # input gradient: ~1e-6 when every ReLU gate agrees.  A unit whose pre-activation is within rounding of zero may
+        # fall on the other side here (other summation order, e.g. split-K) than in the oracle: one such unit in layer1
+        # changes the ~1.1e3 gradient elements of its receptive field (measured: the fp32 and fp64 ORACLES disagree with
+        # each other in exactly this way at 64x64, rel L2 1.0e-3).  Allow a few flips, nothing else.
+        gl2, gout = rel_l2(im2.grad, im.grad), outlier_fraction(im2.grad, im.grad, 1e-3)
+        print(f'resnet18 {h}x{h}: input-gradient rel L2 {gl2:.2e}, outliers {gout:.2e}')
+        assert gl2 < 1e-4 or (gl2 < 5e-3 and gout < 5e-3)
         assert (idx2[:, 0] == idx[:, 0]).all() and np.allclose(p2[:, 0], p[:, 0], atol=1e-5)
         assert p2.shape == (b, 1000) and idx2.shape == (b, 1000)
 
