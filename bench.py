@@ -25,7 +25,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, den
 PEAK_BF16_MFMA_TFLOPS = 2516.0  # dense bf16 MFMA (16x the fp32 rate; "~2.5 PF dense" in MI355X_MICROARCH.md)
 
 
-def build_attack(rank, batch, size, n_scenes, dev):
+def build_attack(rank, batch, size, n_scenes, dev, classifier='resnet18'):
     from spaa_amd import synthetic as syn
     from spaa_amd.models import PCNet, WarpingNet
     from spaa_amd.classifier import Classifier
@@ -36,8 +36,9 @@ def build_attack(rank, batch, size, n_scenes, dev):
     pc = PCNet(sd['mask'], WarpingNet(out_size=sz))
     pc.load_state_dict(sd)
     pc = pc.to(dev)
-    csd = syn.resnet18_state_dict(2, logit_gain=20.0)
-    clf = Classifier('resnet18', dev, state_dict=csd)
+    csd = {'resnet18': syn.resnet18_state_dict, 'vgg16': syn.vgg16_state_dict,
+           'inception_v3': syn.inception_v3_state_dict}[classifier](2, logit_gain=20.0)
+    clf = Classifier(classifier, dev, state_dict=csd)
     per = batch // n_scenes
     scenes = syn.scenes(1 + 1000 * rank, n_scenes, sz)
     scene_b = scenes.repeat_interleave(per, dim=0)
@@ -125,6 +126,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--classifier', default='resnet18', choices=['resnet18', 'vgg16', 'inception_v3'],
+                    help='BASELINE.json configs[1] is resnet18 (the bench line); the others are extra data points')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-out', default=None, help='write the per-layer tapconv timing table (JSON) here')
     args = ap.parse_args()
@@ -143,7 +146,7 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
 
     log('building attack state')
-    st, sd, csd, setup, scenes, targets = build_attack(rank, args.batch, args.size, 8, dev)
+    st, sd, csd, setup, scenes, targets = build_attack(rank, args.batch, args.size, 8, dev, args.classifier)
     torch.cuda.synchronize()
     log('warmup')
     hp = dict(targeted=True, d_thr=5, adv_lr=2, col_lr=1, p_thresh=0.9)
@@ -245,15 +248,15 @@ def main():
             'value': round(value, 3), 'unit': 'attack-iterations/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'configs[1]: batch={args.batch} ({8} scenes x {args.batch // 8} targets) '
-                                   f'{args.size}x{args.size}, ResNet-18, camdE_caml2, per GPU',
+            'config': {'workload': f'{dict(resnet18="configs[1]", inception_v3="configs[2]", vgg16="configs[4] classifier, SPAA loop")[args.classifier]}: batch={args.batch} ({8} scenes x {args.batch // 8} targets) '
+                                   f'{args.size}x{args.size}, {args.classifier}, camdE_caml2, per GPU',
                        'global_batch': args.batch * world, 'parallelism': f'dp{world} (independent shards)'},
             'scene_iterations_per_s': round(value * args.batch, 1),
             'roofline': roof,
         }
         if gather_ms is not None:
             out['gather_ms'] = round(gather_ms, 3)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.classifier == 'resnet18':
             log(f'cpu baseline on {usable_cores()} cores')
             out['cpu_baseline'] = cpu_baseline(sd, csd, setup, scenes)
         else:
