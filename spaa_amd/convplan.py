@@ -28,7 +28,8 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               25: 'x6d_128x128', 26: 'x6d_256x128', 27: 'x6d_128x64', 28: 'thinpatch32', 29: 'thinpatch16',
               30: 'x6d_128x32', 31: 'x6d_64x64', 32: 'x6d_64x128', 33: 'x6d_256x64',
               34: 'x6d16_128x128', 35: 'x6d16_256x128', 36: 'x6d16_128x64', 37: 'x6d16_128x32', 38: 'smallcin',
-              39: 'x6d16co_128x128', 40: 'x6d16co_128x64', 41: 'x6d16co_128x32'}
+              39: 'x6d16co_128x128', 40: 'x6d16co_128x64', 41: 'x6d16co_128x32',
+              42: 'x6d16a3_128x64', 43: 'x6d16a3_128x32', 44: 'x6da3_128x64', 45: 'x6d16coa3_128x64', 46: 'x6d16coa3_128x32'}
 DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
 FOLD_DECONV = True  # k2/s2 transposed convs: parity classes folded into GEMM rows (one read of the input)
 ENABLE_X6 = True  # build the split-bf16 weight planes (needed by tiles 12-14)
@@ -159,7 +160,7 @@ class ConvPlan:
             forced = 0
         if forced in (28, 29) and (self.cout > 4 or self.s_in != 1 or self.cin_p % (32 if forced == 28 else 16)):
             forced = 0
-        if (25 <= forced <= 27 or 30 <= forced <= 37 or 39 <= forced <= 41) and (self.cin_p % 32 or any(c['Kpad'] != c['K'] for c in self.cls)):
+        if (25 <= forced <= 27 or 30 <= forced <= 37 or 39 <= forced <= 46) and (self.cin_p % 32 or any(c['Kpad'] != c['K'] for c in self.cls)):
             forced = 0
         tile = forced if forced else TUNE.get(key, -1)
         if tile < 0:
@@ -168,12 +169,12 @@ class ConvPlan:
         ksplit, tile = (tile // 100, tile % 100) if tile >= 100 else (1, tile)
         if self.nfold > 1:  # only the DMA-staged kernels know the folded epilogue
             ksplit = 1
-            if not (25 <= tile <= 27 or 30 <= tile <= 37 or 39 <= tile <= 41):
+            if not (25 <= tile <= 27 or 30 <= tile <= 37 or 39 <= tile <= 46):
                 tile = 34
             d.nfold = self.nfold
         if ksplit > 1:
             nk = self.cls[0]['Kpad'] // BK
-            if len(self.cls) != 1 or nk < 2 * ksplit or not (25 <= tile <= 27 or 30 <= tile <= 37 or 39 <= tile <= 41) or self.cin_p % 32:
+            if len(self.cls) != 1 or nk < 2 * ksplit or not (25 <= tile <= 27 or 30 <= tile <= 37 or 39 <= tile <= 46) or self.cin_p % 32:
                 ksplit, tile = 1, (0 if forced else tile)
         if ksplit > 1:
             need = ksplit * b * d.Hm * d.Wm * ((self.cout + 127) // 128 * 128)

@@ -544,7 +544,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
     for (int c = 0; c < d.nclass; ++c)
         if ((int64_t)((d.Cout + 127) & ~127) * d.cls[c].Kpad * 4 >= (int64_t)1 << 31) return hipErrorInvalidValue;
     int tile = d.tile;
-    if (d.nfold > 1 && !((tile >= 25 && tile <= 27) || (tile >= 30 && tile <= 37) || (tile >= 39 && tile <= 41)))
+    if (d.nfold > 1 && !((tile >= 25 && tile <= 27) || (tile >= 30 && tile <= 37) || (tile >= 39 && tile <= 46)))
         return hipErrorInvalidValue;
     if (tile == 0) {  // heuristic: widest N tile that fits Cout; shrink M when the grid would not fill 256 CUs twice
         const int64_t M = (int64_t)d.B * d.Hm * d.Wm * d.nclass;
@@ -593,7 +593,12 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         case 38: return spaa_launch_smallcin(d, stream);
         case 39:
         case 40:
-        case 41: return spaa_launch_tapconv_x6d(d, tile, stream);
+        case 41:
+        case 42:
+        case 43:
+        case 44:
+        case 45:
+        case 46: return spaa_launch_tapconv_x6d(d, tile, stream);
         default: return hipErrorInvalidValue;
     }
 }

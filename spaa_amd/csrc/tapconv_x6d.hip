@@ -92,14 +92,16 @@ __device__ __forceinline__ void store4_fold(const spaa_tapconv_t& p, const int m
     store4(p, ((size_t)b * p.Hout + oy) * p.Wout + ox, n0 - c * p.Cout, v, vec);
 }
 
-template <int NW, int BN, int SH, bool CO>
+template <int NW, int BN, int SH, bool CO, int NA>
 __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapconv_t p, const int m_tiles,
                                                                  const int n_tiles) {
     constexpr int BM = 32 * NW;
     constexpr int TN = BN / 32;
     constexpr int A_BYTES = BM * 128;               // fp32 pixels: [BM][32] floats
     constexpr int W_PLANE = BN * 64;                // one bf16 plane: [BN][32] bf16
-    constexpr int STAGE = A_BYTES + 3 * W_PLANE;
+    constexpr int WS_BYTES = 3 * W_PLANE;           // one weight stage (h / m / l planes)
+    constexpr int W_BASE = NA * A_BYTES;            // LDS: NA pixel stages, then 2 weight stages
+    constexpr int LDS_BYTES = NA * A_BYTES + 2 * WS_BYTES;
     constexpr int W_PIECES = 3 * BN / 16;           // 1-KiB pieces (16 rows of one plane)
     constexpr int WPW = (W_PIECES + NW - 1) / NW;   // weight pieces per wave per K-step (piece q -> wave q % NW)
 
@@ -208,10 +210,10 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
         n_dy = ctaps[2 * tn];                                                                                      \
         n_dx = ctaps[2 * tn + 1];                                                                                  \
     }
-#define X6D_DMA_A(sbase, j) dma16(rsrc_in, (sbase) + (4 * wave + (j)) * 1024, voff[j], 0);
-#define X6D_DMA_W(sbase, i, soff)                                                                                  \
+#define X6D_DMA_A(abase, j) dma16(rsrc_in, (abase) + (4 * wave + (j)) * 1024, voff[j], 0);
+#define X6D_DMA_W(wbase, i, soff)                                                                                  \
     if (W_PIECES % NW == 0 || wave + NW * (i) < W_PIECES)                                                          \
-        dma16(rsrc_w, (sbase) + A_BYTES + (wave + NW * (i)) * 1024, w_goff[i], (soff));
+        dma16(rsrc_w, (wbase) + (wave + NW * (i)) * 1024, w_goff[i], (soff));
 #define X6D_LDW(dst, ptr)                                                                                          \
     {                                                                                                              \
         const unsigned char* wb_ = (ptr);                                                                          \
@@ -228,17 +230,25 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
     accv = MF(wf[0], pf[1], accv, 0, 0, 0);                                                                        \
     accv = MF(wf[0], pf[0], accv, 0, 0, 0);
 
-    // DMA issue order inside a K-step: the 4 pixel pieces first, then the weight pieces, spread over the MFMA blocks;
-    // piece s of NP goes to block s * NBLK / NP.  A wave reads back only ITS OWN pixel rows, so the pixel fragments of
-    // step t+1 are read and split at the end of step t, behind a counted vmcnt that covers the pixel pieces (no barrier
-    // needed for own DMA data); the barrier at the top of a step then only orders the weight planes.
+    // DMA schedule.  A wave reads back only ITS OWN pixel rows, so the pixel fragments of step t+1 are read and split at
+    // the end of step t, behind a counted vmcnt that covers the pixel pieces (no barrier needed for own DMA data); the
+    // barrier at the top of a step then only orders the weight planes.  The pieces of a step are spread over its MFMA
+    // blocks (piece s of NP goes to block s * NBLK / NP):
+    //   NA == 2: step t issues pixels(t+1) then weights(t+1); waits: top vmcnt(0), end vmcnt(#weights).
+    //   NA == 3: pixels run TWO steps ahead (narrow tiles: a step's MFMAs are shorter than the gather latency):
+    //            step t issues weights(t+1) then pixels(t+2); waits: top vmcnt(4) (leaves pixels(t+1) in flight), end
+    //            vmcnt(#weights + 4) (leaves weights(t+1), pixels(t+2)).
     constexpr int NP = 4 + WPW;
-    constexpr int W_MIN = W_PIECES / NW;  // weight pieces every wave issues after its last pixel piece
-#define X6D_ISSUE(blk, NBLK, sn, soff)                                                                             \
+    constexpr int W_MIN = W_PIECES / NW;  // weight pieces every wave issues
+#define X6D_ISSUE(blk, NBLK, an, wn, soff)                                                                         \
     {                                                                                                              \
         _Pragma("unroll") for (int s_ = 0; s_ < NP; ++s_)                                                          \
             if (s_ * (NBLK) / NP == (blk)) {                                                                       \
-                if (s_ < 4) { X6D_DMA_A(sn, s_) } else { X6D_DMA_W(sn, s_ - 4, soff) }                             \
+                if (NA == 2) {                                                                                     \
+                    if (s_ < 4) { X6D_DMA_A(an, s_) } else { X6D_DMA_W(wn, s_ - 4, soff) }                         \
+                } else {                                                                                           \
+                    if (s_ < WPW) { X6D_DMA_W(wn, s_, soff) } else { X6D_DMA_A(an, s_ - WPW) }                     \
+                }                                                                                                  \
             }                                                                                                      \
     }
 
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int n = lane & 31;
-            w_addr_l[kk] = A_BYTES + n * 64 + (((2 * kk + (lane >> 5)) ^ swz_w<SH>(n)) * 16);
+            w_addr_l[kk] = n * 64 + (((2 * kk + (lane >> 5)) ^ swz_w<SH>(n)) * 16);
         }
     } else {
         // 16x16x32: pixel (lane & 15) of each of the wave's two 16-pixel blocks; k-chunks 2 (lane >> 4) + {0, 1}
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
 #pragma unroll
             for (int h = 0; h < 2; ++h) p_addr[ib][h] = r * 128 + ((((lane >> 4) * 2 + h) ^ swz_pix<SH>(r)) * 16);
         }
-        w_addr_l[0] = A_BYTES + (lane & 15) * 64 + (((lane >> 4) ^ swz_w<SH>(lane & 15)) * 16);
+        w_addr_l[0] = (lane & 15) * 64 + (((lane >> 4) ^ swz_w<SH>(lane & 15)) * 16);
         w_addr_l[1] = 0;
     }
 #define X6D_LDP(pf, sbase)                                                                                         \
@@ -298,46 +308,61 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
         for (int j = 0; j < (SH == 16 ? TJ : 1); ++j) acc16[ib][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     bf16x8 pfc[2][3];  // pixel fragments of the current K-step (h / m / l planes of the two halves or pixel blocks)
+    int ia = 0;        // pixel stage of the current step (stages rotate 0 .. NA-1)
     if (nk > 0) {
         X6D_PREP(true, 0)
 #pragma unroll
         for (int j = 0; j < 4; ++j) X6D_DMA_A(smem, j)
 #pragma unroll
-        for (int i = 0; i < WPW; ++i) X6D_DMA_W(smem, i, ks_begin * (BK * 2))
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_MIN) : "memory");
+        for (int i = 0; i < WPW; ++i) X6D_DMA_W(smem + W_BASE, i, ks_begin * (BK * 2))
+        if constexpr (NA == 3) {
+            X6D_PREP(nk > 1, 1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) X6D_DMA_A(smem + A_BYTES, j)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_MIN + 4) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_MIN) : "memory");
+        }
         X6D_LDP(pfc, smem)
     }
 
     constexpr int NBLK = SH == 32 ? 2 * TN : TJ;  // MFMA blocks per K-step (6 resp. 12 MFMAs each)
     for (int ks = ks_begin; ks < ks_end; ++ks) {
         // own weight DMAs of step ks have landed (vmcnt) and everybody's have (barrier); every wave is also past its
-        // reads of the other stage's weight planes, which are overwritten during this step
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // reads of the other weight stage, which is overwritten during this step
+        if constexpr (NA == 3) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
         const int cur = (ks - ks_begin) & 1;
-        const unsigned char* sb = smem + cur * STAGE;
-        unsigned char* sn = smem + (cur ^ 1) * STAGE;
-        const bool more = ks + 1 < ks_end;
+        const unsigned char* wc = smem + W_BASE + cur * WS_BYTES;
+        unsigned char* wn = smem + W_BASE + (cur ^ 1) * WS_BYTES;
+        const int ia1 = ia + 1 == NA ? 0 : ia + 1;          // pixel stage of step ks+1 (read at the end of this step)
+        const int ia2 = NA == 3 ? (ia1 + 1 == NA ? 0 : ia1 + 1) : ia1;  // pixel stage filled during this step
+        unsigned char* an = smem + ia2 * A_BYTES;
+        const bool more = ks + (NA - 1) < ks_end;           // is there a step whose pixels are gathered now?
         const int soff = min(ks + 1, ks_end - 1) * (BK * 2);
 
         bf16x8 wf[2][3], pfn[2][3];
-        X6D_LDW(wf[0], sb + w_addr_l[0])
-        X6D_PREP(more, ks + 1)
+        X6D_LDW(wf[0], wc + w_addr_l[0])
+        X6D_PREP(more, ks + NA - 1)
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) {
             if (b + 1 < NBLK) {
                 if constexpr (SH == 32) {
-                    X6D_LDW(wf[(b + 1) & 1], sb + w_addr_l[(b + 1) / TN] + ((b + 1) % TN) * 2048)
+                    X6D_LDW(wf[(b + 1) & 1], wc + w_addr_l[(b + 1) / TN] + ((b + 1) % TN) * 2048)
                 } else {
-                    X6D_LDW(wf[(b + 1) & 1], sb + w_addr_l[0] + (b + 1) * 1024)
+                    X6D_LDW(wf[(b + 1) & 1], wc + w_addr_l[0] + (b + 1) * 1024)
                 }
             }
-            X6D_ISSUE(b, NBLK, sn, soff)
+            X6D_ISSUE(b, NBLK, an, wn, soff)
             if (b == NBLK - 1) {
                 // the pixel pieces of step ks+1 (this wave's own rows) have landed: fetch and split them now, under
                 // the last block's MFMAs
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_MIN) : "memory");
-                X6D_LDP(pfn, sn)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA == 3 ? W_MIN + 4 : W_MIN) : "memory");
+                X6D_LDP(pfn, smem + ia1 * A_BYTES)
             }
             if constexpr (SH == 32) {
                 X6D_MFMA6(__builtin_amdgcn_mfma_f32_32x32x16_bf16, acc32[b % TN], wf[b & 1], pfc[b / TN])
@@ -350,6 +375,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) pfc[i][pl] = pfn[i][pl];
+        ia = ia1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last step's (all-zero) prefetch must not outlive the wave
 
@@ -384,7 +410,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
         // whole rows, instead of 16-byte pieces of 16 different rows.
         static_assert(SH == 16, "coalesced epilogue: 16x16x32 variant only");
         constexpr int PITCH = BN + 4;  // floats: a 16-B bank group apart per row -> conflict-free b128 writes
-        static_assert(BM * PITCH * 4 <= 2 * STAGE, "result tile must fit in the stage buffers");
+        static_assert(BM * PITCH * 4 <= LDS_BYTES, "result tile must fit in the stage buffers");
         if (vec) {
             __syncthreads();  // every wave is past its last reads of the stages
             float* slab = reinterpret_cast<float*>(smem) + (32 * wave) * PITCH;  // this wave's 32 rows
@@ -508,7 +534,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const spaa_tapconv_t
     store4(p, o, n0, v, vec);
 }
 
-template <int NW, int BN, int SH = 32, bool CO = false>
+template <int NW, int BN, int SH = 32, bool CO = false, int NA = 2>
 int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream) {
     constexpr int BM = 32 * NW;
     const int64_t M = (int64_t)d.B * d.Hm * d.Wm;
@@ -516,10 +542,10 @@ int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream) {
     const int nfold = d.nfold > 1 ? d.nfold : 1;
     if (nfold > 1 && (nfold != 4 || d.nclass != 1 || d.s_out != 2 || (d.Cout & 3) || d.ksplit > 1)) return hipErrorInvalidValue;
     const int n_tiles = (d.Cout * nfold + BN - 1) / BN;
-    const size_t smem = 2 * (size_t)(BM * 128 + 3 * BN * 64);
+    const size_t smem = (size_t)NA * (BM * 128) + 2 * (size_t)(3 * BN * 64);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_x6d_kernel<NW, BN, SH, CO>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_x6d_kernel<NW, BN, SH, CO, NA>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -527,7 +553,7 @@ int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream) {
     const int ksplit = d.ksplit > 1 ? d.ksplit : 1;
     if (ksplit > 1 && (d.nclass != 1 || d.splitk_ws == nullptr || d.cls[0].Kpad / BK < 2 * ksplit)) return hipErrorInvalidValue;
     dim3 grid(m_tiles * n_tiles, d.nclass, ksplit);
-    hipLaunchKernelGGL((tapconv_x6d_kernel<NW, BN, SH, CO>), grid, dim3(64 * NW), smem, stream, d, m_tiles, n_tiles);
+    hipLaunchKernelGGL((tapconv_x6d_kernel<NW, BN, SH, CO, NA>), grid, dim3(64 * NW), smem, stream, d, m_tiles, n_tiles);
     if (ksplit > 1) {
         const int npad = (d.Cout + 127) & ~127;
         const int64_t nthr = M * ((d.Cout + 3) >> 2);
@@ -561,6 +587,11 @@ int spaa_launch_tapconv_x6d(const spaa_tapconv_t& d, int tile, hipStream_t strea
         case 39: return launch_x6d<4, 128, 16, true>(d, stream);
         case 40: return launch_x6d<4, 64, 16, true>(d, stream);
         case 41: return launch_x6d<4, 32, 16, true>(d, stream);
+        case 42: return launch_x6d<4, 64, 16, false, 3>(d, stream);
+        case 43: return launch_x6d<4, 32, 16, false, 3>(d, stream);
+        case 44: return launch_x6d<4, 64, 32, false, 3>(d, stream);
+        case 45: return launch_x6d<4, 64, 16, true, 3>(d, stream);
+        case 46: return launch_x6d<4, 32, 16, true, 3>(d, stream);
         default: return hipErrorInvalidValue;
     }
 }

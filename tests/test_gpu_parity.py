@@ -140,7 +140,7 @@ def test_directconv_thin_layers(hip, tile):
         cp.FORCE_TILE = 0
 
 
-@pytest.mark.parametrize('tile', [12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 30, 31, 32, 33, 34, 35, 36, 37, 225, 431, 234, 436, 39, 40, 41])
+@pytest.mark.parametrize('tile', [12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 30, 31, 32, 33, 34, 35, 36, 37, 225, 431, 234, 436, 39, 40, 41, 42, 43, 44, 45, 46, 242])
 def test_tapconv_x6_is_fp32_accurate(hip, tile):
     """fp32 emulated on the bf16 matrix cores (exact 3-way operand split, 6 of 9 partial products, separate
     accumulators): the error against an fp64 reference must not exceed that of the exact-fp32 MFMA kernel."""
@@ -174,7 +174,7 @@ def test_tapconv_x6_is_fp32_accurate(hip, tile):
         cp.FORCE_TILE = 0
 
 
-@pytest.mark.parametrize('tile', [0, 6, 18, 34, 36, 39, 40, 41])
+@pytest.mark.parametrize('tile', [0, 6, 18, 34, 36, 39, 40, 41, 42, 44, 45, 46])
 def test_tapconv_epilogues(hip, tile):
     cp, lib = hip['cp'], hip['lib']
     cp.FORCE_TILE = tile
@@ -578,7 +578,7 @@ def test_compennet_pp_forward_and_perc_al_glue(hip, golden_dir):
     assert cam.shape == (2, 3, 64, 64) and prj.shape == (2, 3, 64, 64) and torch.isfinite(prj).all()
 
 
-@pytest.mark.parametrize('tile', [0, 25, 27, 30, 34, 36, 37, 39, 40, 41])
+@pytest.mark.parametrize('tile', [0, 25, 27, 30, 34, 36, 37, 39, 40, 41, 42, 43, 45, 46])
 def test_folded_deconv_with_epilogue(hip, tile):
     """Kernel-2 stride-2 ConvTranspose2d with the four parity classes folded into the GEMM rows (spaa_tapconv_t.nfold),
     fused residual + ReLU, against torch; every DMA-staged tile shape."""
