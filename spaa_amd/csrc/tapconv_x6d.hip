@@ -327,56 +327,63 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
     }
 
     constexpr int NBLK = SH == 32 ? 2 * TN : TJ;  // MFMA blocks per K-step (6 resp. 12 MFMAs each)
-    for (int ks = ks_begin; ks < ks_end; ++ks) {
-        // own weight DMAs of step ks have landed (vmcnt) and everybody's have (barrier); every wave is also past its
-        // reads of the other weight stage, which is overwritten during this step
-        if constexpr (NA == 3) {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        const int cur = (ks - ks_begin) & 1;
-        const unsigned char* wc = smem + W_BASE + cur * WS_BYTES;
-        unsigned char* wn = smem + W_BASE + (cur ^ 1) * WS_BYTES;
-        const int ia1 = ia + 1 == NA ? 0 : ia + 1;          // pixel stage of step ks+1 (read at the end of this step)
-        const int ia2 = NA == 3 ? (ia1 + 1 == NA ? 0 : ia1 + 1) : ia1;  // pixel stage filled during this step
-        unsigned char* an = smem + ia2 * A_BYTES;
-        const bool more = ks + (NA - 1) < ks_end;           // is there a step whose pixels are gathered now?
-        const int soff = min(ks + 1, ks_end - 1) * (BK * 2);
-
-        bf16x8 wf[2][3], pfn[2][3];
-        X6D_LDW(wf[0], wc + w_addr_l[0])
-        X6D_PREP(more, ks + NA - 1)
-#pragma unroll
-        for (int b = 0; b < NBLK; ++b) {
-            if (b + 1 < NBLK) {
-                if constexpr (SH == 32) {
-                    X6D_LDW(wf[(b + 1) & 1], wc + w_addr_l[(b + 1) / TN] + ((b + 1) % TN) * 2048)
-                } else {
-                    X6D_LDW(wf[(b + 1) & 1], wc + w_addr_l[0] + (b + 1) * 1024)
-                }
-            }
-            X6D_ISSUE(b, NBLK, an, wn, soff)
-            if (b == NBLK - 1) {
-                // the pixel pieces of step ks+1 (this wave's own rows) have landed: fetch and split them now, under
-                // the last block's MFMAs
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA == 3 ? W_MIN + 4 : W_MIN) : "memory");
-                X6D_LDP(pfn, smem + ia1 * A_BYTES)
-            }
-            if constexpr (SH == 32) {
-                X6D_MFMA6(__builtin_amdgcn_mfma_f32_32x32x16_bf16, acc32[b % TN], wf[b & 1], pfc[b / TN])
-            } else {
-                X6D_MFMA6(__builtin_amdgcn_mfma_f32_16x16x32_bf16, acc16[0][b], wf[b & 1], pfc[0])
-                X6D_MFMA6(__builtin_amdgcn_mfma_f32_16x16x32_bf16, acc16[1][b], wf[b & 1], pfc[1])
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) pfc[i][pl] = pfn[i][pl];
-        ia = ia1;
+    // One K-step: multiplies with the pixel fragments PFC and leaves those of the next step in PFN (the loop below is
+    // unrolled by two with the roles swapped, so the fragments never have to be copied).
+#define X6D_STEP(PFC, PFN)                                                                                         \
+    {                                                                                                              \
+        /* own weight DMAs of step ks have landed (vmcnt) and everybody's have (barrier); every wave is also past */  \
+        /* its reads of the other weight stage, which is overwritten during this step */                          \
+        if constexpr (NA == 3) {                                                                                   \
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                       \
+        } else {                                                                                                   \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+        }                                                                                                          \
+        __syncthreads();                                                                                           \
+        const int cur = (ks - ks_begin) & 1;                                                                       \
+        const unsigned char* wc = smem + W_BASE + cur * WS_BYTES;                                                  \
+        unsigned char* wn = smem + W_BASE + (cur ^ 1) * WS_BYTES;                                                  \
+        const int ia1 = ia + 1 == NA ? 0 : ia + 1;         /* pixel stage of step ks+1 (read at the end) */        \
+        const int ia2 = NA == 3 ? (ia1 + 1 == NA ? 0 : ia1 + 1) : ia1; /* pixel stage filled during this step */   \
+        unsigned char* an = smem + ia2 * A_BYTES;                                                                  \
+        const bool more = ks + (NA - 1) < ks_end;          /* is there a step whose pixels are gathered now? */    \
+        const int soff = min(ks + 1, ks_end - 1) * (BK * 2);                                                       \
+        bf16x8 wf[2][3];                                                                                           \
+        X6D_LDW(wf[0], wc + w_addr_l[0])                                                                           \
+        X6D_PREP(more, ks + NA - 1)                                                                                \
+        _Pragma("unroll") for (int b = 0; b < NBLK; ++b) {                                                         \
+            if (b + 1 < NBLK) {                                                                                    \
+                if constexpr (SH == 32) {                                                                          \
+                    X6D_LDW(wf[(b + 1) & 1], wc + w_addr_l[(b + 1) / TN] + ((b + 1) % TN) * 2048)                  \
+                } else {                                                                                           \
+                    X6D_LDW(wf[(b + 1) & 1], wc + w_addr_l[0] + (b + 1) * 1024)                                    \
+                }                                                                                                  \
+            }                                                                                                      \
+            X6D_ISSUE(b, NBLK, an, wn, soff)                                                                       \
+            if (b == NBLK - 1) {                                                                                   \
+                /* the pixel pieces of step ks+1 (this wave's own rows) have landed: fetch and split them now, */  \
+                /* under the last block's MFMAs */                                                                 \
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA == 3 ? W_MIN + 4 : W_MIN) : "memory");                 \
+                X6D_LDP(PFN, smem + ia1 * A_BYTES)                                                                 \
+            }                                                                                                      \
+            if constexpr (SH == 32) {                                                                              \
+                X6D_MFMA6(__builtin_amdgcn_mfma_f32_32x32x16_bf16, acc32[b % TN], wf[b & 1], PFC[b / TN])          \
+            } else {                                                                                               \
+                X6D_MFMA6(__builtin_amdgcn_mfma_f32_16x16x32_bf16, acc16[0][b], wf[b & 1], PFC[0])                 \
+                X6D_MFMA6(__builtin_amdgcn_mfma_f32_16x16x32_bf16, acc16[1][b], wf[b & 1], PFC[1])                 \
+            }                                                                                                      \
+        }                                                                                                          \
+        ia = ia1;                                                                                                  \
     }
+    bf16x8 pfd[2][3];
+    int ks = ks_begin;
+    for (; ks + 1 < ks_end; ks += 2) {
+        X6D_STEP(pfc, pfd)
+        ++ks;
+        X6D_STEP(pfd, pfc)
+        --ks;
+    }
+    if (ks < ks_end) X6D_STEP(pfc, pfd)
+#undef X6D_STEP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last step's (all-zero) prefetch must not outlive the wave
 
     if (p.ksplit > 1) {
