@@ -28,7 +28,8 @@ typedef void* spaa_stream_t; /* hipStream_t */
 /* activation applied after bias + residual add */
 enum { SPAA_ACT_NONE = 0, SPAA_ACT_RELU = 1, SPAA_ACT_RELU_CLAMP1 = 2, SPAA_ACT_LEAKY01 = 3 };
 /* gate applied last (ReLU / clamp backward):  out = pass(gate) ? v : 0 */
-enum { SPAA_GATE_NONE = 0, SPAA_GATE_POS = 1 /* gate > 0 */, SPAA_GATE_POS_LE1 = 2 /* 0 < gate <= 1 */ };
+enum { SPAA_GATE_NONE = 0, SPAA_GATE_POS = 1 /* gate > 0 */, SPAA_GATE_POS_LE1 = 2 /* 0 < gate <= 1 */,
+       SPAA_GATE_MUL = 3 /* value * gate: the chain rule through `x * s` (models.py:342); tiles 25.. only */ };
 
 typedef struct {
     int32_t oy0, ox0;  /* output offset of this parity class */

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'libspaa_hip.so')
 MAX_CLASSES = 4
 MAX_TAPS = 64
 ACT_NONE, ACT_RELU, ACT_RELU_CLAMP1, ACT_LEAKY01 = 0, 1, 2, 3
-GATE_NONE, GATE_POS, GATE_POS_LE1 = 0, 1, 2
+GATE_NONE, GATE_POS, GATE_POS_LE1, GATE_MUL = 0, 1, 2, 3
 
 
 class TapClass(C.Structure):

@@ -42,7 +42,7 @@ __device__ __forceinline__ void store4(const spaa_tapconv_t& p, const size_t o, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (ga[e] > 0.f && ga[e] <= 1.f) : (ga[e] > 0.f);
-                v[e] = pass ? v[e] : 0.f;
+                v[e] = (p.gate_mode == SPAA_GATE_MUL) ? v[e] * ga[e] : (pass ? v[e] : 0.f);
             }
         }
         *reinterpret_cast<f4*>(outp) = f4{v[0], v[1], v[2], v[3]};
@@ -70,7 +70,7 @@ __device__ __forceinline__ void store4(const spaa_tapconv_t& p, const size_t o, 
             if (p.gate != nullptr) {
                 const float gv = p.gate[o * p.gate_cstride + p.gate_coff + n];
                 const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (gv > 0.f && gv <= 1.f) : (gv > 0.f);
-                t = pass ? t : 0.f;
+                t = (p.gate_mode == SPAA_GATE_MUL) ? t * gv : (pass ? t : 0.f);
             }
             p.out[o * p.out_cstride + p.out_coff + n] = t;
             if (p.gate2 != nullptr) {

@@ -544,6 +544,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
     for (int c = 0; c < d.nclass; ++c)
         if ((int64_t)((d.Cout + 127) & ~127) * d.cls[c].Kpad * 4 >= (int64_t)1 << 31) return hipErrorInvalidValue;
     int tile = d.tile;
+    if (d.gate != nullptr && d.gate_mode == SPAA_GATE_MUL && tile < 25) return hipErrorInvalidValue;
     if (d.nfold > 1 && !((tile >= 25 && tile <= 27) || (tile >= 30 && tile <= 37) || (tile >= 39 && tile <= 46)))
         return hipErrorInvalidValue;
     if (tile == 0) {  // heuristic: widest N tile that fits Cout; shrink M when the grid would not fill 256 CUs twice

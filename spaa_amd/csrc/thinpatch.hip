@@ -173,8 +173,12 @@ __global__ __launch_bounds__(256) void thinpatch_kernel(const spaa_tapconv_t p, 
                     t = t > 0.f ? t : 0.1f * t;
                 }
                 if (p.gate != nullptr) {
-                    const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (gv[n] > 0.f && gv[n] <= 1.f) : (gv[n] > 0.f);
-                    t = pass ? t : 0.f;
+                    if (p.gate_mode == SPAA_GATE_MUL) {
+                        t *= gv[n];
+                    } else {
+                        const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (gv[n] > 0.f && gv[n] <= 1.f) : (gv[n] > 0.f);
+                        t = pass ? t : 0.f;
+                    }
                 }
                 outv[n] = t;
                 if (p.gate2 != nullptr) auxv[n] = (g2v[n] > 0.f) ? t : 0.f;
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256) void thinpatch_kernel(const spaa_tapconv_t p, 
                 if (p.gate != nullptr) {
                     const float g = p.gate[o * p.gate_cstride + p.gate_coff + n];
                     const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (g > 0.f && g <= 1.f) : (g > 0.f);
-                    t = pass ? t : 0.f;
+                    t = (p.gate_mode == SPAA_GATE_MUL) ? t * g : (pass ? t : 0.f);
                 }
                 p.out[o * p.out_cstride + p.out_coff + n] = t;
                 if (p.gate2 != nullptr) {

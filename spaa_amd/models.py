@@ -270,6 +270,9 @@ class PCNetEngine:
         bounds = torch.searchsorted(tap_src[order].to(torch.int64),
                                     torch.arange(hwp + 1, dtype=torch.int64, device=dev))
         self.tap_order = order.to(torch.int32).contiguous()
+        # bilinear weight x mask of the camera pixel the tap belongs to (entry 4*campix + tap)
+        self.tap_wm = (self.tap_w.view(hwc, 4) * self.mask.view(hwc, 1)).reshape(-1).contiguous() \
+            if self.mask is not None else self.tap_w
         self.tap_off = bounds.to(torch.int32).contiguous()
         f, d = {}, {}
         for nm, st in (('conv1', 2), ('conv2', 2), ('conv3', 1), ('conv4', 1), ('conv5', 1), ('conv1_s', 2),
@@ -369,19 +372,23 @@ class PCNetEngine:
         d['conv3'].run(g['P3'], g['P2'], add=g['t2'], gate=a['X2'])
         d['skipConv2'].run(g['P6'], g['t1'])
         d['conv2'].run(g['P2'], g['P1'], add=g['t1'], gate=a['X1'])
-        d['conv1'].run(g['P1'], g['xw'])
         # surface branch (depends on x through the rough input x*s)
         d['conv4_s'].run(g['S4'], g['S3'], add=g['P3'], gate=a['S3'])
         d['conv3_s'].run(g['S3'], g['S2'], add=g['P2'], gate=a['S2'])
         d['conv2_s'].run(g['S2'], g['S1'], add=g['P1'], gate=a['S1'])
-        d['conv1_s'].run(g['S1'], g['xs'])
-        return self.warp_backward(g['xw'], g['xs'])
+        # the two 3-channel gradients meet at the warped image: d/d(x_w) = g_direct + g_rough * s (models.py:342); the
+        # product and the sum are epilogues of the two thin convolutions instead of extra reads in the gather
+        d['conv1_s'].run(g['S1'], g['xs'], gate=self.scene, gate_mode=_lib.GATE_MUL)
+        d['conv1'].run(g['P1'], g['xw'], add=g['xs'])
+        return self.warp_backward(g['xw'])
 
-    def warp_backward(self, g_xw, g_xs=None):
+    def warp_backward(self, g_xw):
+        """Adjoint of the masked grid_sample (models.py:184,340): deterministic gather over the transposed tap lists; the
+        mask is folded into the tap weights."""
         g = self.g
-        _lib.call('spaa_warp_bwd_gather', _lib.ptr(g_xw), _lib.ptr(g_xs), _lib.ptr(self._x), _lib.ptr(self.mask),
-                  _lib.ptr(self.scene) if g_xs is not None else None, C_ptr(self.tap_off), C_ptr(self.tap_order),
-                  _lib.ptr(self.tap_w), _lib.ptr(g['x']), self.B, self.Hp, self.Wp, self.Hc, self.Wc, self._clamp)
+        _lib.call('spaa_warp_bwd_gather', _lib.ptr(g_xw), None, _lib.ptr(self._x), None, None, C_ptr(self.tap_off),
+                  C_ptr(self.tap_order), _lib.ptr(self.tap_wm), _lib.ptr(g['x']), self.B, self.Hp, self.Wp, self.Hc,
+                  self.Wc, self._clamp)
         return g['x']
 
     def flops_fwd(self):
