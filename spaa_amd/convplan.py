@@ -29,7 +29,7 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               30: 'x6d_128x32', 31: 'x6d_64x64', 32: 'x6d_64x128', 33: 'x6d_256x64',
               34: 'x6d16_128x128', 35: 'x6d16_256x128', 36: 'x6d16_128x64', 37: 'x6d16_128x32', 38: 'smallcin',
               39: 'x6d16co_128x128', 40: 'x6d16co_128x64', 41: 'x6d16co_128x32',
-              42: 'x6d16a3_128x64', 43: 'x6d16a3_128x32', 44: 'x6da3_128x64', 45: 'x6d16coa3_128x64', 46: 'x6d16coa3_128x32'}
+              42: 'x6d16a3_128x64', 43: 'x6d16a3_128x32', 44: 'x6da3_128x64', 45: 'x6d16coa3_128x64', 46: 'x6d16coa3_128x32', 47: 'thinpatch16x2'}
 DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
 FOLD_DECONV = True  # k2/s2 transposed convs: parity classes folded into GEMM rows (one read of the input)
 ENABLE_X6 = True  # build the split-bf16 weight planes (needed by tiles 12-14)
@@ -158,7 +158,7 @@ class ConvPlan:
         if forced == 38 and (len(self.cls) != 1 or self.cout > 32 or self.cin_p not in (4, 8) or self.ntaps_total > 9
                              or self.s_in > 2):
             forced = 0
-        if forced in (28, 29) and (self.cout > 4 or self.s_in != 1 or self.cin_p % (32 if forced == 28 else 16)):
+        if forced in (28, 29, 47) and (self.cout > 4 or self.s_in != 1 or self.cin_p % (32 if forced == 28 else 16)):
             forced = 0
         if (25 <= forced <= 27 or 30 <= forced <= 37 or 39 <= forced <= 46) and (self.cin_p % 32 or any(c['Kpad'] != c['K'] for c in self.cls)):
             forced = 0

@@ -600,6 +600,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         case 44:
         case 45:
         case 46: return spaa_launch_tapconv_x6d(d, tile, stream);
+        case 47: return spaa_launch_thinpatch(d, stream);
         default: return hipErrorInvalidValue;
     }
 }

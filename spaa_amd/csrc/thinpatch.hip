@@ -23,7 +23,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int TW = 32, TH = 8;  // pixel tile of a workgroup (class-grid coordinates)
+constexpr int TW = 32, TH1 = 8;  // pixel tile of a workgroup (class-grid coordinates): TW x (TH1 * P), P pixels per lane
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(4))) int* cint_ptr;
 typedef const __attribute__((address_space(4))) f16v* cf16_ptr;
@@ -40,11 +40,12 @@ __device__ __forceinline__ int swz(int q) {
     return L == 8 ? (q >> 1) & 7 : (q >> 2) & 3;
 }
 
-template <int L, int NOUT>
+template <int L, int NOUT, int P>
 __global__ __launch_bounds__(256) void thinpatch_kernel(const spaa_tapconv_t p, const int tiles_x, const int tiles_y,
                                                         const int dymin, const int dxmin, const int PH, const int PW) {
     constexpr int PIX_PER_PIECE = 64 / L;
     constexpr int CCH = 4 * L;
+    constexpr int TH = TH1 * P;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -73,18 +74,19 @@ __global__ __launch_bounds__(256) void thinpatch_kernel(const spaa_tapconv_t p, 
     const int npieces = (npix + PIX_PER_PIECE - 1) / PIX_PER_PIECE;
     const int row_bytes = p.in_cstride * 4;
 
-    const int lx = tid & (TW - 1), ly = tid / TW;
-    const int y = y0 + ly, x = x0 + lx;
-    const bool inside = y < p.Hm && x < p.Wm;
+    const int lx = tid & (TW - 1), ly = tid / TW;  // the lane's pixels: (lx, ly + TH1 * pi), pi < P
+    const int x = x0 + lx;
     const bool vec4 = p.out_cstride == 4 && p.out_coff == 0 && (p.add == nullptr || (p.add_cstride == 4 && p.add_coff == 0)) &&
                       (p.gate == nullptr || (p.gate_cstride == 4 && p.gate_coff == 0)) &&
                       (p.gate2 == nullptr || (p.gate2_cstride == 4 && p.gate2_coff == 0));
 
-    f2 acc[MAXCLS][NOUT];
+    f2 acc[MAXCLS][P][NOUT];
 #pragma unroll
     for (int ci = 0; ci < MAXCLS; ++ci)
 #pragma unroll
-        for (int n = 0; n < NOUT; ++n) acc[ci][n] = f2{0.f, 0.f};
+        for (int pi = 0; pi < P; ++pi)
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n) acc[ci][pi][n] = f2{0.f, 0.f};
 
     for (int c0 = 0; c0 < p.Cin; c0 += CCH) {  // 32 input channels per pass
         if (c0 > 0) __syncthreads();           // everybody is done reading the previous pass's patch
@@ -116,9 +118,14 @@ __global__ __launch_bounds__(256) void thinpatch_kernel(const spaa_tapconv_t p, 
             const float* wbase = p.weights + cl.w_off + c0;
             for (int t = 0; t < cl.ntaps; ++t) {
                 const int dy = taps[2 * t], dx = taps[2 * t + 1];
-                const int q = (ly + dy - dymin) * PW + (lx + dx - dxmin);
-                const unsigned char* pp = smem + q * (CCH * 4);
-                const int sw = swz<L>(q);
+                const unsigned char* pp[P];
+                int sw[P];
+#pragma unroll
+                for (int pi = 0; pi < P; ++pi) {
+                    const int q = (ly + TH1 * pi + dy - dymin) * PW + (lx + dx - dxmin);
+                    pp[pi] = smem + q * (CCH * 4);
+                    sw[pi] = swz<L>(q);
+                }
 #pragma unroll
                 for (int g = 0; g < L / 4; ++g) {  // 16 channels at a time: one s_load_dwordx16 per output channel
                     f16v w[NOUT];
@@ -127,13 +134,16 @@ __global__ __launch_bounds__(256) void thinpatch_kernel(const spaa_tapconv_t p, 
                         w[n] = *(cf16_ptr)(uintptr_t)(wbase + (size_t)n * cl.Kpad + t * p.Cin + 16 * g);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const f4 a = *reinterpret_cast<const f4*>(pp + (((4 * g + u) ^ sw) * 16));
-                        const f2 a01 = {a.x, a.y}, a23 = {a.z, a.w};
 #pragma unroll
-                        for (int n = 0; n < NOUT; ++n) {
-                            const f2 w01 = {w[n][4 * u], w[n][4 * u + 1]}, w23 = {w[n][4 * u + 2], w[n][4 * u + 3]};
-                            acc[ci][n] = __builtin_elementwise_fma(a01, w01, acc[ci][n]);
-                            acc[ci][n] = __builtin_elementwise_fma(a23, w23, acc[ci][n]);
+                        for (int pi = 0; pi < P; ++pi) {  // the scalar weights feed every pixel of the lane
+                            const f4 a = *reinterpret_cast<const f4*>(pp[pi] + (((4 * g + u) ^ sw[pi]) * 16));
+                            const f2 a01 = {a.x, a.y}, a23 = {a.z, a.w};
+#pragma unroll
+                            for (int n = 0; n < NOUT; ++n) {
+                                const f2 w01 = {w[n][4 * u], w[n][4 * u + 1]}, w23 = {w[n][4 * u + 2], w[n][4 * u + 3]};
+                                acc[ci][pi][n] = __builtin_elementwise_fma(a01, w01, acc[ci][pi][n]);
+                                acc[ci][pi][n] = __builtin_elementwise_fma(a23, w23, acc[ci][pi][n]);
+                            }
                         }
                     }
                 }
@@ -142,16 +152,18 @@ __global__ __launch_bounds__(256) void thinpatch_kernel(const spaa_tapconv_t p, 
     }
 
 #pragma unroll
-    for (int ci = 0; ci < MAXCLS; ++ci) {
+    for (int cp_ = 0; cp_ < MAXCLS * P; ++cp_) {
+        const int ci = cp_ / P, pi = cp_ % P;
         if (ci >= p.nclass) break;
         const spaa_tapclass_t cl = p.cls[ci];
-        if (!inside) continue;
+        const int y = y0 + ly + TH1 * pi;
+        if (!(y < p.Hm && x < p.Wm)) continue;
         const int oy = cl.oy0 + y * p.s_out, ox = cl.ox0 + x * p.s_out;
         if (oy >= p.Hout || ox >= p.Wout) continue;
         const size_t o = ((size_t)b * p.Hout + oy) * p.Wout + ox;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int n = 0; n < NOUT; ++n) v[n] = acc[ci][n].x + acc[ci][n].y;
+        for (int n = 0; n < NOUT; ++n) v[n] = acc[ci][pi][n].x + acc[ci][pi][n].y;
         if (vec4) {
             // NHWC4 everywhere: one 16-byte access per operand; channels >= Cout stay 0
             f4 addv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f}, g2v = {1.f, 1.f, 1.f, 1.f};
@@ -216,20 +228,21 @@ __global__ __launch_bounds__(256) void thinpatch_kernel(const spaa_tapconv_t p, 
     }
 }
 
-template <int L, int NOUT>
+template <int L, int NOUT, int P>
 int launch_tp(const spaa_tapconv_t& d, int dymin, int dxmin, int PH, int PW, hipStream_t stream) {
+    constexpr int TH = TH1 * P;
     const int tiles_x = (d.Wm + TW - 1) / TW, tiles_y = (d.Hm + TH - 1) / TH;
     const size_t smem = ((size_t)PH * PW * (16 * L) + 1023) / 1024 * 1024;
     if (smem > 64 * 1024) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thinpatch_kernel<L, NOUT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thinpatch_kernel<L, NOUT, P>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid((unsigned)(tiles_x * tiles_y * d.B), 1, 1);
-    hipLaunchKernelGGL((thinpatch_kernel<L, NOUT>), grid, dim3(256), smem, stream, d, tiles_x, tiles_y, dymin, dxmin, PH, PW);
+    hipLaunchKernelGGL((thinpatch_kernel<L, NOUT, P>), grid, dim3(256), smem, stream, d, tiles_x, tiles_y, dymin, dxmin, PH, PW);
     return (int)hipGetLastError();
 }
 
@@ -238,14 +251,18 @@ int launch_tp(const spaa_tapconv_t& d, int dymin, int dxmin, int PH, int PW, hip
 // called by spaa_tapconv_f32 (tapconv.hip) for tiles 28 (32 channels per pass) and 29 (16 per pass) after the common shape checks.  `d.tap_range` = (dymin, dymax,
 // dxmin, dxmax) over the taps of all classes, filled in by the host (the tap list itself lives in device memory).
 int spaa_launch_thinpatch(const spaa_tapconv_t& d, hipStream_t stream) {
-    const int L = d.tile == 29 ? 4 : 8;
+    // tile 28: 32 channels per pass; 29: 16 per pass; 47: 16 per pass, two pixels per lane (the scalar weights and their
+    // latency are shared by twice the FMAs)
+    const int L = d.tile == 28 ? 8 : 4;
+    const int P = d.tile == 47 ? 2 : 1;
     if (d.Cout > 4 || d.s_in != 1 || (d.Cin % (4 * L)) != 0) return hipErrorInvalidValue;
     const int dymin = d.tap_range[0], dymax = d.tap_range[1], dxmin = d.tap_range[2], dxmax = d.tap_range[3];
     if (dymax < dymin || dxmax < dxmin || dymax - dymin > 16 || dxmax - dxmin > 16) return hipErrorInvalidValue;
-    const int PH = TH + dymax - dymin, PW = TW + dxmax - dxmin;
+    const int PH = TH1 * P + dymax - dymin, PW = TW + dxmax - dxmin;
     for (int c = 0; c < d.nclass; ++c)
         if (d.cls[c].Kpad % 16) return hipErrorInvalidValue;
-    if (L == 4)
-        return d.Cout <= 3 ? launch_tp<4, 3>(d, dymin, dxmin, PH, PW, stream) : launch_tp<4, 4>(d, dymin, dxmin, PH, PW, stream);
-    return d.Cout <= 3 ? launch_tp<8, 3>(d, dymin, dxmin, PH, PW, stream) : launch_tp<8, 4>(d, dymin, dxmin, PH, PW, stream);
+    const bool n3 = d.Cout <= 3;
+    if (L == 8) return n3 ? launch_tp<8, 3, 1>(d, dymin, dxmin, PH, PW, stream) : launch_tp<8, 4, 1>(d, dymin, dxmin, PH, PW, stream);
+    if (P == 2) return n3 ? launch_tp<4, 3, 2>(d, dymin, dxmin, PH, PW, stream) : launch_tp<4, 4, 2>(d, dymin, dxmin, PH, PW, stream);
+    return n3 ? launch_tp<4, 3, 1>(d, dymin, dxmin, PH, PW, stream) : launch_tp<4, 4, 1>(d, dymin, dxmin, PH, PW, stream);
 }

@@ -107,14 +107,14 @@ def test_tapconv_deconv_forward_and_dgrad(hip, ci, co, k, p, op, h, w):
     assert rel_inf(nchw(gx.cpu(), ci), x.grad) < 1e-5
 
 
-@pytest.mark.parametrize('tile', [9, 10, 11, 28, 29, 38])
+@pytest.mark.parametrize('tile', [9, 10, 11, 28, 29, 38, 47])
 def test_directconv_thin_layers(hip, tile):
     """The VALU variants for thin layers (few output or few input channels) compute the same tap-list convolution."""
     cp, lib = hip['cp'], hip['lib']
     torch.manual_seed(11)
     cases = [(32, 3, 3, 1, 1, 20, 24), (64, 3, 7, 2, 3, 28, 28), (6, 32, 3, 2, 1, 16, 16)] if tile == 9 else \
         [(3, 32, 3, 1, 1, 20, 24), (3, 32, 3, 2, 1, 16, 16), (6, 32, 3, 2, 1, 12, 20)]
-    if tile in (11, 28, 29):  # (the dgrad of ci=3 layers has 32/64 gradient channels in and 3 out: the thin-N case)
+    if tile in (11, 28, 29, 47):  # (the dgrad of ci=3 layers has 32/64 gradient channels in and 3 out: the thin-N case)
         cases = [(32, 3, 3, 1, 1, 21, 24), (64, 3, 7, 2, 3, 28, 30), (3, 32, 3, 2, 1, 16, 18), (3, 64, 7, 2, 3, 30, 28),
                  (32, 4, 3, 1, 1, 37, 70), (64, 2, 3, 1, 1, 9, 33)]
     try:
