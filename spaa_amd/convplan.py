@@ -167,11 +167,6 @@ class ConvPlan:
             tile = self._default_tile(b * d.Hm * d.Wm)
         # tune values >= 100 encode split-K: tile + 100 * ksplit (x6d tiles, one class, enough K-steps per split)
         ksplit, tile = (tile // 100, tile % 100) if tile >= 100 else (1, tile)
-        if gate is not None and gate_mode == _lib.GATE_MUL and tile < 25:  # multiplicative gate: newer epilogues only
-            tile = self._default_tile(b * d.Hm * d.Wm)
-            if tile < 25:
-                raise ValueError('GATE_MUL needs a layer shape served by the DMA-staged kernels')
-            ksplit, tile = (tile // 100, tile % 100) if tile >= 100 else (1, tile)
         if self.nfold > 1:  # only the DMA-staged kernels know the folded epilogue
             ksplit = 1
             if not (25 <= tile <= 27 or 30 <= tile <= 37 or 39 <= tile <= 46):
@@ -186,6 +181,11 @@ class ConvPlan:
             if self._ws is None or self._ws.numel() < need:
                 self._ws = torch.empty(need, device=inp.device, dtype=torch.float32)
             d.splitk_ws, d.ksplit = self._ws.data_ptr(), ksplit
+        if gate is not None and gate_mode == _lib.GATE_MUL and tile < 25:  # multiplicative gate: newer epilogues only
+            tile = self._default_tile(b * d.Hm * d.Wm) % 100
+            d.ksplit, d.splitk_ws = 0, None
+            if tile < 25:
+                raise ValueError('GATE_MUL needs a layer shape served by the DMA-staged kernels')
         d.tile = tile
         d.nclass = len(self.cls)
         d.tap_range[:] = self.tap_range
