@@ -103,13 +103,13 @@ def pmc_traffic(tile):
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
     if not os.path.exists(path):
         return None
-    m = re.match(r'(x6d16co|x6d16|x6d|x6v\d|x6)_(\d+)x(\d+)(?:g(\d))?', tile)
+    m = re.match(r'(x6d(?:16)?(?:co)?(?:a3)?|x6v\d|x6)_(\d+)x(\d+)(?:g(\d))?', tile)
     if not m:
         return None
     fam, bm, bn, g = m.groups()
-    if fam.startswith('x6d'):
-        want = (f'tapconv_x6d_kernel<{int(bm) // 32}, {bn}, {16 if fam.startswith("x6d16") else 32}, '
-                f'{"true" if fam.endswith("co") else "false"}>')
+    if fam.startswith('x6d'):  # tapconv_x6d_kernel<waves, BN, MFMA shape, coalesced epilogue, pixel stages>
+        want = (f'tapconv_x6d_kernel<{int(bm) // 32}, {bn}, {16 if "16" in fam else 32}, '
+                f'{"true" if "co" in fam else "false"}, {3 if fam.endswith("a3") else 2}>')
     else:
         want = f'tapconv_{fam}_kernel<{bm}, {bn}' + (f', {g}>' if g else '>')
     with open(path) as fh:
