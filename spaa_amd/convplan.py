@@ -187,6 +187,7 @@ class ConvPlan:
             if tile < 25:
                 raise ValueError('GATE_MUL needs a layer shape served by the DMA-staged kernels')
         d.tile = tile
+        d.reserved0 = int(os.environ.get('SPAA_X6D_TAPMAJOR', '0'))  # 1: tap-major K order (A/B measurements only)
         d.nclass = len(self.cls)
         d.tap_range[:] = self.tap_range
         for i, c in enumerate(self.cls):

@@ -189,7 +189,28 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
     // scalar loads issued one K-step before they are used
     typedef const __attribute__((address_space(4))) int* cint_ptr;
     cint_ptr ctaps = (cint_ptr)(uintptr_t)taps;
-    int s_tap = (ks_begin * BK) / Cin, s_kc = (ks_begin * BK) % Cin;
+    // K-step order: with several taps and several 32-channel chunks the steps run CHUNK-major (all taps of a chunk, then
+    // the next chunk): the 128-byte slice of a pixel is then re-read by the 9 taps within 9 consecutive steps and stays
+    // in the XCD's L2 (tap-major order re-reads every slice 12+ steps later, when 64 workgroups' traffic has evicted it).
+    // The sum over K is the same set of products either way.
+    const bool chunk_major = (cl.ntaps > 1) && (Cin > BK) && p.reserved0 != 1;  // (reserved0 == 1: tap-major, for A/B runs)
+#define X6D_ADVANCE(tap, kc)                                                                                       \
+    if (chunk_major) {                                                                                             \
+        tap += 1;                                                                                                  \
+        if (tap >= cl.ntaps) {                                                                                     \
+            tap = 0;                                                                                               \
+            kc += BK;                                                                                              \
+        }                                                                                                          \
+    } else {                                                                                                       \
+        kc += BK;                                                                                                  \
+        if (kc >= Cin) {                                                                                           \
+            kc = 0;                                                                                                \
+            tap += 1;                                                                                              \
+        }                                                                                                          \
+    }
+    int s_tap = chunk_major ? ks_begin % cl.ntaps : (ks_begin * BK) / Cin;
+    int s_kc = chunk_major ? (ks_begin / cl.ntaps) * BK : (ks_begin * BK) % Cin;
+    int w_tap = s_tap, w_kc = s_kc;  // (tap, channel offset) of the step whose WEIGHTS are staged next
     int n_dy = ctaps[2 * min(s_tap, cl.ntaps - 1)], n_dx = ctaps[2 * min(s_tap, cl.ntaps - 1) + 1];
     int voff[4];
 
@@ -201,11 +222,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
             const uint32_t mw = s_tap < 32 ? a_mlo[j] : a_mhi[j];                                                  \
             voff[j] = (mw & bit) ? a_off[j] + tapoff : (int)0x80000000;                                            \
         }                                                                                                          \
-        s_kc += BK;                                                                                                \
-        if (s_kc >= Cin) {                                                                                         \
-            s_kc = 0;                                                                                              \
-            s_tap += 1;                                                                                            \
-        }                                                                                                          \
+        X6D_ADVANCE(s_tap, s_kc)                                                                                   \
         const int tn = min(s_tap, cl.ntaps - 1);                                                                   \
         n_dy = ctaps[2 * tn];                                                                                      \
         n_dx = ctaps[2 * tn + 1];                                                                                  \
@@ -314,7 +331,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
 #pragma unroll
         for (int j = 0; j < 4; ++j) X6D_DMA_A(smem, j)
 #pragma unroll
-        for (int i = 0; i < WPW; ++i) X6D_DMA_W(smem + W_BASE, i, ks_begin * (BK * 2))
+        for (int i = 0; i < WPW; ++i) X6D_DMA_W(smem + W_BASE, i, (w_tap * Cin + w_kc) * 2)
         if constexpr (NA == 3) {
             X6D_PREP(nk > 1, 1)
 #pragma unroll
@@ -346,7 +363,8 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
         const int ia2 = NA == 3 ? (ia1 + 1 == NA ? 0 : ia1 + 1) : ia1; /* pixel stage filled during this step */   \
         unsigned char* an = smem + ia2 * A_BYTES;                                                                  \
         const bool more = ks + (NA - 1) < ks_end;          /* is there a step whose pixels are gathered now? */    \
-        const int soff = min(ks + 1, ks_end - 1) * (BK * 2);                                                       \
+        if (ks + 1 < ks_end) { X6D_ADVANCE(w_tap, w_kc) }  /* weights of step ks+1 (the last step is re-staged) */ \
+        const int soff = (w_tap * Cin + w_kc) * 2;                                                                 \
         bf16x8 wf[2][3];                                                                                           \
         X6D_LDW(wf[0], wc + w_addr_l[0])                                                                           \
         X6D_PREP(more, ks + NA - 1)                                                                                \
@@ -516,6 +534,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
 #undef X6D_ISSUE
 #undef X6D_LDP
 #undef X6D_PREP
+#undef X6D_ADVANCE
 #undef X6D_DMA_A
 #undef X6D_DMA_W
 #undef X6D_LDW
