@@ -14,7 +14,8 @@ from spaa_amd import convplan  # noqa: E402
 
 def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-    st, *_ = bench.build_attack(0, batch, 256, 8, 'cuda:0')
+    classifier = sys.argv[2] if len(sys.argv) > 2 else 'resnet18'  # other classifiers: their layer shapes are MERGED
+    st, *_ = bench.build_attack(0, batch, 256, 8, 'cuda:0', classifier)
     hp = dict(targeted=True, d_thr=5, adv_lr=2, col_lr=1, p_thresh=0.9)
     st.iteration(**hp)
     torch.cuda.synchronize()
@@ -51,6 +52,10 @@ def main():
     print(f'sum of best per-launch times: {total_best:.2f} ms/iteration')
     out = os.path.join(ROOT, 'gpurun_out', 'tapconv_tune.json')
     os.makedirs(os.path.dirname(out), exist_ok=True)
+    if classifier != 'resnet18':  # keep the measured choices of the other workloads; add this one's new shapes
+        merged = dict(convplan.TUNE)
+        merged.update({k: v for k, v in tune.items() if k not in merged})
+        tune = merged
     with open(out, 'w') as fh:
         json.dump(tune, fh, indent=0, sort_keys=True)
     print('wrote', out)
