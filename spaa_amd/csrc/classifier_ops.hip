@@ -52,21 +52,27 @@ __global__ void preproc_bwd_kernel(const float4* __restrict__ g_out, float4* __r
     const int py = r / W - cy0, px = r % W - cx0;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     if ((unsigned)py < (unsigned)ch && (unsigned)px < (unsigned)cw) {
-        // candidate outputs: o in [floor(p*out/in) - 1, ... + 1]
-        const int oyc = (int)(((int64_t)py * oh) / ch), oxc = (int)(((int64_t)px * ow) / cw);
-        for (int oy = max(oyc - 2, 0); oy <= min(oyc + 2, oh - 1); ++oy) {
+        // outputs whose window covers p: o in [floor(p*out/in), ceil((p+1)*out/in) - 1] (+-1 for the float window
+        // bounds); the covering ones are collected per axis first, then combined (row-major order, as before)
+        int oys[5], ylen[5], oxs[5], xlen[5], ny = 0, nx = 0;
+        const int oy_lo = max((py * oh) / ch - 1, 0), oy_hi = min(((py + 1) * oh + ch - 1) / ch, oh - 1);
+        for (int oy = oy_lo; oy <= oy_hi && ny < 5; ++oy) {
             const int ys = win_start(oy, oh, ch), ye = win_end(oy, oh, ch);
-            if (py < ys || py >= ye) continue;
-            for (int ox = max(oxc - 2, 0); ox <= min(oxc + 2, ow - 1); ++ox) {
-                const int xs = win_start(ox, ow, cw), xe = win_end(ox, ow, cw);
-                if (px < xs || px >= xe) continue;
-                const float inv = 1.f / (float)((ye - ys) * (xe - xs));
-                const float4 g = g_out[((size_t)b * oh + oy) * ow + ox];
+            if (py >= ys && py < ye) { oys[ny] = oy; ylen[ny] = ye - ys; ++ny; }
+        }
+        const int ox_lo = max((px * ow) / cw - 1, 0), ox_hi = min(((px + 1) * ow + cw - 1) / cw, ow - 1);
+        for (int ox = ox_lo; ox <= ox_hi && nx < 5; ++ox) {
+            const int xs = win_start(ox, ow, cw), xe = win_end(ox, ow, cw);
+            if (px >= xs && px < xe) { oxs[nx] = ox; xlen[nx] = xe - xs; ++nx; }
+        }
+        for (int i = 0; i < ny; ++i)
+            for (int j = 0; j < nx; ++j) {
+                const float inv = 1.f / (float)(ylen[i] * xlen[j]);
+                const float4 g = g_out[((size_t)b * oh + oys[i]) * ow + oxs[j]];
                 a0 += g.x * inv;
                 a1 += g.y * inv;
                 a2 += g.z * inv;
             }
-        }
     }
     g_y[idx] = make_float4(a0 / s0, a1 / s1, a2 / s2, 0.f);
 }
@@ -191,6 +197,8 @@ int spaa_preproc_bwd(const float* g_out, float* g_y, int B, int H, int W, int cy
         return hipErrorInvalidValue;
     // the +-2 candidate search of the gather is exact while a window spans at most 3 inputs
     if (ch > 2 * oh || cw > 2 * ow) return hipErrorInvalidValue;
+    // ... and an input pixel is covered by at most 5 outputs per axis (the gather's list length) up to 4x upscaling
+    if (oh > 4 * ch || ow > 4 * cw) return hipErrorInvalidValue;
     hipLaunchKernelGGL(preproc_bwd_kernel, dim3(nblk((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)g_out, (float4*)g_y, B, H, W, cy0, cx0, ch, cw, oh, ow, std3[0], std3[1],
                        std3[2]);
