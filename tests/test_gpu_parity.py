@@ -621,3 +621,129 @@ def test_img_dists_metrics(hip, golden_dir):
         assert np.array_equal(single, got)
     with pytest.raises(ValueError):
         metrics.calc_img_dists(torch.rand(3, 8, 8), torch.rand(3, 8, 9))
+
+
+def test_tapconv_fuzz_all_kernels(hip):
+    """Seeded random layer shapes x every kernel family (forced tile; a tile that does not apply to a shape falls back
+    inside ConvPlan.run and is still checked): conv / conv-dgrad / transposed conv against torch on the CPU, with ragged
+    sizes, channel counts that are not multiples of 4, channel windows (offsets into wider buffers), residual + ReLU."""
+    cp, lib = hip['cp'], hip['lib']
+    rng = np.random.default_rng(2024)
+    tiles = [0, 1, 5, 6, 9, 10, 11, 12, 15, 16, 17, 18, 19, 20, 22, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39,
+             40, 41, 42, 43, 44, 45, 46, 47, 225, 234, 236, 242, 434]
+    worst = 0.0
+    try:
+        for case in range(60):
+            kind = ['conv', 'dgrad', 'deconv'][case % 3]
+            ci = int(rng.choice([3, 4, 6, 8, 32, 64, 96, 128]))
+            co = int(rng.choice([2, 3, 4, 5, 32, 48, 64, 96, 130]))
+            k = int(rng.choice([1, 2, 3])) if kind == 'deconv' else int(rng.choice([1, 3, 5]))
+            s = 2 if kind == 'deconv' else int(rng.choice([1, 2]))
+            pad = 0 if kind == 'deconv' and k < 3 else k // 2
+            h, w, b = int(rng.integers(5, 23)), int(rng.integers(5, 27)), int(rng.integers(1, 4))
+            tile = int(rng.choice(tiles))
+            g = torch.Generator().manual_seed(case)
+            if kind == 'deconv':
+                op = 1 if k == 3 else 0
+                x = torch.randn(b, ci, h, w, generator=g)
+                wt = torch.randn(ci, co, k, k, generator=g) / (ci * k * k) ** 0.5
+                bias = torch.randn(co, generator=g)
+                ref = F.conv_transpose2d(x, wt, bias, 2, pad, op)
+                plan = cp.deconv_fwd_plan(wt, bias, 2, pad, DEV)
+                inp, cout = x, co
+            elif kind == 'conv':
+                x = torch.randn(b, ci, h, w, generator=g)
+                wt = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+                bias = torch.randn(co, generator=g)
+                ref = F.conv2d(x, wt, bias, s, pad)
+                plan = cp.conv_fwd_plan(wt, bias, s, pad, DEV)
+                inp, cout = x, co
+            else:
+                wt = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+                ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+                gy = torch.randn(b, co, ho, wo, generator=g)
+                ref = torch.nn.grad.conv2d_input((b, ci, h, w), wt, gy, s, pad)
+                plan = cp.conv_dgrad_plan(wt, s, pad, DEV)
+                inp, cout = gy, ci
+            add = torch.randn(ref.shape, generator=g)
+            want = F.relu(ref + add)
+            # operands live in wider NHWC buffers at channel offsets (multiples of 4)
+            cin_p = plan.cin_p
+            ioff, ooff, aoff = 4 * int(rng.integers(0, 3)), 4 * int(rng.integers(0, 3)), 4 * int(rng.integers(0, 3))
+            ibuf = torch.randn(inp.shape[0], inp.shape[2], inp.shape[3], cin_p + ioff + 4, generator=g)
+            ibuf[..., ioff:ioff + cin_p] = nhwc(inp, cin_p)
+            cs_out = (cout + 3) // 4 * 4 + ooff + 4
+            obuf = torch.full((ref.shape[0], ref.shape[2], ref.shape[3], cs_out), 7.0)
+            abuf = torch.zeros(ref.shape[0], ref.shape[2], ref.shape[3], (cout + 3) // 4 * 4 + aoff)
+            abuf[..., aoff:aoff + cout] = nhwc(add)
+            od = obuf.to(DEV)
+            cp.FORCE_TILE = tile
+            plan.run(ibuf.to(DEV), od, add=abuf.to(DEV), act=lib.ACT_RELU, in_coff=ioff, out_coff=ooff, add_coff=aoff)
+            cp.FORCE_TILE = 0
+            got = od.cpu()
+            err = rel_inf(nchw(got[..., ooff:ooff + cout]), want)
+            worst = max(worst, err)
+            assert err < 2e-5, (case, kind, ci, co, k, s, pad, h, w, b, tile, err)
+            # nothing outside the channel window was written
+            assert (got[..., :ooff] == 7.0).all() and (got[..., ooff + cout:] == 7.0).all(), (case, kind, tile)
+    finally:
+        cp.FORCE_TILE = 0
+    print(f'fuzz: worst relative error {worst:.2e}')
+
+
+def test_tapconv_fuzz_epilogues(hip):
+    """Seeded random epilogue combinations (activation, gate mode, second gate / second output, bias) x kernel
+    families on random conv shapes, against torch on the CPU."""
+    cp, lib = hip['cp'], hip['lib']
+    rng = np.random.default_rng(7)
+    tiles = [0, 6, 16, 18, 22, 25, 27, 30, 31, 33, 34, 35, 36, 37, 39, 40, 41, 42, 43, 44, 45, 46, 234, 436]
+    try:
+        for case in range(60):
+            ci, co = int(rng.choice([32, 64, 96])), int(rng.choice([4, 32, 64, 100, 128]))
+            k, s = int(rng.choice([1, 3])), int(rng.choice([1, 2]))
+            h, w, b = int(rng.integers(6, 20)), int(rng.integers(6, 24)), int(rng.integers(1, 4))
+            tile = int(rng.choice(tiles))
+            act = int(rng.choice([lib.ACT_NONE, lib.ACT_RELU, lib.ACT_RELU_CLAMP1, lib.ACT_LEAKY01]))
+            gmode = int(rng.choice([0, lib.GATE_POS, lib.GATE_POS_LE1, lib.GATE_MUL]))
+            use_gate2 = bool(rng.integers(0, 2)) and act != lib.ACT_RELU_CLAMP1
+            use_bias, use_add = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+            g = torch.Generator().manual_seed(1000 + case)
+            x = torch.randn(b, ci, h, w, generator=g)
+            wt = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+            bias = torch.randn(co, generator=g) if use_bias else None
+            y = F.conv2d(x, wt, bias, s, k // 2)
+            add = torch.randn(y.shape, generator=g)
+            gate = torch.randn(y.shape, generator=g) * 0.8
+            gate2 = torch.randn(y.shape, generator=g)
+            t = y + add if use_add else y
+            pre = None
+            if act == lib.ACT_RELU:
+                t = F.relu(t)
+            elif act == lib.ACT_RELU_CLAMP1:
+                pre = F.relu(t)
+                t = pre.clamp(max=1)
+            elif act == lib.ACT_LEAKY01:
+                t = F.leaky_relu(t, 0.1)
+            if gmode == lib.GATE_POS:
+                t = t * (gate > 0)
+            elif gmode == lib.GATE_POS_LE1:
+                t = t * ((gate > 0) & (gate <= 1))
+            elif gmode == lib.GATE_MUL:
+                t = t * gate
+            plan = cp.conv_fwd_plan(wt, bias, s, k // 2, DEV)
+            cs = (co + 3) // 4 * 4
+            out = torch.zeros(b, y.shape[2], y.shape[3], cs, device=DEV)
+            aux = torch.zeros_like(out) if (use_gate2 or act == lib.ACT_RELU_CLAMP1) else None
+            cp.FORCE_TILE = tile
+            plan.run(nhwc(x).to(DEV), out, add=nhwc(add, cs).to(DEV) if use_add else None, act=act,
+                     gate=nhwc(gate, cs).to(DEV) if gmode else None, gate_mode=gmode if gmode else lib.GATE_POS,
+                     aux_out=aux, gate2=nhwc(gate2, cs).to(DEV) if use_gate2 else None)
+            cp.FORCE_TILE = 0
+            info = (case, ci, co, k, s, h, w, b, tile, act, gmode, use_gate2, use_bias, use_add)
+            assert rel_inf(nchw(out.cpu(), co), t) < 2e-5, info
+            if use_gate2:
+                assert rel_inf(nchw(aux.cpu(), co), t * (gate2 > 0)) < 2e-5, info
+            elif act == lib.ACT_RELU_CLAMP1:
+                assert rel_inf(nchw(aux.cpu(), co), pre) < 2e-5, info
+    finally:
+        cp.FORCE_TILE = 0
