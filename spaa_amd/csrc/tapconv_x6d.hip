@@ -351,11 +351,15 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
         /* own weight DMAs of step ks have landed (vmcnt) and everybody's have (barrier); every wave is also past */  \
         /* its reads of the other weight stage, which is overwritten during this step */                          \
         if constexpr (NA == 3) {                                                                                   \
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                       \
+            /* raw barrier: __syncthreads() would drain vmcnt to 0 and with it the pixel gather that is meant to */ \
+            /* stay in flight across this barrier; own LDS reads are retired by lgkmcnt(0) */                      \
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                                            \
+            __builtin_amdgcn_s_barrier();                                                                          \
+            asm volatile("" ::: "memory");                                                                         \
         } else {                                                                                                   \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+            __syncthreads();                                                                                       \
         }                                                                                                          \
-        __syncthreads();                                                                                           \
         const int cur = (ks - ks_begin) & 1;                                                                       \
         const unsigned char* wc = smem + W_BASE + cur * WS_BYTES;                                                  \
         unsigned char* wn = smem + W_BASE + (cur ^ 1) * WS_BYTES;                                                  \
