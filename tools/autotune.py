@@ -42,7 +42,8 @@ def main():
     for key, per in res.items():
         # a key may be launched several times per iteration; compare mean time per launch
         avg = {t: sum(v) / len(v) for t, v in per.items()}
-        best = min(avg, key=avg.get)
+        # ties (run-to-run noise is ~1-2 %) go to the plainer kernel: the LDS-coalesced-epilogue variants must win by 2 %
+        best = min(avg, key=lambda t: avg[t] * (1.02 if t % 100 in (39, 40, 41, 45, 46) else 1.0))
         tune[key] = best
         n = len(per[best]) / 2
         total_best += avg[best] * n
