@@ -29,8 +29,12 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               30: 'x6d_128x32', 31: 'x6d_64x64', 32: 'x6d_64x128', 33: 'x6d_256x64',
               34: 'x6d16_128x128', 35: 'x6d16_256x128', 36: 'x6d16_128x64', 37: 'x6d16_128x32', 38: 'smallcin',
               39: 'x6d16co_128x128', 40: 'x6d16co_128x64', 41: 'x6d16co_128x32',
-              42: 'x6d16a3_128x64', 43: 'x6d16a3_128x32', 44: 'x6da3_128x64', 45: 'x6d16coa3_128x64', 46: 'x6d16coa3_128x32', 47: 'thinpatch16x2'}
+              42: 'x6d16a3_128x64', 43: 'x6d16a3_128x32', 44: 'x6da3_128x64', 45: 'x6d16coa3_128x64', 46: 'x6d16coa3_128x32', 47: 'thinpatch16x2',
+              48: 'x6d16p_128x128', 49: 'x6d16p_128x64', 50: 'x6d16a3p_128x64', 51: 'x6da3p_128x64', 52: 'x6d16p_256x128',
+              53: 'x6d16p_128x32', 54: 'x6dp_128x128'}
 DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
+DEBUG_TAPMAJOR = int(os.environ.get('SPAA_X6D_TAPMAJOR', '0'))      # 1: tap-major K order (A/B measurements only)
+DEBUG_PERSIST_CAP = int(os.environ.get('SPAA_X6D_PERSIST_CAP', '0'))  # > 0: persistent launches use this many workgroups
 FOLD_DECONV = True  # k2/s2 transposed convs: parity classes folded into GEMM rows (one read of the input)
 ENABLE_X6 = True  # build the split-bf16 weight planes (needed by tiles 12-14)
 
@@ -160,7 +164,7 @@ class ConvPlan:
             forced = 0
         if forced in (28, 29, 47) and (self.cout > 4 or self.s_in != 1 or self.cin_p % (32 if forced == 28 else 16)):
             forced = 0
-        if (25 <= forced <= 27 or 30 <= forced <= 37 or 39 <= forced <= 46) and (self.cin_p % 32 or any(c['Kpad'] != c['K'] for c in self.cls)):
+        if (25 <= forced <= 27 or 30 <= forced <= 37 or (39 <= forced <= 46 or 48 <= forced <= 54)) and (self.cin_p % 32 or any(c['Kpad'] != c['K'] for c in self.cls)):
             forced = 0
         tile = forced if forced else TUNE.get(key, -1)
         if tile < 0:
@@ -169,12 +173,12 @@ class ConvPlan:
         ksplit, tile = (tile // 100, tile % 100) if tile >= 100 else (1, tile)
         if self.nfold > 1:  # only the DMA-staged kernels know the folded epilogue
             ksplit = 1
-            if not (25 <= tile <= 27 or 30 <= tile <= 37 or 39 <= tile <= 46):
+            if not (25 <= tile <= 27 or 30 <= tile <= 37 or (39 <= tile <= 46 or 48 <= tile <= 54)):
                 tile = 34
             d.nfold = self.nfold
         if ksplit > 1:
             nk = self.cls[0]['Kpad'] // BK
-            if len(self.cls) != 1 or nk < 2 * ksplit or not (25 <= tile <= 27 or 30 <= tile <= 37 or 39 <= tile <= 46) or self.cin_p % 32:
+            if len(self.cls) != 1 or nk < 2 * ksplit or not (25 <= tile <= 27 or 30 <= tile <= 37 or (39 <= tile <= 46 or 48 <= tile <= 54)) or self.cin_p % 32:
                 ksplit, tile = 1, (0 if forced else tile)
         if ksplit > 1:
             need = ksplit * b * d.Hm * d.Wm * ((self.cout + 127) // 128 * 128)
@@ -187,7 +191,7 @@ class ConvPlan:
             if tile < 25:
                 raise ValueError('GATE_MUL needs a layer shape served by the DMA-staged kernels')
         d.tile = tile
-        d.reserved0 = int(os.environ.get('SPAA_X6D_TAPMAJOR', '0'))  # 1: tap-major K order (A/B measurements only)
+        d.reserved0 = DEBUG_TAPMAJOR | (DEBUG_PERSIST_CAP << 8)  # measurement / test switches of the x6d kernels
         d.nclass = len(self.cls)
         d.tap_range[:] = self.tap_range
         for i, c in enumerate(self.cls):

@@ -545,7 +545,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         if ((int64_t)((d.Cout + 127) & ~127) * d.cls[c].Kpad * 4 >= (int64_t)1 << 31) return hipErrorInvalidValue;
     int tile = d.tile;
     if (d.gate != nullptr && d.gate_mode == SPAA_GATE_MUL && tile < 25) return hipErrorInvalidValue;
-    if (d.nfold > 1 && !((tile >= 25 && tile <= 27) || (tile >= 30 && tile <= 37) || (tile >= 39 && tile <= 46)))
+    if (d.nfold > 1 && !((tile >= 25 && tile <= 27) || (tile >= 30 && tile <= 37) || (tile >= 39 && tile <= 46) || (tile >= 48 && tile <= 54)))
         return hipErrorInvalidValue;
     if (tile == 0) {  // heuristic: widest N tile that fits Cout; shrink M when the grid would not fill 256 CUs twice
         const int64_t M = (int64_t)d.B * d.Hm * d.Wm * d.nclass;
@@ -601,6 +601,13 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         case 45:
         case 46: return spaa_launch_tapconv_x6d(d, tile, stream);
         case 47: return spaa_launch_thinpatch(d, stream);
+        case 48:
+        case 49:
+        case 50:
+        case 51:
+        case 52:
+        case 53:
+        case 54: return spaa_launch_tapconv_x6d(d, tile, stream);
         default: return hipErrorInvalidValue;
     }
 }

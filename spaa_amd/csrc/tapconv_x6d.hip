@@ -112,15 +112,23 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const spaa_tapclass_t cl = p.cls[blockIdx.y];
 
+    // Work distribution.  The grid's x dimension may be SMALLER than the number of tiles (persistent launch): workgroup g
+    // then walks the tiles orig = (g & 7) + 8 j, j = g >> 3, (g >> 3) + G8, ... — the share of its own XCD (blockIdx.x % 8),
+    // in the XCD-aware order below — and overlaps the epilogue of a tile with the first gathers of the next one.  With
+    // gridDim.x == number of tiles every workgroup has exactly one tile (the plain launch).
     const int nwg = m_tiles * n_tiles;
-    int tile;
-    {
-        const int orig = blockIdx.x;
-        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int xcd_ = blockIdx.x & 7;
+    const int q_x = (nwg - xcd_ + 7) >> 3;              // tiles whose index is congruent to this XCD
+    const int G8 = ((int)gridDim.x - xcd_ + 7) >> 3;    // workgroups on this XCD
+    int jt = blockIdx.x >> 3;
+    int n_blk = 0, m_blk = 0;
+#define X6D_TILE_COORDS()                                                                                          \
+    {                                                                                                              \
+        const int q = nwg >> 3, r = nwg & 7;                                                                       \
+        const int tile = (xcd_ < r ? xcd_ * (q + 1) : r * (q + 1) + (xcd_ - r) * q) + jt;                          \
+        n_blk = (tile % n_tiles) * BN;                                                                             \
+        m_blk = (tile / n_tiles) * BM;                                                                             \
     }
-    const int n_blk = (tile % n_tiles) * BN;
-    const int m_blk = (tile / n_tiles) * BM;
 
     const int HWm = p.Hm * p.Wm;
     const int M = p.B * HWm;
@@ -130,29 +138,6 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
     // ---- activation staging: this wave's 32 pixels = 4 pieces of 8 rows; lane -> (row, physical chunk)
     int a_off[4];
     uint32_t a_mlo[4], a_mhi[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = 32 * wave + 8 * j + (lane >> 3);
-        const int c = (lane & 7) ^ swz_pix<SH>(r);  // logical 16-byte chunk held at this lane's LDS slot
-        const int m = m_blk + r;
-        const bool ok = m < M;
-        const int mm = ok ? m : 0;
-        const int b = mm / HWm;
-        const int rr = mm - b * HWm;
-        const int y = rr / p.Wm;
-        const int x = rr - y * p.Wm;
-        const int iy0 = y * p.s_in, ix0 = x * p.s_in;
-        a_off[j] = ((b * p.Hin + iy0) * p.Win + ix0) * row_bytes + p.in_coff * 4 + c * 16;
-        uint32_t lo = 0, hi = 0;
-        for (int t = 0; t < cl.ntaps; ++t) {
-            const int dy = taps[2 * t], dx = taps[2 * t + 1];
-            const bool v = ok && (unsigned)(iy0 + dy) < (unsigned)p.Hin && (unsigned)(ix0 + dx) < (unsigned)p.Win;
-            if (t < 32) lo |= (v ? 1u : 0u) << t;
-            else hi |= (v ? 1u : 0u) << (t - 32);
-        }
-        a_mlo[j] = lo;
-        a_mhi[j] = hi;
-    }
     const uint32_t in_bytes = (uint32_t)p.B * (uint32_t)(p.Hin * p.Win) * (uint32_t)row_bytes;
     const uint64_t in_addr = reinterpret_cast<uint64_t>(p.in);
     const uint32_t in_lo = __builtin_amdgcn_readfirstlane((uint32_t)in_addr);
@@ -169,14 +154,6 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
                                                            (int)__builtin_amdgcn_readfirstlane(3u * (uint32_t)plane_bytes),
                                                            0x00020000);
     int w_goff[WPW];
-#pragma unroll
-    for (int i = 0; i < WPW; ++i) {
-        const int q = wave + NW * i;  // (q >= W_PIECES: no such piece, never issued)
-        const int pl = q / (BN / 16), rb = q % (BN / 16);
-        const int n = 16 * rb + (lane >> 2);
-        const int c = (lane & 3) ^ swz_w<SH>(n);
-        w_goff[i] = pl * plane_bytes + (n_blk + n) * cl.Kpad * 2 + c * 16;
-    }
 
     const int nk_all = cl.Kpad / BK;
     const int Cin = p.Cin;
@@ -193,7 +170,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
     // the next chunk): the 128-byte slice of a pixel is then re-read by the 9 taps within 9 consecutive steps and stays
     // in the XCD's L2 (tap-major order re-reads every slice 12+ steps later, when 64 workgroups' traffic has evicted it).
     // The sum over K is the same set of products either way.
-    const bool chunk_major = (cl.ntaps > 1) && (Cin > BK) && p.reserved0 != 1;  // (reserved0 == 1: tap-major, for A/B runs)
+    const bool chunk_major = (cl.ntaps > 1) && (Cin > BK) && !(p.reserved0 & 1);  // (reserved0 bit 0: tap-major, A/B runs)
 #define X6D_ADVANCE(tap, kc)                                                                                       \
     if (chunk_major) {                                                                                             \
         tap += 1;                                                                                                  \
@@ -208,10 +185,9 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
             tap += 1;                                                                                              \
         }                                                                                                          \
     }
-    int s_tap = chunk_major ? ks_begin % cl.ntaps : (ks_begin * BK) / Cin;
-    int s_kc = chunk_major ? (ks_begin / cl.ntaps) * BK : (ks_begin * BK) % Cin;
-    int w_tap = s_tap, w_kc = s_kc;  // (tap, channel offset) of the step whose WEIGHTS are staged next
-    int n_dy = ctaps[2 * min(s_tap, cl.ntaps - 1)], n_dx = ctaps[2 * min(s_tap, cl.ntaps - 1) + 1];
+    int s_tap = 0, s_kc = 0;  // (tap, channel offset) of the step whose PIXELS are staged next
+    int w_tap = 0, w_kc = 0;  // ... and of the step whose WEIGHTS are staged next
+    int n_dy = 0, n_dx = 0;
     int voff[4];
 
 #define X6D_PREP(more, ks_next)                                                                                    \
@@ -315,6 +291,79 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
     constexpr int NACC = SH == 32 ? TN : 1;
     f32x16 acc32[NACC];
     f32x4 acc16[2][SH == 16 ? TJ : 1];
+
+    // The tap offsets are needed by every tile setup (validity masks): fetch the first NTREG of them once, back to back
+    // (a dependent scalar load per tap and pixel piece costs ~4 us per tile otherwise).
+    constexpr int NTREG = 9;
+    int tdy[NTREG], tdx[NTREG];
+#pragma unroll
+    for (int t = 0; t < NTREG; ++t) {
+        const int tt = min(t, cl.ntaps - 1);
+        tdy[t] = ctaps[2 * tt];
+        tdx[t] = ctaps[2 * tt + 1];
+    }
+    // Everything that depends on the tile: gather offsets and tap-validity masks of the lane's pixel rows, weight row
+    // offsets, the K-step state, and the DMAs of the tile's first K-step (and second pixel step when NA == 3).
+#define X6D_TILE_SETUP()                                                                                           \
+    {                                                                                                              \
+        X6D_TILE_COORDS()                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                            \
+            const int r = 32 * wave + 8 * j + (lane >> 3);                                                         \
+            const int c = (lane & 7) ^ swz_pix<SH>(r); /* logical 16-byte chunk held at this lane's LDS slot */    \
+            const int m = m_blk + r;                                                                               \
+            const bool ok = m < M;                                                                                 \
+            const int mm = ok ? m : 0;                                                                             \
+            const int b = mm / HWm;                                                                                \
+            const int rr = mm - b * HWm;                                                                           \
+            const int y = rr / p.Wm;                                                                               \
+            const int x = rr - y * p.Wm;                                                                           \
+            const int iy0 = y * p.s_in, ix0 = x * p.s_in;                                                          \
+            a_off[j] = ((b * p.Hin + iy0) * p.Win + ix0) * row_bytes + p.in_coff * 4 + c * 16;                     \
+            uint32_t lo = 0, hi = 0;                                                                               \
+            _Pragma("unroll") for (int t = 0; t < NTREG; ++t) { /* tap offsets preloaded in registers */           \
+                const bool v = t < cl.ntaps && ok && (unsigned)(iy0 + tdy[t]) < (unsigned)p.Hin &&                 \
+                               (unsigned)(ix0 + tdx[t]) < (unsigned)p.Win;                                         \
+                lo |= (v ? 1u : 0u) << t;                                                                          \
+            }                                                                                                      \
+            for (int t = NTREG; t < cl.ntaps; ++t) { /* (more taps than registers hold: 5x5 kernels) */            \
+                const int dy = ctaps[2 * t], dx = ctaps[2 * t + 1];                                                \
+                const bool v = ok && (unsigned)(iy0 + dy) < (unsigned)p.Hin && (unsigned)(ix0 + dx) < (unsigned)p.Win; \
+                if (t < 32) lo |= (v ? 1u : 0u) << t;                                                              \
+                else hi |= (v ? 1u : 0u) << (t - 32);                                                              \
+            }                                                                                                      \
+            a_mlo[j] = lo;                                                                                         \
+            a_mhi[j] = hi;                                                                                         \
+        }                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < WPW; ++i) {                                                          \
+            const int q = wave + NW * i; /* (q >= W_PIECES: no such piece, never issued) */                        \
+            const int pl = q / (BN / 16), rb = q % (BN / 16);                                                      \
+            const int n = 16 * rb + (lane >> 2);                                                                   \
+            const int c = (lane & 3) ^ swz_w<SH>(n);                                                               \
+            w_goff[i] = pl * plane_bytes + (n_blk + n) * cl.Kpad * 2 + c * 16;                                     \
+        }                                                                                                          \
+        s_tap = chunk_major ? ks_begin % cl.ntaps : (ks_begin * BK) / Cin;                                         \
+        s_kc = chunk_major ? (ks_begin / cl.ntaps) * BK : (ks_begin * BK) % Cin;                                   \
+        w_tap = s_tap;                                                                                             \
+        w_kc = s_kc;                                                                                               \
+        n_dy = ctaps[2 * min(s_tap, cl.ntaps - 1)];                                                                \
+        n_dx = ctaps[2 * min(s_tap, cl.ntaps - 1) + 1];                                                            \
+        if (nk > 0) {                                                                                              \
+            X6D_PREP(true, 0)                                                                                      \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) X6D_DMA_A(smem, j)                                       \
+            _Pragma("unroll") for (int i = 0; i < WPW; ++i) X6D_DMA_W(smem + W_BASE, i, (w_tap * Cin + w_kc) * 2)  \
+            if constexpr (NA == 3) {                                                                               \
+                X6D_PREP(nk > 1, 1)                                                                                \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) X6D_DMA_A(smem + A_BYTES, j)                         \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
+
+    bf16x8 pfc[2][3];  // pixel fragments of the current K-step (h / m / l planes of the two halves or pixel blocks)
+    bf16x8 pfd[2][3];
+    int ia = 0;        // pixel stage of the current step (stages rotate 0 .. NA-1)
+    X6D_TILE_SETUP()
+
+  for (;;) {  // one tile per pass (persistent launch: several)
 #pragma unroll
     for (int j = 0; j < NACC; ++j)
 #pragma unroll
@@ -323,19 +372,9 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
     for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
         for (int j = 0; j < (SH == 16 ? TJ : 1); ++j) acc16[ib][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    bf16x8 pfc[2][3];  // pixel fragments of the current K-step (h / m / l planes of the two halves or pixel blocks)
-    int ia = 0;        // pixel stage of the current step (stages rotate 0 .. NA-1)
+    ia = 0;
     if (nk > 0) {
-        X6D_PREP(true, 0)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) X6D_DMA_A(smem, j)
-#pragma unroll
-        for (int i = 0; i < WPW; ++i) X6D_DMA_W(smem + W_BASE, i, (w_tap * Cin + w_kc) * 2)
         if constexpr (NA == 3) {
-            X6D_PREP(nk > 1, 1)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) X6D_DMA_A(smem + A_BYTES, j)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_MIN + 4) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_MIN) : "memory");
@@ -396,7 +435,6 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
         }                                                                                                          \
         ia = ia1;                                                                                                  \
     }
-    bf16x8 pfd[2][3];
     int ks = ks_begin;
     for (; ks + 1 < ks_end; ks += 2) {
         X6D_STEP(pfc, pfd)
@@ -407,31 +445,43 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
     if (ks < ks_end) X6D_STEP(pfc, pfd)
 #undef X6D_STEP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last step's (all-zero) prefetch must not outlive the wave
+    // the tile is finished; in a persistent launch the next tile's first gathers are issued BEFORE this tile's
+    // epilogue (the stage buffers are free once every wave is past its last reads), so the stores below overlap them
+    const int m_blk_e = m_blk, n_blk_e = n_blk;
+    const bool has_next = jt + G8 < q_x;
+    if constexpr (!CO) {
+        if (has_next) {
+            __syncthreads();
+            jt += G8;
+            X6D_TILE_SETUP()
+        }
+    }
+    do {
 
     if (p.ksplit > 1) {
         // split-K: raw partial sums to the workspace [split][M][Npad]; splitk_reduce_kernel finishes the layer
         float* ws = p.splitk_ws + (size_t)blockIdx.z * M * npad;
         if constexpr (SH == 32) {
-            const int m = m_blk + 32 * wave + (lane & 31);
+            const int m = m_blk_e + 32 * wave + (lane & 31);
             if (m < M) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<f4*>(ws + (size_t)m * npad + n_blk + 32 * j + 8 * g + 4 * (lane >> 5)) =
+                        *reinterpret_cast<f4*>(ws + (size_t)m * npad + n_blk_e + 32 * j + 8 * g + 4 * (lane >> 5)) =
                             f4{acc32[j][4 * g], acc32[j][4 * g + 1], acc32[j][4 * g + 2], acc32[j][4 * g + 3]};
             }
         } else {
 #pragma unroll
             for (int ib = 0; ib < 2; ++ib) {
-                const int m = m_blk + 32 * wave + 16 * ib + (lane & 15);
+                const int m = m_blk_e + 32 * wave + 16 * ib + (lane & 15);
                 if (m >= M) continue;
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
-                    *reinterpret_cast<f4*>(ws + (size_t)m * npad + n_blk + 16 * j + 4 * (lane >> 4)) = acc16[ib][j];
+                    *reinterpret_cast<f4*>(ws + (size_t)m * npad + n_blk_e + 16 * j + 4 * (lane >> 4)) = acc16[ib][j];
             }
         }
-        return;
+        break;
     }
     if constexpr (CO) {
         // ---- coalesced epilogue (memory-heavy layers): the result tile goes through LDS (the stage buffers are free
@@ -450,11 +500,11 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
                     *reinterpret_cast<f32x4*>(slab + (16 * ib + (lane & 15)) * PITCH + 16 * j + 4 * (lane >> 4)) = acc16[ib][j];
             constexpr int LPR = BN / 4;    // lanes per row (4 channels each)
             constexpr int RPI = 64 / LPR;  // rows per store instruction
-            const int n0 = n_blk + 4 * (lane % LPR);
+            const int n0 = n_blk_e + 4 * (lane % LPR);
             const int cfold = p.nfold > 1 ? n0 / p.Cout : 0;
             const bool linear = p.nfold <= 1 && (p.s_out == 1) && (cl.oy0 == 0) && (cl.ox0 == 0) && (p.Hm == p.Hout) &&
                                 (p.Wm == p.Wout);
-            int m = m_blk + 32 * wave + lane / LPR;
+            int m = m_blk_e + 32 * wave + lane / LPR;
             int pb = m / HWm, py = (m - pb * HWm) / p.Wm, px = m - pb * HWm - py * p.Wm;
 #pragma unroll
             for (int i = 0; i < 32 / RPI; ++i) {
@@ -483,7 +533,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
                     pb += 1;
                 }
             }
-            return;
+            break;
         }
     }
     if (p.nfold > 1) {
@@ -495,7 +545,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc32[j][4 * g + e];
-                    store4_fold(p, m_blk + 32 * wave + (lane & 31), M, HWm, n_blk + 32 * j + 8 * g + 4 * (lane >> 5), v, vec);
+                    store4_fold(p, m_blk_e + 32 * wave + (lane & 31), M, HWm, n_blk_e + 32 * j + 8 * g + 4 * (lane >> 5), v, vec);
                 }
         } else {
 #pragma unroll
@@ -503,16 +553,16 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
                     float v[4] = {acc16[ib][j][0], acc16[ib][j][1], acc16[ib][j][2], acc16[ib][j][3]};
-                    store4_fold(p, m_blk + 32 * wave + 16 * ib + (lane & 15), M, HWm, n_blk + 16 * j + 4 * (lane >> 4), v, vec);
+                    store4_fold(p, m_blk_e + 32 * wave + 16 * ib + (lane & 15), M, HWm, n_blk_e + 16 * j + 4 * (lane >> 4), v, vec);
                 }
         }
-        return;
+        break;
     }
     if constexpr (SH == 32) {
         // D layout of a 32x32 tile: column (lane & 31) = pixel, row (r&3) + 8*(r>>2) + 4*(lane>>5) = output channel:
         // registers 4g..4g+3 of a lane are 4 consecutive channels of its pixel.
         size_t o;
-        if (!out_pixel(p, cl, m_blk + 32 * wave + (lane & 31), M, HWm, o)) return;
+        if (!out_pixel(p, cl, m_blk_e + 32 * wave + (lane & 31), M, HWm, o)) break;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -520,24 +570,36 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc32[j][4 * g + e];
-                store4(p, o, n_blk + 32 * j + 8 * g + 4 * (lane >> 5), v, vec);
+                store4(p, o, n_blk_e + 32 * j + 8 * g + 4 * (lane >> 5), v, vec);
             }
     } else {
         // D layout of a 16x16 tile: column (lane & 15) = pixel, rows 4*(lane>>4) + i = 4 consecutive output channels
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
             size_t o;
-            if (!out_pixel(p, cl, m_blk + 32 * wave + 16 * ib + (lane & 15), M, HWm, o)) continue;
+            if (!out_pixel(p, cl, m_blk_e + 32 * wave + 16 * ib + (lane & 15), M, HWm, o)) continue;
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 float v[4] = {acc16[ib][j][0], acc16[ib][j][1], acc16[ib][j][2], acc16[ib][j][3]};
-                store4(p, o, n_blk + 16 * j + 4 * (lane >> 4), v, vec);
+                store4(p, o, n_blk_e + 16 * j + 4 * (lane >> 4), v, vec);
             }
         }
     }
+    } while (0);
+    if constexpr (CO) {  // (its epilogue goes through the stage buffers: set the next tile up afterwards)
+        if (has_next) {
+            __syncthreads();
+            jt += G8;
+            X6D_TILE_SETUP()
+        }
+    }
+    if (!has_next) break;
+  }
 #undef X6D_ISSUE
 #undef X6D_LDP
 #undef X6D_PREP
+#undef X6D_TILE_SETUP
+#undef X6D_TILE_COORDS
 #undef X6D_ADVANCE
 #undef X6D_DMA_A
 #undef X6D_DMA_W
@@ -565,7 +627,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const spaa_tapconv_t
 }
 
 template <int NW, int BN, int SH = 32, bool CO = false, int NA = 2>
-int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream) {
+int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream, bool persistent = false) {
     constexpr int BM = 32 * NW;
     const int64_t M = (int64_t)d.B * d.Hm * d.Wm;
     const int m_tiles = (int)((M + BM - 1) / BM);
@@ -582,7 +644,18 @@ int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream) {
     }
     const int ksplit = d.ksplit > 1 ? d.ksplit : 1;
     if (ksplit > 1 && (d.nclass != 1 || d.splitk_ws == nullptr || d.cls[0].Kpad / BK < 2 * ksplit)) return hipErrorInvalidValue;
-    dim3 grid(m_tiles * n_tiles, d.nclass, ksplit);
+    int gx = m_tiles * n_tiles;
+    if (persistent) {
+        // as many workgroups as the chip holds at once (LDS-limited), a multiple of 8 so every XCD gets the same number;
+        // each walks its XCD's tiles and overlaps a tile's epilogue with the next tile's first gathers
+        const int per_cu = (int)(160 * 1024 / smem) < 1 ? 1 : (int)(160 * 1024 / smem);
+        const int resident = 256 * (per_cu > 8 * 4 / NW ? 8 * 4 / NW : per_cu);
+        int cap = resident / (d.nclass * ksplit);
+        if ((d.reserved0 >> 8) > 0) cap = d.reserved0 >> 8;  // tests: force several tiles per workgroup on small layers
+        cap = cap < 8 ? 8 : (cap & ~7);
+        if (gx > cap) gx = cap;
+    }
+    dim3 grid(gx, d.nclass, ksplit);
     hipLaunchKernelGGL((tapconv_x6d_kernel<NW, BN, SH, CO, NA>), grid, dim3(64 * NW), smem, stream, d, m_tiles, n_tiles);
     if (ksplit > 1) {
         const int npad = (d.Cout + 127) & ~127;
@@ -622,6 +695,13 @@ int spaa_launch_tapconv_x6d(const spaa_tapconv_t& d, int tile, hipStream_t strea
         case 44: return launch_x6d<4, 64, 32, false, 3>(d, stream);
         case 45: return launch_x6d<4, 64, 16, true, 3>(d, stream);
         case 46: return launch_x6d<4, 32, 16, true, 3>(d, stream);
+        case 48: return launch_x6d<4, 128, 16>(d, stream, true);
+        case 49: return launch_x6d<4, 64, 16>(d, stream, true);
+        case 50: return launch_x6d<4, 64, 16, false, 3>(d, stream, true);
+        case 51: return launch_x6d<4, 64, 32, false, 3>(d, stream, true);
+        case 52: return launch_x6d<8, 128, 16>(d, stream, true);
+        case 53: return launch_x6d<4, 32, 16>(d, stream, true);
+        case 54: return launch_x6d<4, 128, 32>(d, stream, true);
         default: return hipErrorInvalidValue;
     }
 }

@@ -140,7 +140,7 @@ def test_directconv_thin_layers(hip, tile):
         cp.FORCE_TILE = 0
 
 
-@pytest.mark.parametrize('tile', [12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 30, 31, 32, 33, 34, 35, 36, 37, 225, 431, 234, 436, 39, 40, 41, 42, 43, 44, 45, 46, 242])
+@pytest.mark.parametrize('tile', [12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 30, 31, 32, 33, 34, 35, 36, 37, 225, 431, 234, 436, 39, 40, 41, 42, 43, 44, 45, 46, 242, 48, 49, 50, 51, 52, 53, 54, 248, 450])
 def test_tapconv_x6_is_fp32_accurate(hip, tile):
     """fp32 emulated on the bf16 matrix cores (exact 3-way operand split, 6 of 9 partial products, separate
     accumulators): the error against an fp64 reference must not exceed that of the exact-fp32 MFMA kernel."""
@@ -174,7 +174,7 @@ def test_tapconv_x6_is_fp32_accurate(hip, tile):
         cp.FORCE_TILE = 0
 
 
-@pytest.mark.parametrize('tile', [0, 6, 18, 34, 36, 39, 40, 41, 42, 44, 45, 46])
+@pytest.mark.parametrize('tile', [0, 6, 18, 34, 36, 39, 40, 41, 42, 44, 45, 46, 48, 50, 51, 52])
 def test_tapconv_epilogues(hip, tile):
     cp, lib = hip['cp'], hip['lib']
     cp.FORCE_TILE = tile
@@ -580,7 +580,7 @@ def test_compennet_pp_forward_and_perc_al_glue(hip, golden_dir):
     assert cam.shape == (2, 3, 64, 64) and prj.shape == (2, 3, 64, 64) and torch.isfinite(prj).all()
 
 
-@pytest.mark.parametrize('tile', [0, 25, 27, 30, 34, 36, 37, 39, 40, 41, 42, 43, 45, 46])
+@pytest.mark.parametrize('tile', [0, 25, 27, 30, 34, 36, 37, 39, 40, 41, 42, 43, 45, 46, 48, 49, 53])
 def test_folded_deconv_with_epilogue(hip, tile):
     """Kernel-2 stride-2 ConvTranspose2d with the four parity classes folded into the GEMM rows (spaa_tapconv_t.nfold),
     fused residual + ReLU, against torch; every DMA-staged tile shape."""
@@ -630,7 +630,7 @@ def test_tapconv_fuzz_all_kernels(hip):
     cp, lib = hip['cp'], hip['lib']
     rng = np.random.default_rng(2024)
     tiles = [0, 1, 5, 6, 9, 10, 11, 12, 15, 16, 17, 18, 19, 20, 22, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39,
-             40, 41, 42, 43, 44, 45, 46, 47, 225, 234, 236, 242, 434]
+             40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 225, 234, 236, 242, 434, 248]
     worst = 0.0
     try:
         for case in range(60):
@@ -696,7 +696,7 @@ def test_tapconv_fuzz_epilogues(hip):
     families on random conv shapes, against torch on the CPU."""
     cp, lib = hip['cp'], hip['lib']
     rng = np.random.default_rng(7)
-    tiles = [0, 6, 16, 18, 22, 25, 27, 30, 31, 33, 34, 35, 36, 37, 39, 40, 41, 42, 43, 44, 45, 46, 234, 436]
+    tiles = [0, 6, 16, 18, 22, 25, 27, 30, 31, 33, 34, 35, 36, 37, 39, 40, 41, 42, 43, 44, 45, 46, 48, 49, 50, 52, 53, 234, 436]
     try:
         for case in range(60):
             ci, co = int(rng.choice([32, 64, 96])), int(rng.choice([4, 32, 64, 100, 128]))
@@ -747,3 +747,40 @@ def test_tapconv_fuzz_epilogues(hip):
                 assert rel_inf(nchw(aux.cpu(), co), pre) < 2e-5, info
     finally:
         cp.FORCE_TILE = 0
+
+
+@pytest.mark.parametrize('tile', [48, 49, 50, 51, 52, 53, 54, 248])
+def test_persistent_launch_walks_several_tiles(hip, tile):
+    """Persistent launches of the DMA-staged kernel (a workgroup walks its XCD's tiles and overlaps a tile's epilogue
+    with the next tile's first gathers), forced down to 8 workgroups so that every workgroup handles many tiles:
+    conv, strided-class transposed conv and folded transposed conv, ragged sizes, against torch."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(5)
+    cp.DEBUG_PERSIST_CAP = 8
+    try:
+        for ci, co, k, s, h, w, b in [(64, 96, 3, 1, 37, 41, 3), (32, 160, 3, 2, 50, 33, 2), (128, 40, 1, 1, 29, 31, 4)]:
+            x = torch.randn(b, ci, h, w)
+            wt = torch.randn(co, ci, k, k) / (ci * k * k) ** 0.5
+            bias = torch.randn(co)
+            y = F.conv2d(x, wt, bias, s, k // 2)
+            add, gate = torch.randn_like(y), torch.randn_like(y)
+            plan = cp.conv_fwd_plan(wt, bias, s, k // 2, DEV)
+            cs = (co + 3) // 4 * 4
+            out = torch.zeros(b, y.shape[2], y.shape[3], cs, device=DEV)
+            cp.FORCE_TILE = tile
+            plan.run(nhwc(x).to(DEV), out, add=nhwc(add, cs).to(DEV), act=lib.ACT_RELU, gate=nhwc(gate, cs).to(DEV))
+            cp.FORCE_TILE = 0
+            assert rel_inf(nchw(out.cpu(), co), F.relu(y + add) * (gate > 0)) < 2e-5, (ci, co, k, s)
+        xt, wtt, bt = torch.randn(2, 64, 19, 23), torch.randn(64, 48, 3, 3) / 24, torch.randn(48)
+        for kk, pad, op in [(3, 1, 1), (2, 0, 0)]:
+            wk = wtt[:, :, :kk, :kk].contiguous()
+            ref = F.conv_transpose2d(xt, wk, bt, 2, pad, op)
+            tplan = cp.deconv_fwd_plan(wk, bt, 2, pad, DEV)
+            outt = torch.zeros(2, ref.shape[2], ref.shape[3], 48, device=DEV)
+            cp.FORCE_TILE = tile
+            tplan.run(nhwc(xt).to(DEV), outt)
+            cp.FORCE_TILE = 0
+            assert rel_inf(nchw(outt.cpu()), ref) < 2e-5, (kk, tile)
+    finally:
+        cp.FORCE_TILE = 0
+        cp.DEBUG_PERSIST_CAP = 0
