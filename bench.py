@@ -200,7 +200,7 @@ def main():
             ms = e0.elapsed_time(e1)
             # roofline groups = kernel instantiations (as rocprofv3 reports them): split-K launches of a tile belong to it
             base = convplan.TILE_NAMES.get(tile_id % 100, 'auto')
-            tile = base + (f'_splitk{tile_id // 100}' if tile_id >= 100 else '')
+            tile = base + (('_streamk' if tile_id // 100 == 9 else f'_splitk{tile_id // 100}') if tile_id >= 100 else '')
             a = per_tile.setdefault(base, [0.0, 0.0, 0, 0.0])
             a[0] += flops
             a[1] += ms

@@ -75,7 +75,9 @@ typedef struct {
     int32_t gate2_cstride, gate2_coff;
     int32_t tap_range[4]; /* (dy_min, dy_max, dx_min, dx_max) over the taps of all classes: patch-staged kernels */
     float* splitk_ws;     /* split-K workspace, ksplit * B*Hm*Wm * Npad floats (Npad = Cout rounded up to 128), or NULL */
-    int32_t ksplit;       /* <= 1: off.  > 1 (tiles 25.., one class): K is cut into `ksplit` ranges computed by separate
+    int32_t ksplit;       /* -1 (persistent tiles 48..54, one class): stream-K — the K-steps of all tiles are cut into equal
+                             ranges per workgroup; splitk_ws must hold 2 * 768 * 128 * 128 floats; cut tiles are summed in
+                             segment order by a second kernel.  0, 1: off.  > 1 (tiles 25.., one class): K is cut into `ksplit` ranges computed by separate
                              workgroups into splitk_ws; a second kernel adds them in fixed order and applies the epilogue
                              (layers with few output pixels and long K, e.g. ResNet layer4: fills the chip) */
     int32_t nfold;        /* <= 1: off.  4 (tiles 25.., one class, s_out == 2, Cout % 4 == 0): the four output-parity classes of

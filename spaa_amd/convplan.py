@@ -52,6 +52,17 @@ def _load_tune():
 TUNE = _load_tune()  # shape key -> tile id, measured on MI355X by tools/autotune.py (absent key = heuristic)
 
 
+_STREAMK_WS = {}
+
+
+def _streamk_workspace(device):
+    """2 slots x 768 workgroups x (128 x 128) floats (include/spaa_hip.h: ksplit == -1)."""
+    key = str(device)
+    if key not in _STREAMK_WS:
+        _STREAMK_WS[key] = torch.empty(2 * 768 * 128 * 128, device=device, dtype=torch.float32)
+    return _STREAMK_WS[key]
+
+
 def _ceil(a, b):
     return (a + b - 1) // b * b
 
@@ -176,6 +187,12 @@ class ConvPlan:
             if not (25 <= tile <= 27 or 30 <= tile <= 37 or (39 <= tile <= 46 or 48 <= tile <= 54)):
                 tile = 34
             d.nfold = self.nfold
+        if ksplit == 9:  # stream-K (persistent x6d tiles, one class): workspace shared by all plans (one stream)
+            if len(self.cls) != 1 or self.nfold > 1 or not (48 <= tile <= 54) or self.cin_p % 32:
+                ksplit, tile = 1, (0 if forced else tile)
+            else:
+                d.splitk_ws, d.ksplit = _streamk_workspace(inp.device).data_ptr(), -1
+                ksplit = 1
         if ksplit > 1:
             nk = self.cls[0]['Kpad'] // BK
             if len(self.cls) != 1 or nk < 2 * ksplit or not (25 <= tile <= 27 or 30 <= tile <= 37 or (39 <= tile <= 46 or 48 <= tile <= 54)) or self.cin_p % 32:
@@ -209,7 +226,7 @@ class ConvPlan:
             nbytes = 4 * (b * hin * win * self.cin_p + npx * self.cout * (1 + (add is not None) + (gate is not None)
                                                                          + (aux_out is not None) + (gate2 is not None))
                           + self.ntaps_total * self.cin_p * self.cout)
-            PROFILE.append((self.name, key, self.flops(b, hout, wout), e0, e1, d.tile + 100 * (d.ksplit if d.ksplit > 1 else 0), nbytes))
+            PROFILE.append((self.name, key, self.flops(b, hout, wout), e0, e1, d.tile + 100 * (d.ksplit if d.ksplit > 1 else (9 if d.ksplit == -1 else 0)), nbytes))
         return out
 
     def _default_tile(self, m):

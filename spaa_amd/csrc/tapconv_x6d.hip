@@ -159,9 +159,27 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
     const int Cin = p.Cin;
     // split-K: this workgroup multiplies K-steps [ks_begin, ks_end) only
     const int nsplit = p.ksplit > 1 ? p.ksplit : 1;
-    const int ks_begin = (int)((int64_t)blockIdx.z * nk_all / nsplit);
-    const int ks_end = (int)((int64_t)(blockIdx.z + 1) * nk_all / nsplit);
-    const int nk = ks_end - ks_begin;
+    int ks_begin = (int)((int64_t)blockIdx.z * nk_all / nsplit);
+    int ks_end = (int)((int64_t)(blockIdx.z + 1) * nk_all / nsplit);
+    int nk = ks_end - ks_begin;
+    // stream-K (p.ksplit == -1, persistent launch): the K-steps of ALL tiles of this XCD form one sequence of
+    // q_x * nk_all iterations that is cut into G8 equal ranges, one per workgroup: whole tiles are finished as usual; a
+    // tile cut by a range boundary leaves raw partial sums in the workspace (two slots per workgroup: slot 0 for a
+    // segment that starts inside a tile, slot 1 for one that starts a tile but does not finish it) and
+    // streamk_reduce_kernel adds the segments in order and applies the epilogue.  Removes the last-round quantisation
+    // of layers whose tile count is not a multiple of the resident workgroups.
+    const bool streamk = p.ksplit == -1;
+    const int64_t total_x = (int64_t)q_x * nk_all;
+    int64_t it = 0, it1 = 0;
+    if (streamk) {
+        it = (int64_t)(blockIdx.x >> 3) * total_x / G8;
+        it1 = (int64_t)((blockIdx.x >> 3) + 1) * total_x / G8;
+        if (it >= it1) return;  // (more workgroups than iterations: nothing to do; uniform for the workgroup)
+        jt = (int)(it / nk_all);
+        ks_begin = (int)(it - (int64_t)jt * nk_all);
+        ks_end = (int)((int64_t)nk_all < ks_begin + (it1 - it) ? (int64_t)nk_all : ks_begin + (it1 - it));
+        nk = ks_end - ks_begin;
+    }
     // wave-uniform state of the K-step being STAGED (one ahead of the one being multiplied); the tap offsets come through
     // scalar loads issued one K-step before they are used
     typedef const __attribute__((address_space(4))) int* cint_ptr;
@@ -448,15 +466,52 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
     // the tile is finished; in a persistent launch the next tile's first gathers are issued BEFORE this tile's
     // epilogue (the stage buffers are free once every wave is past its last reads), so the stores below overlap them
     const int m_blk_e = m_blk, n_blk_e = n_blk;
-    const bool has_next = jt + G8 < q_x;
+    const bool partial_e = streamk && !(ks_begin == 0 && ks_end == nk_all);
+    const int slot_e = ks_begin > 0 ? 0 : 1;
+    bool has_next;
+    if (streamk) {
+        it += nk;
+        has_next = it < it1;
+    } else {
+        has_next = jt + G8 < q_x;
+    }
+#define X6D_NEXT_TILE()                                                                                            \
+    {                                                                                                              \
+        __syncthreads();                                                                                           \
+        if (streamk) {                                                                                             \
+            jt = (int)(it / nk_all);                                                                               \
+            ks_begin = (int)(it - (int64_t)jt * nk_all);                                                           \
+            ks_end = (int)((int64_t)nk_all < ks_begin + (it1 - it) ? (int64_t)nk_all : ks_begin + (it1 - it));     \
+            nk = ks_end - ks_begin;                                                                                \
+        } else {                                                                                                   \
+            jt += G8;                                                                                              \
+        }                                                                                                          \
+        X6D_TILE_SETUP()                                                                                           \
+    }
     if constexpr (!CO) {
-        if (has_next) {
-            __syncthreads();
-            jt += G8;
-            X6D_TILE_SETUP()
-        }
+        if (has_next) X6D_NEXT_TILE()
     }
     do {
+        if (partial_e) {
+            // stream-K segment: raw partial sums, tile-local [BM][BN], into this workgroup's slot
+            float* ws = p.splitk_ws + ((size_t)blockIdx.x * 2 + slot_e) * (BM * BN);
+            if constexpr (SH == 32) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<f4*>(ws + (32 * wave + (lane & 31)) * BN + 32 * j + 8 * g + 4 * (lane >> 5)) =
+                            f4{acc32[j][4 * g], acc32[j][4 * g + 1], acc32[j][4 * g + 2], acc32[j][4 * g + 3]};
+            } else {
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        *reinterpret_cast<f32x4*>(ws + (32 * wave + 16 * ib + (lane & 15)) * BN + 16 * j + 4 * (lane >> 4)) =
+                            acc16[ib][j];
+            }
+            break;
+        }
 
     if (p.ksplit > 1) {
         // split-K: raw partial sums to the workspace [split][M][Npad]; splitk_reduce_kernel finishes the layer
@@ -587,12 +642,9 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
     }
     } while (0);
     if constexpr (CO) {  // (its epilogue goes through the stage buffers: set the next tile up afterwards)
-        if (has_next) {
-            __syncthreads();
-            jt += G8;
-            X6D_TILE_SETUP()
-        }
+        if (has_next) X6D_NEXT_TILE()
     }
+#undef X6D_NEXT_TILE
     if (!has_next) break;
   }
 #undef X6D_ISSUE
@@ -626,6 +678,46 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const spaa_tapconv_t
     store4(p, o, n0, v, vec);
 }
 
+// second pass of stream-K: tiles that were cut into segments are summed in segment order and finished.  Workgroup s
+// of XCD x owns iterations [s*T/G, (s+1)*T/G) of that XCD's q_x*nk iterations; iteration I belongs to workgroup
+// ceil((I+1)*G/T) - 1.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void streamk_reduce_kernel(const spaa_tapconv_t p, const int m_tiles, const int n_tiles,
+                                                             const int gx, const int nk_all) {
+    const int nwg = m_tiles * n_tiles;
+    const int orig = blockIdx.y;  // tile in launch order: XCD = orig & 7, position in the XCD's list = orig >> 3
+    const int xcd = orig & 7, j = orig >> 3;
+    const int q_x = (nwg - xcd + 7) >> 3, G8 = (gx - xcd + 7) >> 3;
+    const int64_t T = (int64_t)q_x * nk_all;
+    const int s_a = (int)((((int64_t)j * nk_all + 1) * G8 + T - 1) / T) - 1;
+    const int s_b = (int)((((int64_t)(j + 1) * nk_all) * G8 + T - 1) / T) - 1;
+    if (s_a == s_b) return;  // the tile was computed whole by one workgroup
+    const int e = blockIdx.x * 256 + threadIdx.x;  // 4 channels of one tile row
+    if (e >= BM * BN / 4) return;
+    const int row = e / (BN / 4), col = (e - row * (BN / 4)) * 4;
+    const size_t slot = (size_t)BM * BN;
+    const float* ws = p.splitk_ws;
+    f4 sum = *reinterpret_cast<const f4*>(ws + ((size_t)(xcd + 8 * s_a) * 2 + 1) * slot + row * BN + col);
+    for (int s = s_a + 1; s <= s_b; ++s)
+        sum += *reinterpret_cast<const f4*>(ws + ((size_t)(xcd + 8 * s) * 2 + 0) * slot + row * BN + col);
+    const int q = nwg >> 3, r = nwg & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const int n0 = (tile % n_tiles) * BN + col;
+    const int m = (tile / n_tiles) * BM + row;
+    const spaa_tapclass_t cl = p.cls[0];
+    const int M = p.B * p.Hm * p.Wm;
+    size_t o;
+    if (!out_pixel(p, cl, m, M, p.Hm * p.Wm, o)) return;
+    const bool vec = !((p.Cout | p.out_cstride | p.out_coff) & 3) &&
+                     (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
+                     (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
+                     (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
+    float v[4] = {sum.x, sum.y, sum.z, sum.w};
+    store4(p, o, n0, v, vec);
+}
+
+constexpr int STREAMK_MAX_WG = 768;  // workspace contract: 2 * STREAMK_MAX_WG * 128 * 128 floats
+
 template <int NW, int BN, int SH = 32, bool CO = false, int NA = 2>
 int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream, bool persistent = false) {
     constexpr int BM = 32 * NW;
@@ -642,6 +734,10 @@ int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream, bool persistent = fa
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
+    const bool streamk = d.ksplit == -1;
+    if (streamk && (!persistent || CO || d.nclass != 1 || d.nfold > 1 || d.splitk_ws == nullptr ||
+                    (int64_t)m_tiles * ((d.Cout + BN - 1) / BN) > 65535))
+        return hipErrorInvalidValue;
     const int ksplit = d.ksplit > 1 ? d.ksplit : 1;
     if (ksplit > 1 && (d.nclass != 1 || d.splitk_ws == nullptr || d.cls[0].Kpad / BK < 2 * ksplit)) return hipErrorInvalidValue;
     int gx = m_tiles * n_tiles;
@@ -653,10 +749,23 @@ int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream, bool persistent = fa
         int cap = resident / (d.nclass * ksplit);
         if ((d.reserved0 >> 8) > 0) cap = d.reserved0 >> 8;  // tests: force several tiles per workgroup on small layers
         cap = cap < 8 ? 8 : (cap & ~7);
-        if (gx > cap) gx = cap;
+        if (streamk && cap > STREAMK_MAX_WG) cap = STREAMK_MAX_WG;
+        if (streamk) {
+            // every resident workgroup gets a share of the K-steps, however few tiles there are (>= 4 steps each)
+            const int64_t iters = (int64_t)gx * (d.cls[0].Kpad / BK);
+            gx = cap;
+            while (gx > 8 && iters / gx < 4) gx -= 8;
+        } else if (gx > cap) {
+            gx = cap;
+        }
     }
     dim3 grid(gx, d.nclass, ksplit);
     hipLaunchKernelGGL((tapconv_x6d_kernel<NW, BN, SH, CO, NA>), grid, dim3(64 * NW), smem, stream, d, m_tiles, n_tiles);
+    if (streamk) {
+        dim3 rgrid((BM * BN / 4 + 255) / 256, m_tiles * n_tiles, 1);
+        hipLaunchKernelGGL((streamk_reduce_kernel<BM, BN>), rgrid, dim3(256), 0, stream, d, m_tiles, n_tiles, gx,
+                           d.cls[0].Kpad / BK);
+    }
     if (ksplit > 1) {
         const int npad = (d.Cout + 127) & ~127;
         const int64_t nthr = M * ((d.Cout + 3) >> 2);
