@@ -199,8 +199,10 @@ def main():
         for name, key, flops, e0, e1, tile_id, nbytes in convplan.PROFILE:
             ms = e0.elapsed_time(e1)
             # roofline groups = kernel instantiations (as rocprofv3 reports them): split-K launches of a tile belong to it
-            base = convplan.TILE_NAMES.get(tile_id % 100, 'auto')
-            tile = base + (('_streamk' if tile_id // 100 == 9 else f'_splitk{tile_id // 100}') if tile_id >= 100 else '')
+            # (persistent launches 48..54 run the same instantiations as 34, 36, 42, 44, 35, 37, 25)
+            kern = {48: 34, 49: 36, 50: 42, 51: 44, 52: 35, 53: 37, 54: 25}.get(tile_id % 100, tile_id % 100)
+            base = convplan.TILE_NAMES.get(kern, 'auto')
+            tile = convplan.TILE_NAMES.get(tile_id % 100, 'auto') + (('_streamk' if tile_id // 100 == 9 else f'_splitk{tile_id // 100}') if tile_id >= 100 else '')
             a = per_tile.setdefault(base, [0.0, 0.0, 0, 0.0])
             a[0] += flops
             a[1] += ms
