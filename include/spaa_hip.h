@@ -67,7 +67,8 @@ typedef struct {
     const float* gate;    /* indexed like `out`, or NULL */
     int32_t gate_cstride, gate_coff, gate_mode;
     int32_t act;
-    int32_t tile;         /* 0 = auto; 1..28 = explicit kernel / workgroup tile (tuning; see tapconv.hip) */
+    int32_t tile;         /* 0 = auto; 1..54 = explicit kernel / workgroup tile (the dispatcher in tapconv.hip lists them;
+                             spaa_amd/convplan.py: TILE_NAMES; chosen per layer shape by tools/autotune.py) */
     float* aux_out;       /* optional second output (indexed like `out`):
                              act == SPAA_ACT_RELU_CLAMP1: the value BEFORE the clamp;
                              otherwise, with gate2: (gate2 > 0) ? out_value : 0  (a second ReLU-backward gate) */
@@ -75,11 +76,13 @@ typedef struct {
     int32_t gate2_cstride, gate2_coff;
     int32_t tap_range[4]; /* (dy_min, dy_max, dx_min, dx_max) over the taps of all classes: patch-staged kernels */
     float* splitk_ws;     /* split-K workspace, ksplit * B*Hm*Wm * Npad floats (Npad = Cout rounded up to 128), or NULL */
-    int32_t ksplit;       /* -1 (persistent tiles 48..54, one class): stream-K — the K-steps of all tiles are cut into equal
+    int32_t ksplit;       /* 0, 1: off.
+                             > 1 (tiles 25.., one class): K is cut into `ksplit` ranges computed by separate workgroups into
+                             splitk_ws; a second kernel adds them in fixed order and applies the epilogue (layers with few
+                             output pixels and long K, e.g. ResNet layer4: fills the chip).
+                             -1 (persistent tiles 48..54, one class): stream-K — the K-steps of all tiles are cut into equal
                              ranges per workgroup; splitk_ws must hold 2 * 768 * 128 * 128 floats; cut tiles are summed in
-                             segment order by a second kernel.  0, 1: off.  > 1 (tiles 25.., one class): K is cut into `ksplit` ranges computed by separate
-                             workgroups into splitk_ws; a second kernel adds them in fixed order and applies the epilogue
-                             (layers with few output pixels and long K, e.g. ResNet layer4: fills the chip) */
+                             segment order by a second kernel. */
     int32_t nfold;        /* <= 1: off.  4 (tiles 25.., one class, s_out == 2, Cout % 4 == 0): the four output-parity classes of
                              a kernel-2 stride-2 ConvTranspose2d share their single tap, so they are folded into the GEMM N
                              dimension: weight rows [nfold*Cout], row c*Cout + n -> output pixel (2y + c/2, 2x + c%2),
