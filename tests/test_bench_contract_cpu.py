@@ -1,0 +1,55 @@
+"""CPU: the bench line committed under profiles/ (produced by `python bench.py` on the GPU box, tools/collect_profiles.sh)
+carries every field of the measurement contract, and its numbers are mutually consistent."""
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def latest_bench():
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench.json')), key=lambda f: int(f.split('_v')[-1].split('_')[0]))
+    assert files, 'no committed bench line under profiles/'
+    with open(files[-1]) as fh:
+        return json.load(fh), files[-1]
+
+
+def test_bench_line_fields():
+    b, path = latest_bench()
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in b, (k, path)
+    assert b['higher_is_better'] is True and b['scaling'] == 'weak' and b['vs_baseline'] is None
+    assert b['dtype'] == 'f32' and b['data'] == 'synthetic' and 'workload' in b['config'] and 'model' not in b['config']
+    assert abs(b['value'] - b['n_gpus'] * 1e3 / b['ms_per_step']) < 0.02 * b['value']
+    r = b['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 2e-3
+    assert abs(r['achieved'] - r['flop_per_launch'] / (r['avg_launch_us'] * 1e-6) / 1e12) < 0.02 * r['achieved']
+    c = b['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0
+
+
+def test_rocprof_summary_agrees_with_bench_roofline():
+    """The committed rocprofv3 --stats summary of the same command: its average duration of the dominant kernel agrees
+    with the HIP-event average the bench line reports (within 5 %)."""
+    import csv
+    import re
+    b, path = latest_bench()
+    stats = path.replace('_bench.json', '_rocprofv3_kernel_stats.csv')
+    assert os.path.exists(stats), stats
+    kern = b['roofline']['kernel']
+    m = re.match(r'tapconv_(x6d(?:16)?(?:co)?(?:a3)?)_(\d+)x(\d+)', kern)
+    assert m, kern
+    fam, bm, bn = m.groups()
+    want = (f'tapconv_x6d_kernel<{int(bm) // 32}, {bn}, {16 if "16" in fam else 32}, {"true" if "co" in fam else "false"}, '
+            f'{3 if fam.endswith("a3") else 2}>')
+    with open(stats) as fh:
+        rows = [r for r in csv.DictReader(fh) if want in r['Name']]
+    assert len(rows) == 1, (want, len(rows))
+    avg_us = float(rows[0]['AverageNs']) / 1e3
+    assert abs(avg_us - b['roofline']['avg_launch_us']) < 0.05 * avg_us, (avg_us, b['roofline']['avg_launch_us'])
