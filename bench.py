@@ -132,6 +132,12 @@ def main():
     ap.add_argument('--profile-out', default=None, help='write the per-layer tapconv timing table (JSON) here')
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: anything libraries print there (RCCL's start-up banner does) is
+    # sent to stderr instead
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -140,7 +146,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = f'cuda:{local_rank}'
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('SPAA_BENCH_FORCE_DIST'):  # (the switch rehearses the RCCL path with one rank)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
@@ -263,7 +269,8 @@ def main():
             out['cpu_baseline'] = cpu_baseline(sd, csd, setup, scenes)
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + '\n')
+        json_out.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
