@@ -784,3 +784,39 @@ def test_persistent_launch_walks_several_tiles(hip, tile):
     finally:
         cp.FORCE_TILE = 0
         cp.DEBUG_PERSIST_CAP = 0
+
+
+@pytest.mark.parametrize('cam_sz,prj_sz,b,mask', [((96, 160), (96, 160), 3, 'ones'), ((128, 128), (128, 128), 4, 'rect'),
+                                                  ((64, 96), (80, 112), 2, 'ones')])
+def test_first_iteration_other_sizes(hip, cam_sz, prj_sz, b, mask):
+    """The whole loop body at sizes the tune table has never seen (kernels chosen by ConvPlan._default_tile), non-square
+    images, projector size != camera size: the first iteration from identical state against the oracle (<= 1e-4
+    relative L_inf on the updated projector image, BASELINE.json's bar; later iterations are chaotic)."""
+    from spaa_amd.projector_based_attack import AttackState
+    sd = syn.pcnet_state_dict(3, cam_sz=cam_sz, mask=mask)
+    csd = syn.resnet18_state_dict(2, logit_gain=20.0)
+    crop = (cam_sz[0] - 8, cam_sz[0] - 8) if cam_sz[0] <= cam_sz[1] else (cam_sz[1] - 8, cam_sz[1] - 8)
+    insz = (crop[0] - 8, crop[1] - 8)
+    scene = syn.scenes(7, 1, cam_sz)
+    setup = dict(classifier_crop_sz=crop, prj_brightness=0.5, prj_im_sz=prj_sz)
+    targets = [204, 291, 7, 950][:b]
+    pc = make_pcnet(hip, sd, cam_sz)
+    clf = hip['clf'].Classifier('resnet18', DEV, state_dict=csd, input_sz=insz)
+    st = AttackState(pc, clf, targets, scene, 'camdE_caml2', setup, DEV)
+    st.iteration(True, 5, 2, 1, 0.9)
+    x1 = hip['models'].to_nchw(st.x).cpu()
+    tr = []
+    so.spaa(sd, so.OracleClassifier('resnet18', csd, input_sz=insz), targets, True, scene, 5, 'camdE_caml2', setup,
+            iters=1, trace=tr)
+    ref = torch.from_numpy(tr[0]['prj_adv'])
+    assert x1.shape == ref.shape == (b, 3) + tuple(prj_sz)
+    err = rel_inf(x1, ref)
+    # forward of the same iteration: camera image the loop just evaluated (identical input -> rounding-level agreement)
+    y_err = rel_inf(hip['models'].to_nchw(st.eng.a['Y']).cpu(), torch.from_numpy(tr[0]['cam_infer']))
+    out_frac = outlier_fraction(x1 - 0.5, ref - 0.5, 1e-4)
+    print(f'first iteration at cam {cam_sz} prj {prj_sz}: projector image rel Linf {err:.2e} (elements off by > 1e-4: '
+          f'{out_frac:.2e}), camera image rel Linf {y_err:.2e}')
+    assert y_err < 1e-5
+    # the update is a normalised gradient step: <= 1e-4 unless a ReLU gate within rounding of zero falls on the other
+    # side (then the elements in that unit's receptive field differ: sparse, bounded; see DESIGN.md section 4)
+    assert err < 1e-4 or (err < 5e-3 and out_frac < 2e-2)
