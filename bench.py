@@ -7,12 +7,15 @@ Workload = BASELINE.json configs[1]: batch 64 (8 synthetic 256x256 scenes x 8 ta
 stealth loss camdE_caml2, d_thr 5, targeted.  A "step" is one pass of the loop body
 (/root/reference/src/python/projector_based_attack.py:264-328) over the batch, inputs resident in HBM.
 N > 1: every rank attacks its own 64 samples (weak scaling, no data-path collective); the only exchange is the final
-result gather, timed separately (`gather_ms`).  Prints ONE JSON line on rank 0.
+result gather, timed separately (`gather_ms`).  `--gpus N` without a torchrun environment starts the N ranks itself
+(before anything touches the GPU).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import re
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,6 +26,14 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2516.0  # dense bf16 MFMA (16x the fp32 rate; "~2.5 PF dense" in MI355X_MICROARCH.md)
+PEAK_HBM_TBS = 8.0  # HBM3E spec (MI355X_MICROARCH.md; 6.3 TB/s is what a float4 copy achieves)
+
+# algorithmic bytes per scene-iteration at 256x256 (3-channel fp32 images, per-batch constants
+# excluded), scaled by the pixel count for other sizes
+MB_PER_SCENE_256 = {'warp_fwd': 1.57 + 2.36,    # grid_sample (read x, write x_w) + the rough input cat([s, x_w*s]) it also writes
+                    'warp_bwd_gather': 1.57,   # read g, write g_x
+                    'stealth_loss': 2.36,      # read cam_infer, scene; write gradient
+                    'step_and_track': 3.9}     # read g, read/write x, conditional copies of x and cam_infer
 
 
 def build_attack(rank, batch, size, n_scenes, dev, classifier='resnet18'):
@@ -79,7 +90,9 @@ def log(msg):
 
 def cpu_baseline(sd, csd, setup, scenes, budget_b=16, iters=8):
     """Oracle (CPU restatement of the reference composition: per-iteration grid rebuild, two backward passes) timed on
-    the host cores on a bounded sample: `budget_b` samples x `iters` iterations of the same workload."""
+    the host cores on a bounded sample: `budget_b` samples x `iters` iterations of the bench workload, plus the two call
+    shapes of BASELINE.json configs[0] (one scene: untargeted B=1 for 50 iterations; targeted K=10, 5 of its 50
+    iterations)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import spaa_oracle as so
     from spaa_amd import synthetic as syn
@@ -92,20 +105,33 @@ def cpu_baseline(sd, csd, setup, scenes, budget_b=16, iters=8):
     so.spaa(sd, clf, tg, True, scenes[:1], 5, 'camdE_caml2', setup, iters=iters, per_batch_grid=True)
     dt = time.time() - t0
     scene_it_s = budget_b * iters / dt
+    # configs[0]: the reference's own CPU-runnable case (projector_based_attack.py:107 and :120)
+    t0 = time.time()
+    so.spaa(sd, clf, [1], False, scenes[:1], 5, 'camdE_caml2', setup, iters=50, per_batch_grid=True)
+    dt1 = time.time() - t0
+    t0 = time.time()
+    so.spaa(sd, clf, syn.IMAGENET10_TARGETS, True, scenes[:1], 5, 'camdE_caml2', setup, iters=5, per_batch_grid=True)
+    dt10 = time.time() - t0
     return {'value': scene_it_s / 64.0, 'unit': 'attack-iterations/s (batch-64 equivalent)', 'cores': cores,
             'kind': 'port', 'scene_iterations_per_s': scene_it_s,
             'sample': f'{budget_b} samples x {iters} iterations of the same 256x256 ResNet-18 workload on the host '
-                      f'CPU ({dt:.1f} s), scaled by 1/64 to a batch-64 iteration'}
+                      f'CPU ({dt:.1f} s), scaled by 1/64 to a batch-64 iteration',
+            'configs0': {'untargeted_B1_50it': {'seconds': round(dt1, 2), 'iterations_per_s': round(50 / dt1, 3)},
+                         'targeted_K10': {'seconds': round(dt10, 2), 'iterations_timed': 5,
+                                          'iterations_per_s': round(5 / dt10, 3),
+                                          'note': '5 of the 50 iterations timed (every iteration costs the same)'}}}
 
 
 def pmc_traffic(tile):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py), or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
-    if not os.path.exists(path):
-        return None
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
+    path = next((os.path.join(prof, f) for f in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+                 if os.path.exists(os.path.join(prof, f))), None)
+    if path is None:
+        return None, None
     m = re.match(r'(x6d(?:16)?(?:co)?(?:a3)?|x6v\d|x6)_(\d+)x(\d+)(?:g(\d))?', tile)
     if not m:
-        return None
+        return None, None
     fam, bm, bn, g = m.groups()
     if fam.startswith('x6d'):  # tapconv_x6d_kernel<waves, BN, MFMA shape, coalesced epilogue, pixel stages>
         want = (f'tapconv_x6d_kernel<{int(bm) // 32}, {bn}, {16 if "16" in fam else 32}, '
@@ -115,8 +141,147 @@ def pmc_traffic(tile):
     with open(path) as fh:
         for k, e in json.load(fh)['kernels'].items():
             if k.startswith(want):
-                return round(e['hbm_bytes_per_launch'])
-    return None
+                return round(e['hbm_bytes_per_launch']), os.path.relpath(path, ROOT)
+    return None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# multi-rank glue (launcher, timed region, result gather): independent of the GPU so that tests/ can rehearse it on gloo
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as CHILD processes (torch.distributed.run) and
+    return its exit code.  Called before this process has made any GPU call; nothing is exec'd."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr',
+           '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + list(argv)
+    log('launching: ' + ' '.join(cmd))
+    return subprocess.call(cmd)
+
+
+def timed_steps(step, steps, warmup, dist, sync):
+    """W untimed steps, then exactly K steps bracketed by barrier + device sync on both sides; seconds of THIS rank."""
+    for _ in range(warmup):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    return time.perf_counter() - t0
+
+
+def reduce_times(dt, dist, world, dev):
+    """(max over ranks, per-rank list) of the timed region."""
+    if dist is None:
+        return dt, [dt]
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    every = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(every, t)
+    per_rank = [float(e.item()) for e in every]
+    return max(per_rank), per_rank
+
+
+def gather_final(cam, prj, dist, world, sync):
+    """The path's only exchange: every rank's (cam_infer_best, prj_adv_best).  Receive buffers are allocated BEFORE the
+    timed gather."""
+    if dist is None:
+        return None, (cam, prj)
+    outs = [torch.empty_like(prj) for _ in range(world)]
+    outs2 = [torch.empty_like(cam) for _ in range(world)]
+    sync()
+    dist.barrier()
+    g0 = time.perf_counter()
+    dist.all_gather(outs, prj)
+    dist.all_gather(outs2, cam)
+    sync()
+    return (time.perf_counter() - g0) * 1e3, (torch.cat(outs2), torch.cat(outs))
+
+
+def rehearse_glue(args, world, rank, json_out):
+    """CPU rehearsal of the N-rank glue (launcher -> rendezvous -> barrier-bracketed timed region -> MAX over ranks ->
+    preallocated result gather -> one line on rank 0) on gloo with a stand-in step.  NOT a measurement: `value` is null."""
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(free_port()))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    state = torch.zeros(4, 3, 8, 8)
+
+    def step():
+        state.add_(1.0)
+
+    dt = timed_steps(step, args.steps, args.warmup, dist, lambda: None)
+    dt_max, per_rank = reduce_times(dt, dist, world, 'cpu')
+    gather_ms, (cam_all, prj_all) = gather_final(state + rank, state * 2 + rank, dist, world, lambda: None)
+    ok = (cam_all.shape[0] == 4 * world and
+          all(float(cam_all[4 * r, 0, 0, 0]) == args.steps + args.warmup + r for r in range(world)))
+    if rank == 0:
+        json_out.write(json.dumps({'metric': 'attack-iterations/sec (PCNet+classifier fwd/bwd), 256x256 batch=64',
+                                   'value': None, 'rehearsal': 'multi-rank glue only (gloo, stand-in step): not a measurement',
+                                   'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                                   'per_rank_ms_per_step': [round(t / args.steps * 1e3, 4) for t in per_rank],
+                                   'ms_per_step': round(dt_max / args.steps * 1e3, 4), 'gather_ms': round(gather_ms, 3),
+                                   'gather_ok': bool(ok)}) + '\n')
+        json_out.flush()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def instrumented_pass(st, hp, args, n_prof=3):
+    """Per-kernel event timing (HIP events on the launch stream): every tapconv launch, then every other entry point."""
+    from spaa_amd import convplan, _lib
+    convplan.PROFILE = []
+    for _ in range(n_prof):
+        st.iteration(**hp)
+    torch.cuda.synchronize()
+    conv_events = convplan.PROFILE
+    convplan.PROFILE = None
+    per_tile, per_layer = {}, {}
+    t_roof_x6 = t_roof_f32 = 0.0
+    for name, key, flops, e0, e1, tile_id, nbytes in conv_events:
+        ms = e0.elapsed_time(e1)
+        # roofline groups = kernel instantiations (as rocprofv3 reports them): split-K launches of a tile belong to it
+        # (persistent launches 48..54 run the same instantiations as 34, 36, 42, 44, 35, 37, 25)
+        kern = {48: 34, 49: 36, 50: 42, 51: 44, 52: 35, 53: 37, 54: 25}.get(tile_id % 100, tile_id % 100)
+        base = convplan.TILE_NAMES.get(kern, 'auto')
+        tile = convplan.TILE_NAMES.get(tile_id % 100, 'auto') + (('_streamk' if tile_id // 100 == 9 else f'_splitk{tile_id // 100}') if tile_id >= 100 else '')
+        a = per_tile.setdefault(base, [0.0, 0.0, 0, 0.0])
+        a[0] += flops
+        a[1] += ms
+        a[2] += 1
+        a[3] += nbytes
+        b = per_layer.setdefault(name, [0.0, 0.0, 0, tile, 0.0])
+        b[0] += flops
+        b[1] += ms
+        b[2] += 1
+        b[4] += nbytes
+        t_hbm = nbytes / (PEAK_HBM_TBS * 1e12)
+        t_roof_x6 += max(t_hbm, flops / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12)) / n_prof
+        t_roof_f32 += max(t_hbm, flops / (PEAK_F32_MFMA_TFLOPS * 1e12)) / n_prof
+    # second pass: the non-convolution entry points
+    _lib.PROFILE = []
+    for _ in range(n_prof):
+        st.iteration(**hp)
+    torch.cuda.synchronize()
+    other = {}
+    for name, e0, e1 in _lib.PROFILE:
+        if name == 'spaa_tapconv_f32':
+            continue
+        o = other.setdefault(name, [0.0, 0])
+        o[0] += e0.elapsed_time(e1)
+        o[1] += 1
+    _lib.PROFILE = None
+    return per_tile, per_layer, other, t_roof_x6, t_roof_f32
 
 
 def main():
@@ -130,7 +295,20 @@ def main():
                     help='BASELINE.json configs[1] is resnet18 (the bench line); the others are extra data points')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-out', default=None, help='write the per-layer tapconv timing table (JSON) here')
+    ap.add_argument('--rehearse-glue', action='store_true',
+                    help='CPU/gloo rehearsal of the multi-rank glue with a stand-in step (tests/); not a measurement')
     args = ap.parse_args()
+
+    world_env = os.environ.get('WORLD_SIZE')
+    if args.gpus > 1 and world_env is None:
+        # not under torchrun: start the ranks ourselves, as children, BEFORE any GPU call in this process
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(world_env or '1')
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU '
+                         f'(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)')
 
     # stdout carries exactly ONE line, the JSON result: anything libraries print there (RCCL's start-up banner does) is
     # sent to stderr instead
@@ -138,9 +316,9 @@ def main():
     json_out = os.fdopen(os.dup(1), 'w')
     os.dup2(2, 1)
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.rehearse_glue:
+        return rehearse_glue(args, world, rank, json_out)
+
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: spaa_amd has no CPU fallback')
     torch.cuda.set_device(local_rank)
@@ -149,76 +327,28 @@ def main():
     if world > 1 or os.environ.get('SPAA_BENCH_FORCE_DIST'):  # (the switch rehearses the RCCL path with one rank)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(free_port()))
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
 
     log('building attack state')
     st, sd, csd, setup, scenes, targets = build_attack(rank, args.batch, args.size, 8, dev, args.classifier)
     torch.cuda.synchronize()
-    log('warmup')
     hp = dict(targeted=True, d_thr=5, adv_lr=2, col_lr=1, p_thresh=0.9)
-
-    for _ in range(args.warmup):
-        st.iteration(**hp)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    log('timed region')
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st.iteration(**hp)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    log(f'{args.steps} steps in {dt:.3f}s')
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    log('warmup + timed region')
+    dt_local = timed_steps(lambda: st.iteration(**hp), args.steps, args.warmup, dist, torch.cuda.synchronize)
+    log(f'{args.steps} steps in {dt_local:.3f}s')
+    dt, per_rank = reduce_times(dt_local, dist, world, dev)
 
     # final result gather (the path's only exchange, once per attack): prj_adv_best + cam_infer_best of every rank
-    gather_ms = None
     cam, prj = st.results()
-    if dist is not None:
-        torch.cuda.synchronize()
-        dist.barrier()
-        g0 = time.perf_counter()
-        outs = [torch.empty_like(prj) for _ in range(world)]
-        outs2 = [torch.empty_like(cam) for _ in range(world)]
-        dist.all_gather(outs, prj)
-        dist.all_gather(outs2, cam)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
+    gather_ms, _ = gather_final(cam, prj, dist, world, torch.cuda.synchronize)
 
-    # instrumented pass: HIP events around every tapconv launch (same stream) -> per-kernel roofline
+    # instrumented passes: HIP events around every launch (same stream) -> per-kernel rooflines
     from spaa_amd import convplan
     roof, table = None, {}
     if rank == 0:
-        convplan.PROFILE = []
         n_prof = 3
-        for _ in range(n_prof):
-            st.iteration(**hp)
-        torch.cuda.synchronize()
-        per_tile, per_layer = {}, {}
-        for name, key, flops, e0, e1, tile_id, nbytes in convplan.PROFILE:
-            ms = e0.elapsed_time(e1)
-            # roofline groups = kernel instantiations (as rocprofv3 reports them): split-K launches of a tile belong to it
-            # (persistent launches 48..54 run the same instantiations as 34, 36, 42, 44, 35, 37, 25)
-            kern = {48: 34, 49: 36, 50: 42, 51: 44, 52: 35, 53: 37, 54: 25}.get(tile_id % 100, tile_id % 100)
-            base = convplan.TILE_NAMES.get(kern, 'auto')
-            tile = convplan.TILE_NAMES.get(tile_id % 100, 'auto') + (('_streamk' if tile_id // 100 == 9 else f'_splitk{tile_id // 100}') if tile_id >= 100 else '')
-            a = per_tile.setdefault(base, [0.0, 0.0, 0, 0.0])
-            a[0] += flops
-            a[1] += ms
-            a[2] += 1
-            a[3] += nbytes
-            b = per_layer.setdefault(name, [0.0, 0.0, 0, tile])
-            b[0] += flops
-            b[1] += ms
-            b[2] += 1
-        convplan.PROFILE = None
+        per_tile, per_layer, other, t_roof_x6, t_roof_f32 = instrumented_pass(st, hp, args, n_prof)
         tot_ms = sum(v[1] for v in per_tile.values())
         dom = max(per_tile, key=lambda k: per_tile[k][1])
         f, ms, n, nb = per_tile[dom]
@@ -229,25 +359,50 @@ def main():
             peak, kname = PEAK_BF16_MFMA_TFLOPS / 6.0, f'tapconv_{dom} (bf16x6-split MFMA implicit-GEMM, fp32-exact operands)'
         else:
             peak, kname = PEAK_F32_MFMA_TFLOPS, f'tapconv_kernel<{dom}> (fp32 MFMA implicit-GEMM conv/deconv/dgrad)'
+        traffic, traffic_src = pmc_traffic(dom)
+        # HBM-bound kernel groups named by north_star (grid_sample, dE2000 loss, PGD step): algorithmic bytes of SURVEY 8(d)
+        scale = args.batch * (args.size * args.size) / 65536.0 * 1e6
+        groups = {}
+        for gname, entry in (('warp_fwd', 'spaa_warp_fwd'), ('warp_bwd_gather', 'spaa_warp_bwd_gather'),
+                             ('stealth_loss', 'spaa_stealth_loss_fwd_bwd'), ('step_and_track', 'spaa_step_and_track')):
+            if entry in other:
+                us = other[entry][0] * 1e3 / other[entry][1]
+                gb = MB_PER_SCENE_256[gname] * scale
+                groups[gname] = {'bound': 'hbm', 'achieved': round(gb / (us * 1e-6) / 1e9, 1), 'peak': PEAK_HBM_TBS * 1e3,
+                                 'unit': 'GB/s', 'frac': round(gb / (us * 1e-6) / 1e12 / PEAK_HBM_TBS, 4),
+                                 'avg_launch_us': round(us, 2), 'algorithmic_bytes_per_launch': round(gb)}
+        other_ms = sum(v[0] for v in other.values()) / n_prof
+        other_roof = sum(MB_PER_SCENE_256[g] for g in MB_PER_SCENE_256) * scale / (PEAK_HBM_TBS * 1e12) * 1e3
+        ms_step = dt / args.steps * 1e3
         roof = {'kernel': kname, 'bound': 'mfma',
                 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                'frac': round(ach / peak, 4), 'traffic': pmc_traffic(dom), 'traffic_unit': 'bytes/launch',
-                'traffic_source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate '
-                                  'passes over this same command; bench.py cannot collect PMC itself)',
+                'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_unit': 'bytes/launch',
+                'traffic_source': f'{traffic_src} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes over this '
+                                  'same command; bench.py cannot collect PMC itself)',
                 'algorithmic_bytes_per_launch': round(nb / n),
                 'peak_note': 'algorithmic fp32 FLOP/s; dense bf16 MFMA peak 2516 TF / 6 partial products for the x6 kernels, '
                              '157.3 TF for the fp32-MFMA kernels',
                 'avg_launch_us': round(ms * 1e3 / n, 2), 'launches_per_step': n // n_prof,
                 'flop_per_launch': f / n, 'share_of_conv_time': round(ms / tot_ms, 3),
                 'all_tapconv_tflops': round(sum(v[0] for v in per_tile.values()) / (tot_ms * 1e-3) / 1e12, 2),
-                'conv_ms_per_step': round(tot_ms / n_prof, 3)}
+                'conv_ms_per_step': round(tot_ms / n_prof, 3),
+                'other_kernels_ms_per_step': round(other_ms, 3),
+                'groups': groups,
+                'step': {'T_roof_ms': round(t_roof_x6 * 1e3 + other_roof, 3),
+                         'T_roof_ms_f32_mfma_peak': round(t_roof_f32 * 1e3 + other_roof, 3),
+                         'ms_per_step': round(ms_step, 3),
+                         'frac': round((t_roof_x6 * 1e3 + other_roof) / ms_step, 4),
+                         'note': 'T_roof = sum over launches of max(algorithmic bytes / 8 TB/s, FLOP / peak) (SURVEY 8d); '
+                                 'conv peak 419.3 TF (bf16x6) resp. 157.3 TF (fp32 MFMA)'}}
         table = {k: {'tile': v[3], 'gflop_per_launch': v[0] / v[2] / 1e9, 'us_per_launch': v[1] * 1e3 / v[2],
-                     'tflops': v[0] / (v[1] * 1e-3) / 1e12} for k, v in per_layer.items()}
+                     'tflops': v[0] / (v[1] * 1e-3) / 1e12, 'algorithmic_tb_s': v[4] / (v[1] * 1e-3) / 1e12}
+                 for k, v in per_layer.items()}
         if args.profile_out:
             with open(args.profile_out, 'w') as fh:
                 json.dump({'per_tile': {k: {'flop': v[0], 'ms': v[1], 'launches': v[2], 'algorithmic_bytes': v[3]}
                                         for k, v in per_tile.items()},
-                           'per_layer': table}, fh, indent=1)
+                           'per_layer': table,
+                           'other_entry_points_us': {k: v[0] * 1e3 / v[1] for k, v in other.items()}}, fh, indent=1)
 
     if rank == 0:
         value = world * args.steps / dt
@@ -260,6 +415,7 @@ def main():
                                    f'{args.size}x{args.size}, {args.classifier}, camdE_caml2, per GPU',
                        'global_batch': args.batch * world, 'parallelism': f'dp{world} (independent shards)'},
             'scene_iterations_per_s': round(value * args.batch, 1),
+            'per_rank_ms_per_step': [round(t / args.steps * 1e3, 3) for t in per_rank],
             'roofline': roof,
         }
         if gather_ms is not None:

@@ -135,6 +135,12 @@ int spaa_warp_bwd_gather(const float* g_xw, const float* g_xs, const float* x, c
 int spaa_rgb2lab(const float* rgb, float* lab, int npix, spaa_stream_t stream);
 /* per-pixel CIEDE2000 map (ciede2000_diff :109-180) of two Lab images -> de [npix] */
 int spaa_ciede2000(const float* lab1, const float* lab2, float* de, int npix, spaa_stream_t stream);
+/* autograd of the two functions above (the reference differentiates them with torch.autograd — the `_diff` in
+ * their names): g_rgb = J_lab(rgb)^T g_lab;  g_lab1 = g_de * d dE/d lab1, g_lab2 = g_de * d dE/d lab2 (either may
+ * be NULL).  All images [npix][4]. */
+int spaa_rgb2lab_bwd(const float* rgb, const float* g_lab, float* g_rgb, int npix, spaa_stream_t stream);
+int spaa_ciede2000_bwd(const float* lab1, const float* lab2, const float* g_de, float* g_lab1, float* g_lab2, int npix,
+                       spaa_stream_t stream);
 /* Fused camera-side stealth loss + gradient (one launch replaces ~600 ATen ops):
  *   caml2_px = ||scene - y||_2 over rgb ; camdE_px = dE00(lab(y), scene_lab)
  *   g_y      = gscale * (caml2_w * d caml2_px/dy + camdE_w * d camdE_px/dy)      gscale = 1/(B*H*W)

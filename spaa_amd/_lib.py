@@ -57,6 +57,8 @@ _SIGNATURES = {
     'spaa_warp_bwd_gather': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'spaa_rgb2lab': [_p, _p, _i, _p],
     'spaa_ciede2000': [_p, _p, _p, _i, _p],
+    'spaa_rgb2lab_bwd': [_p, _p, _p, _i, _p],
+    'spaa_ciede2000_bwd': [_p, _p, _p, _p, _p, _i, _p],
     'spaa_stealth_loss_fwd_bwd': [_p, _p, _p, _f, _f, _f, _p, _p, _p, _i, _i, _p],
     'spaa_img_dists': [_p, _p, _p, _i, _p],
     'spaa_ssim': [_p, _p, _p, _p, _i, _i, _i, _p],
@@ -114,22 +116,53 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _same_device(t):
+    """Kernels are launched on torch's CURRENT device and stream with raw pointers: a tensor that lives on another GPU
+    would be a wild pointer there (a GPU memory fault, not an exception), so it is refused here.  The Python entry
+    points (`spaa`, `PCNet.forward`, `Classifier.classify`, ...) switch to their tensors' device with `on_device`."""
+    if t.is_cuda and t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f'tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: wrap the '
+                           'call in `with torch.cuda.device(tensor.device)` (spaa_amd launches on the current device)')
+
+
+def on_device(dev):
+    """Context manager: make `dev` (a cuda torch.device / tensor device) the current device for the launches inside."""
+    dev = torch.device(dev)
+    if dev.type != 'cuda':
+        raise RuntimeError(f'spaa_amd runs on the GPU only (no CPU fallback); got device={dev}')
+    return torch.cuda.device(dev)
+
+
 def ptr(t):
     if t is None:
         return None
+    _same_device(t)
     return C.c_void_p(t.data_ptr())
 
 
 def check_dev(*tensors):
     for t in tensors:
-        if t is not None and (not t.is_cuda or not t.is_contiguous() or t.dtype != torch.float32):
+        if t is None:
+            continue
+        if not t.is_cuda or not t.is_contiguous() or t.dtype != torch.float32:
             raise ValueError('spaa_amd kernels need contiguous float32 tensors on the GPU '
                              f'(got device={t.device}, dtype={t.dtype}, contiguous={t.is_contiguous()})')
+        _same_device(t)
+
+
+PROFILE = None  # bench.py's instrumented pass: a list that receives (entry point, start event, end event) per launch
 
 
 def call(name, *args):
-    """Invoke an entry point on torch's current stream; non-zero return -> RuntimeError."""
+    """Invoke an entry point on torch's current device and stream; non-zero return -> RuntimeError."""
     lib = load()
-    rc = getattr(lib, name)(*args, _stream())
+    if PROFILE is None:
+        rc = getattr(lib, name)(*args, _stream())
+    else:  # HIP events on the launch stream around this one entry point
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args, _stream())
+        e1.record()
+        PROFILE.append((name, e0, e1))
     if rc != 0:
         raise RuntimeError(f'{name} failed with HIP error {rc}')

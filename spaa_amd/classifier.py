@@ -10,6 +10,8 @@ them by URL, classifier.py:24-36): pass `state_dict=` (torchvision key names) or
 `ClassifierEngine` is what the fused attack loop drives: forward = crop + area-resize + normalise -> net -> logits;
 backward = input gradient only (all parameters frozen, classifier.py:41-44).
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -289,10 +291,13 @@ class ClassifierEngine:
         self._mean = (C.c_float * 3)(*IMAGENET_MEAN)
         self._std = (C.c_float * 3)(*IMAGENET_STD)
         self.ncls = self.body.ncls
+        self.owner = None   # weakref to the attack state this engine is leased to (Classifier.engine)
+        self.version = 0    # bumped whenever the activation workspaces are overwritten
 
     def forward(self, y4):
         _lib.check_dev(y4)
         assert y4.shape == (self.B, self.H, self.W, 4)
+        self.version += 1
         _lib.call('spaa_preproc_fwd', _lib.ptr(y4), _lib.ptr(self.pre), self.B, self.H, self.W, self.cy0, self.cx0,
                   self.ch, self.cw, self.oh, self.ow, self._mean, self._std)
         return self.body.forward(self.pre)
@@ -308,15 +313,22 @@ class _ClassifyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, im, clf, crop_sz):
         b, _, h, w = im.shape
-        eng = clf.engine(b, (h, w), crop_sz)
-        logits = eng.forward(to_nhwc4(im))
-        ctx.eng = eng
-        return logits.clone()
+        with _lib.on_device(im.device):
+            eng = clf.engine(b, (h, w), crop_sz)
+            im4 = to_nhwc4(im)
+            logits = eng.forward(im4)
+            ctx.eng, ctx.version, ctx.im4 = eng, eng.version, im4
+            return logits.clone()
 
     @staticmethod
     def backward(ctx, g):
-        gy4 = ctx.eng.backward(g.detach().float().contiguous())
-        return to_nchw(gy4), None, None
+        eng = ctx.eng
+        with _lib.on_device(g.device):
+            if eng.version != ctx.version:  # workspaces reused by a later forward: recompute this call's activations
+                eng.forward(ctx.im4)
+                ctx.version = eng.version
+            gy4 = eng.backward(g.detach().float().contiguous())
+            return to_nchw(gy4), None, None
 
 
 class Classifier(object):
@@ -342,18 +354,28 @@ class Classifier(object):
         self.state_dict = {k: v.detach().float().cpu() for k, v in _strip(state_dict).items()}
         self._engines = {}
 
-    def engine(self, batch, im_hw, crop_sz):
+    def engine(self, batch, im_hw, crop_sz, owner=None):
+        """Cached engine for a batch size / geometry; an engine leased to an `owner` (attack state) is not handed to
+        anyone else while the owner lives (see PCNet.engine)."""
         key = (batch, tuple(im_hw), tuple(crop_sz))
-        if key not in self._engines:
-            self._engines[key] = ClassifierEngine(self.name, self.state_dict, batch, im_hw, crop_sz, self.input_sz,
-                                                  self.device)
-        return self._engines[key]
+        pool = self._engines.setdefault(key, [])
+        for e in pool:
+            if e.owner is None or e.owner() is None:
+                break
+        else:
+            with _lib.on_device(self.device):
+                e = ClassifierEngine(self.name, self.state_dict, batch, im_hw, crop_sz, self.input_sz, self.device)
+            pool.append(e)
+        e.owner = weakref.ref(owner) if owner is not None else None
+        return e
 
     def classify(self, im, crop_sz=(240, 240)):
         if im.dtype == torch.uint8:
             im = im.type(torch.float32) / 255
         while im.ndim < 4:
             im = im[None]
+        if self.device.type != 'cuda':
+            raise RuntimeError('spaa_amd.Classifier runs on the GPU only (no CPU fallback); got device=%s' % self.device)
         raw_score = _ClassifyFn.apply(im.to(self.device), self, tuple(crop_sz))
         # Compatibility outputs (classifier.py:64-72).  The fused attack loop does NOT use these: it takes top-1 and
         # its probability on device (spaa_decide); the full 1000-way sort is only done for API parity here.

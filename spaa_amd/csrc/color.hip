@@ -236,6 +236,50 @@ __global__ void ciede2000_kernel(const float4* __restrict__ lab1, const float4* 
     de[idx] = ciede2000<false>(a.x, a.y, a.z, b.x, b.y, b.z).de;
 }
 
+// autograd of rgb2lab_diff (:39-64): g_rgb = J^T g_lab, per pixel
+__global__ void rgb2lab_bwd_kernel(const float4* __restrict__ rgb, const float4* __restrict__ g_lab,
+                                   float4* __restrict__ g_rgb, int npix) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix) return;
+    const float4 v = rgb[idx], gl = g_lab[idx];
+    float dr, dg, db;
+    const float lr = srgb_lin(v.x, dr), lg = srgb_lin(v.y, dg), lb = srgb_lin(v.z, db);
+    const float X = 0.4124f * lr + 0.3576f * lg + 0.1805f * lb;
+    const float Y = 0.2126f * lr + 0.7152f * lg + 0.0722f * lb;
+    const float Z = 0.0193f * lr + 0.1192f * lg + 0.9504f * lb;
+    float dfx, dfy, dfz;
+    lab_f(X / kXn, dfx);
+    lab_f(Y / kYn, dfy);
+    lab_f(Z / kZn, dfz);
+    const float fy_b = 116.f * gl.x - 500.f * gl.y + 200.f * gl.z;
+    const float fx_b = 500.f * gl.y;
+    const float fz_b = -200.f * gl.z;
+    const float X_b = fx_b * dfx / kXn, Y_b = fy_b * dfy / kYn, Z_b = fz_b * dfz / kZn;
+    g_rgb[idx] = make_float4((0.4124f * X_b + 0.2126f * Y_b + 0.0193f * Z_b) * dr,
+                             (0.3576f * X_b + 0.7152f * Y_b + 0.1192f * Z_b) * dg,
+                             (0.1805f * X_b + 0.0722f * Y_b + 0.9504f * Z_b) * db, 0.f);
+}
+
+// autograd of ciede2000_diff (:109-180): g_lab1 = g_de * d dE/d lab1 and (optionally) g_lab2 = g_de * d dE/d lab2.
+// The map is symmetric in its two colours (dLP, dCP, dHP change sign together; aL, aCP, aHP, T, rT do not change), so
+// the second gradient is the first-colour adjoint of the swapped pair.
+__global__ void ciede2000_bwd_kernel(const float4* __restrict__ lab1, const float4* __restrict__ lab2,
+                                     const float* __restrict__ g_de, float4* __restrict__ g_lab1,
+                                     float4* __restrict__ g_lab2, int npix) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix) return;
+    const float4 a = lab1[idx], b = lab2[idx];
+    const float g = g_de[idx];
+    if (g_lab1 != nullptr) {
+        const DE d = ciede2000<true>(a.x, a.y, a.z, b.x, b.y, b.z);
+        g_lab1[idx] = make_float4(g * d.gL, g * d.gA, g * d.gB, 0.f);
+    }
+    if (g_lab2 != nullptr) {
+        const DE d = ciede2000<true>(b.x, b.y, b.z, a.x, a.y, a.z);
+        g_lab2[idx] = make_float4(g * d.gL, g * d.gA, g * d.gB, 0.f);
+    }
+}
+
 // d dE(lab(rgb), lab2) / d rgb, and dE
 __device__ __forceinline__ float de_rgb_grad(float r, float g, float b, float L2, float A2, float B2, float& gr,
                                              float& gg, float& gb) {
@@ -438,6 +482,21 @@ int spaa_ciede2000(const float* lab1, const float* lab2, float* de, int npix, sp
     if (!lab1 || !lab2 || !de || npix < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ciede2000_kernel, dim3((npix + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)lab1, (const float4*)lab2, de, npix);
+    return (int)hipGetLastError();
+}
+
+int spaa_rgb2lab_bwd(const float* rgb, const float* g_lab, float* g_rgb, int npix, spaa_stream_t stream) {
+    if (!rgb || !g_lab || !g_rgb || npix < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rgb2lab_bwd_kernel, dim3((npix + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)rgb, (const float4*)g_lab, (float4*)g_rgb, npix);
+    return (int)hipGetLastError();
+}
+
+int spaa_ciede2000_bwd(const float* lab1, const float* lab2, const float* g_de, float* g_lab1, float* g_lab2, int npix,
+                       spaa_stream_t stream) {
+    if (!lab1 || !lab2 || !g_de || (!g_lab1 && !g_lab2) || npix < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ciede2000_bwd_kernel, dim3((npix + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)lab1, (const float4*)lab2, g_de, (float4*)g_lab1, (float4*)g_lab2, npix);
     return (int)hipGetLastError();
 }
 

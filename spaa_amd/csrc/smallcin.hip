@@ -15,6 +15,7 @@
 //     writes 8 pixels' complete 128-byte channel rows (and the gate / residual loads read complete rows) instead of
 //     sixteen-byte pieces of 32 different rows.
 #include <hip/hip_runtime.h>
+#include "launch_util.hpp"
 #include <stdint.h>
 #include "../../include/spaa_hip.h"
 #include "epilogue.hpp"
@@ -176,12 +177,10 @@ int launch_sc(const spaa_tapconv_t& d, int dymin, int dxmin, int PH, int PW, hip
     const int tiles_x = (d.Wm + TW - 1) / TW, tiles_y = (d.Hm + TH - 1) / TH;
     const size_t smem = ((size_t)PH * PW * (16 * CG) + 1023) / 1024 * 1024 + (SLAB ? 4 * 32 * 36 * sizeof(float) : 0);
     if (smem > 64 * 1024) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&smallcin_kernel<CG, SLAB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    static bool attr_set[SPAA_MAX_DEVICES] = {};
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&smallcin_kernel<CG, SLAB>), 64 * 1024, attr_set);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
     }
     dim3 grid((unsigned)(tiles_x * tiles_y * d.B), 1, 1);
     hipLaunchKernelGGL((smallcin_kernel<CG, SLAB>), grid, dim3(256), smem, stream, d, tiles_x, tiles_y, dymin, dxmin, PH, PW);

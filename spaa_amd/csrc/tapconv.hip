@@ -14,6 +14,7 @@
 // models.py:284-301 and their autograd (projector_based_attack.py:302,310), and torchvision's convs
 // (classifier.py:60).
 #include <hip/hip_runtime.h>
+#include "launch_util.hpp"
 #include <stdint.h>
 #include "../../include/spaa_hip.h"
 
@@ -509,12 +510,10 @@ int launch(const spaa_tapconv_t& d, hipStream_t stream) {
     const int m_tiles = (int)((M + BM - 1) / BM);
     const int n_tiles = (d.Cout + BN - 1) / BN;
     const size_t smem = (size_t)(TAP_SMEM_FLOATS + 2 * (BM + BN) * LDK) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<BM, BN, WM, WN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static bool attr_set[SPAA_MAX_DEVICES] = {};
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&tapconv_kernel<BM, BN, WM, WN>), (int)smem, attr_set);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
     }
     dim3 grid(m_tiles * n_tiles, d.nclass, 1);
     hipLaunchKernelGGL((tapconv_kernel<BM, BN, WM, WN>), grid, dim3(256), smem, stream, d, m_tiles, n_tiles);

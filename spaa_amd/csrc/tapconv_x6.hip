@@ -16,6 +16,7 @@
 // output channel) is contiguous there, so waves load B fragments straight from L2 into registers (no LDS), one K-step
 // ahead.  LDS holds only the gathered operand: 2 x 3 x BM x 80 B = 30 KB at BM = 64 -> 4-5 workgroups per CU.
 #include <hip/hip_runtime.h>
+#include "launch_util.hpp"
 #include <stdint.h>
 #include "../../include/spaa_hip.h"
 
@@ -588,12 +589,10 @@ int launch_x6v2(const spaa_tapconv_t& d, hipStream_t stream) {
     const int m_tiles = (int)((M + BM - 1) / BM);
     const int n_tiles = (d.Cout + BN - 1) / BN;
     const size_t smem = (size_t)TAP_BYTES + 3 * (BM + BN) * ROWB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_x6v2_kernel<BM, BN, NG>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static bool attr_set[SPAA_MAX_DEVICES] = {};
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&tapconv_x6v2_kernel<BM, BN, NG>), (int)smem, attr_set);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
     }
     dim3 grid(m_tiles * n_tiles, d.nclass, 1);
     hipLaunchKernelGGL((tapconv_x6v2_kernel<BM, BN, NG>), grid, dim3(256), smem, stream, d, m_tiles, n_tiles);
@@ -917,12 +916,10 @@ int launch_x6v3(const spaa_tapconv_t& d, hipStream_t stream) {
     const int m_tiles = (int)((M + BM - 1) / BM);
     const int n_tiles = (d.Cout + BN - 1) / BN;
     const size_t smem = (size_t)TAP_BYTES + 2 * 3 * (BM + BN) * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_x6v3_kernel<BM, BN, NG>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static bool attr_set[SPAA_MAX_DEVICES] = {};
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&tapconv_x6v3_kernel<BM, BN, NG>), (int)smem, attr_set);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
     }
     dim3 grid(m_tiles * n_tiles, d.nclass, 1);
     hipLaunchKernelGGL((tapconv_x6v3_kernel<BM, BN, NG>), grid, dim3(256), smem, stream, d, m_tiles, n_tiles);

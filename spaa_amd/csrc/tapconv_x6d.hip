@@ -13,6 +13,7 @@
 // Two LDS stages; one __syncthreads() per 32-deep K-step; the DMA of step t+1 is issued right after the barrier of
 // step t and lands during its MFMAs.  Needs Cin % 32 == 0 (a K-step lies inside one tap: the tap is wave-uniform).
 #include <hip/hip_runtime.h>
+#include "launch_util.hpp"
 #include <stdint.h>
 #include "../../include/spaa_hip.h"
 #include "epilogue.hpp"
@@ -727,12 +728,10 @@ int launch_x6d(const spaa_tapconv_t& d, hipStream_t stream, bool persistent = fa
     if (nfold > 1 && (nfold != 4 || d.nclass != 1 || d.s_out != 2 || (d.Cout & 3) || d.ksplit > 1)) return hipErrorInvalidValue;
     const int n_tiles = (d.Cout * nfold + BN - 1) / BN;
     const size_t smem = (size_t)NA * (BM * 128) + 2 * (size_t)(3 * BN * 64);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_x6d_kernel<NW, BN, SH, CO, NA>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static bool attr_set[SPAA_MAX_DEVICES] = {};
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&tapconv_x6d_kernel<NW, BN, SH, CO, NA>), (int)smem, attr_set);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
     }
     const bool streamk = d.ksplit == -1;
     if (streamk && (!persistent || CO || d.nclass != 1 || d.nfold > 1 || d.splitk_ws == nullptr ||

@@ -14,6 +14,7 @@
 // neighbouring pixels reading the same channel quad hit 16 different bank groups; the DMA writes lane-linear, so the
 // swizzle is applied on the source side (which chunk a lane fetches).
 #include <hip/hip_runtime.h>
+#include "launch_util.hpp"
 #include <stdint.h>
 #include "../../include/spaa_hip.h"
 
@@ -234,12 +235,10 @@ int launch_tp(const spaa_tapconv_t& d, int dymin, int dxmin, int PH, int PW, hip
     const int tiles_x = (d.Wm + TW - 1) / TW, tiles_y = (d.Hm + TH - 1) / TH;
     const size_t smem = ((size_t)PH * PW * (16 * L) + 1023) / 1024 * 1024;
     if (smem > 64 * 1024) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thinpatch_kernel<L, NOUT, P>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    static bool attr_set[SPAA_MAX_DEVICES] = {};
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&thinpatch_kernel<L, NOUT, P>), 64 * 1024, attr_set);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
     }
     dim3 grid((unsigned)(tiles_x * tiles_y * d.B), 1, 1);
     hipLaunchKernelGGL((thinpatch_kernel<L, NOUT, P>), grid, dim3(256), smem, stream, d, tiles_x, tiles_y, dymin, dxmin, PH, PW);

@@ -10,6 +10,7 @@ passes).  Parameters are treated as frozen, as the attack does (projector_based_
 gradients are produced.
 """
 import copy
+import weakref
 
 import torch
 import torch.nn as nn
@@ -203,11 +204,22 @@ class PCNet(nn.Module):
         self._engines = {}
         return r
 
-    def engine(self, batch, prj_size):
-        key = (batch, tuple(prj_size), self.mask.device if self.use_mask else None)
-        if key not in self._engines:
-            self._engines[key] = PCNetEngine(self, batch, prj_size)
-        return self._engines[key]
+    def engine(self, batch, prj_size, owner=None):
+        """Engine (packed weights + workspaces) for a batch size / projector size.  Engines are cached, but an engine
+        handed to an `owner` (an AttackState) is that owner's alone for as long as the owner lives: two attacks built
+        from one PCNet never share activation workspaces.  Without an owner (the autograd path) any free engine is
+        returned; `_PCNetFn.backward` detects a workspace that has been reused since its forward and recomputes it."""
+        key = (batch, tuple(prj_size), self.shading_net.conv1.weight.device)
+        pool = self._engines.setdefault(key, [])
+        for e in pool:
+            if e.owner is None or e.owner() is None:
+                break
+        else:
+            with _lib.on_device(key[2]):
+                e = PCNetEngine(self, batch, prj_size)
+            pool.append(e)
+        e.owner = weakref.ref(owner) if owner is not None else None
+        return e
 
     def invalidate(self):
         """Call after changing parameters in place (packed weights are cached)."""
@@ -237,6 +249,23 @@ def to_nchw(x4, clamp01=False):
     return out
 
 
+def transposed_taps(grid, prj_size, cam_size, mask=None):
+    """Transposed sampling structure for the deterministic backward of grid_sample (index plumbing, once per grid):
+    the 4 bilinear taps of every camera pixel (spaa_warp_taps), sorted by the projector pixel they read (CSR).
+    Returns (tap_off [Hp*Wp+1], tap_order [4*Hc*Wc], tap_weight x mask [4*Hc*Wc]) for spaa_warp_bwd_gather."""
+    dev = grid.device
+    (hp, wp), (hc, wc) = prj_size, cam_size
+    hwc, hwp = hc * wc, hp * wp
+    tap_src = torch.zeros(hwc * 4, dtype=torch.int32, device=dev)
+    tap_w = torch.zeros(hwc * 4, device=dev)
+    _lib.call('spaa_warp_taps', _lib.ptr(grid), hp, wp, hc, wc, C_ptr(tap_src), _lib.ptr(tap_w))
+    order = torch.argsort(tap_src, stable=True)
+    bounds = torch.searchsorted(tap_src[order].to(torch.int64), torch.arange(hwp + 1, dtype=torch.int64, device=dev))
+    # bilinear weight x mask of the camera pixel the tap belongs to (entry 4*campix + tap)
+    tap_wm = (tap_w.view(hwc, 4) * mask.view(hwc, 1)).reshape(-1).contiguous() if mask is not None else tap_w
+    return bounds.to(torch.int32).contiguous(), order.to(torch.int32).contiguous(), tap_wm
+
+
 class PCNetEngine:
     """Packed weights, sampling grid and workspaces of one PCNet for a fixed batch size; HIP forward and
     input-gradient passes over NHWC4 tensors."""
@@ -260,20 +289,7 @@ class PCNetEngine:
         self.mask = pcnet.mask.detach().float().contiguous().view(-1).to(dev) if pcnet.use_mask else None
         if self.mask is not None:
             assert self.mask.numel() == self.Hc * self.Wc
-        # transposed sampling structure for the deterministic backward of grid_sample (index plumbing, once per model)
-        hwc, hwp = self.Hc * self.Wc, self.Hp * self.Wp
-        tap_src = torch.zeros(hwc * 4, dtype=torch.int32, device=dev)
-        self.tap_w = torch.zeros(hwc * 4, device=dev)
-        _lib.call('spaa_warp_taps', _lib.ptr(self.grid), self.Hp, self.Wp, self.Hc, self.Wc,
-                  C_ptr(tap_src), _lib.ptr(self.tap_w))
-        order = torch.argsort(tap_src, stable=True)
-        bounds = torch.searchsorted(tap_src[order].to(torch.int64),
-                                    torch.arange(hwp + 1, dtype=torch.int64, device=dev))
-        self.tap_order = order.to(torch.int32).contiguous()
-        # bilinear weight x mask of the camera pixel the tap belongs to (entry 4*campix + tap)
-        self.tap_wm = (self.tap_w.view(hwc, 4) * self.mask.view(hwc, 1)).reshape(-1).contiguous() \
-            if self.mask is not None else self.tap_w
-        self.tap_off = bounds.to(torch.int32).contiguous()
+        self.tap_off, self.tap_order, self.tap_wm = transposed_taps(self.grid, prj_size, (self.Hc, self.Wc), self.mask)
         f, d = {}, {}
         for nm, st in (('conv1', 2), ('conv2', 2), ('conv3', 1), ('conv4', 1), ('conv5', 1), ('conv1_s', 2),
                        ('conv2_s', 2), ('conv3_s', 1), ('conv4_s', 1), ('conv6', 1), ('skipConv3', 1)):
@@ -315,11 +331,14 @@ class PCNetEngine:
         self.scene = None
         self._x = None
         self._clamp = 1
+        self.owner = None    # weakref to the AttackState this engine is leased to (PCNet.engine)
+        self.version = 0     # bumped whenever the activation workspaces are overwritten (set_scene / forward)
 
     # ------------------------------------------------------------------------------------------------------
     def set_scene(self, scene4):
         """scene4: [B,Hc,Wc,4] camera-captured scene(s); precomputes the loop-invariant skipConv1(s) (models.py:291)."""
         assert scene4.shape == (self.B, self.Hc, self.Wc, 4)
+        self.version += 1
         self.scene = scene4
         t0, t1 = torch.zeros_like(scene4), torch.zeros_like(scene4)
         self.f['skip1a'].run(scene4, t0, act=_lib.ACT_RELU)
@@ -342,6 +361,7 @@ class PCNetEngine:
             raise RuntimeError('call set_scene() first')
         a, f = self.a, self.f
         R, N = _lib.ACT_RELU, _lib.ACT_NONE
+        self.version += 1
         self.warp(x4, clamp01)
         f['conv1_s'].run(a['cat8'], a['S1'], act=R)
         f['conv2_s'].run(a['S1'], a['S2'], act=R)
@@ -405,53 +425,66 @@ class _PCNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, s, pcnet):
         b = x.shape[0]
-        eng = pcnet.engine(b, x.shape[-2:])
-        s4 = to_nhwc4(s.expand(b, -1, -1, -1) if s.shape[0] != b else s)
-        eng.set_scene(s4)
-        x4 = to_nhwc4(x)
-        y4 = eng.forward(x4, clamp01=False)
-        ctx.eng = eng
-        return to_nchw(y4)
+        with _lib.on_device(x.device):
+            eng = pcnet.engine(b, x.shape[-2:])
+            s4 = to_nhwc4(s.expand(b, -1, -1, -1) if s.shape[0] != b else s)
+            eng.set_scene(s4)
+            x4 = to_nhwc4(x)
+            y4 = eng.forward(x4, clamp01=False)
+            ctx.eng, ctx.version, ctx.x4, ctx.s4 = eng, eng.version, x4, s4
+            return to_nchw(y4)
 
     @staticmethod
     def backward(ctx, gy):
         eng = ctx.eng
-        g4 = to_nhwc4(gy)
-        gP = torch.zeros_like(g4)
-        state = torch.ones(eng.B, 4, dtype=torch.int32, device=g4.device)  # best_adv=1 -> take the 2nd argument
-        _lib.call('spaa_select_grad', _lib.ptr(g4), _lib.ptr(g4), _lib.ptr(state), _lib.ptr(eng.a['Ypre']),
-                  _lib.ptr(gP), eng.B, eng.Hc * eng.Wc)
-        gx4 = eng.backward(gP)
-        return to_nchw(gx4), None, None
+        with _lib.on_device(gy.device):
+            if eng.version != ctx.version:
+                # the engine's workspaces were overwritten by a later forward (y1 = pcnet(x1, s); y2 = pcnet(x2, s);
+                # (l1 + l2).backward()): recompute this call's activations from its own saved inputs
+                eng.set_scene(ctx.s4)
+                eng.forward(ctx.x4, clamp01=False)
+                ctx.version = eng.version
+            g4 = to_nhwc4(gy)
+            gP = torch.zeros_like(g4)
+            state = torch.ones(eng.B, 4, dtype=torch.int32, device=g4.device)  # best_adv=1 -> take the 2nd argument
+            _lib.call('spaa_select_grad', _lib.ptr(g4), _lib.ptr(g4), _lib.ptr(state), _lib.ptr(eng.a['Ypre']),
+                      _lib.ptr(gP), eng.B, eng.Hc * eng.Wc)
+            gx4 = eng.backward(gP)
+            return to_nchw(gx4), None, None
 
 
 class _WarpFn(torch.autograd.Function):
+    """WarpingNet.forward (models.py:163-185) as a differentiable op; the backward is the same deterministic gather over
+    transposed tap lists that the attack loop uses (no float atomics)."""
+
     @staticmethod
     def forward(ctx, x, wn):
         b = x.shape[0]
-        holder = type('H', (), {})()
-        x4 = to_nhwc4(x)
-        grid = wn.build_fine_grid(x.shape[-2:]) if wn.fine_grid is None else None
-        if grid is None:
-            grid = torch.zeros(*wn.out_size, 4, device=x.device)
-            grid[..., :2] = wn.fine_grid[0]
-        hc, wc = wn.out_size
-        xw = torch.zeros(b, hc, wc, 4, device=x.device)
-        _lib.call('spaa_warp_fwd', _lib.ptr(x4), _lib.ptr(grid), None, None, _lib.ptr(xw), None, b, x.shape[-2],
-                  x.shape[-1], hc, wc, 0)
-        holder.x4, holder.grid = x4, grid
-        ctx.h = holder
-        return to_nchw(xw)
+        with _lib.on_device(x.device):
+            x4 = to_nhwc4(x)
+            if wn.fine_grid is None:
+                grid = wn.build_fine_grid(x.shape[-2:])
+            else:
+                grid = torch.zeros(*wn.out_size, 4, device=x.device)
+                grid[..., :2] = wn.fine_grid[0]
+            hc, wc = wn.out_size
+            xw = torch.zeros(b, hc, wc, 4, device=x.device)
+            _lib.call('spaa_warp_fwd', _lib.ptr(x4), _lib.ptr(grid), None, None, _lib.ptr(xw), None, b, x.shape[-2],
+                      x.shape[-1], hc, wc, 0)
+            ctx.x4, ctx.grid, ctx.cam = x4, grid, (hc, wc)
+            return to_nchw(xw)
 
     @staticmethod
     def backward(ctx, gy):
-        h = ctx.h
-        g4 = to_nhwc4(gy)
-        b, hp, wp, _ = h.x4.shape
-        gx = torch.zeros_like(h.x4)
-        _lib.call('spaa_warp_bwd', _lib.ptr(g4), None, _lib.ptr(h.x4), _lib.ptr(h.grid), None, None, _lib.ptr(gx), b,
-                  hp, wp, g4.shape[1], g4.shape[2], 0)
-        return to_nchw(gx), None
+        with _lib.on_device(gy.device):
+            g4 = to_nhwc4(gy)
+            b, hp, wp, _ = ctx.x4.shape
+            hc, wc = ctx.cam
+            off, order, wgt = transposed_taps(ctx.grid, (hp, wp), (hc, wc))
+            gx = torch.zeros_like(ctx.x4)
+            _lib.call('spaa_warp_bwd_gather', _lib.ptr(g4), None, _lib.ptr(ctx.x4), None, None, C_ptr(off), C_ptr(order),
+                      _lib.ptr(wgt), _lib.ptr(gx), b, hp, wp, hc, wc, 0)
+            return to_nchw(gx), None
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -47,6 +47,11 @@ class PerC_AL:
         dev = self.device
         if dev.type != 'cuda':
             raise RuntimeError('spaa_amd.PerC_AL runs on the GPU only (no CPU fallback)')
+        with _lib.on_device(dev):
+            return self._adversary_projector(classifier, inputs, labels, d_thr, targeted, cp_sz, trace)
+
+    def _adversary_projector(self, classifier, inputs, labels, d_thr, targeted, cp_sz, trace):
+        dev = self.device
         p = _lib.ptr
         B, _, H, W = inputs.shape
         HW = H * W

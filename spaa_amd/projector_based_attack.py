@@ -30,7 +30,15 @@ class AttackState:
         dev = torch.device(device)
         if dev.type != 'cuda':
             raise RuntimeError('spaa_amd.spaa runs on the GPU only (no CPU fallback); got device=%s' % device)
+        if dev.index is None:
+            dev = torch.device('cuda', torch.cuda.current_device())
+        with _lib.on_device(dev):  # kernels launch on the current device: make it the one the state lives on
+            self._build(pcnet, classifier, target_idx, cam_scene, stealth_loss, setup_info, dev)
+
+    def _build(self, pcnet, classifier, target_idx, cam_scene, stealth_loss, setup_info, dev):
         B = len(target_idx)
+        if B < 1:
+            raise ValueError('target_idx is empty: nothing to attack')
         self.B, self.dev = B, dev
         prj_sz = tuple(setup_info['prj_im_sz'])
         self.cp_sz = tuple(setup_info['classifier_crop_sz'])
@@ -42,11 +50,11 @@ class AttackState:
             cam_scene = cam_scene.expand(B, -1, -1, -1)
         if cam_scene.shape[0] != B:
             raise ValueError('cam_scene must hold 1 or len(target_idx) scenes')
-        self.eng = pcnet.engine(B, prj_sz)
+        self.eng = pcnet.engine(B, prj_sz, owner=self)
         Hc, Wc = self.eng.Hc, self.eng.Wc
         if tuple(cam_scene.shape[-2:]) != (Hc, Wc):
             raise ValueError(f'cam_scene is {tuple(cam_scene.shape[-2:])} but PCNet outputs {(Hc, Wc)}')
-        self.clf = classifier.engine(B, (Hc, Wc), self.cp_sz)
+        self.clf = classifier.engine(B, (Hc, Wc), self.cp_sz, owner=self)
         self.scene4 = to_nhwc4(cam_scene.contiguous().to(dev))
         self.eng.set_scene(self.scene4)
         self.scene_lab = torch.zeros_like(self.scene4)
@@ -75,6 +83,10 @@ class AttackState:
 
     def iteration(self, targeted, d_thr, adv_lr, col_lr, p_thresh, adv_w=1.0):
         """One pass of the loop body (projector_based_attack.py:264-328), ~90 kernel launches, no host sync."""
+        with torch.cuda.device(self.dev):
+            self._iteration(targeted, d_thr, adv_lr, col_lr, p_thresh, adv_w)
+
+    def _iteration(self, targeted, d_thr, adv_lr, col_lr, p_thresh, adv_w):
         B, p = self.B, _lib.ptr
         y = self.eng.forward(self.x, clamp01=True)                                   # :265
         logits = self.clf.forward(y)                                                 # :266
@@ -96,7 +108,8 @@ class AttackState:
                   float(col_lr), p(self.x_best), p(y), p(self.cam_best), B, self.HWp, self.HWc)   # :307,315,323-328
 
     def results(self):
-        return to_nchw(self.cam_best), to_nchw(self.x_best, clamp01=True)            # :337
+        with torch.cuda.device(self.dev):
+            return to_nchw(self.cam_best), to_nchw(self.x_best, clamp01=True)        # :337
 
 
 def spaa(pcnet, classifier, imagenet_labels, target_idx, targeted, cam_scene, d_thr, stealth_loss, device, setup_info,
@@ -116,9 +129,13 @@ def spaa(pcnet, classifier, imagenet_labels, target_idx, targeted, cam_scene, d_
     :return: (cam_infer_best [B,3,Hc,Wc], prj_adv_best [B,3,Hp,Wp] in [0,1])
     """
     pcnet, classifier = _unwrap(pcnet), _unwrap(classifier)
-    if not isinstance(pcnet, PCNet) or not isinstance(classifier, Classifier):
-        raise TypeError('spaa_amd.spaa needs spaa_amd.PCNet and spaa_amd.Classifier (the fused HIP path has no '
-                        'generic fallback)')
+    if not isinstance(pcnet, PCNet):
+        raise TypeError('spaa_amd.spaa needs a spaa_amd.PCNet (the HIP path has no generic PCNet fallback)')
+    if not isinstance(classifier, Classifier):
+        if not callable(classifier):
+            raise TypeError('classifier must be a spaa_amd.Classifier or a callable (im, crop_sz) -> (raw_score, p, idx)')
+        return _spaa_foreign_classifier(pcnet, classifier, imagenet_labels, target_idx, targeted, cam_scene, d_thr,
+                                        stealth_loss, device, setup_info, iters, adv_lr, col_lr, p_thresh, trace)
     st = AttackState(pcnet, classifier, target_idx, cam_scene, stealth_loss, setup_info, device)
     for i in range(iters):
         st.iteration(targeted, d_thr, adv_lr, col_lr, p_thresh)
@@ -132,6 +149,92 @@ def spaa(pcnet, classifier, imagenet_labels, target_idx, targeted, cam_scene, d_
                   f'{f[:, 1].mean() * 255:<9.4f} | camdE = {f[:, 2].mean():<9.4f} | p = {f[v, 0]:.4f} | y = '
                   f'{int(s[v, 3]):3d} ({name})')
     return st.results()
+
+
+class _StealthFn(torch.autograd.Function):
+    """Per-sample camera-side stealth loss caml2_w * caml2 + camdE_w * camdE (projector_based_attack.py:279-284) through
+    the fused HIP kernel; the kernel's analytic gradient is kept for backward."""
+
+    @staticmethod
+    def forward(ctx, cam_infer, scene4, scene_lab, caml2_w, camdE_w):
+        from .models import to_nhwc4 as _to4
+        y4 = _to4(cam_infer)
+        b, h, w, _ = y4.shape
+        nblk = (h * w + 255) // 256
+        part = torch.zeros(b, nblk, 3, device=y4.device)
+        g = torch.zeros_like(y4)
+        _lib.call('spaa_stealth_loss_fwd_bwd', _lib.ptr(y4), _lib.ptr(scene4), _lib.ptr(scene_lab), float(caml2_w),
+                  float(camdE_w), 1.0 / (h * w), _lib.ptr(g), None, _lib.ptr(part), b, h * w)
+        sums = part.sum(dim=1) / (h * w)
+        ctx.g = to_nchw(g)
+        ctx.mark_non_differentiable(sums)
+        return caml2_w * sums[:, 0] + camdE_w * sums[:, 1], sums
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_sums):
+        return ctx.g * g_loss.view(-1, 1, 1, 1), None, None, None, None
+
+
+def _spaa_foreign_classifier(pcnet, classifier, imagenet_labels, target_idx, targeted, cam_scene, d_thr, stealth_loss,
+                             device, setup_info, iters, adv_lr, col_lr, p_thresh, trace):
+    """The reference accepts ANY callable `classifier(im, crop_sz) -> (raw_score, p_sorted, idx)`
+    (projector_based_attack.py:266).  For a classifier that is not a spaa_amd.Classifier the fused loop cannot run its
+    body, so this route keeps PCNet (forward + input gradient) and the stealth loss on the HIP kernels, lets torch.autograd
+    carry the gradient through the foreign classifier, and follows the reference's loop :264-328 step by step — with one
+    backward pass of the per-sample-selected loss instead of two (samples are independent, see AttackState)."""
+    from .models import to_nhwc4 as _to4
+    dev = torch.device(device)
+    if dev.type != 'cuda':
+        raise RuntimeError('spaa_amd.spaa runs on the GPU only (no CPU fallback); got device=%s' % device)
+    B = len(target_idx)
+    with _lib.on_device(dev):
+        cp_sz = tuple(setup_info['classifier_crop_sz'])
+        gray = float(setup_info['prj_brightness'])
+        scene = cam_scene.detach().float().to(dev)
+        while scene.ndim < 4:
+            scene = scene[None]
+        scene = (scene.expand(B, -1, -1, -1) if scene.shape[0] == 1 else scene).contiguous()
+        scene4 = _to4(scene)
+        scene_lab = torch.zeros_like(scene4)
+        _lib.call('spaa_rgb2lab', _lib.ptr(scene4), _lib.ptr(scene_lab), scene4.numel() // 4)
+        im_gray = torch.full((B, 3) + tuple(setup_info['prj_im_sz']), gray, device=dev)
+        prj_adv = im_gray.clone().requires_grad_(True)
+        prjl2_w = 0.1 if 'prjl2' in stealth_loss else 0.0
+        caml2_w = 1.0 if 'caml2' in stealth_loss else 0.0
+        camdE_w = 1.0 if 'camdE' in stealth_loss else 0.0
+        tgt = torch.as_tensor([int(t) for t in target_idx], device=dev)
+        ar = torch.arange(B, device=dev)
+        prj_best, cam_best = prj_adv.detach().clone(), scene.clone()
+        col_best = torch.full((B,), 1e6, device=dev)
+        for _ in range(iters):
+            cam_infer = pcnet(torch.clamp(prj_adv, 0, 1), scene)                                   # :265
+            raw_score, p, idx = classifier(cam_infer, cp_sz)                                       # :266
+            sel = raw_score[ar, tgt.to(raw_score.device)].to(dev)
+            adv_b = (-sel if targeted else sel) / B                                                # :269-272 (per sample)
+            col_b, sums = _StealthFn.apply(cam_infer, scene4, scene_lab, caml2_w, camdE_w)         # :279-284
+            if prjl2_w:
+                col_b = col_b + prjl2_w * torch.norm(im_gray - prj_adv, dim=1).mean(1).mean(1)     # :275-276
+            top1 = torch.as_tensor(idx[:, 0]).to(dev)
+            p1 = torch.as_tensor(p[:, 0]).to(dev)
+            high_pert = sums[:, 0] * 255 > d_thr                                                   # :291
+            succ = (top1 == tgt) if targeted else (top1 != tgt)                                    # :294,298
+            best_adv = succ & high_pert & ((p1 > p_thresh) if targeted else torch.ones_like(succ))  # :295,299
+            loss = torch.where(best_adv, col_b / B, adv_b).sum()
+            g, = torch.autograd.grad(loss, prj_adv)                                                # :302 / :310
+            norm = g.flatten(1).norm(dim=1).view(-1, 1, 1, 1)
+            lr = torch.where(best_adv, float(col_lr), float(adv_lr)).view(-1, 1, 1, 1)
+            with torch.no_grad():
+                prj_adv -= lr * g / norm                                                           # :307, :315
+                col = col_b.detach()
+                best = (col < col_best) & best_adv                                                 # :318-320
+                col_best = torch.where(best, col, col_best)
+                upd = (succ | best).view(-1, 1, 1, 1)
+                prj_best = torch.where(upd, prj_adv.detach(), prj_best)                            # :323-328 (post-step, Q4)
+                cam_best = torch.where(upd, cam_infer.detach(), cam_best)
+            if trace is not None:
+                trace.append(dict(succ=succ.clone(), best_adv=best_adv.clone(), best=best.clone(), top1=top1.clone(),
+                                  caml2=sums[:, 0].clone(), camdE=sums[:, 1].clone(), prj_adv=prj_adv.detach().clone()))
+        return cam_best, torch.clamp(prj_best, 0, 1)                                               # :337
 
 
 spaa_attack = spaa  # name used by BASELINE.json's north_star

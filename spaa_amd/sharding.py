@@ -39,16 +39,26 @@ def gather_results(local_tensors, n_total, dist=None):
 
 
 def spaa_sharded(pcnet, classifier, imagenet_labels, target_idx, targeted, cam_scene, d_thr, stealth_loss, device,
-                 setup_info, dist=None, **kw):
-    """`spaa()` over this rank's block of the batch, then one gather. `cam_scene`: [1|B,3,H,W]."""
-    from .projector_based_attack import spaa
+                 setup_info, dist=None, attack=None, **kw):
+    """`spaa()` over this rank's block of the batch, then one gather. `cam_scene`: [1|B,3,H,W].
+    A rank whose block is empty (fewer samples than ranks) runs no attack and contributes zero-length blocks, so every
+    rank still enters the collective.  `attack` replaces `spaa` (the CPU tests pass a stand-in)."""
+    if attack is None:
+        from .projector_based_attack import spaa as attack
     n = len(target_idx)
     world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
     rank = dist.get_rank() if world > 1 else 0
     lo, hi = shard_range(n, rank, world)
     while cam_scene.ndim < 4:
         cam_scene = cam_scene[None]
+    if cam_scene.shape[0] not in (1, n):
+        raise ValueError('cam_scene must hold 1 or len(target_idx) scenes')   # (raised on every rank, before the gather)
     scene = cam_scene if cam_scene.shape[0] == 1 else cam_scene[lo:hi]
-    cam, prj = spaa(pcnet, classifier, imagenet_labels, list(target_idx[lo:hi]), targeted, scene, d_thr, stealth_loss,
-                    device, setup_info, **kw)
+    if hi > lo:
+        cam, prj = attack(pcnet, classifier, imagenet_labels, list(target_idx[lo:hi]), targeted, scene, d_thr,
+                          stealth_loss, device, setup_info, **kw)
+    else:
+        dev = torch.device(device)
+        cam = torch.zeros((0, 3) + tuple(cam_scene.shape[-2:]), device=dev)
+        prj = torch.zeros((0, 3) + tuple(setup_info['prj_im_sz']), device=dev)
     return gather_results((cam, prj), n, dist)

@@ -53,3 +53,25 @@ def test_rocprof_summary_agrees_with_bench_roofline():
     assert len(rows) == 1, (want, len(rows))
     avg_us = float(rows[0]['AverageNs']) / 1e3
     assert abs(avg_us - b['roofline']['avg_launch_us']) < 0.05 * avg_us, (avg_us, b['roofline']['avg_launch_us'])
+
+
+def test_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` (no torchrun environment) must start 2 ranks itself and print ONE line with n_gpus 2:
+    rehearsed here on gloo with a stand-in step (`--rehearse-glue`: launcher, rendezvous, barrier-bracketed timed region,
+    MAX over ranks, preallocated result gather)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--rehearse-glue'], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith('{')]
+    assert len(lines) == 1, r.stdout
+    b = json.loads(lines[0])
+    assert b['n_gpus'] == 2 and len(b['per_rank_ms_per_step']) == 2 and b['gather_ok'] is True and b['value'] is None
+    assert b['steps'] == 3 and b['warmup'] == 1 and b['gather_ms'] >= 0
+    # a rank count that contradicts the environment is an error, not a silent 1-rank run
+    env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rehearse-glue'],
+                        capture_output=True, text=True, timeout=120, env=env2)
+    assert r2.returncode != 0 and 'WORLD_SIZE=1' in r2.stderr

@@ -60,8 +60,12 @@ def test_no_cpu_fallback():
     setup = dict(classifier_crop_sz=(60, 60), prj_brightness=0.5, prj_im_sz=(64, 64))
     with pytest.raises(RuntimeError):
         spaa(pc, clf, None, [1], True, syn.scenes(1, 1, (64, 64)), 5, 'caml2', 'cpu', setup)
-    with pytest.raises(TypeError):
-        spaa(pc, lambda im, cp: None, None, [1], True, syn.scenes(1, 1, (64, 64)), 5, 'caml2', 'cuda', setup)
+    with pytest.raises(TypeError):   # neither a spaa_amd.Classifier nor a callable
+        spaa(pc, object(), None, [1], True, syn.scenes(1, 1, (64, 64)), 5, 'caml2', 'cuda', setup)
+    with pytest.raises(RuntimeError):  # a foreign callable takes the autograd route, which is GPU-only as well
+        spaa(pc, lambda im, cp: None, None, [1], True, syn.scenes(1, 1, (64, 64)), 5, 'caml2', 'cpu', setup)
+    with pytest.raises(TypeError):   # PCNet must be ours
+        spaa(torch.nn.Identity(), clf, None, [1], True, syn.scenes(1, 1, (64, 64)), 5, 'caml2', 'cuda', setup)
 
 
 def test_shard_range_partitions():

@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from spaa_amd.sharding import shard_range, gather_results
+from spaa_amd.sharding import shard_range, gather_results, spaa_sharded
 
 
 def _free_port():
@@ -38,3 +38,43 @@ def test_two_rank_gather_uneven_and_even():
             ret = m.dict()
             mp.spawn(_worker, args=(2, port, n_total, ret), nprocs=2, join=True)
             assert dict(ret) == {0: True, 1: True}
+
+
+def _stub_attack(pcnet, classifier, labels, target_idx, targeted, cam_scene, d_thr, stealth_loss, device, setup_info):
+    """Stand-in for spaa(): encodes which (target, scene) pair every sample saw, so the test can check the slicing."""
+    assert len(target_idx) >= 1, 'an empty shard must not reach the attack'
+    b = len(target_idx)
+    scene = cam_scene.expand(b, -1, -1, -1) if cam_scene.shape[0] == 1 else cam_scene
+    assert scene.shape[0] == b
+    cam = scene + torch.tensor(target_idx, dtype=torch.float32).view(-1, 1, 1, 1)
+    prj = torch.tensor(target_idx, dtype=torch.float32).view(-1, 1, 1, 1).expand(-1, 3, *setup_info['prj_im_sz']).contiguous()
+    return cam.contiguous(), prj
+
+
+def _sharded_worker(rank, world, port, n_total, per_sample_scene, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    targets = [100 + i for i in range(n_total)]
+    scenes = torch.arange(n_total if per_sample_scene else 1, dtype=torch.float32).view(-1, 1, 1, 1).expand(-1, 3, 4, 6) * 1e-3
+    setup = dict(prj_im_sz=(2, 3))
+    cam, prj = spaa_sharded(None, None, None, targets, True, scenes.contiguous(), 5, 'caml2', 'cpu', setup, dist=dist,
+                            attack=_stub_attack)
+    want_scene = scenes if per_sample_scene else scenes.expand(n_total, -1, -1, -1)
+    want_cam = want_scene + torch.tensor(targets, dtype=torch.float32).view(-1, 1, 1, 1)
+    ok = (cam.shape == (n_total, 3, 4, 6) and prj.shape == (n_total, 3, 2, 3) and torch.equal(cam, want_cam)
+          and torch.equal(prj[:, 0, 0, 0], torch.tensor(targets, dtype=torch.float32)))
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_spaa_sharded_slices_targets_and_scenes():
+    """spaa_sharded's own slicing (targets, per-sample scenes or one shared scene) with a stand-in attack: uneven split,
+    even split, and FEWER samples than ranks (the empty rank contributes a zero-length block instead of hanging)."""
+    for n_total, per_sample in ((5, True), (4, False), (1, True), (1, False)):
+        port = _free_port()
+        with mp.Manager() as m:
+            ret = m.dict()
+            mp.spawn(_sharded_worker, args=(2, port, n_total, per_sample, ret), nprocs=2, join=True)
+            assert dict(ret) == {0: True, 1: True}, (n_total, per_sample, dict(ret))
