@@ -138,10 +138,11 @@ def shading_net(sd, x, s_list, return_all=False):
     x5 = F.relu(conv('conv5', x4) + res3)
     x6 = F.relu(F.conv_transpose2d(x5, p['transConv1.weight'], p['transConv1.bias'], 2, 1, 1) + res2)
     x7 = F.relu(F.conv_transpose2d(x6, p['transConv2.weight'], p['transConv2.bias'], 2, 0))
-    y = torch.clamp(F.relu(conv('conv6', x7) + res1), max=1)
+    ypre = F.relu(conv('conv6', x7) + res1)
+    y = torch.clamp(ypre, max=1)
     if return_all:
         return y, dict(res1_s=res1_s, res2_s=res2_s, res3_s=res3_s, res4_s=res4_s, res1=res1, x1=x1, res2=res2,
-                       x2=x2, res3=res3, x3=x3, x4=x4, x5=x5, x6=x6, x7=x7)
+                       x2=x2, res3=res3, x3=x3, x4=x4, x5=x5, x6=x6, x7=x7, ypre=ypre)
     return y
 
 
@@ -319,38 +320,51 @@ def _bn(sd, p, x, eps=1e-5):
                         False, 0.0, eps)
 
 
-def resnet18_forward(sd, x):
-    """torchvision.models.resnet18 (eval mode), v0.15.1 architecture."""
+def resnet18_forward(sd, x, return_all=False):
+    """torchvision.models.resnet18 (eval mode), v0.15.1 architecture.  `return_all`: also every post-ReLU activation
+    and the max-pool arg-max (flat input index), for the gate comparisons of tests/test_gpu_parity.py."""
+    acts = {}
     x = F.relu(_bn(sd, 'bn1', F.conv2d(x, sd['conv1.weight'], None, 2, 3)))
-    x = F.max_pool2d(x, 3, 2, 1)
+    acts['c1'] = x
+    x, acts['mp_idx'] = F.max_pool2d(x, 3, 2, 1, return_indices=True)
     for li in range(1, 5):
         for bi in range(2):
             p = f'layer{li}.{bi}'
             stride = 2 if (li > 1 and bi == 0) else 1
             idt = x
             o = F.relu(_bn(sd, p + '.bn1', F.conv2d(x, sd[p + '.conv1.weight'], None, stride, 1)))
+            acts[p + '.o1'] = o
             o = _bn(sd, p + '.bn2', F.conv2d(o, sd[p + '.conv2.weight'], None, 1, 1))
             if p + '.downsample.0.weight' in sd:
                 idt = _bn(sd, p + '.downsample.1', F.conv2d(x, sd[p + '.downsample.0.weight'], None, stride, 0))
             x = F.relu(o + idt)
+            acts[p + '.out'] = x
     x = F.adaptive_avg_pool2d(x, 1).flatten(1)
-    return F.linear(x, sd['fc.weight'], sd['fc.bias'])
+    logits = F.linear(x, sd['fc.weight'], sd['fc.bias'])
+    return (logits, acts) if return_all else logits
 
 
-def vgg16_forward(sd, x):
-    """torchvision.models.vgg16 (eval), v0.15.1 architecture (configuration 'D', no batch norm)."""
-    idx = 0
+def vgg16_forward(sd, x, return_all=False):
+    """torchvision.models.vgg16 (eval), v0.15.1 architecture (configuration 'D', no batch norm).  `return_all`: also the
+    post-ReLU activations ('conv<i>', 'fc1', 'fc2') and max-pool arg-maxes ('pool<i>', flat input index) in layer order."""
+    idx, acts, nc, npool = 0, {}, 0, 0
     for v in [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']:
         if v == 'M':
-            x = F.max_pool2d(x, 2, 2)
+            x, acts[f'pool{npool}'] = F.max_pool2d(x, 2, 2, return_indices=True)
+            npool += 1
             idx += 1
         else:
             x = F.relu(F.conv2d(x, sd[f'features.{idx}.weight'], sd[f'features.{idx}.bias'], 1, 1))
+            acts[f'conv{nc}'] = x
+            nc += 1
             idx += 2
     x = F.adaptive_avg_pool2d(x, (7, 7)).flatten(1)
     x = F.relu(F.linear(x, sd['classifier.0.weight'], sd['classifier.0.bias']))
+    acts['fc1'] = x
     x = F.relu(F.linear(x, sd['classifier.3.weight'], sd['classifier.3.bias']))
-    return F.linear(x, sd['classifier.6.weight'], sd['classifier.6.bias'])
+    acts['fc2'] = x
+    logits = F.linear(x, sd['classifier.6.weight'], sd['classifier.6.bias'])
+    return (logits, acts) if return_all else logits
 
 
 def inception_v3_forward(sd, x):

@@ -84,9 +84,21 @@ class AttackState:
     def iteration(self, targeted, d_thr, adv_lr, col_lr, p_thresh, adv_w=1.0):
         """One pass of the loop body (projector_based_attack.py:264-328), ~90 kernel launches, no host sync."""
         with torch.cuda.device(self.dev):
-            self._iteration(targeted, d_thr, adv_lr, col_lr, p_thresh, adv_w)
+            self._forward_decide(targeted, d_thr, p_thresh, adv_w)
+            self._backward_step(adv_lr, col_lr)
 
-    def _iteration(self, targeted, d_thr, adv_lr, col_lr, p_thresh, adv_w):
+    def forward_decide(self, targeted, d_thr, p_thresh, adv_w=1.0):
+        """First half of `iteration` (:265-299): forward passes, losses and their gradient at the camera image, masks."""
+        with torch.cuda.device(self.dev):
+            self._forward_decide(targeted, d_thr, p_thresh, adv_w)
+
+    def backward_step(self, adv_lr, col_lr):
+        """Second half of `iteration` (:302-328): the backward pass, the normalised step and the best-so-far bookkeeping.
+        (The halves are separate entry points so that the parity tests can compare / exchange the ReLU gates in between.)"""
+        with torch.cuda.device(self.dev):
+            self._backward_step(adv_lr, col_lr)
+
+    def _forward_decide(self, targeted, d_thr, p_thresh, adv_w):
         B, p = self.B, _lib.ptr
         y = self.eng.forward(self.x, clamp01=True)                                   # :265
         logits = self.clf.forward(y)                                                 # :266
@@ -98,6 +110,10 @@ class AttackState:
                   self.nblk_c, self.HWc, p(self.prjl2) if self.prjl2_w else None, self.prjl2_w, self.caml2_w,
                   self.camdE_w, float(d_thr), float(p_thresh), adv_w / B, p(self.state), p(self.stats),
                   p(self.g_logits), B)                                               # :269-272, :290-299, :318-320
+        self._y = y
+
+    def _backward_step(self, adv_lr, col_lr):
+        B, p, y = self.B, _lib.ptr, self._y
         g_adv = self.clf.backward(self.g_logits)                                     # :302 (classifier part)
         _lib.call('spaa_select_grad', p(g_adv), p(self.g_col), p(self.state), p(self.eng.a['Ypre']), p(self.gP), B,
                   self.HWc)

@@ -1,0 +1,106 @@
+"""TEST INFRASTRUCTURE: ReLU / clamp / max-pool gate bookkeeping between the HIP engines and the oracle.
+
+The input gradient of a ReLU network is a discontinuous function of its activations' signs: a unit whose value is
+within rounding of zero may be "on" in one fp32 implementation and "off" in another (different summation order), and
+that one bit changes the gradient inside the unit's whole receptive field by O(1).  The parity tests therefore
+  (1) count, per sample, the gates on which the HIP forward and the oracle forward disagree, and check that every such
+      unit is within rounding of zero on BOTH sides;
+  (2) assert the 1e-4 bar on every sample without a disagreeing gate;
+  (3) re-run the HIP backward with the ORACLE's gates copied into the engine's activation buffers and assert the 1e-4
+      bar on every sample: whatever exceeded it in (2) is then shown to be the gates and nothing else.
+"""
+import torch
+
+
+def _nhwc(o, cpad=None):
+    """oracle NCHW (or [B,C]) -> NHWC float tensor, channels zero-padded to `cpad`."""
+    if o.ndim == 2:
+        o = o[:, :, None, None]
+    t = o.detach().float().permute(0, 2, 3, 1).contiguous()
+    if cpad is not None and cpad > t.shape[-1]:
+        t = torch.cat([t, torch.zeros(*t.shape[:-1], cpad - t.shape[-1])], -1)
+    return t
+
+
+def _argmax_codes(idx, hin_win, k, s, p):
+    """F.max_pool2d(return_indices=True) flat input indices [B,C,Ho,Wo] -> the HIP kernels' window codes ky*k+kx, NHWC uint8."""
+    hin, win = hin_win
+    b, c, ho, wo = idx.shape
+    iy, ix = idx // win, idx % win
+    oy = torch.arange(ho).view(1, 1, ho, 1)
+    ox = torch.arange(wo).view(1, 1, 1, wo)
+    code = (iy - (oy * s - p)) * k + (ix - (ox * s - p))
+    assert int(code.min()) >= 0 and int(code.max()) < k * k
+    return code.permute(0, 2, 3, 1).contiguous().to(torch.uint8)
+
+
+def pcnet_pairs(eng, acts):
+    """(name, kind, HIP buffer, oracle tensor in the HIP layout) for every gate of PCNetEngine.backward + select_grad."""
+    m = dict(x1='X1', x2='X2', x3='X3', x4='X4', x5='X5', x6='X6', x7='X7', res1_s='S1', res2_s='S2', res3_s='S3',
+             res4_s='S4')
+    out = [(f'pcnet.{k}', 'relu', eng.a[v], _nhwc(acts[k])) for k, v in m.items()]
+    out.append(('pcnet.ypre', 'clamp01', eng.a['Ypre'], _nhwc(acts['ypre'], 4)))
+    return out
+
+
+def resnet18_pairs(body, cacts):
+    out = [('resnet.c1', 'relu', body.c1, _nhwc(cacts['c1']))]
+    out.append(('resnet.maxpool', 'argmax', body.mp_arg,
+                _argmax_codes(cacts['mp_idx'], body.c1.shape[1:3], 3, 2, 1)))
+    for blk in body.blocks:
+        out.append((f'resnet.{blk["name"]}.o1', 'relu', blk['o1'], _nhwc(cacts[blk['name'] + '.o1'])))
+        out.append((f'resnet.{blk["name"]}.out', 'relu', blk['out'], _nhwc(cacts[blk['name'] + '.out'])))
+    return out
+
+
+def vgg16_pairs(body, cacts):
+    out, nc, npool = [], 0, 0
+    for op in body.ops:
+        if op['kind'] == 'conv':
+            out.append((f'vgg.conv{nc}', 'relu', op['out'], _nhwc(cacts[f'conv{nc}'])))
+            nc += 1
+        else:
+            out.append((f'vgg.pool{npool}', 'argmax', op['arg'],
+                        _argmax_codes(cacts[f'pool{npool}'], (op['hin'], op['win']), 2, 2, 0)))
+            npool += 1
+    out.append(('vgg.fc1', 'relu', body.h1, _nhwc(cacts['fc1'])))
+    out.append(('vgg.fc2', 'relu', body.h2, _nhwc(cacts['fc2'])))
+    return out
+
+
+def count_flips(pairs, near_zero=2e-4, value_tol=2e-4):
+    """Per-sample number of gates on which HIP and oracle disagree.  Asserts (a) the activations themselves agree to
+    `value_tol` relative L-inf per layer, (b) every disagreeing ReLU/clamp unit is within `near_zero` x layer scale of the
+    gate's threshold on both sides.  Returns (flips [B] int tensor, {layer: count})."""
+    flips, per_layer = None, {}
+    for name, kind, hip, orc in pairs:
+        h = hip.detach().cpu()
+        assert h.shape == orc.shape, (name, h.shape, orc.shape)
+        if kind == 'argmax':
+            mism = h != orc
+        else:
+            hf = h.float()
+            scale = float(orc.abs().max()) + 1e-30
+            assert float((hf - orc).abs().max()) <= value_tol * scale, (name, float((hf - orc).abs().max()) / scale)
+            if kind == 'relu':
+                mism = (hf > 0) != (orc > 0)
+                if mism.any():
+                    assert float(torch.maximum(hf.abs(), orc.abs())[mism].max()) < near_zero * scale, name
+            else:  # 0 < v <= 1
+                mism = ((hf > 0) & (hf <= 1)) != ((orc > 0) & (orc <= 1))
+                if mism.any():
+                    d0 = torch.maximum(hf.abs(), orc.abs())[mism]
+                    d1 = torch.maximum((hf - 1).abs(), (orc - 1).abs())[mism]
+                    assert float(torch.minimum(d0, d1).max()) < near_zero * max(scale, 1.0), name
+        n = mism.flatten(1).sum(dim=1)
+        flips = n if flips is None else flips + n
+        if int(n.sum()):
+            per_layer[name] = int(n.sum())
+    return flips, per_layer
+
+
+def inject(pairs):
+    """Copy the oracle's activations / arg-maxes into the HIP engine's buffers (they agree to rounding: only the gates
+    that sit within rounding of zero change)."""
+    for name, kind, hip, orc in pairs:
+        hip.copy_(orc.to(hip.dtype).to(hip.device))

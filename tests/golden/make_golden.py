@@ -226,7 +226,100 @@ def gen_percal(ref, name, sz, targeted, d_thr, confidence):
          crop=cp, input_sz=in_sz, x_adv_best=out.detach(), oracle_maxdiff=diff)
 
 
+def _exec_defs(path, names, ns):
+    """exec single function definitions out of a reference module that cannot be imported as a whole (missing cv2 /
+    torchvision at import time); nothing of the source text is kept."""
+    import ast
+    src = open(path).read()
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module([node], []), os.path.basename(path), 'exec'), ns)
+    return ns
+
+
+def _reference_classifier(body, input_sz):
+    """The reference's own `Classifier.classify` / `__call__` (classifier.py:55-75) and `img_proc.expand_4d / resize /
+    center_crop` (img_proc.py:110-132), exec'd from their source, around a network body we supply (torchvision and the
+    pretrained weights are absent): pins the wrapper contract and the preprocessing, not the body."""
+    import ast
+    import torch.nn.functional as F
+    ns = dict(torch=torch, F=F)
+    _exec_defs(os.path.join(ref_shims.REF_ROOT, 'img_proc.py'), ('expand_4d', 'resize', 'center_crop'), ns)
+    ns['cc'] = ns['center_crop']
+    src = open(os.path.join(ref_shims.REF_ROOT, 'classifier.py')).read()
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.ClassDef) and node.name == 'Classifier':
+            node.body = [n for n in node.body if isinstance(n, ast.FunctionDef) and n.name in ('classify', '__call__')]
+            exec(compile(ast.Module([node], []), 'classifier.py', 'exec'), ns)
+    clf = object.__new__(ns['Classifier'])
+    mean = torch.tensor((0.485, 0.456, 0.406)).view(-1, 1, 1)
+    std = torch.tensor((0.229, 0.224, 0.225)).view(-1, 1, 1)
+
+    def normalize(t):  # torchvision.transforms.functional.normalize: tensor.clone().sub_(mean).div_(std)
+        return t.clone().sub_(mean).div_(std)
+
+    seen = []
+
+    def model(x):
+        seen.append(x)
+        return body(x)
+
+    clf.normalize = lambda x: torch.stack([normalize(x[i]) for i in range(x.shape[0])], 0)  # classifier.py:51
+    clf.model, clf.device, clf.sort_results, clf.input_sz = model, 'cpu', True, tuple(input_sz)
+    return clf, seen, ns
+
+
+def gen_preproc(name, im_hw, crop, input_sz, seed, bsz=1):
+    """a6/a7: Classifier.classify + img_proc helpers of the reference on seeded inputs; expected = the tensor the
+    reference hands to the network, its gradient, and the (raw_score, p, idx) triple for the oracle's ResNet-18 body."""
+    csd = syn.resnet18_state_dict(2, logit_gain=GAIN)
+    clf, seen, ns = _reference_classifier(lambda x: so.resnet18_forward(csd, x), input_sz)
+    rng = np.random.default_rng(seed)
+    im = torch.from_numpy(rng.random((bsz, 3, *im_hw)).astype(np.float32)).requires_grad_(True)
+    r = torch.from_numpy(rng.standard_normal((bsz, 3, *input_sz)).astype(np.float32))
+    raw, p, idx = clf(im, crop)
+    pre = seen[-1]
+    (pre * r).sum().backward()
+    g = im.grad.clone()
+    # 3-D and uint8 inputs take the same route (classifier.py:56-59, img_proc.py:110-114)
+    u8 = (im.detach()[0] * 255).to(torch.uint8)
+    raw_u8, _, idx_u8 = clf(u8, crop)
+    # oracle restatement on the same inputs
+    im2 = im.detach().clone().requires_grad_(True)
+    pre_o = so.classifier_preprocess(im2, crop, input_sz)
+    (pre_o * r).sum().backward()
+    raw_o, p_o, idx_o = so.OracleClassifier('resnet18', csd, input_sz=input_sz)(im.detach(), crop)
+    diff = max((pre_o - pre).abs().max().item(), (im2.grad - g).abs().max().item(), (raw_o - raw).abs().max().item(),
+               float(np.abs(p_o - p).max()))
+    assert (idx_o == idx).all()
+    print(f'  {name}: oracle maxdiff {diff:.3e}; crop origin via reference center_crop; up-sampling: {input_sz[0] > crop[0]}')
+    save(name, seed=seed, im_hw=im_hw, crop=crop, input_sz=input_sz, bsz=bsz, pre=pre.detach(), grad_im=g,
+         raw_score=raw.detach(), p5=p[:, :5], idx5=idx[:, :5], raw_score_u8=raw_u8.detach(), idx5_u8=idx_u8[:, :5],
+         gain=GAIN, oracle_maxdiff=diff)
+
+
+def gen_io(name):
+    """f3: the reference's sample image (a data file) decoded independently of any image library; the file itself is
+    committed next to the fixture so that spaa_amd.io.torch_imread can be checked on a reference-held PNG."""
+    import hashlib
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from png_ref import decode_png
+    src = os.path.join(os.path.dirname(os.path.dirname(ref_shims.REF_ROOT)), 'data', 'sample', 'anemone_fish.png')
+    dst = os.path.join(HERE, 'anemone_fish.png')
+    shutil.copyfile(src, dst)
+    os.chmod(dst, 0o644)
+    rgb = decode_png(dst)
+    save(name, shape=rgb.shape, sha256=hashlib.sha256(rgb.tobytes()).hexdigest(), mean_rgb=rgb.reshape(-1, 3).mean(0),
+         corner=rgb[:4, :4], center=rgb[126:130, 126:130])
+    print(f'  {name}: {rgb.shape} mean {rgb.reshape(-1, 3).mean(0)}')
+
+
 CASES = {
+    'preproc_240_224': lambda r: gen_preproc('preproc_240_224', (256, 256), (240, 240), (224, 224), 41),
+    'preproc_240_299': lambda r: gen_preproc('preproc_240_299', (256, 256), (240, 240), (299, 299), 42),
+    'preproc_nonsq_small': lambda r: gen_preproc('preproc_nonsq_small', (60, 84), (56, 56), (48, 48), 43, bsz=3),
+    'io_sample_png': lambda r: gen_io('io_sample_png'),
     'color_kat': lambda r: gen_color(r),
     'pcnet_64': lambda r: gen_pcnet(r, 'pcnet_64', (64, 64), (64, 64), 'rect', 0),
     'pcnet_nonsq': lambda r: gen_pcnet(r, 'pcnet_nonsq', (64, 64), (48, 80), 'ones', 3),

@@ -329,50 +329,87 @@ def _setup_case(hip, z):
     return sd, pc, clf, oclf, scene, setup
 
 
+def _oracle_activations(sd, csd, x_prev, scene_b, cam_sz, crop, insz, body='resnet18'):
+    """The oracle's forward for one teacher-forced iteration, with every gate-carrying activation (tests/gates.py)."""
+    with torch.no_grad():
+        xw = so.warp(sd, x_prev.clamp(0, 1), cam_sz) * sd['mask']
+        y, acts = so.shading_net(sd, xw, (scene_b, xw * scene_b), return_all=True)
+        fwd = dict(resnet18=so.resnet18_forward, vgg16=so.vgg16_forward)[body]
+        _, cacts = fwd(csd, so.classifier_preprocess(y, crop, insz), return_all=True)
+    return acts, cacts
+
+
 @pytest.mark.parametrize('name', ['spaa_64_near', 'spaa_64_prjl2', 'spaa_64_caml2_dthr', 'spaa_64_camdE'])
 def test_spaa_teacher_forced_iterations(hip, golden_dir, name):
-    """One HIP iteration from the oracle's state at iteration k must reproduce the oracle's iteration k:
-    losses, masks, top-1, and the updated projector image to 1e-4 relative L-inf."""
+    """One HIP iteration from the oracle's state at iteration k must reproduce the oracle's iteration k: losses, masks,
+    top-1, and the updated projector image to 1e-4 relative L-inf (BASELINE.json's bar) — on EVERY sample whose ReLU /
+    clamp / max-pool gates agree with the oracle's, and on ALL samples once the oracle's gates are used in the HIP
+    backward (tests/gates.py): every excess over 1e-4 is a unit within rounding of zero falling on the other side."""
+    import gates
     z = load(golden_dir, name)
     sd, pc, clf, oclf, scene, setup = _setup_case(hip, z)
     targets, targeted = [int(t) for t in z['targets']], bool(z['targeted'])
     d_thr, stealth = float(z['d_thr']), str(z['stealth'])
+    csd = syn.resnet18_state_dict(2, logit_gain=float(z['gain']))
+    crop, insz, cam_sz = setup['classifier_crop_sz'], tuple(int(v) for v in z['input_sz']), setup['prj_im_sz']
     tr = []
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     so.spaa(sd, oclf, targets, targeted, scene, d_thr, stealth, setup, iters=14, trace=tr)
     assert (np.stack([t['top1'] for t in tr])[:3] == z['top1'][:3]).all()  # oracle here == reference golden
     A, M = hip['attack'], hip['models']
+    B = len(targets)
     st = A.AttackState(pc, clf, targets, scene, stealth, setup, DEV)
-    errs_inf, errs_l2 = [], []
+    scene_b = scene.expand(B, -1, -1, -1)
+    worst_clean = worst_forced = worst_plain = 0.0
+    n_flip_samples = n_flips = n_clean = 0
+    layers = {}
     for k in range(len(tr)):
-        x_prev = torch.full((len(targets), 3, *setup['prj_im_sz']), 0.5) if k == 0 else torch.from_numpy(tr[k - 1]['prj_adv'])
-        st.x.copy_(M.to_nhwc4(x_prev.to(DEV)))
-        st.stats[:, 5] = torch.from_numpy(tr[k]['col_loss_best_before']).to(DEV)
-        st.iteration(targeted, d_thr, 2, 1, 0.9)
-        stt, sts = st.state.cpu().numpy(), st.stats.cpu().numpy()
         t = tr[k]
-        assert np.allclose(sts[:, 1], t['caml2'], rtol=1e-4), (k, 'caml2')
-        assert np.allclose(sts[:, 2], t['camdE'], rtol=1e-4), (k, 'camdE')
-        assert np.allclose(sts[:, 0], t['p1'], atol=2e-4), (k, 'p1')
-        assert np.allclose(sts[:, 6], t['target_logit'], rtol=1e-4, atol=1e-4), (k, 'logit')
-        assert rel_inf(M.to_nchw(st.eng.a['Y']), torch.from_numpy(t['cam_infer'])) < 1e-4, (k, 'cam_infer')
-        # decisions: equal unless the oracle itself sits on a knife edge
-        edge = (np.abs(t['p1'] - 0.9) < 1e-3) | (np.abs(t['caml2'] * 255 - d_thr) < 1e-2)
-        assert ((stt[:, 3] == t['top1']) | edge).all(), (k, 'top1')
-        assert ((stt[:, 0] == t['succ']) | edge).all() and ((stt[:, 1] == t['best_adv']) | edge).all(), (k, 'masks')
-        same = (stt[:, 1] == t['best_adv'])
-        xn = M.to_nchw(st.x).cpu()
+        x_prev = torch.full((B, 3, *setup['prj_im_sz']), 0.5) if k == 0 else torch.from_numpy(tr[k - 1]['prj_adv'])
         ref = torch.from_numpy(t['prj_adv'])
-        errs_inf.append(rel_inf(xn[same], ref[same]))
-        errs_l2.append(rel_l2(xn[same] - x_prev[same], ref[same] - x_prev[same]))  # error of the STEP itself
-    print(f'{name}: one-iteration parity over {len(tr)} teacher-forced iterations: image rel Linf median '
-          f'{np.median(errs_inf):.2e} max {max(errs_inf):.2e}; step rel L2 median {np.median(errs_l2):.2e} max '
-          f'{max(errs_l2):.2e}')
-    # north_star's 1e-4 relative L-inf holds for the typical iteration; an iteration in which a ReLU unit sits within
-    # rounding of zero (gate flip, see test_pcnet_forward_and_input_gradient) moves a few pixels by up to ~1e-3.
-    # Bimodal by construction: iterations with no gate flip in any of the B samples agree to rounding (~1e-6).
-    assert np.percentile(errs_inf, 25) < 2e-5 and np.median(errs_inf) < 1e-3 and max(errs_inf) < 5e-2
-    assert np.percentile(errs_l2, 25) < 2e-5 and np.median(errs_l2) < 1e-3 and max(errs_l2) < 5e-2
+        acts, cacts = _oracle_activations(sd, csd, x_prev, scene_b, cam_sz, crop, insz)
+        results = {}
+        for mode in ('plain', 'oracle_gates'):
+            st.x.copy_(M.to_nhwc4(x_prev.to(DEV)))
+            st.stats[:, 5] = torch.from_numpy(t['col_loss_best_before']).to(DEV)
+            st.forward_decide(targeted, d_thr, 0.9)
+            pairs = gates.pcnet_pairs(st.eng, acts) + gates.resnet18_pairs(st.clf.body, cacts)
+            if mode == 'plain':
+                flips, per_layer = gates.count_flips(pairs)
+                for kk, vv in per_layer.items():
+                    layers[kk] = layers.get(kk, 0) + vv
+                stt, sts = st.state.cpu().numpy(), st.stats.cpu().numpy()
+                assert np.allclose(sts[:, 1], t['caml2'], rtol=1e-4), (k, 'caml2')
+                assert np.allclose(sts[:, 2], t['camdE'], rtol=1e-4), (k, 'camdE')
+                assert np.allclose(sts[:, 0], t['p1'], atol=2e-4), (k, 'p1')
+                assert np.allclose(sts[:, 6], t['target_logit'], rtol=1e-4, atol=1e-4), (k, 'logit')
+                assert rel_inf(M.to_nchw(st.eng.a['Y']), torch.from_numpy(t['cam_infer'])) < 1e-4, (k, 'cam_infer')
+                # decisions: equal unless the oracle itself sits on a knife edge
+                edge = (np.abs(t['p1'] - 0.9) < 1e-3) | (np.abs(t['caml2'] * 255 - d_thr) < 1e-2)
+                assert ((stt[:, 3] == t['top1']) | edge).all(), (k, 'top1')
+                assert ((stt[:, 0] == t['succ']) | edge).all() and ((stt[:, 1] == t['best_adv']) | edge).all(), (k, 'masks')
+                same = torch.from_numpy(stt[:, 1] == t['best_adv'])
+            else:
+                gates.inject(pairs)
+            st.backward_step(2, 1)
+            xn = M.to_nchw(st.x).cpu()
+            results[mode] = torch.tensor([rel_inf(xn[b], ref[b]) for b in range(B)])
+        clean = same & (flips == 0)
+        flipped = same & (flips > 0)
+        n_clean += int(clean.sum())
+        n_flip_samples += int(flipped.sum())
+        n_flips += int(flips[same].sum())
+        if clean.any():
+            worst_clean = max(worst_clean, float(results['plain'][clean].max()))
+        if same.any():
+            worst_forced = max(worst_forced, float(results['oracle_gates'][same].max()))
+            worst_plain = max(worst_plain, float(results['plain'][same].max()))
+        assert (results['plain'][clean] < 1e-4).all(), (k, results['plain'])
+        assert (results['oracle_gates'][same] < 1e-4).all(), (k, results['oracle_gates'])
+    print(f'{name}: {len(tr)} teacher-forced iterations x {B} samples: {n_clean} sample-iterations with identical gates: '
+          f'image rel Linf max {worst_clean:.2e}; {n_flip_samples} with {n_flips} differing gates {layers} (all within rounding '
+          f'of zero): plain max {worst_plain:.2e}, with the oracle\'s gates max {worst_forced:.2e}')
+    assert n_clean > 0
 
 
 def test_spaa_exact_cases_and_quirks(hip, golden_dir):
@@ -406,25 +443,54 @@ def test_spaa_exact_cases_and_quirks(hip, golden_dir):
     assert cam.shape == (3, 3, 64, 64) and prj.min() >= 0 and prj.max() <= 1
 
 
-def test_reference_sensitivity_envelope(hip, golden_dir):
-    """The full 50-iteration output of the HIP path vs the reference golden, judged against the reference's own
-    sensitivity: the oracle (== reference, bit-exact) run with 1 CPU thread instead of 8."""
-    A = hip['attack']
+def _oracle_fp64(sd, csd, insz, targets, targeted, scene, d_thr, stealth, setup, iters):
+    """The oracle in float64: the common yardstick for 'how far may an fp32 implementation drift'."""
+    torch.set_default_dtype(torch.float64)
+    try:
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        csd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in csd.items()}
+        tr = []
+        so.spaa(sd64, so.OracleClassifier('resnet18', csd64, input_sz=insz), targets, targeted, scene.double(), d_thr, stealth,
+                setup, iters=iters, trace=tr)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    return tr
+
+
+def test_free_running_drift_vs_fp64_oracle(hip, golden_dir):
+    """Free-running trajectories (no teacher forcing).  The loop amplifies rounding differences ~3x per iteration (the fp32
+    oracle == reference drifts from the SAME code run in float64 by 3e-6, 1e-4, 8e-4, 3e-3, ... 2e-1 relative L-inf), so
+    'identical results' for 50 iterations is not defined for any two fp32 implementations.  What is defined: the HIP path
+    must not drift from the fp64 trajectory faster than the fp32 reference itself does."""
+    A, M = hip['attack'], hip['models']
     z = load(golden_dir, 'spaa_64_near')
     sd, pc, clf, oclf, scene, setup = _setup_case(hip, z)
-    targets = [int(t) for t in z['targets']]
-    cam, prj = A.spaa(pc, clf, None, targets, True, scene, float(z['d_thr']), str(z['stealth']), DEV, setup)
-    ref_prj, ref_cam = torch.from_numpy(z['prj_adv_best']), torch.from_numpy(z['cam_infer_best'])
-    ours = rel_inf(prj, ref_prj)
-    nt = torch.get_num_threads()
-    torch.set_num_threads(1)
-    cam1, prj1 = so.spaa(sd, oclf, targets, True, scene, float(z['d_thr']), str(z['stealth']), setup)
-    torch.set_num_threads(nt)
-    env = rel_inf(prj1, ref_prj)
-    print(f'50-iteration projector image rel Linf vs reference: HIP {ours:.3f}; reference 1-thread vs 8-thread {env:.3f}')
-    assert env > 1e-3, 'the reference should be visibly thread-count sensitive (chaotic loop)'
-    assert ours < max(3 * env, 0.5)
-    # statistics of the result are preserved: camera-side distortion of the best images within 5 %
+    csd = syn.resnet18_state_dict(2, logit_gain=float(z['gain']))
+    insz = tuple(int(v) for v in z['input_sz'])
+    targets, d_thr, stealth = [int(t) for t in z['targets']], float(z['d_thr']), str(z['stealth'])
+    iters = 12
+    tr64 = _oracle_fp64(sd, csd, insz, targets, True, scene, d_thr, stealth, setup, iters)
+    tr32 = []
+    so.spaa(sd, oclf, targets, True, scene, d_thr, stealth, setup, iters=iters, trace=tr32)
+    st = A.AttackState(pc, clf, targets, scene, stealth, setup, DEV)
+    d_hip, d_f32 = [], []
+    for k in range(iters):
+        st.iteration(True, d_thr, 2, 1, 0.9)
+        ref = torch.from_numpy(tr64[k]['prj_adv'])
+        d_hip.append(rel_inf(M.to_nchw(st.x).double(), ref))
+        d_f32.append(rel_inf(torch.from_numpy(tr32[k]['prj_adv']).double(), ref))
+    print('free-running drift from the fp64 oracle, relative Linf of the projector image per iteration:')
+    print('   HIP          ', ' '.join(f'{v:.1e}' for v in d_hip))
+    print('   fp32 oracle  ', ' '.join(f'{v:.1e}' for v in d_f32))
+    assert d_hip[0] < 1e-4 and d_f32[0] < 1e-4                      # first iteration: BASELINE.json's bar, both
+    # drift is multiplicative (chaotic amplification): compare in the log domain, geometric mean over the iterations
+    ratio = float(np.exp(np.mean(np.log(np.array(d_hip) / np.array(d_f32)))))
+    print(f'   geometric-mean ratio HIP / fp32 oracle = {ratio:.2f}')
+    assert ratio < 3.0
+    assert all(h < 10 * max(f, 1e-6) for h, f in zip(d_hip, d_f32))
+    # 50-iteration statistics are preserved: camera-side distortion of the best images within 5 % of the reference golden
+    cam, prj = A.spaa(pc, clf, None, targets, True, scene, d_thr, stealth, DEV, setup)
+    ref_cam = torch.from_numpy(z['cam_infer_best'])
     d_ours = torch.norm(cam.cpu() - scene, dim=1).mean().item()
     d_ref = torch.norm(ref_cam - scene, dim=1).mean().item()
     assert abs(d_ours - d_ref) / d_ref < 0.05
@@ -820,3 +886,291 @@ def test_first_iteration_other_sizes(hip, cam_sz, prj_sz, b, mask):
     # the update is a normalised gradient step: <= 1e-4 unless a ReLU gate within rounding of zero falls on the other
     # side (then the elements in that unit's receptive field differ: sparse, bounded)
     assert err < 1e-4 or (err < 5e-3 and out_frac < 2e-2)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 2: reference-pinned preprocessing (a6/a7), loop-level runs with the other classifier bodies (configs[2], [4]),
+# API-compatibility paths (differentiable colour functions, engine reuse under autograd, foreign classifiers)
+@pytest.mark.parametrize('name', ['preproc_240_224', 'preproc_240_299', 'preproc_nonsq_small'])
+def test_preproc_and_classifier_wrapper_vs_reference_fixture(hip, golden_dir, name):
+    """spaa_preproc_fwd / spaa_preproc_bwd and the Classifier wrapper against what the REFERENCE's own
+    Classifier.classify + img_proc.center_crop/resize produced (tests/golden/make_golden.py: gen_preproc): 240->224
+    area down-sampling, 240->299 area UP-sampling (Inception-v3), a non-square image."""
+    from spaa_amd.classifier import Classifier
+    z = load(golden_dir, name)
+    rng = np.random.default_rng(int(z['seed']))
+    bsz, im_hw, insz = int(z['bsz']), tuple(int(v) for v in z['im_hw']), tuple(int(v) for v in z['input_sz'])
+    crop = tuple(int(v) for v in z['crop'])
+    im = torch.from_numpy(rng.random((bsz, 3, *im_hw)).astype(np.float32))
+    r = torch.from_numpy(rng.standard_normal((bsz, 3, *insz)).astype(np.float32))
+    csd = syn.resnet18_state_dict(2, logit_gain=float(z['gain']))
+    clf = Classifier('resnet18', DEV, state_dict=csd, input_sz=insz)
+    M = hip['models']
+    eng = clf.engine(bsz, im_hw, crop)
+    eng.forward(M.to_nhwc4(im.to(DEV)))
+    pre = M.to_nchw(eng.pre).cpu()
+    assert np.abs(pre.numpy() - z['pre']).max() <= 2e-6 * np.abs(z['pre']).max()
+    # adjoint of the preprocessing alone: spaa_preproc_bwd on the cotangent r
+    lib = hip['lib']
+    g_pre = M.to_nhwc4(r.to(DEV))
+    g_y = torch.zeros(bsz, *im_hw, 4, device=DEV)
+    lib.call('spaa_preproc_bwd', lib.ptr(g_pre), lib.ptr(g_y), bsz, im_hw[0], im_hw[1], eng.cy0, eng.cx0, crop[0], crop[1],
+             insz[0], insz[1], eng._std)
+    g = M.to_nchw(g_y).cpu().numpy()
+    assert np.abs(g - z['grad_im']).max() <= 1e-5 * np.abs(z['grad_im']).max()
+    raw, p, idx = clf(im.to(DEV), crop)
+    assert np.abs(raw.detach().cpu().numpy() - z['raw_score']).max() <= 1e-4 * np.abs(z['raw_score']).max()
+    assert (idx[:, :5] == z['idx5']).all() and np.allclose(p[:, :5], z['p5'], atol=2e-4)
+    raw8, _, idx8 = clf((im[0] * 255).to(torch.uint8), crop)   # 3-D uint8 input (classifier.py:56-57)
+    assert np.abs(raw8.detach().cpu().numpy() - z['raw_score_u8']).max() <= 1e-4 * np.abs(z['raw_score_u8']).max()
+    assert (idx8[:, :5] == z['idx5_u8']).all()
+
+
+def test_color_functions_are_differentiable(hip, golden_dir):
+    """rgb2lab_diff / ciede2000_diff carry gradients like the reference's (`_diff`): autograd through the HIP ops vs
+    autograd through the oracle, w.r.t. BOTH colours (PerC-AL differentiates the second, perc_al/__init__.py:197)."""
+    dcf = hip['dcf']
+    z = load(golden_dir, 'color_kat')
+    a0, b0 = torch.from_numpy(z['rgb_a']), torch.from_numpy(z['rgb_b'])
+    a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    wgt = torch.linspace(0.5, 1.5, a0.shape[0] * a0.shape[2] * a0.shape[3]).view(a0.shape[0], a0.shape[2], a0.shape[3])
+    (so.ciede2000_diff(so.rgb2lab_diff(a), so.rgb2lab_diff(b)) * wgt).sum().backward()
+    ag, bg = a0.clone().to(DEV).requires_grad_(True), b0.clone().to(DEV).requires_grad_(True)
+    de = dcf.ciede2000_diff(dcf.rgb2lab_diff(ag, DEV), dcf.rgb2lab_diff(bg, DEV), DEV)
+    assert de.requires_grad and de.shape == wgt.shape
+    (de * wgt.to(DEV)).sum().backward()
+    lab_a_ref, lab_b_ref = torch.from_numpy(z['lab_a']), torch.from_numpy(z['lab_b'])
+    chroma = torch.minimum(lab_a_ref[:, 1:].norm(dim=1), lab_b_ref[:, 1:].norm(dim=1))
+    for ours, ref in ((ag.grad.cpu(), a.grad), (bg.grad.cpu(), b.grad)):
+        fin = torch.isfinite(ref)
+        well = (chroma > 1.0)[:, None].expand_as(ref) & fin   # (grey pixels: hue is rounding noise, see the KAT test)
+        assert ((ours - ref)[well].abs().max() / ref[fin].abs().max()) < 1e-4
+    # the Lab conversion alone
+    x = torch.rand(2, 3, 9, 11)
+    r = torch.randn(2, 3, 9, 11)
+    xc = x.clone().requires_grad_(True)
+    (so.rgb2lab_diff(xc) * r).sum().backward()
+    xg = x.clone().to(DEV).requires_grad_(True)
+    (dcf.rgb2lab_diff(xg) * r.to(DEV)).sum().backward()
+    assert rel_inf(xg.grad, xc.grad) < 1e-5
+
+
+def test_autograd_survives_engine_reuse(hip, golden_dir):
+    """y1 = pcnet(x1, s); y2 = pcnet(x2, s); (y1 + y2).backward(): the cached engine's workspaces hold the SECOND forward
+    when the first call's backward runs — it must recompute, not silently use the wrong activations.  Same for the
+    classifier, and two attack states built from one PCNet/Classifier must not share workspaces."""
+    z = load(golden_dir, 'pcnet_64')
+    cam_sz = tuple(int(v) for v in z['cam_sz'])
+    sd = syn.pcnet_state_dict(int(z['seed']), cam_sz=cam_sz, mask=str(z['mask']))
+    pc = make_pcnet(hip, sd, cam_sz)
+    s = torch.from_numpy(z['s'])
+    x1 = syn.scenes(5, 2, cam_sz)
+    x2 = syn.scenes(6, 2, cam_sz)
+    r1, r2 = torch.randn(2, 3, *cam_sz), torch.randn(2, 3, *cam_sz)
+    g_ref = []
+    for x, r in ((x1, r1), (x2, r2)):
+        xc = x.clone().requires_grad_(True)
+        (so.pcnet_forward(sd, xc, s) * r).sum().backward()
+        g_ref.append(xc.grad)
+    a, b = x1.clone().to(DEV).requires_grad_(True), x2.clone().to(DEV).requires_grad_(True)
+    y1 = pc(a, s.to(DEV))
+    y2 = pc(b, s.to(DEV))
+    ((y1 * r1.to(DEV)).sum() + (y2 * r2.to(DEV)).sum()).backward()
+    assert rel_l2(a.grad, g_ref[0]) < 1e-4 and rel_l2(b.grad, g_ref[1]) < 1e-4
+    csd = syn.resnet18_state_dict(2, logit_gain=20.0)
+    clf = hip['clf'].Classifier('resnet18', DEV, state_dict=csd, input_sz=(56, 56))
+    oc = so.OracleClassifier('resnet18', csd, input_sz=(56, 56))
+    q = torch.randn(2, 1000)
+    c_ref = []
+    for x in (x1, x2):
+        xc = x.clone().requires_grad_(True)
+        (oc(xc, (60, 60))[0] * q).sum().backward()
+        c_ref.append(xc.grad)
+    a, b = x1.clone().to(DEV).requires_grad_(True), x2.clone().to(DEV).requires_grad_(True)
+    l1 = clf(a, (60, 60))[0]
+    l2 = clf(b, (60, 60))[0]
+    ((l1 * q.to(DEV)).sum() + (l2 * q.to(DEV)).sum()).backward()
+    assert rel_l2(a.grad, c_ref[0]) < 2e-3 and rel_l2(b.grad, c_ref[1]) < 2e-3
+    setup = dict(classifier_crop_sz=(60, 60), prj_brightness=0.5, prj_im_sz=cam_sz)
+    A = hip['attack']
+    st1 = A.AttackState(pc, clf, [204, 291], s[:1], 'camdE_caml2', setup, DEV)
+    st2 = A.AttackState(pc, clf, [7, 950], syn.scenes(9, 1, cam_sz), 'camdE_caml2', setup, DEV)
+    assert st1.eng is not st2.eng and st1.clf is not st2.clf
+    assert st1.eng.a['Y'].data_ptr() != st2.eng.a['Y'].data_ptr()
+    st1.iteration(True, 5, 2, 1, 0.9)
+    y_before = st1.eng.a['Y'].clone()
+    st2.iteration(True, 5, 2, 1, 0.9)
+    assert torch.equal(st1.eng.a['Y'], y_before) and torch.equal(st1.eng.scene, st1.scene4)
+
+
+def test_warping_net_forward_is_differentiable(hip, golden_dir):
+    """WarpingNet.forward through the reference interface: value and (gather-form, deterministic) input gradient vs
+    F.grid_sample on the oracle's fine grid."""
+    z = load(golden_dir, 'pcnet_nonsq')
+    cam_sz = tuple(int(v) for v in z['cam_sz'])
+    sd = syn.pcnet_state_dict(int(z['seed']), cam_sz=cam_sz, mask=str(z['mask']))
+    pc = make_pcnet(hip, sd, cam_sz)
+    x = syn.scenes(3, 2, tuple(int(v) for v in z['prj_sz']))
+    r = torch.randn(2, 3, *cam_sz)
+    xc = x.clone().requires_grad_(True)
+    (so.warp(sd, xc, cam_sz) * r).sum().backward()
+    xg = x.clone().to(DEV).requires_grad_(True)
+    y = pc.warping_net(xg)
+    (y * r.to(DEV)).sum().backward()
+    assert rel_inf(y, so.warp(sd, x, cam_sz)) < 1e-5
+    g1 = xg.grad.clone()
+    assert rel_inf(g1, xc.grad) < 1e-4
+    xg.grad = None
+    (pc.warping_net(xg) * r.to(DEV)).sum().backward()
+    assert torch.equal(xg.grad, g1)   # run-to-run identical: no float atomics on this path either
+
+
+def test_spaa_accepts_a_foreign_classifier(hip, golden_dir):
+    """The reference's spaa() takes any callable classifier(im, crop_sz) -> (raw_score, p, idx)
+    (projector_based_attack.py:266).  A foreign callable takes the autograd route (PCNet + stealth loss on HIP, classifier
+    by torch.autograd); its first iterations must agree with the fused path and with the oracle."""
+    A = hip['attack']
+    z = load(golden_dir, 'spaa_64_near')
+    sd, pc, clf, oclf, scene, setup = _setup_case(hip, z)
+    targets = [int(t) for t in z['targets']]
+    d_thr, stealth = float(z['d_thr']), str(z['stealth'])
+
+    class Foreign:   # not a spaa_amd.Classifier: an arbitrary callable with the reference's contract
+        def __call__(self, im, crop_sz):
+            return clf(im, crop_sz)
+
+    tr_f, tr_o = [], []
+    cam_f, prj_f = A.spaa(pc, Foreign(), None, targets, True, scene, d_thr, stealth, DEV, setup, iters=3, trace=tr_f)
+    so.spaa(sd, oclf, targets, True, scene, d_thr, stealth, setup, iters=3, trace=tr_o)
+    assert cam_f.shape == (len(targets), 3, 64, 64) and prj_f.min() >= 0 and prj_f.max() <= 1
+    assert (tr_f[0]['top1'].cpu().numpy() == tr_o[0]['top1']).all()
+    assert np.allclose(tr_f[0]['caml2'].cpu().numpy(), tr_o[0]['caml2'], rtol=1e-4)
+    assert np.allclose(tr_f[0]['camdE'].cpu().numpy(), tr_o[0]['camdE'], rtol=1e-4)
+    e0 = rel_inf(tr_f[0]['prj_adv'], torch.from_numpy(tr_o[0]['prj_adv']))
+    print(f'foreign-classifier route: projector image rel Linf vs oracle after iteration 0: {e0:.2e}')
+    assert e0 < 1e-4
+    # untargeted, prjl2 term, B = 1 (the reference's first call shape, :107)
+    cam1, prj1 = A.spaa(pc, Foreign(), None, [int(z['top1'][0][0])], False, scene[0], d_thr, 'camdE_caml2_prjl2', DEV, setup,
+                        iters=2)
+    assert cam1.shape == (1, 3, 64, 64) and torch.isfinite(prj1).all()
+
+
+def _first_iteration_gate_aware(hip, body, csd, insz, im_sz, crop, targets, seed):
+    """First iteration of the fused loop with another classifier body vs the oracle, gate-aware (tests/gates.py)."""
+    import gates
+    A, M = hip['attack'], hip['models']
+    sd = syn.pcnet_state_dict(seed, cam_sz=im_sz, mask='ones')
+    pc = make_pcnet(hip, sd, im_sz)
+    clf = hip['clf'].Classifier(body, DEV, state_dict=csd, input_sz=insz)
+    scene = syn.scenes(seed + 1, 1, im_sz)
+    setup = dict(classifier_crop_sz=crop, prj_brightness=0.5, prj_im_sz=im_sz)
+    B = len(targets)
+    tr = []
+    so.spaa(sd, so.OracleClassifier(body, csd, input_sz=insz), targets, True, scene, 5, 'camdE_caml2', setup, iters=1, trace=tr)
+    ref = torch.from_numpy(tr[0]['prj_adv'])
+    st = A.AttackState(pc, clf, targets, scene, 'camdE_caml2', setup, DEV)
+    x0 = torch.full((B, 3, *im_sz), 0.5)
+    have_gates = body in ('resnet18', 'vgg16')
+    if have_gates:
+        acts, cacts = _oracle_activations(sd, csd, x0, scene.expand(B, -1, -1, -1), im_sz, crop, insz, body)
+    errs = {}
+    for mode in ('plain', 'oracle_gates') if have_gates else ('plain',):
+        st.x.copy_(M.to_nhwc4(x0.to(DEV)))
+        st.stats[:, 5] = 1e6
+        st.forward_decide(True, 5, 0.9)
+        if have_gates:
+            pairs = gates.pcnet_pairs(st.eng, acts) + (gates.vgg16_pairs if body == 'vgg16' else gates.resnet18_pairs)(st.clf.body, cacts)
+            if mode == 'plain':
+                flips, per_layer = gates.count_flips(pairs)
+            else:
+                gates.inject(pairs)
+        if mode == 'plain':
+            assert rel_inf(M.to_nchw(st.eng.a['Y']), torch.from_numpy(tr[0]['cam_infer'])) < 1e-5
+            assert (st.state[:, 3].cpu().numpy() == tr[0]['top1']).all()
+            assert np.allclose(st.stats[:, 6].cpu().numpy(), tr[0]['target_logit'], rtol=1e-4, atol=1e-4)
+        st.backward_step(2, 1)
+        xn = M.to_nchw(st.x).cpu()
+        errs[mode] = torch.tensor([rel_inf(xn[b], ref[b]) for b in range(B)])
+    if have_gates:
+        print(f'{body} loop, first iteration at {im_sz}: gates differing per sample {flips.tolist()} {per_layer}; projector image '
+              f'rel Linf plain {errs["plain"].tolist()}, with the oracle\'s gates {errs["oracle_gates"].tolist()}')
+        assert (errs['plain'][flips == 0] < 1e-4).all() and (errs['oracle_gates'] < 1e-4).all()
+    else:
+        out = outlier_fraction(xn - 0.5, ref - 0.5, 1e-4)
+        print(f'{body} loop, first iteration at {im_sz}: projector image rel Linf {errs["plain"].tolist()}, elements off by '
+              f'more than 1e-4: {out:.2e}')
+        # (no gate bookkeeping for this body's 94 convolutions: 1e-4, or sparse gate-flip differences — see DESIGN.md §4)
+        assert (errs['plain'] < 1e-4).all() or (float(errs['plain'].max()) < 5e-3 and out < 2e-2)
+    return st
+
+
+def test_vgg16_attack_loop_first_iteration(hip):
+    """configs[4]'s classifier inside the SPAA loop (not just as a bare classifier)."""
+    csd = syn.vgg16_state_dict(3, logit_gain=5.0, fc_width=512)
+    _first_iteration_gate_aware(hip, 'vgg16', csd, (48, 48), (64, 64), (60, 60), [204, 291, 7], 11)
+
+
+def test_inception_v3_attack_loop_first_iteration(hip):
+    """configs[2]'s classifier (299-style up-sampling preprocessing, scaled down) inside the SPAA loop."""
+    csd = syn.inception_v3_state_dict(4, logit_gain=20.0)
+    _first_iteration_gate_aware(hip, 'inception_v3', csd, (107, 107), (128, 128), (120, 120), [204, 291], 12)
+
+
+@pytest.mark.parametrize('body', ['inception_v3', 'vgg16'])
+def test_full_size_properties_other_classifiers(hip, body):
+    """BASELINE.json configs[2] (Inception-v3, 299x299) and the SPAA loop with configs[4]'s VGG-16 at full size:
+    batch 64, 256x256, size-independent properties of the HIP path."""
+    A = hip['attack']
+    sz = (256, 256)
+    sd = syn.pcnet_state_dict(0, cam_sz=sz, mask='ones')
+    pc = make_pcnet(hip, sd, sz)
+    csd = {'vgg16': syn.vgg16_state_dict, 'inception_v3': syn.inception_v3_state_dict}[body](2, logit_gain=20.0)
+    clf = hip['clf'].Classifier(body, DEV, state_dict=csd)
+    scenes = syn.scenes(11, 8, sz).repeat_interleave(8, dim=0)
+    targets = (syn.IMAGENET10_TARGETS[:8]) * 8
+    setup = dict(classifier_crop_sz=(240, 240), prj_brightness=0.5, prj_im_sz=sz)
+    st = A.AttackState(pc, clf, targets, scenes, 'camdE_caml2', setup, DEV)
+    st.iteration(True, 5, 2, 1, 0.9)
+    x1, y1, logit1 = st.x.clone(), st.eng.a['Y'].clone(), st.stats[:, 6].clone()
+    step = (x1[..., :3] - 0.5).flatten(1).norm(dim=1).cpu()
+    lr = torch.where(st.state[:, 1].cpu() != 0, torch.tensor(1.0), torch.tensor(2.0))
+    assert torch.allclose(step, lr, rtol=1e-4)                       # prescribed step length per sample
+    st8 = A.AttackState(pc, clf, targets[8:16], scenes[8:16], 'camdE_caml2', setup, DEV)
+    st8.iteration(True, 5, 2, 1, 0.9)
+    assert rel_inf(st8.eng.a['Y'], y1[8:16]) < 1e-6                  # samples are independent
+    assert torch.allclose(st8.stats[:, 6], logit1[8:16], rtol=1e-4, atol=1e-4)
+    assert rel_inf(st8.x, x1[8:16]) < 1e-4
+    st2 = A.AttackState(pc, clf, targets, scenes, 'camdE_caml2', setup, DEV)
+    st2.iteration(True, 5, 2, 1, 0.9)
+    assert torch.equal(st2.x, x1)                                    # bitwise reproducible
+    for _ in range(2):
+        st.iteration(True, 5, 2, 1, 0.9)
+    cam, prj = st.results()
+    assert torch.isfinite(cam).all() and torch.isfinite(prj).all() and prj.min() >= 0 and prj.max() <= 1
+
+
+def test_perc_al_with_vgg16_at_full_size(hip):
+    """configs[4] (fp32 part): PerC_AL.adversary_projector with VGG-16 at 256x256 — iteration 0 from identical state vs the
+    oracle, and output properties over more iterations."""
+    from spaa_amd.perc_al import PerC_AL
+    csd = syn.vgg16_state_dict(3, logit_gain=5.0, fc_width=256)
+    clf = hip['clf'].Classifier('vgg16', DEV, state_dict=csd)
+    oclf = so.OracleClassifier('vgg16', csd)
+    scene = syn.scenes(1, 1, (256, 256)).expand(4, -1, -1, -1).contiguous()
+    _, _, idx = oclf(scene[:1], (240, 240))
+    labels = torch.tensor([int(i) for i in idx[0, 1:5]])
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    otr = []
+    so.perc_al_adversary_projector(oclf, scene, labels, 2.0, True, (240, 240), 400, 1., 0.5, 0, stop_after=1, trace=otr)
+    tr = []
+    att6 = PerC_AL(device=DEV, max_iterations=6, alpha_l_init=1, alpha_c_init=0.5, confidence=0)
+    out = att6.adversary_projector(clf, scene, labels, None, 2.0, True, (240, 240), trace=tr)
+    assert out.shape == scene.shape and out.min() >= 0 and out.max() <= 1
+    assert (torch.round(out * 255) / 255 - out).abs().max() < 1e-6
+    # iteration 0: alpha schedules of a 6- and a 400-iteration run coincide at i = 0
+    st0, stats0, d0 = tr[0]
+    e = rel_inf(d0, otr[0]['delta'])
+    print(f'PerC-AL + VGG-16 at 256x256: delta rel Linf after iteration 0 = {e:.2e}')
+    assert e < 1e-4 or (e < 5e-3 and outlier_fraction(d0, otr[0]['delta'], 1e-4) < 2e-2)
+    assert np.allclose(stats0[:, 3].cpu().numpy(), otr[0]['color_dis'].numpy(), rtol=1e-4)
+    assert (st0[:, 3].cpu().numpy() == otr[0]['top1']).all()

@@ -60,3 +60,36 @@ def test_setup_info_and_checkpoint_names(tmp_path):
     assert fn.endswith(title + '.pth')
     lin2 = sio.load_checkpoint(torch.nn.Linear(3, 2), fn)
     assert all(torch.equal(a, b) for a, b in zip(lin.state_dict().values(), lin2.state_dict().values()))
+
+
+def test_reads_the_reference_sample_png(golden_dir):
+    """SURVEY §8 f3 with a reference-held file: tests/golden/anemone_fish.png is /root/reference/data/sample/anemone_fish.png
+    (a data file, copied by tests/golden/make_golden.py).  torch_imread (Pillow) must return exactly the bytes the file
+    holds, as decoded by a codec-independent PNG decoder (tests/png_ref.py) and pinned by the committed hash —
+    the reference reads the same bytes through cv.imread + BGR->RGB (utils.py:116-117)."""
+    import hashlib
+    from png_ref import decode_png
+    path = os.path.join(golden_dir, 'anemone_fish.png')
+    z = np.load(os.path.join(golden_dir, 'io_sample_png.npz'))
+    rgb = decode_png(path)
+    assert rgb.shape == tuple(z['shape']) == (256, 256, 3)
+    assert hashlib.sha256(rgb.tobytes()).hexdigest() == str(z['sha256'])
+    im = sio.torch_imread(path)
+    assert im.shape == (3, 256, 256) and im.dtype == torch.float32 and float(im.max()) <= 1.0
+    assert torch.equal(im, torch.from_numpy(rgb.transpose(2, 0, 1).copy()).float() / 255)
+    assert np.array_equal(rgb[:4, :4], z['corner']) and np.array_equal(rgb[126:130, 126:130], z['center'])
+    assert np.allclose(rgb.reshape(-1, 3).mean(0), z['mean_rgb'])
+
+
+def test_loads_an_omegaconf_style_setup_info(tmp_path):
+    """train_network.py:85-95 reads `setup_info.yml` written by OmegaConf.save (utils.py:674-675): block-style YAML with
+    tuples as lists.  The values are main.py:19-33's defaults."""
+    text = ('prj_screen_sz:\n- 800\n- 600\nprj_im_sz:\n- 256\n- 256\nprj_offset:\n- 3840\n- 0\ncam_raw_sz:\n- 1280\n- 720\n'
+            'cam_crop_sz:\n- 960\n- 720\ncam_im_sz:\n- 320\n- 240\nclassifier_crop_sz:\n- 240\n- 240\n'
+            'prj_brightness: 0.5\ndelay_frames: 13\ndelay_time: 0.02\n')
+    d = tmp_path / 'setups' / 'camera'
+    os.makedirs(d)
+    (d / 'setup_info.yml').write_text(text)
+    cfg = sio.load_setup_info(str(d))
+    assert cfg.prj_im_sz == (256, 256) and cfg.cam_im_sz == (320, 240) and cfg.classifier_crop_sz == (240, 240)
+    assert cfg['prj_brightness'] == 0.5 and cfg.delay_frames == 13 and cfg.prj_offset == (3840, 0)

@@ -120,3 +120,34 @@ def test_img_dists_metrics(golden_dir):
     z = load(golden_dir, 'img_dists')
     got = np.array(so.calc_img_dists(torch.from_numpy(z['x']), torch.from_numpy(z['y'])))
     assert np.abs(got - z['dists']).max() <= 1e-6 * np.abs(z['dists']).max()
+
+
+def _preproc_inputs(z):
+    rng = np.random.default_rng(int(z['seed']))
+    bsz, im_hw, input_sz = int(z['bsz']), tuple(int(v) for v in z['im_hw']), tuple(int(v) for v in z['input_sz'])
+    im = torch.from_numpy(rng.random((bsz, 3, *im_hw)).astype(np.float32))
+    r = torch.from_numpy(rng.standard_normal((bsz, 3, *input_sz)).astype(np.float32))
+    return im, r, tuple(int(v) for v in z['crop']), input_sz
+
+
+@pytest.mark.parametrize('name', ['preproc_240_224', 'preproc_240_299', 'preproc_nonsq_small'])
+def test_classifier_wrapper_and_preprocessing(golden_dir, name):
+    """the fixtures hold what the REFERENCE's own `Classifier.classify` (classifier.py:55-72) and
+    `img_proc.expand_4d / center_crop / resize` (img_proc.py:110-132) produce (area down-sampling 240->224, area
+    UP-sampling 240->299, non-square images; float 4-D, uint8 3-D inputs): the oracle's restatement reproduces the
+    tensor handed to the network, its input gradient, and the (raw_score, p, idx) triple."""
+    z = load(golden_dir, name)
+    im, r, crop, input_sz = _preproc_inputs(z)
+    x = im.clone().requires_grad_(True)
+    pre = so.classifier_preprocess(x, crop, input_sz)
+    (pre * r).sum().backward()
+    assert np.abs(pre.detach().numpy() - z['pre']).max() <= 1e-6
+    assert np.abs(x.grad.numpy() - z['grad_im']).max() <= 1e-6 * max(1.0, np.abs(z['grad_im']).max())
+    csd = syn.resnet18_state_dict(2, logit_gain=float(z['gain']))
+    oc = so.OracleClassifier('resnet18', csd, input_sz=input_sz)
+    raw, p, idx = oc(im, crop)
+    assert np.abs(raw.detach().numpy() - z['raw_score']).max() <= 1e-4 * np.abs(z['raw_score']).max()
+    assert (idx[:, :5] == z['idx5']).all() and np.allclose(p[:, :5], z['p5'], atol=1e-6)
+    raw8, _, idx8 = oc((im[0] * 255).to(torch.uint8), crop)  # 3-D uint8 (classifier.py:56-57, img_proc.py:110-114)
+    assert np.abs(raw8.detach().numpy() - z['raw_score_u8']).max() <= 1e-4 * np.abs(z['raw_score_u8']).max()
+    assert (idx8[:, :5] == z['idx5_u8']).all()
