@@ -74,6 +74,13 @@ typedef struct {
                              otherwise, with gate2: (gate2 > 0) ? out_value : 0  (a second ReLU-backward gate) */
     const float* gate2;
     int32_t gate2_cstride, gate2_coff;
+    uint8_t* mask_out;         /* optional ReLU-gate mask of this launch's output: one BYTE per 4 consecutive channels, bit e =
+                                  (out[n0 + e] > 0), at index (o * out_cstride + out_coff + n0) >> 2 (o = output pixel).  A
+                                  dgrad launch then reads 2 bits per element instead of the 32-bit activation.  Needs Cout,
+                                  out_cstride, out_coff % 4 == 0 and a tile of the families 15..27, 30..46, 48..54 */
+    const uint8_t* gate_bits;  /* alternative to `gate` (meaning SPAA_GATE_POS): a mask written through `mask_out` by the
+                                  launch that produced the activation; indexed with gate_cstride / gate_coff */
+    const uint8_t* gate2_bits; /* likewise for `gate2` (gate2_cstride / gate2_coff) */
     int32_t tap_range[4]; /* (dy_min, dy_max, dx_min, dx_max) over the taps of all classes: patch-staged kernels */
     float* splitk_ws;     /* split-K workspace, ksplit * B*Hm*Wm * Npad floats (Npad = Cout rounded up to 128), or NULL */
     int32_t ksplit;       /* 0, 1: off.
@@ -168,11 +175,12 @@ int spaa_preproc_fwd(const float* y, float* out, int B, int H, int W, int cy0, i
 /* adjoint: g_out [B,oh,ow,4] -> g_y [B,H,W,4] (zero outside the crop) */
 int spaa_preproc_bwd(const float* g_out, float* g_y, int B, int H, int W, int cy0, int cx0, int ch, int cw,
                      int oh, int ow, const float* std3, spaa_stream_t stream);
-/* max_pool2d k3 s2 p1 forward (writes argmax offset 0..8 per element) and backward (gather; optional ReLU gate of
- * the pooled tensor's producer), NHWC, C % 4 == 0 */
+/* max_pool2d k3 s2 p1 forward (writes per element the argmax window offset 0..8 in bits 0-6 and, in bit 7, whether the
+ * maximum is positive) and backward (gather; `relu_gate` != 0: the pooled tensor's producer is a ReLU, windows whose
+ * maximum is not positive pass no gradient — read from bit 7, not from the activation), NHWC, C % 4 == 0 */
 int spaa_maxpool3s2_fwd(const float* in, float* out, uint8_t* argmax, int B, int Hin, int Win, int C, int Hout,
                         int Wout, spaa_stream_t stream);
-int spaa_maxpool3s2_bwd(const float* g_out, const uint8_t* argmax, const float* gate_in, float* g_in, int B,
+int spaa_maxpool3s2_bwd(const float* g_out, const uint8_t* argmax, int relu_gate, float* g_in, int B,
                         int Hin, int Win, int C, int Hout, int Wout, spaa_stream_t stream);
 /* adaptive_avg_pool2d(1): [B,HW,C] -> [B,C]; backward broadcasts g/HW and applies the ReLU gate of `act` */
 int spaa_avgpool_fwd(const float* in, float* out, int B, int HW, int C, spaa_stream_t stream);
@@ -183,7 +191,7 @@ int spaa_avgpool_bwd(const float* g_out, const float* act, float* g_in, int B, i
  * of a concatenated buffer; backward passes are deterministic gathers with an optional ReLU gate of the input. */
 int spaa_maxpool_fwd(const float* in, float* out, uint8_t* argmax, int B, int Hin, int Win, int C, int Hout, int Wout,
                      int k, int s, int p, int out_cstride, int out_coff, spaa_stream_t stream);
-int spaa_maxpool_bwd(const float* g_out, const uint8_t* argmax, const float* gate_in, float* g_in, int B, int Hin,
+int spaa_maxpool_bwd(const float* g_out, const uint8_t* argmax, int relu_gate, float* g_in, int B, int Hin,
                      int Win, int C, int Hout, int Wout, int k, int s, int p, int gout_cstride, int gout_coff,
                      spaa_stream_t stream);
 /* avg_pool2d(k, s, p), count_include_pad=True */

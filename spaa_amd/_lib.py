@@ -35,6 +35,7 @@ class TapConv(C.Structure):
         ('act', C.c_int32), ('tile', C.c_int32),
         ('aux_out', C.c_void_p),
         ('gate2', C.c_void_p), ('gate2_cstride', C.c_int32), ('gate2_coff', C.c_int32),
+        ('mask_out', C.c_void_p), ('gate_bits', C.c_void_p), ('gate2_bits', C.c_void_p),
         ('tap_range', C.c_int32 * 4),
         ('splitk_ws', C.c_void_p), ('ksplit', C.c_int32), ('nfold', C.c_int32), ('reserved0', C.c_int32),
         ('nclass', C.c_int32),
@@ -72,9 +73,9 @@ _SIGNATURES = {
     'spaa_preproc_fwd': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p],
     'spaa_preproc_bwd': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), _p],
     'spaa_maxpool3s2_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    'spaa_maxpool3s2_bwd': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'spaa_maxpool3s2_bwd': [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     'spaa_maxpool_fwd': [_p, _p, _p] + [_i] * 11 + [_p],
-    'spaa_maxpool_bwd': [_p, _p, _p, _p] + [_i] * 11 + [_p],
+    'spaa_maxpool_bwd': [_p, _p, _i, _p] + [_i] * 11 + [_p],
     'spaa_avgpool2d_fwd': [_p, _p] + [_i] * 11 + [_p],
     'spaa_avgpool2d_bwd': [_p, _p] + [_i] * 11 + [_p],
     'spaa_adaptive_avgpool_fwd': [_p, _p] + [_i] * 6 + [_p],
@@ -148,6 +149,27 @@ def check_dev(*tensors):
             raise ValueError('spaa_amd kernels need contiguous float32 tensors on the GPU '
                              f'(got device={t.device}, dtype={t.dtype}, contiguous={t.is_contiguous()})')
         _same_device(t)
+
+
+def check_mask(*tensors):
+    """ReLU-gate masks: contiguous uint8 tensors on the current GPU."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda or not t.is_contiguous() or t.dtype != torch.uint8:
+            raise ValueError(f'gate masks must be contiguous uint8 GPU tensors (got {t.device}, {t.dtype})')
+        _same_device(t)
+
+
+def pack_gate_mask(act):
+    """The mask a `mask_out` launch writes for the activation `act` [..., C] (C % 4 == 0): uint8 [..., C/4], bit e of byte q =
+    (act[..., 4q + e] > 0).  Index plumbing with torch ops; used when gates come from somewhere else than a launch
+    (parity tests that exchange gates, tools)."""
+    c = act.shape[-1]
+    assert c % 4 == 0
+    bits = (act > 0).view(*act.shape[:-1], c // 4, 4).to(torch.uint8)
+    wgt = torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device=act.device)
+    return (bits * wgt).sum(dim=-1).to(torch.uint8).contiguous()
 
 
 PROFILE = None  # bench.py's instrumented pass: a list that receives (entry point, start event, end event) per launch

@@ -89,6 +89,9 @@ class ResNet18Body:
                     blk['g_t'] = z(batch, hh, ww, cin)
                 blk['o1'] = z(batch, ho, wo, cout)
                 blk['out'] = z(batch, ho, wo, cout)
+                # ReLU gates as byte masks (1 byte per 4 channels), written by the forward epilogues
+                blk['m_o1'] = torch.zeros(batch, ho, wo, cout // 4, dtype=torch.uint8, device=dev)
+                blk['m_out'] = torch.zeros(batch, ho, wo, cout // 4, dtype=torch.uint8, device=dev)
                 blk['g_o1'] = z(batch, ho, wo, cout)
                 blk['g_x'] = z(batch, hh, ww, cin)
                 self.blocks.append(blk)
@@ -114,13 +117,13 @@ class ResNet18Body:
         _lib.call('spaa_maxpool3s2_fwd', _lib.ptr(self.c1), _lib.ptr(self.mp), _lib.ptr(self.mp_arg), B, h1, w1, 64,
                   h2, w2)
         for blk in self.blocks:
-            blk['f1'].run(blk['x'], blk['o1'], act=R)
+            blk['f1'].run(blk['x'], blk['o1'], act=R, mask_out=blk['m_o1'])
             if 'fd' in blk:
                 blk['fd'].run(blk['x'], blk['idt'])
                 idt = blk['idt']
             else:
                 idt = blk['x']
-            blk['f2'].run(blk['o1'], blk['out'], add=idt, act=R)
+            blk['f2'].run(blk['o1'], blk['out'], add=idt, act=R, mask_out=blk['m_out'])
         last = self.blocks[-1]['out']
         _lib.call('spaa_avgpool_fwd', _lib.ptr(last), _lib.ptr(self.feat), B, self.feat_hw, 512)
         self.fc_f.run(self.feat, self.logits)
@@ -136,20 +139,27 @@ class ResNet18Body:
         gP = self.g_last
         for i in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[i]
-            blk['d2'].run(gP, blk['g_o1'], gate=blk['o1'])
-            gate_x = blk['x'] if i > 0 else None  # block 0's input is the max-pool output (gated in maxpool_bwd)
+            blk['d2'].run(gP, blk['g_o1'], gate_bits=blk['m_o1'])
+            # the block's input is the previous block's output; block 0's is the max-pool output (gated in maxpool_bwd)
+            gate_x = self.blocks[i - 1]['m_out'] if i > 0 else None
             if 'dd' in blk:
                 blk['dd'].run(gP, blk['g_t'])
-                blk['d1'].run(blk['g_o1'], blk['g_x'], add=blk['g_t'], gate=gate_x)
+                blk['d1'].run(blk['g_o1'], blk['g_x'], add=blk['g_t'], gate_bits=gate_x)
             else:
-                blk['d1'].run(blk['g_o1'], blk['g_x'], add=gP, gate=gate_x)
+                blk['d1'].run(blk['g_o1'], blk['g_x'], add=gP, gate_bits=gate_x)
             gP = blk['g_x']
         _, h1, w1, _ = self.c1.shape
         _, h2, w2, _ = self.mp.shape
-        _lib.call('spaa_maxpool3s2_bwd', _lib.ptr(gP), _lib.ptr(self.mp_arg), _lib.ptr(self.c1), _lib.ptr(self.g_c1),
+        _lib.call('spaa_maxpool3s2_bwd', _lib.ptr(gP), _lib.ptr(self.mp_arg), 1, _lib.ptr(self.g_c1),
                   B, h1, w1, 64, h2, w2)
         self.stem_d.run(self.g_c1, self.g_in)
         return self.g_in
+
+    def refresh_masks(self):
+        """Recompute the gate masks from the activation buffers (after a test has overwritten the activations)."""
+        for blk in self.blocks:
+            blk['m_o1'].copy_(_lib.pack_gate_mask(blk['o1']))
+            blk['m_out'].copy_(_lib.pack_gate_mask(blk['out']))
 
     def flops_fwd(self):
         h, w = self.in_hw
@@ -248,7 +258,7 @@ class VGG16Body:
             op = self.ops[i]
             if op['kind'] == 'pool':
                 # input of a pool is a conv+ReLU output: gather + ReLU gate -> gradient w.r.t. that conv's pre-activation
-                _lib.call('spaa_maxpool_bwd', _lib.ptr(g), _lib.ptr(op['arg']), _lib.ptr(op['inp']), _lib.ptr(op['g']),
+                _lib.call('spaa_maxpool_bwd', _lib.ptr(g), _lib.ptr(op['arg']), 1, _lib.ptr(op['g']),
                           B, op['hin'], op['win'], op['c'], op['hin'] // 2, op['win'] // 2, 2, 2, 0, op['c'], 0)
             else:
                 prev = self.ops[i - 1] if i > 0 else None

@@ -130,9 +130,12 @@ class ConvPlan:
         self._ws = None  # split-K workspace, allocated on first use
 
     def run(self, inp, out, add=None, gate=None, gate_mode=_lib.GATE_POS, act=_lib.ACT_NONE, aux_out=None,
-            gate2=None, in_coff=0, out_coff=0, add_coff=0, gate_coff=0):
-        """inp: [B,Hin,Win,Cs_in], out: [B,Hout,Wout,Cs_out] NHWC float32 CUDA tensors."""
+            gate2=None, in_coff=0, out_coff=0, add_coff=0, gate_coff=0, mask_out=None, gate_bits=None, gate2_bits=None):
+        """inp: [B,Hin,Win,Cs_in], out: [B,Hout,Wout,Cs_out] NHWC float32 CUDA tensors.
+        `mask_out` / `gate_bits` / `gate2_bits`: uint8 [B,Hout,Wout,Cs/4] ReLU-gate masks (one byte per 4 channels,
+        include/spaa_hip.h): written for this launch's output resp. read instead of a float `gate` / `gate2`."""
         _lib.check_dev(inp, out, add, gate, aux_out, gate2)
+        _lib.check_mask(mask_out, gate_bits, gate2_bits)
         b, hin, win, cs_in = inp.shape
         b2, hout, wout, cs_out = out.shape
         assert b == b2 and cs_in % 4 == 0 and in_coff % 4 == 0 and in_coff + self.cin_p <= cs_in
@@ -162,6 +165,16 @@ class ConvPlan:
         if gate2 is not None:
             assert aux_out is not None and gate2.shape[:3] == out.shape[:3] and self.cout <= gate2.shape[3]
             d.gate2, d.gate2_cstride, d.gate2_coff = gate2.data_ptr(), gate2.shape[3], 0
+        masked = mask_out is not None or gate_bits is not None or gate2_bits is not None
+        if mask_out is not None:
+            assert mask_out.shape == out.shape[:3] + (cs_out // 4,), (mask_out.shape, out.shape)
+            d.mask_out = mask_out.data_ptr()
+        if gate_bits is not None:
+            assert gate is None and gate_bits.shape[:3] == out.shape[:3] and gate_coff + self.cout <= 4 * gate_bits.shape[3]
+            d.gate_bits, d.gate_cstride, d.gate_coff = gate_bits.data_ptr(), 4 * gate_bits.shape[3], gate_coff
+        if gate2_bits is not None:
+            assert gate2 is None and aux_out is not None and gate2_bits.shape[:3] == out.shape[:3] and self.cout <= 4 * gate2_bits.shape[3]
+            d.gate2_bits, d.gate2_cstride, d.gate2_coff = gate2_bits.data_ptr(), 4 * gate2_bits.shape[3], 0
         key = f'{self.cin_p}_{self.cout}_{self.ntaps_total}_{self.s_in}_{self.s_out}_{b * d.Hm * d.Wm}' + ('_fold' if self.nfold > 1 else '')
         forced = FORCE_TILE
         if forced == 9 and self.cout > 4:
@@ -207,6 +220,12 @@ class ConvPlan:
             d.ksplit, d.splitk_ws = 0, None
             if tile < 25:
                 raise ValueError('GATE_MUL needs a layer shape served by the DMA-staged kernels')
+        if masked and not (15 <= tile <= 27 or 30 <= tile <= 46 or 48 <= tile <= 54):
+            # byte masks live in the shared 4-channel epilogue (epilogue.hpp): thin / fp32-MFMA kernels do not have it
+            tile = self._default_tile(b * d.Hm * d.Wm) % 100
+            d.ksplit, d.splitk_ws = 0, None
+            if not (15 <= tile <= 27 or 30 <= tile <= 46 or 48 <= tile <= 54):
+                raise ValueError(f'{self.name}: gate masks need a layer shape served by the bf16x6 / smallcin kernels')
         d.tile = tile
         d.reserved0 = DEBUG_TAPMAJOR | (DEBUG_PERSIST_CAP << 8)  # measurement / test switches of the x6d kernels
         d.nclass = len(self.cls)
@@ -226,6 +245,7 @@ class ConvPlan:
             nbytes = 4 * (b * hin * win * self.cin_p + npx * self.cout * (1 + (add is not None) + (gate is not None)
                                                                          + (aux_out is not None) + (gate2 is not None))
                           + self.ntaps_total * self.cin_p * self.cout)
+            nbytes += npx * self.cout // 4 * ((mask_out is not None) + (gate_bits is not None) + (gate2_bits is not None))
             PROFILE.append((self.name, key, self.flops(b, hout, wout), e0, e1, d.tile + 100 * (d.ksplit if d.ksplit > 1 else (9 if d.ksplit == -1 else 0)), nbytes))
         return out
 

@@ -105,13 +105,18 @@ __global__ void maxpool_fwd_kernel(const float4* __restrict__ in, float4* __rest
             if (v.w > best.w || v.w != v.w) { best.w = v.w; am.w = k; }
         }
     }
+    // bit 7: the maximum is positive — the ReLU gate of the pooled tensor's producer, for the backward pass
+    am.x |= best.x > 0.f ? 0x80 : 0;
+    am.y |= best.y > 0.f ? 0x80 : 0;
+    am.z |= best.z > 0.f ? 0x80 : 0;
+    am.w |= best.w > 0.f ? 0x80 : 0;
     out[idx] = best;
     argmax[idx] = am;
 }
 
 // backward as a gather over the (at most 4) windows covering each input pixel; optional ReLU gate of the input
 __global__ void maxpool_bwd_kernel(const float4* __restrict__ g_out, const uchar4* __restrict__ argmax,
-                                   const float4* __restrict__ gate_in, float4* __restrict__ g_in, int B, int Hin,
+                                   const int relu_gate, float4* __restrict__ g_in, int B, int Hin,
                                    int Win, int C4, int Hout, int Wout) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * Hin * Win * C4) return;
@@ -122,6 +127,7 @@ __global__ void maxpool_bwd_kernel(const float4* __restrict__ g_out, const uchar
     const int iy = r % Hin;
     const int b = r / Hin;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned char need = relu_gate ? 0x80 : 0xff;  // relu_gate: only windows whose maximum is positive pass
     for (int ky = 0; ky < 3; ++ky) {
         const int t = iy + 1 - ky;
         if (t < 0 || (t & 1)) continue;
@@ -136,18 +142,11 @@ __global__ void maxpool_bwd_kernel(const float4* __restrict__ g_out, const uchar
             const uchar4 am = argmax[o];
             const float4 g = g_out[o];
             const unsigned char k = (unsigned char)(ky * 3 + kx);
-            if (am.x == k) acc.x += g.x;
-            if (am.y == k) acc.y += g.y;
-            if (am.z == k) acc.z += g.z;
-            if (am.w == k) acc.w += g.w;
+            if ((am.x & 0x7f) == k && (am.x & need)) acc.x += g.x;
+            if ((am.y & 0x7f) == k && (am.y & need)) acc.y += g.y;
+            if ((am.z & 0x7f) == k && (am.z & need)) acc.z += g.z;
+            if ((am.w & 0x7f) == k && (am.w & need)) acc.w += g.w;
         }
-    }
-    if (gate_in != nullptr) {
-        const float4 a = gate_in[idx];
-        acc.x = a.x > 0.f ? acc.x : 0.f;
-        acc.y = a.y > 0.f ? acc.y : 0.f;
-        acc.z = a.z > 0.f ? acc.z : 0.f;
-        acc.w = a.w > 0.f ? acc.w : 0.f;
     }
     g_in[idx] = acc;
 }
@@ -215,13 +214,13 @@ int spaa_maxpool3s2_fwd(const float* in, float* out, uint8_t* argmax, int B, int
     return (int)hipGetLastError();
 }
 
-int spaa_maxpool3s2_bwd(const float* g_out, const uint8_t* argmax, const float* gate_in, float* g_in, int B, int Hin,
+int spaa_maxpool3s2_bwd(const float* g_out, const uint8_t* argmax, int relu_gate, float* g_in, int B, int Hin,
                         int Win, int C, int Hout, int Wout, spaa_stream_t stream) {
     if (!g_out || !argmax || !g_in || (C & 3) || B < 1 || Hout != (Hin + 2 - 3) / 2 + 1 ||
         Wout != (Win + 2 - 3) / 2 + 1)
         return hipErrorInvalidValue;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk((int64_t)B * Hin * Win * (C / 4))), dim3(256), 0,
-                       (hipStream_t)stream, (const float4*)g_out, (const uchar4*)argmax, (const float4*)gate_in,
+                       (hipStream_t)stream, (const float4*)g_out, (const uchar4*)argmax, relu_gate,
                        (float4*)g_in, B, Hin, Win, C / 4, Hout, Wout);
     return (int)hipGetLastError();
 }

@@ -44,12 +44,23 @@ __device__ __forceinline__ void store4(const spaa_tapconv_t& p, const size_t o, 
                 const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (ga[e] > 0.f && ga[e] <= 1.f) : (ga[e] > 0.f);
                 v[e] = (p.gate_mode == SPAA_GATE_MUL) ? v[e] * ga[e] : (pass ? v[e] : 0.f);
             }
+        } else if (p.gate_bits != nullptr) {  // the same ReLU gate as 1 byte per 4 channels (written through mask_out)
+            const unsigned int mb = p.gate_bits[(o * p.gate_cstride + p.gate_coff + n0) >> 2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((mb >> e) & 1u) ? v[e] : 0.f;
         }
         *reinterpret_cast<f4*>(outp) = f4{v[0], v[1], v[2], v[3]};
+        if (p.mask_out != nullptr)
+            p.mask_out[(o * p.out_cstride + p.out_coff + n0) >> 2] =
+                (uint8_t)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
         if (p.gate2 != nullptr) {
             const f4 gg = *reinterpret_cast<const f4*>(p.gate2 + o * p.gate2_cstride + p.gate2_coff + n0);
             *reinterpret_cast<f4*>(p.aux_out + o * p.out_cstride + p.out_coff + n0) =
                 f4{gg.x > 0.f ? v[0] : 0.f, gg.y > 0.f ? v[1] : 0.f, gg.z > 0.f ? v[2] : 0.f, gg.w > 0.f ? v[3] : 0.f};
+        } else if (p.gate2_bits != nullptr) {
+            const unsigned int mb = p.gate2_bits[(o * p.gate2_cstride + p.gate2_coff + n0) >> 2];
+            *reinterpret_cast<f4*>(p.aux_out + o * p.out_cstride + p.out_coff + n0) =
+                f4{(mb & 1u) ? v[0] : 0.f, (mb & 2u) ? v[1] : 0.f, (mb & 4u) ? v[2] : 0.f, (mb & 8u) ? v[3] : 0.f};
         }
     } else {
 #pragma unroll

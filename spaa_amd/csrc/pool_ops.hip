@@ -41,12 +41,17 @@ __global__ void maxpool_fwd_kernel(const float4* __restrict__ in, float4* __rest
             if (v.w > best.w || v.w != v.w) { best.w = v.w; am.w = kk; }
         }
     }
+    // bit 7: the maximum is positive — the ReLU gate of the pooled tensor's producer, for the backward pass
+    am.x |= best.x > 0.f ? 0x80 : 0;
+    am.y |= best.y > 0.f ? 0x80 : 0;
+    am.z |= best.z > 0.f ? 0x80 : 0;
+    am.w |= best.w > 0.f ? 0x80 : 0;
     out[(((size_t)b * g.Hout + oy) * g.Wout + ox) * out_c4stride + out_c4off + c] = best;
     argmax[idx] = am;
 }
 
 __global__ void maxpool_bwd_kernel(const float4* __restrict__ g_out, const uchar4* __restrict__ argmax,
-                                   const float4* __restrict__ gate_in, float4* __restrict__ g_in, Geo g,
+                                   const int relu_gate, float4* __restrict__ g_in, Geo g,
                                    int gout_c4stride, int gout_c4off) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= g.B * g.Hin * g.Win * g.C4) return;
@@ -57,6 +62,7 @@ __global__ void maxpool_bwd_kernel(const float4* __restrict__ g_out, const uchar
     const int iy = r % g.Hin;
     const int b = r / g.Hin;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned char need = relu_gate ? 0x80 : 0xff;  // relu_gate: only windows whose maximum is positive pass
     for (int ky = 0; ky < g.k; ++ky) {
         const int t = iy + g.p - ky;
         if (t < 0 || (t % g.s)) continue;
@@ -71,18 +77,11 @@ __global__ void maxpool_bwd_kernel(const float4* __restrict__ g_out, const uchar
             const uchar4 am = argmax[opix * g.C4 + c];
             const float4 go = g_out[opix * gout_c4stride + gout_c4off + c];
             const unsigned char kk = (unsigned char)(ky * g.k + kx);
-            if (am.x == kk) acc.x += go.x;
-            if (am.y == kk) acc.y += go.y;
-            if (am.z == kk) acc.z += go.z;
-            if (am.w == kk) acc.w += go.w;
+            if ((am.x & 0x7f) == kk && (am.x & need)) acc.x += go.x;
+            if ((am.y & 0x7f) == kk && (am.y & need)) acc.y += go.y;
+            if ((am.z & 0x7f) == kk && (am.z & need)) acc.z += go.z;
+            if ((am.w & 0x7f) == kk && (am.w & need)) acc.w += go.w;
         }
-    }
-    if (gate_in != nullptr) {
-        const float4 a = gate_in[idx];
-        acc.x = a.x > 0.f ? acc.x : 0.f;
-        acc.y = a.y > 0.f ? acc.y : 0.f;
-        acc.z = a.z > 0.f ? acc.z : 0.f;
-        acc.w = a.w > 0.f ? acc.w : 0.f;
     }
     g_in[idx] = acc;
 }
@@ -222,7 +221,7 @@ int spaa_maxpool_fwd(const float* in, float* out, uint8_t* argmax, int B, int Hi
     return (int)hipGetLastError();
 }
 
-int spaa_maxpool_bwd(const float* g_out, const uint8_t* argmax, const float* gate_in, float* g_in, int B, int Hin,
+int spaa_maxpool_bwd(const float* g_out, const uint8_t* argmax, int relu_gate, float* g_in, int B, int Hin,
                      int Win, int C, int Hout, int Wout, int k, int s, int p, int gout_cstride, int gout_coff,
                      spaa_stream_t stream) {
     if (!g_out || !argmax || !g_in || !geo_ok(B, Hin, Win, C, Hout, Wout, k, s, p) || (gout_cstride & 3) ||
@@ -230,7 +229,7 @@ int spaa_maxpool_bwd(const float* g_out, const uint8_t* argmax, const float* gat
         return hipErrorInvalidValue;
     Geo g{B, Hin, Win, C / 4, Hout, Wout, k, s, p};
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nb((int64_t)B * Hin * Win * g.C4)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)g_out, (const uchar4*)argmax, (const float4*)gate_in, (float4*)g_in, g,
+                       (const float4*)g_out, (const uchar4*)argmax, relu_gate, (float4*)g_in, g,
                        gout_cstride / 4, gout_coff / 4);
     return (int)hipGetLastError();
 }

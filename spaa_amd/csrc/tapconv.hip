@@ -531,6 +531,20 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         return hipErrorInvalidValue;
     if (d.Cout <= 0 || d.out_coff + d.Cout > d.out_cstride) return hipErrorInvalidValue;
     if (d.gate2 != nullptr && (d.aux_out == nullptr || d.act == SPAA_ACT_RELU_CLAMP1)) return hipErrorInvalidValue;
+    if (d.mask_out != nullptr || d.gate_bits != nullptr || d.gate2_bits != nullptr) {
+        // byte masks (1 byte per 4 channels): only the epilogues built on epilogue.hpp's store4 know them, and only in its
+        // 4-channel-vector form
+        const int t = d.tile;
+        if (!((t >= 15 && t <= 27) || (t >= 30 && t <= 46) || (t >= 48 && t <= 54))) return hipErrorInvalidValue;
+        if ((d.Cout | d.out_cstride | d.out_coff) & 3) return hipErrorInvalidValue;
+        if (d.add != nullptr && ((d.add_cstride | d.add_coff) & 3)) return hipErrorInvalidValue;
+        if (d.gate_bits != nullptr && (d.gate != nullptr || ((d.gate_cstride | d.gate_coff) & 3))) return hipErrorInvalidValue;
+        if (d.gate2_bits != nullptr && (d.gate2 != nullptr || d.aux_out == nullptr || d.act == SPAA_ACT_RELU_CLAMP1 ||
+                                        ((d.gate2_cstride | d.gate2_coff) & 3)))
+            return hipErrorInvalidValue;
+        if (d.gate != nullptr && ((d.gate_cstride | d.gate_coff) & 3)) return hipErrorInvalidValue;
+        if (d.gate2 != nullptr && ((d.gate2_cstride | d.gate2_coff) & 3)) return hipErrorInvalidValue;
+    }
     if (d.nclass < 1 || d.nclass > SPAA_MAX_CLASSES || d.B <= 0 || d.Hm <= 0 || d.Wm <= 0) return hipErrorInvalidValue;
     if (d.s_in < 1 || d.s_out < 1) return hipErrorInvalidValue;
     for (int c = 0; c < d.nclass; ++c) {

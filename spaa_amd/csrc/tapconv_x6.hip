@@ -19,6 +19,7 @@
 #include "launch_util.hpp"
 #include <stdint.h>
 #include "../../include/spaa_hip.h"
+#include "epilogue.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -511,73 +512,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_x6v2_kernel(const spaa_tapconv
                     if (NG == 3) t += acc[NG > 1 ? 1 : 0][i][j][r] + acc[NG > 2 ? 2 : 0][i][j][r];
                     v[e] = t;
                 }
-                if (vec) {
-                    if (p.bias != nullptr) {
-                        const f4 bb = *reinterpret_cast<const f4*>(p.bias + n0);
-                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                    }
-                    if (p.add != nullptr) {
-                        const f4 aa = *reinterpret_cast<const f4*>(p.add + o * p.add_cstride + p.add_coff + n0);
-                        v[0] += aa.x; v[1] += aa.y; v[2] += aa.z; v[3] += aa.w;
-                    }
-                    float* outp = p.out + o * p.out_cstride + p.out_coff + n0;
-                    if (p.act == SPAA_ACT_RELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    } else if (p.act == SPAA_ACT_RELU_CLAMP1) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                        if (p.aux_out != nullptr)
-                            *reinterpret_cast<f4*>(p.aux_out + o * p.out_cstride + p.out_coff + n0) = f4{v[0], v[1], v[2], v[3]};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fminf(v[e], 1.f);
-                    } else if (p.act == SPAA_ACT_LEAKY01) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.1f * v[e];
-                    }
-                    if (p.gate != nullptr) {
-                        const f4 gg = *reinterpret_cast<const f4*>(p.gate + o * p.gate_cstride + p.gate_coff + n0);
-                        const float ga[4] = {gg.x, gg.y, gg.z, gg.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (ga[e] > 0.f && ga[e] <= 1.f) : (ga[e] > 0.f);
-                            v[e] = pass ? v[e] : 0.f;
-                        }
-                    }
-                    *reinterpret_cast<f4*>(outp) = f4{v[0], v[1], v[2], v[3]};
-                    if (p.gate2 != nullptr) {
-                        const f4 gg = *reinterpret_cast<const f4*>(p.gate2 + o * p.gate2_cstride + p.gate2_coff + n0);
-                        *reinterpret_cast<f4*>(p.aux_out + o * p.out_cstride + p.out_coff + n0) =
-                            f4{gg.x > 0.f ? v[0] : 0.f, gg.y > 0.f ? v[1] : 0.f, gg.z > 0.f ? v[2] : 0.f, gg.w > 0.f ? v[3] : 0.f};
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int n = n0 + e;
-                        if (n >= p.Cout) continue;
-                        float t = v[e] + (p.bias != nullptr ? p.bias[n] : 0.f);
-                        if (p.add != nullptr) t += p.add[o * p.add_cstride + p.add_coff + n];
-                        if (p.act == SPAA_ACT_RELU) {
-                            t = fmaxf(t, 0.f);
-                        } else if (p.act == SPAA_ACT_RELU_CLAMP1) {
-                            t = fmaxf(t, 0.f);
-                            if (p.aux_out != nullptr) p.aux_out[o * p.out_cstride + p.out_coff + n] = t;
-                            t = fminf(t, 1.f);
-                        } else if (p.act == SPAA_ACT_LEAKY01) {
-                            t = t > 0.f ? t : 0.1f * t;
-                        }
-                        if (p.gate != nullptr) {
-                            const float gv = p.gate[o * p.gate_cstride + p.gate_coff + n];
-                            const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (gv > 0.f && gv <= 1.f) : (gv > 0.f);
-                            t = pass ? t : 0.f;
-                        }
-                        p.out[o * p.out_cstride + p.out_coff + n] = t;
-                        if (p.gate2 != nullptr) {
-                            const float g2 = p.gate2[o * p.gate2_cstride + p.gate2_coff + n];
-                            p.aux_out[o * p.out_cstride + p.out_coff + n] = (g2 > 0.f) ? t : 0.f;
-                        }
-                    }
-                }
+                store4(p, o, n0, v, vec);  // bias + residual + activation + gates (epilogue.hpp)
             }
         }
     }
@@ -837,73 +772,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_x6v3_kernel(const spaa_tapconv
                     if (NG == 3) t += acc[NG > 1 ? 1 : 0][i][j][r] + acc[NG > 2 ? 2 : 0][i][j][r];
                     v[e] = t;
                 }
-                if (vec) {
-                    if (p.bias != nullptr) {
-                        const f4 bb = *reinterpret_cast<const f4*>(p.bias + n0);
-                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                    }
-                    if (p.add != nullptr) {
-                        const f4 aa = *reinterpret_cast<const f4*>(p.add + o * p.add_cstride + p.add_coff + n0);
-                        v[0] += aa.x; v[1] += aa.y; v[2] += aa.z; v[3] += aa.w;
-                    }
-                    float* outp = p.out + o * p.out_cstride + p.out_coff + n0;
-                    if (p.act == SPAA_ACT_RELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    } else if (p.act == SPAA_ACT_RELU_CLAMP1) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                        if (p.aux_out != nullptr)
-                            *reinterpret_cast<f4*>(p.aux_out + o * p.out_cstride + p.out_coff + n0) = f4{v[0], v[1], v[2], v[3]};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fminf(v[e], 1.f);
-                    } else if (p.act == SPAA_ACT_LEAKY01) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.1f * v[e];
-                    }
-                    if (p.gate != nullptr) {
-                        const f4 gg = *reinterpret_cast<const f4*>(p.gate + o * p.gate_cstride + p.gate_coff + n0);
-                        const float ga[4] = {gg.x, gg.y, gg.z, gg.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (ga[e] > 0.f && ga[e] <= 1.f) : (ga[e] > 0.f);
-                            v[e] = pass ? v[e] : 0.f;
-                        }
-                    }
-                    *reinterpret_cast<f4*>(outp) = f4{v[0], v[1], v[2], v[3]};
-                    if (p.gate2 != nullptr) {
-                        const f4 gg = *reinterpret_cast<const f4*>(p.gate2 + o * p.gate2_cstride + p.gate2_coff + n0);
-                        *reinterpret_cast<f4*>(p.aux_out + o * p.out_cstride + p.out_coff + n0) =
-                            f4{gg.x > 0.f ? v[0] : 0.f, gg.y > 0.f ? v[1] : 0.f, gg.z > 0.f ? v[2] : 0.f, gg.w > 0.f ? v[3] : 0.f};
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int n = n0 + e;
-                        if (n >= p.Cout) continue;
-                        float t = v[e] + (p.bias != nullptr ? p.bias[n] : 0.f);
-                        if (p.add != nullptr) t += p.add[o * p.add_cstride + p.add_coff + n];
-                        if (p.act == SPAA_ACT_RELU) {
-                            t = fmaxf(t, 0.f);
-                        } else if (p.act == SPAA_ACT_RELU_CLAMP1) {
-                            t = fmaxf(t, 0.f);
-                            if (p.aux_out != nullptr) p.aux_out[o * p.out_cstride + p.out_coff + n] = t;
-                            t = fminf(t, 1.f);
-                        } else if (p.act == SPAA_ACT_LEAKY01) {
-                            t = t > 0.f ? t : 0.1f * t;
-                        }
-                        if (p.gate != nullptr) {
-                            const float gv = p.gate[o * p.gate_cstride + p.gate_coff + n];
-                            const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (gv > 0.f && gv <= 1.f) : (gv > 0.f);
-                            t = pass ? t : 0.f;
-                        }
-                        p.out[o * p.out_cstride + p.out_coff + n] = t;
-                        if (p.gate2 != nullptr) {
-                            const float g2 = p.gate2[o * p.gate2_cstride + p.gate2_coff + n];
-                            p.aux_out[o * p.out_cstride + p.out_coff + n] = (g2 > 0.f) ? t : 0.f;
-                        }
-                    }
-                }
+                store4(p, o, n0, v, vec);  // bias + residual + activation + gates (epilogue.hpp)
             }
         }
     }

@@ -254,7 +254,7 @@ class InceptionV3Body:
                 ho, wo = o.hw
                 if op['kind'] == 'max':
                     _lib.call('spaa_maxpool_bwd', _lib.ptr(o.gbuf), _lib.ptr(op['arg']),
-                              _lib.ptr(gate) if gate is not None else None, _lib.ptr(i.gbuf), B, hin, win, i.c, ho, wo,
+                              int(gate is not None), _lib.ptr(i.gbuf), B, hin, win, i.c, ho, wo,
                               op['k'], op['s'], op['p'], o.gbuf.shape[3], o.coff)
                 else:
                     assert gate is None, 'avg-pool is never the only consumer in Inception-v3'

@@ -321,6 +321,11 @@ class PCNetEngine:
         a['X6'], a['X7'] = z(B, H2, W2, 64), z(B, H, W, 32)
         a['Y'], a['Ypre'], a['R1'] = z(B, H, W, 4), z(B, H, W, 4), z(B, H, W, 4)
         self.a = a
+        # ReLU gates of the activations, one byte per 4 channels (include/spaa_hip.h: mask_out / gate_bits): written by
+        # the forward launches' epilogues, read by the input-gradient launches instead of the fp32 activations (for X7
+        # alone that is 34 MB instead of 537 MB per backward pass at batch 64)
+        self.m = {k: torch.zeros(*a[k].shape[:3], a[k].shape[3] // 4, dtype=torch.uint8, device=dev)
+                  for k in ('S1', 'S2', 'S3', 'S4', 'X1', 'X2', 'X3', 'X4', 'X5', 'X6', 'X7')}
         g = {}
         g['P7'], g['P6'], g['P5'], g['P4'] = z(B, H, W, 32), z(B, H2, W2, 64), z(B, H4, W4, 128), z(B, H4, W4, 256)
         g['S4'], g['P3'], g['t2'], g['P2'] = z(B, H4, W4, 256), z(B, H4, W4, 128), z(B, H4, W4, 64), z(B, H4, W4, 64)
@@ -363,44 +368,50 @@ class PCNetEngine:
         R, N = _lib.ACT_RELU, _lib.ACT_NONE
         self.version += 1
         self.warp(x4, clamp01)
-        f['conv1_s'].run(a['cat8'], a['S1'], act=R)
-        f['conv2_s'].run(a['S1'], a['S2'], act=R)
-        f['conv3_s'].run(a['S2'], a['S3'], act=R)
-        f['conv4_s'].run(a['S3'], a['S4'], act=R)
-        f['conv1'].run(a['xw'], a['X1'], add=a['S1'], act=R)
+        m = self.m
+        f['conv1_s'].run(a['cat8'], a['S1'], act=R, mask_out=m['S1'])
+        f['conv2_s'].run(a['S1'], a['S2'], act=R, mask_out=m['S2'])
+        f['conv3_s'].run(a['S2'], a['S3'], act=R, mask_out=m['S3'])
+        f['conv4_s'].run(a['S3'], a['S4'], act=R, mask_out=m['S4'])
+        f['conv1'].run(a['xw'], a['X1'], add=a['S1'], act=R, mask_out=m['X1'])
         f['skipConv2'].run(a['X1'], a['R2'], act=N)
-        f['conv2'].run(a['X1'], a['X2'], add=a['S2'], act=R)
+        f['conv2'].run(a['X1'], a['X2'], add=a['S2'], act=R, mask_out=m['X2'])
         f['skipConv3'].run(a['X2'], a['R3'], act=N)
-        f['conv3'].run(a['X2'], a['X3'], add=a['S3'], act=R)
-        f['conv4'].run(a['X3'], a['X4'], add=a['S4'], act=R)
-        f['conv5'].run(a['X4'], a['X5'], add=a['R3'], act=R)
-        f['transConv1'].run(a['X5'], a['X6'], add=a['R2'], act=R)
-        f['transConv2'].run(a['X6'], a['X7'], act=R)
+        f['conv3'].run(a['X2'], a['X3'], add=a['S3'], act=R, mask_out=m['X3'])
+        f['conv4'].run(a['X3'], a['X4'], add=a['S4'], act=R, mask_out=m['X4'])
+        f['conv5'].run(a['X4'], a['X5'], add=a['R3'], act=R, mask_out=m['X5'])
+        f['transConv1'].run(a['X5'], a['X6'], add=a['R2'], act=R, mask_out=m['X6'])
+        f['transConv2'].run(a['X6'], a['X7'], act=R, mask_out=m['X7'])
         f['conv6'].run(a['X7'], a['Y'], add=a['R1'], act=_lib.ACT_RELU_CLAMP1, aux_out=a['Ypre'])
         return a['Y']
 
     def backward(self, gP):
         """gP: gradient w.r.t. conv6's pre-activation (already gated by 0 < Ypre <= 1), [B,Hc,Wc,4].
         Returns the gradient w.r.t. the projector image x4 [B,Hp,Wp,4] (workspace)."""
-        a, g, d = self.a, self.g, self.d
-        d['conv6'].run(gP, g['P7'], gate=a['X7'])
-        d['transConv2'].run(g['P7'], g['P6'], gate=a['X6'])
-        d['transConv1'].run(g['P6'], g['P5'], gate=a['X5'])
-        d['conv5'].run(g['P5'], g['P4'], gate=a['X4'], aux_out=g['S4'], gate2=a['S4'])
-        d['conv4'].run(g['P4'], g['P3'], gate=a['X3'])
+        g, d, m = self.g, self.d, self.m
+        d['conv6'].run(gP, g['P7'], gate_bits=m['X7'])
+        d['transConv2'].run(g['P7'], g['P6'], gate_bits=m['X6'])
+        d['transConv1'].run(g['P6'], g['P5'], gate_bits=m['X5'])
+        d['conv5'].run(g['P5'], g['P4'], gate_bits=m['X4'], aux_out=g['S4'], gate2_bits=m['S4'])
+        d['conv4'].run(g['P4'], g['P3'], gate_bits=m['X3'])
         d['skipConv3'].run(g['P5'], g['t2'])
-        d['conv3'].run(g['P3'], g['P2'], add=g['t2'], gate=a['X2'])
+        d['conv3'].run(g['P3'], g['P2'], add=g['t2'], gate_bits=m['X2'])
         d['skipConv2'].run(g['P6'], g['t1'])
-        d['conv2'].run(g['P2'], g['P1'], add=g['t1'], gate=a['X1'])
+        d['conv2'].run(g['P2'], g['P1'], add=g['t1'], gate_bits=m['X1'])
         # surface branch (depends on x through the rough input x*s)
-        d['conv4_s'].run(g['S4'], g['S3'], add=g['P3'], gate=a['S3'])
-        d['conv3_s'].run(g['S3'], g['S2'], add=g['P2'], gate=a['S2'])
-        d['conv2_s'].run(g['S2'], g['S1'], add=g['P1'], gate=a['S1'])
+        d['conv4_s'].run(g['S4'], g['S3'], add=g['P3'], gate_bits=m['S3'])
+        d['conv3_s'].run(g['S3'], g['S2'], add=g['P2'], gate_bits=m['S2'])
+        d['conv2_s'].run(g['S2'], g['S1'], add=g['P1'], gate_bits=m['S1'])
         # the two 3-channel gradients meet at the warped image: d/d(x_w) = g_direct + g_rough * s (models.py:342); the
         # product and the sum are epilogues of the two thin convolutions instead of extra reads in the gather
         d['conv1_s'].run(g['S1'], g['xs'], gate=self.scene, gate_mode=_lib.GATE_MUL)
         d['conv1'].run(g['P1'], g['xw'], add=g['xs'])
         return self.warp_backward(g['xw'])
+
+    def refresh_masks(self):
+        """Recompute the gate masks from the activation buffers (after a test has overwritten the activations)."""
+        for k, mk in self.m.items():
+            mk.copy_(_lib.pack_gate_mask(self.a[k]))
 
     def warp_backward(self, g_xw):
         """Adjoint of the masked grid_sample (models.py:184,340): deterministic gather over the transposed tap lists; the

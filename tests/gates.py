@@ -22,8 +22,9 @@ def _nhwc(o, cpad=None):
     return t
 
 
-def _argmax_codes(idx, hin_win, k, s, p):
-    """F.max_pool2d(return_indices=True) flat input indices [B,C,Ho,Wo] -> the HIP kernels' window codes ky*k+kx, NHWC uint8."""
+def _argmax_codes(idx, pooled_in, hin_win, k, s, p):
+    """F.max_pool2d(return_indices=True) flat input indices [B,C,Ho,Wo] (+ the pooled tensor's input, a ReLU output) ->
+    the HIP kernels' argmax bytes, NHWC uint8: window code ky*k+kx in bits 0-6, bit 7 = (maximum > 0)."""
     hin, win = hin_win
     b, c, ho, wo = idx.shape
     iy, ix = idx // win, idx % win
@@ -31,7 +32,8 @@ def _argmax_codes(idx, hin_win, k, s, p):
     ox = torch.arange(wo).view(1, 1, 1, wo)
     code = (iy - (oy * s - p)) * k + (ix - (ox * s - p))
     assert int(code.min()) >= 0 and int(code.max()) < k * k
-    return code.permute(0, 2, 3, 1).contiguous().to(torch.uint8)
+    pos = pooled_in.flatten(2).gather(2, idx.flatten(2)).view_as(idx) > 0
+    return (code + 128 * pos).permute(0, 2, 3, 1).contiguous().to(torch.uint8)
 
 
 def pcnet_pairs(eng, acts):
@@ -46,7 +48,7 @@ def pcnet_pairs(eng, acts):
 def resnet18_pairs(body, cacts):
     out = [('resnet.c1', 'relu', body.c1, _nhwc(cacts['c1']))]
     out.append(('resnet.maxpool', 'argmax', body.mp_arg,
-                _argmax_codes(cacts['mp_idx'], body.c1.shape[1:3], 3, 2, 1)))
+                _argmax_codes(cacts['mp_idx'], cacts['c1'], body.c1.shape[1:3], 3, 2, 1)))
     for blk in body.blocks:
         out.append((f'resnet.{blk["name"]}.o1', 'relu', blk['o1'], _nhwc(cacts[blk['name'] + '.o1'])))
         out.append((f'resnet.{blk["name"]}.out', 'relu', blk['out'], _nhwc(cacts[blk['name'] + '.out'])))
@@ -61,7 +63,7 @@ def vgg16_pairs(body, cacts):
             nc += 1
         else:
             out.append((f'vgg.pool{npool}', 'argmax', op['arg'],
-                        _argmax_codes(cacts[f'pool{npool}'], (op['hin'], op['win']), 2, 2, 0)))
+                        _argmax_codes(cacts[f'pool{npool}'], cacts[f'conv{nc - 1}'], (op['hin'], op['win']), 2, 2, 0)))
             npool += 1
     out.append(('vgg.fc1', 'relu', body.h1, _nhwc(cacts['fc1'])))
     out.append(('vgg.fc2', 'relu', body.h2, _nhwc(cacts['fc2'])))
@@ -99,8 +101,11 @@ def count_flips(pairs, near_zero=2e-4, value_tol=2e-4):
     return flips, per_layer
 
 
-def inject(pairs):
+def inject(pairs, engines=()):
     """Copy the oracle's activations / arg-maxes into the HIP engine's buffers (they agree to rounding: only the gates
-    that sit within rounding of zero change)."""
+    that sit within rounding of zero change), then let the engines rebuild the byte masks their backward passes read."""
     for name, kind, hip, orc in pairs:
         hip.copy_(orc.to(hip.dtype).to(hip.device))
+    for e in engines:
+        if hasattr(e, 'refresh_masks'):
+            e.refresh_masks()

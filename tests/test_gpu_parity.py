@@ -390,7 +390,7 @@ def test_spaa_teacher_forced_iterations(hip, golden_dir, name):
                 assert ((stt[:, 0] == t['succ']) | edge).all() and ((stt[:, 1] == t['best_adv']) | edge).all(), (k, 'masks')
                 same = torch.from_numpy(stt[:, 1] == t['best_adv'])
             else:
-                gates.inject(pairs)
+                gates.inject(pairs, (st.eng, st.clf.body))
             st.backward_step(2, 1)
             xn = M.to_nchw(st.x).cpu()
             results[mode] = torch.tensor([rel_inf(xn[b], ref[b]) for b in range(B)])
@@ -427,14 +427,13 @@ def test_spaa_exact_cases_and_quirks(hip, golden_dir):
     assert not st[:, :, 0].any() and (st[:3, :, 3] == z['top1'][:3]).all()
     for name in ('spaa_64_untargeted', 'spaa_64_near', 'spaa_256_untargeted'):
         z = load(golden_dir, name)
-        sd, pc, clf, oclf, scene, setup = _setup_case(hip, z)
-        s = A.AttackState(pc, clf, [int(t) for t in z['targets']], scene, str(z['stealth']), setup, DEV)
-        s.iteration(bool(z['targeted']), float(z['d_thr']), 2, 1, 0.9)
-        k = z['prj_adv_it0'].shape[0]
-        x1, ref1 = hip['models'].to_nchw(s.x)[:k].cpu(), torch.from_numpy(z['prj_adv_it0'])
-        # 1e-6 when no ReLU unit sits within rounding of zero; a gate flip moves a few pixels by ~1e-3
-        assert rel_inf(x1, ref1) < 5e-3 and rel_l2(x1 - 0.5, ref1 - 0.5) < 5e-3, name
-        assert (s.state[:, 3].cpu().numpy() == z['top1'][0]).all()
+        sz = tuple(int(v) for v in z['sz'])
+        st1 = _first_iteration_gate_aware(hip, 'resnet18', syn.resnet18_state_dict(2, logit_gain=float(z['gain'])),
+                                          tuple(int(v) for v in z['input_sz']), sz, tuple(int(v) for v in z['crop']),
+                                          [int(t) for t in z['targets']], int(z['seed']), mask=str(z['mask']),
+                                          targeted=bool(z['targeted']), scene_seed=int(z['scene_seed']),
+                                          d_thr=float(z['d_thr']), stealth=str(z['stealth']), golden_it0=z['prj_adv_it0'])
+        assert (st1.state[:, 3].cpu().numpy() == z['top1'][0]).all()
     # B < 8 targeted works (the reference raises IndexError: Q10), and a [B,3,H,W] scene batch is accepted (Q9)
     z = load(golden_dir, 'spaa_64_near')
     sd, pc, clf, oclf, scene, setup = _setup_case(hip, z)
@@ -578,7 +577,7 @@ def test_perc_al_adversary_projector(hip, golden_dir, targeted, confidence):
     assert (st0[:, 0].cpu().numpy().astype(bool) == o0['isadv'].numpy()).all()
     print(f'PerC-AL targeted={targeted} conf={confidence}: delta rel Linf after it 0/1/2 = '
           f'{[round(rel_inf(tr[k][2], otr[k]["delta"]), 6) for k in range(3)]}')
-    assert rel_inf(tr[2][2], otr[2]['delta']) < 5e-2
+    assert rel_inf(tr[2][2], otr[2]['delta']) < 1e-4   # (measured 2e-6 ... 3.4e-5: profiles/r02_parity.txt)
     # (the 50-iteration result itself is chaotic, like spaa(): see test_reference_sensitivity_envelope)
     ref = torch.from_numpy(z['x_adv_best'])
     assert ref.shape == out.shape
@@ -856,37 +855,14 @@ def test_persistent_launch_walks_several_tiles(hip, tile):
                                                   ((64, 96), (80, 112), 2, 'ones')])
 def test_first_iteration_other_sizes(hip, cam_sz, prj_sz, b, mask):
     """The whole loop body at sizes the tune table has never seen (kernels chosen by ConvPlan._default_tile), non-square
-    images, projector size != camera size: the first iteration from identical state against the oracle (<= 1e-4
-    relative L_inf on the updated projector image, BASELINE.json's bar; later iterations are chaotic)."""
-    from spaa_amd.projector_based_attack import AttackState
-    sd = syn.pcnet_state_dict(3, cam_sz=cam_sz, mask=mask)
+    images, projector size != camera size: the first iteration from identical state against the oracle, gate-aware:
+    <= 1e-4 relative L_inf on the updated projector image (BASELINE.json's bar) for every sample whose gates agree, and
+    for every sample with the oracle's gates."""
     csd = syn.resnet18_state_dict(2, logit_gain=20.0)
     crop = (cam_sz[0] - 8, cam_sz[0] - 8) if cam_sz[0] <= cam_sz[1] else (cam_sz[1] - 8, cam_sz[1] - 8)
     insz = (crop[0] - 8, crop[1] - 8)
-    scene = syn.scenes(7, 1, cam_sz)
-    setup = dict(classifier_crop_sz=crop, prj_brightness=0.5, prj_im_sz=prj_sz)
-    targets = [204, 291, 7, 950][:b]
-    pc = make_pcnet(hip, sd, cam_sz)
-    clf = hip['clf'].Classifier('resnet18', DEV, state_dict=csd, input_sz=insz)
-    st = AttackState(pc, clf, targets, scene, 'camdE_caml2', setup, DEV)
-    st.iteration(True, 5, 2, 1, 0.9)
-    x1 = hip['models'].to_nchw(st.x).cpu()
-    tr = []
-    so.spaa(sd, so.OracleClassifier('resnet18', csd, input_sz=insz), targets, True, scene, 5, 'camdE_caml2', setup,
-            iters=1, trace=tr)
-    ref = torch.from_numpy(tr[0]['prj_adv'])
-    assert x1.shape == ref.shape == (b, 3) + tuple(prj_sz)
-    err = rel_inf(x1, ref)
-    # forward of the same iteration: camera image the loop just evaluated (identical input -> rounding-level agreement)
-    y_err = rel_inf(hip['models'].to_nchw(st.eng.a['Y']).cpu(), torch.from_numpy(tr[0]['cam_infer']))
-    out_frac = outlier_fraction(x1 - 0.5, ref - 0.5, 1e-4)
-    print(f'first iteration at cam {cam_sz} prj {prj_sz}: projector image rel Linf {err:.2e} (elements off by > 1e-4: '
-          f'{out_frac:.2e}), camera image rel Linf {y_err:.2e}')
-    assert y_err < 1e-5
-    # the update is a normalised gradient step: <= 1e-4 unless a ReLU gate within rounding of zero falls on the other
-    # side (then the elements in that unit's receptive field differ: sparse, bounded; see DESIGN.md section 4)
-    assert err < 1e-4 or (err < 5e-3 and out_frac < 2e-2)
-
+    _first_iteration_gate_aware(hip, 'resnet18', csd, insz, cam_sz, crop, [204, 291, 7, 950][:b], 3, prj_sz=prj_sz, mask=mask,
+                                scene_seed=7)
 
 # ---------------------------------------------------------------------------------------------------------------
 # round 2: reference-pinned preprocessing (a6/a7), loop-level runs with the other classifier bodies (configs[2], [4]),
@@ -1055,21 +1031,27 @@ def test_spaa_accepts_a_foreign_classifier(hip, golden_dir):
     assert cam1.shape == (1, 3, 64, 64) and torch.isfinite(prj1).all()
 
 
-def _first_iteration_gate_aware(hip, body, csd, insz, im_sz, crop, targets, seed):
-    """First iteration of the fused loop with another classifier body vs the oracle, gate-aware (tests/gates.py)."""
+def _first_iteration_gate_aware(hip, body, csd, insz, im_sz, crop, targets, seed, prj_sz=None, mask='ones', targeted=True,
+                                scene_seed=None, d_thr=5, stealth='camdE_caml2', golden_it0=None):
+    """First iteration of the fused loop vs the oracle, gate-aware (tests/gates.py): 1e-4 on every sample whose gates agree
+    with the oracle's, and on every sample with the oracle's gates in the HIP backward."""
     import gates
     A, M = hip['attack'], hip['models']
-    sd = syn.pcnet_state_dict(seed, cam_sz=im_sz, mask='ones')
+    prj_sz = tuple(prj_sz) if prj_sz is not None else tuple(im_sz)
+    sd = syn.pcnet_state_dict(seed, cam_sz=im_sz, mask=mask)
     pc = make_pcnet(hip, sd, im_sz)
     clf = hip['clf'].Classifier(body, DEV, state_dict=csd, input_sz=insz)
-    scene = syn.scenes(seed + 1, 1, im_sz)
-    setup = dict(classifier_crop_sz=crop, prj_brightness=0.5, prj_im_sz=im_sz)
+    scene = syn.scenes(seed + 1 if scene_seed is None else scene_seed, 1, im_sz)
+    setup = dict(classifier_crop_sz=crop, prj_brightness=0.5, prj_im_sz=prj_sz)
     B = len(targets)
     tr = []
-    so.spaa(sd, so.OracleClassifier(body, csd, input_sz=insz), targets, True, scene, 5, 'camdE_caml2', setup, iters=1, trace=tr)
+    so.spaa(sd, so.OracleClassifier(body, csd, input_sz=insz), targets, targeted, scene, d_thr, stealth, setup, iters=1,
+            trace=tr)
     ref = torch.from_numpy(tr[0]['prj_adv'])
-    st = A.AttackState(pc, clf, targets, scene, 'camdE_caml2', setup, DEV)
-    x0 = torch.full((B, 3, *im_sz), 0.5)
+    if golden_it0 is not None:   # the oracle IS the reference here (fixture produced by the unmodified reference)
+        assert np.array_equal(tr[0]['prj_adv'][:golden_it0.shape[0]], golden_it0)
+    st = A.AttackState(pc, clf, targets, scene, stealth, setup, DEV)
+    x0 = torch.full((B, 3, *prj_sz), 0.5)
     have_gates = body in ('resnet18', 'vgg16')
     if have_gates:
         acts, cacts = _oracle_activations(sd, csd, x0, scene.expand(B, -1, -1, -1), im_sz, crop, insz, body)
@@ -1077,13 +1059,13 @@ def _first_iteration_gate_aware(hip, body, csd, insz, im_sz, crop, targets, seed
     for mode in ('plain', 'oracle_gates') if have_gates else ('plain',):
         st.x.copy_(M.to_nhwc4(x0.to(DEV)))
         st.stats[:, 5] = 1e6
-        st.forward_decide(True, 5, 0.9)
+        st.forward_decide(targeted, d_thr, 0.9)
         if have_gates:
             pairs = gates.pcnet_pairs(st.eng, acts) + (gates.vgg16_pairs if body == 'vgg16' else gates.resnet18_pairs)(st.clf.body, cacts)
             if mode == 'plain':
                 flips, per_layer = gates.count_flips(pairs)
             else:
-                gates.inject(pairs)
+                gates.inject(pairs, (st.eng, st.clf.body))
         if mode == 'plain':
             assert rel_inf(M.to_nchw(st.eng.a['Y']), torch.from_numpy(tr[0]['cam_infer'])) < 1e-5
             assert (st.state[:, 3].cpu().numpy() == tr[0]['top1']).all()
@@ -1092,7 +1074,7 @@ def _first_iteration_gate_aware(hip, body, csd, insz, im_sz, crop, targets, seed
         xn = M.to_nchw(st.x).cpu()
         errs[mode] = torch.tensor([rel_inf(xn[b], ref[b]) for b in range(B)])
     if have_gates:
-        print(f'{body} loop, first iteration at {im_sz}: gates differing per sample {flips.tolist()} {per_layer}; projector image '
+        print(f'{body} loop, first iteration at cam {im_sz} prj {prj_sz}: gates differing per sample {flips.tolist()} {per_layer}; projector image '
               f'rel Linf plain {errs["plain"].tolist()}, with the oracle\'s gates {errs["oracle_gates"].tolist()}')
         assert (errs['plain'][flips == 0] < 1e-4).all() and (errs['oracle_gates'] < 1e-4).all()
     else:
@@ -1174,3 +1156,69 @@ def test_perc_al_with_vgg16_at_full_size(hip):
     assert e < 1e-4 or (e < 5e-3 and outlier_fraction(d0, otr[0]['delta'], 1e-4) < 2e-2)
     assert np.allclose(stats0[:, 3].cpu().numpy(), otr[0]['color_dis'].numpy(), rtol=1e-4)
     assert (st0[:, 3].cpu().numpy() == otr[0]['top1']).all()
+
+
+@pytest.mark.parametrize('tile', [0, 16, 18, 22, 25, 27, 34, 36, 39, 40, 42, 44, 45, 48, 49, 50, 234, 948])
+def test_gate_byte_masks(hip, tile):
+    """ReLU gates as byte masks (1 byte per 4 channels, include/spaa_hip.h: mask_out / gate_bits / gate2_bits): the mask a
+    forward launch writes equals (out > 0), and an input-gradient launch gated by masks is BITWISE equal to the same launch
+    gated by the fp32 activations; conv, strided-class and folded transposed conv."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(tile)
+    try:
+        for ci, co, k, s, h, w, b in [(64, 96, 3, 1, 19, 23, 2), (32, 64, 3, 2, 22, 18, 3), (128, 32, 1, 1, 17, 9, 2)]:
+            x = torch.randn(b, ci, h, w)
+            wt = torch.randn(co, ci, k, k) / (ci * k * k) ** 0.5
+            bias = torch.randn(co)
+            plan = cp.conv_fwd_plan(wt, bias, s, k // 2, DEV)
+            ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+            out = torch.zeros(b, ho, wo, co, device=DEV)
+            mask = torch.full((b, ho, wo, co // 4), 255, dtype=torch.uint8, device=DEV)
+            cp.FORCE_TILE = tile
+            plan.run(nhwc(x).to(DEV), out, act=lib.ACT_RELU, mask_out=mask)
+            cp.FORCE_TILE = 0
+            assert rel_inf(nchw(out.cpu(), co), F.relu(F.conv2d(x, wt, bias, s, k // 2))) < 2e-5
+            assert torch.equal(mask, lib.pack_gate_mask(out)), (tile, ci, co)
+            # dgrad of a following layer whose output has `co` channels... use the transposed role: gradient w.r.t. this
+            # layer's OUTPUT shape is what a later dgrad produces; gate it by this activation
+            wt2 = torch.randn(48, co, 3, 3) / (co * 9) ** 0.5
+            dplan = cp.conv_dgrad_plan(wt2, 1, 1, DEV)
+            gy = nhwc(torch.randn(b, 48, ho, wo)).to(DEV)
+            act2 = torch.randn(b, ho, wo, co, device=DEV)
+            g_f, g_m = torch.zeros(b, ho, wo, co, device=DEV), torch.zeros(b, ho, wo, co, device=DEV)
+            a_f, a_m = torch.zeros_like(g_f), torch.zeros_like(g_f)
+            cp.FORCE_TILE = tile
+            dplan.run(gy, g_f, gate=out, aux_out=a_f, gate2=act2)
+            dplan.run(gy, g_m, gate_bits=mask, aux_out=a_m, gate2_bits=lib.pack_gate_mask(act2))
+            cp.FORCE_TILE = 0
+            assert torch.equal(g_f, g_m) and torch.equal(a_f, a_m), (tile, ci, co)
+        for kk, pad, op in [(3, 1, 1), (2, 0, 0)]:
+            xt, wtt, bt = torch.randn(2, 64, 11, 13), torch.randn(64, 32, kk, kk) / 16, torch.randn(32)
+            ref = F.relu(F.conv_transpose2d(xt, wtt, bt, 2, pad, op))
+            tplan = cp.deconv_fwd_plan(wtt, bt, 2, pad, DEV)
+            outt = torch.zeros(2, ref.shape[2], ref.shape[3], 32, device=DEV)
+            maskt = torch.zeros(2, ref.shape[2], ref.shape[3], 8, dtype=torch.uint8, device=DEV)
+            cp.FORCE_TILE = tile
+            tplan.run(nhwc(xt).to(DEV), outt, act=lib.ACT_RELU, mask_out=maskt)
+            cp.FORCE_TILE = 0
+            assert rel_inf(nchw(outt.cpu()), ref) < 2e-5 and torch.equal(maskt, lib.pack_gate_mask(outt)), (tile, kk)
+    finally:
+        cp.FORCE_TILE = 0
+    with pytest.raises(ValueError):   # masks are uint8
+        plan.run(nhwc(x).to(DEV), out, mask_out=torch.zeros(b, ho, wo, co // 4, device=DEV))
+
+
+def test_engine_masks_match_activations(hip, golden_dir):
+    """After a forward pass the engines' byte masks are exactly the signs of their activation buffers (PCNet + ResNet-18),
+    and the max-pool argmax bytes carry the 'maximum is positive' flag."""
+    z = load(golden_dir, 'spaa_64_near')
+    sd, pc, clf, oclf, scene, setup = _setup_case(hip, z)
+    st = hip['attack'].AttackState(pc, clf, [int(t) for t in z['targets']], scene, 'camdE_caml2', setup, DEV)
+    st.forward_decide(True, 5, 0.9)
+    lib = hip['lib']
+    for k, m in st.eng.m.items():
+        assert torch.equal(m, lib.pack_gate_mask(st.eng.a[k])), k
+    body = st.clf.body
+    for blk in body.blocks:
+        assert torch.equal(blk['m_o1'], lib.pack_gate_mask(blk['o1'])) and torch.equal(blk['m_out'], lib.pack_gate_mask(blk['out']))
+    assert torch.equal((body.mp_arg & 128) != 0, body.mp > 0)
