@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from . import convplan as cp
-from .models import to_nhwc4, to_nchw
+from .models import to_nhwc4, to_nchw, USE_GATE_MASKS
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
@@ -117,13 +117,13 @@ class ResNet18Body:
         _lib.call('spaa_maxpool3s2_fwd', _lib.ptr(self.c1), _lib.ptr(self.mp), _lib.ptr(self.mp_arg), B, h1, w1, 64,
                   h2, w2)
         for blk in self.blocks:
-            blk['f1'].run(blk['x'], blk['o1'], act=R, mask_out=blk['m_o1'])
+            blk['f1'].run(blk['x'], blk['o1'], act=R, mask_out=blk['m_o1'] if USE_GATE_MASKS else None)
             if 'fd' in blk:
                 blk['fd'].run(blk['x'], blk['idt'])
                 idt = blk['idt']
             else:
                 idt = blk['x']
-            blk['f2'].run(blk['o1'], blk['out'], add=idt, act=R, mask_out=blk['m_out'])
+            blk['f2'].run(blk['o1'], blk['out'], add=idt, act=R, mask_out=blk['m_out'] if USE_GATE_MASKS else None)
         last = self.blocks[-1]['out']
         _lib.call('spaa_avgpool_fwd', _lib.ptr(last), _lib.ptr(self.feat), B, self.feat_hw, 512)
         self.fc_f.run(self.feat, self.logits)
@@ -139,14 +139,17 @@ class ResNet18Body:
         gP = self.g_last
         for i in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[i]
-            blk['d2'].run(gP, blk['g_o1'], gate_bits=blk['m_o1'])
             # the block's input is the previous block's output; block 0's is the max-pool output (gated in maxpool_bwd)
-            gate_x = self.blocks[i - 1]['m_out'] if i > 0 else None
+            if USE_GATE_MASKS:
+                kw2, kw1 = dict(gate_bits=blk['m_o1']), dict(gate_bits=self.blocks[i - 1]['m_out'] if i > 0 else None)
+            else:
+                kw2, kw1 = dict(gate=blk['o1']), dict(gate=blk['x'] if i > 0 else None)
+            blk['d2'].run(gP, blk['g_o1'], **kw2)
             if 'dd' in blk:
                 blk['dd'].run(gP, blk['g_t'])
-                blk['d1'].run(blk['g_o1'], blk['g_x'], add=blk['g_t'], gate_bits=gate_x)
+                blk['d1'].run(blk['g_o1'], blk['g_x'], add=blk['g_t'], **kw1)
             else:
-                blk['d1'].run(blk['g_o1'], blk['g_x'], add=gP, gate_bits=gate_x)
+                blk['d1'].run(blk['g_o1'], blk['g_x'], add=gP, **kw1)
             gP = blk['g_x']
         _, h1, w1, _ = self.c1.shape
         _, h2, w2, _ = self.mp.shape

@@ -233,7 +233,9 @@ __global__ void ciede2000_kernel(const float4* __restrict__ lab1, const float4* 
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npix) return;
     const float4 a = lab1[idx], b = lab2[idx];
-    de[idx] = ciede2000<false>(a.x, a.y, a.z, b.x, b.y, b.z).de;
+    // identical colours: the reference's res_square is exactly 0 -> dE = 0 (:174-178); do not leave it to how the compiler
+    // contracts the two (textually different) chroma expressions
+    de[idx] = (a.x == b.x && a.y == b.y && a.z == b.z) ? 0.f : ciede2000<false>(a.x, a.y, a.z, b.x, b.y, b.z).de;
 }
 
 // autograd of rgb2lab_diff (:39-64): g_rgb = J^T g_lab, per pixel
@@ -269,7 +271,10 @@ __global__ void ciede2000_bwd_kernel(const float4* __restrict__ lab1, const floa
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npix) return;
     const float4 a = lab1[idx], b = lab2[idx];
-    const float g = g_de[idx];
+    float g = g_de[idx];
+    // identical colours: dE = 0 through the reference's `res_square <= 0` mask, whose gradient is exactly zero (the map is
+    // |x|-like there: any rounding asymmetry between the two chroma expressions would otherwise give an O(1) gradient)
+    if (a.x == b.x && a.y == b.y && a.z == b.z) g = 0.f;
     if (g_lab1 != nullptr) {
         const DE d = ciede2000<true>(a.x, a.y, a.z, b.x, b.y, b.z);
         g_lab1[idx] = make_float4(g * d.gL, g * d.gA, g * d.gB, 0.f);

@@ -10,6 +10,7 @@ passes).  Parameters are treated as frozen, as the attack does (projector_based_
 gradients are produced.
 """
 import copy
+import os
 import weakref
 
 import torch
@@ -18,6 +19,9 @@ import torch.nn as nn
 from . import _lib
 from . import convplan as cp
 from .synthetic import uniform_ctrl_pts
+
+
+USE_GATE_MASKS = os.environ.get('SPAA_GATE_MASKS', '1') != '0'   # 0: fp32 activations as ReLU gates (A/B measurements)
 
 
 def C_ptr(t):
@@ -368,7 +372,7 @@ class PCNetEngine:
         R, N = _lib.ACT_RELU, _lib.ACT_NONE
         self.version += 1
         self.warp(x4, clamp01)
-        m = self.m
+        m = self.m if USE_GATE_MASKS else {k: None for k in self.m}
         f['conv1_s'].run(a['cat8'], a['S1'], act=R, mask_out=m['S1'])
         f['conv2_s'].run(a['S1'], a['S2'], act=R, mask_out=m['S2'])
         f['conv3_s'].run(a['S2'], a['S3'], act=R, mask_out=m['S3'])
@@ -388,6 +392,8 @@ class PCNetEngine:
     def backward(self, gP):
         """gP: gradient w.r.t. conv6's pre-activation (already gated by 0 < Ypre <= 1), [B,Hc,Wc,4].
         Returns the gradient w.r.t. the projector image x4 [B,Hp,Wp,4] (workspace)."""
+        if not USE_GATE_MASKS:
+            return self._backward_float_gates(gP)
         g, d, m = self.g, self.d, self.m
         d['conv6'].run(gP, g['P7'], gate_bits=m['X7'])
         d['transConv2'].run(g['P7'], g['P6'], gate_bits=m['X6'])
@@ -404,6 +410,25 @@ class PCNetEngine:
         d['conv2_s'].run(g['S2'], g['S1'], add=g['P1'], gate_bits=m['S1'])
         # the two 3-channel gradients meet at the warped image: d/d(x_w) = g_direct + g_rough * s (models.py:342); the
         # product and the sum are epilogues of the two thin convolutions instead of extra reads in the gather
+        d['conv1_s'].run(g['S1'], g['xs'], gate=self.scene, gate_mode=_lib.GATE_MUL)
+        d['conv1'].run(g['P1'], g['xw'], add=g['xs'])
+        return self.warp_backward(g['xw'])
+
+    def _backward_float_gates(self, gP):
+        """The same backward pass reading the fp32 activations as gates (SPAA_GATE_MASKS=0: A/B measurements)."""
+        a, g, d = self.a, self.g, self.d
+        d['conv6'].run(gP, g['P7'], gate=a['X7'])
+        d['transConv2'].run(g['P7'], g['P6'], gate=a['X6'])
+        d['transConv1'].run(g['P6'], g['P5'], gate=a['X5'])
+        d['conv5'].run(g['P5'], g['P4'], gate=a['X4'], aux_out=g['S4'], gate2=a['S4'])
+        d['conv4'].run(g['P4'], g['P3'], gate=a['X3'])
+        d['skipConv3'].run(g['P5'], g['t2'])
+        d['conv3'].run(g['P3'], g['P2'], add=g['t2'], gate=a['X2'])
+        d['skipConv2'].run(g['P6'], g['t1'])
+        d['conv2'].run(g['P2'], g['P1'], add=g['t1'], gate=a['X1'])
+        d['conv4_s'].run(g['S4'], g['S3'], add=g['P3'], gate=a['S3'])
+        d['conv3_s'].run(g['S3'], g['S2'], add=g['P2'], gate=a['S2'])
+        d['conv2_s'].run(g['S2'], g['S1'], add=g['P1'], gate=a['S1'])
         d['conv1_s'].run(g['S1'], g['xs'], gate=self.scene, gate_mode=_lib.GATE_MUL)
         d['conv1'].run(g['P1'], g['xw'], add=g['xs'])
         return self.warp_backward(g['xw'])

@@ -1048,8 +1048,12 @@ def _first_iteration_gate_aware(hip, body, csd, insz, im_sz, crop, targets, seed
     so.spaa(sd, so.OracleClassifier(body, csd, input_sz=insz), targets, targeted, scene, d_thr, stealth, setup, iters=1,
             trace=tr)
     ref = torch.from_numpy(tr[0]['prj_adv'])
-    if golden_it0 is not None:   # the oracle IS the reference here (fixture produced by the unmodified reference)
-        assert np.array_equal(tr[0]['prj_adv'][:golden_it0.shape[0]], golden_it0)
+    if golden_it0 is not None:
+        # the reference's own first iteration (fixture produced by the unmodified reference in the build container); the
+        # oracle run on THIS host's CPU may differ from it by rounding and, rarely, by a gate of its own
+        d = float(np.abs(tr[0]['prj_adv'][:golden_it0.shape[0]] - golden_it0).max())
+        print(f'oracle on this host vs reference fixture, first iteration: max abs diff {d:.2e}')
+        assert d < 5e-3
     st = A.AttackState(pc, clf, targets, scene, stealth, setup, DEV)
     x0 = torch.full((B, 3, *prj_sz), 0.5)
     have_gates = body in ('resnet18', 'vgg16')
