@@ -27,6 +27,8 @@ typedef void* spaa_stream_t; /* hipStream_t */
 
 /* activation applied after bias + residual add */
 enum { SPAA_ACT_NONE = 0, SPAA_ACT_RELU = 1, SPAA_ACT_RELU_CLAMP1 = 2, SPAA_ACT_LEAKY01 = 3 };
+/* fp16-storage flags (spaa_tapconv_t.io_dtype) */
+enum { SPAA_IO_IN_F16 = 1, SPAA_IO_OUT_F16 = 2 };
 /* gate applied last (ReLU / clamp backward):  out = pass(gate) ? v : 0 */
 enum { SPAA_GATE_NONE = 0, SPAA_GATE_POS = 1 /* gate > 0 */, SPAA_GATE_POS_LE1 = 2 /* 0 < gate <= 1 */,
        SPAA_GATE_MUL = 3 /* value * gate: the chain rule through `x * s` (models.py:342); tiles 25.. only */ };
@@ -60,6 +62,8 @@ typedef struct {
     const uint16_t* w_split; /* optional: the same weights as three bf16 planes per class, [3][Npad][Kpad] with
                                 w == h + m + l exactly (tiles 12-14: fp32 emulated on the bf16 matrix cores); class c
                                 starts at element 3 * cls[c].w_off */
+    const uint16_t* w_half; /* SPAA_IO_IN_F16: the weights rounded to fp16, per class [Npad][Kpad64] (Kpad64 = K rounded up to 64,
+                               zero padded); class c starts at element cls[c].w_off / Kpad * Kpad64 */
     const int32_t* taps;  /* device array of (dy, dx) pairs */
     const float* bias;    /* [Cout] or NULL */
     const float* add;     /* residual, indexed like `out`, or NULL */
@@ -95,11 +99,22 @@ typedef struct {
                              dimension: weight rows [nfold*Cout], row c*Cout + n -> output pixel (2y + c/2, 2x + c%2),
                              channel n.  The input is read once instead of once per class. */
     int32_t reserved0;
+    int32_t io_dtype;     /* fp16-STORAGE mode (BASELINE.json configs[4]: "fp16 with fp32 dE2000"), bit flags:
+                             SPAA_IO_IN_F16  (tiles 60..63 only): `in` is fp16 NHWC (strides / offsets still in elements) and the
+                                             weights come from `w_half`; fp32 accumulation on v_mfma_f32_16x16x32_f16;
+                             SPAA_IO_OUT_F16 (tiles 60..63, and the kernels that read fp32 IMAGES: 15..24, 38):
+                                             `out`, `add`, `gate`, `aux_out`, `gate2` are fp16.
+                             0 = everything fp32 (the default path; dtype "f32" in bench.py). */
+    int32_t reserved1;
     int32_t nclass;
     spaa_tapclass_t cls[SPAA_MAX_CLASSES];
 } spaa_tapconv_t;
 
 int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream);
+/* layout probes for language bindings: sizeof(spaa_tapconv_t) and the byte offset of field # `field`
+ * (0 out, 1 weights, 2 taps, 3 gate2, 4 mask_out, 5 tap_range, 6 splitk_ws, 7 io_dtype, 8 nclass, 9 cls; else -1) */
+int spaa_tapconv_sizeof(void);
+int spaa_tapconv_offsetof(int field);
 
 /* ---- layout conversion at the NCHW boundary ---------------------------------------------------------------- */
 /* src [B,3,H,W] -> dst [B,H,W,4] (lane 3 = 0); optional clamp to [0,1] (projector_based_attack.py:265) */

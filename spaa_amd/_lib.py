@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'libspaa_hip.so')
 MAX_CLASSES = 4
 MAX_TAPS = 64
 ACT_NONE, ACT_RELU, ACT_RELU_CLAMP1, ACT_LEAKY01 = 0, 1, 2, 3
+IO_IN_F16, IO_OUT_F16 = 1, 2
 GATE_NONE, GATE_POS, GATE_POS_LE1, GATE_MUL = 0, 1, 2, 3
 
 
@@ -29,7 +30,7 @@ class TapConv(C.Structure):
         ('out', C.c_void_p), ('Hout', C.c_int32), ('Wout', C.c_int32), ('Cout', C.c_int32), ('out_cstride', C.c_int32),
         ('out_coff', C.c_int32),
         ('B', C.c_int32), ('Hm', C.c_int32), ('Wm', C.c_int32), ('s_in', C.c_int32), ('s_out', C.c_int32),
-        ('weights', C.c_void_p), ('w_split', C.c_void_p), ('taps', C.c_void_p), ('bias', C.c_void_p),
+        ('weights', C.c_void_p), ('w_split', C.c_void_p), ('w_half', C.c_void_p), ('taps', C.c_void_p), ('bias', C.c_void_p),
         ('add', C.c_void_p), ('add_cstride', C.c_int32), ('add_coff', C.c_int32),
         ('gate', C.c_void_p), ('gate_cstride', C.c_int32), ('gate_coff', C.c_int32), ('gate_mode', C.c_int32),
         ('act', C.c_int32), ('tile', C.c_int32),
@@ -38,7 +39,7 @@ class TapConv(C.Structure):
         ('mask_out', C.c_void_p), ('gate_bits', C.c_void_p), ('gate2_bits', C.c_void_p),
         ('tap_range', C.c_int32 * 4),
         ('splitk_ws', C.c_void_p), ('ksplit', C.c_int32), ('nfold', C.c_int32), ('reserved0', C.c_int32),
-        ('nclass', C.c_int32),
+        ('io_dtype', C.c_int32), ('reserved1', C.c_int32), ('nclass', C.c_int32),
         ('cls', TapClass * MAX_CLASSES),
     ]
 
@@ -90,7 +91,7 @@ _SIGNATURES = {
     'spaa_zero': [_p, _l, _p],
 }
 
-EXPORTS = sorted(list(_SIGNATURES) + ['spaa_version'])
+EXPORTS = sorted(list(_SIGNATURES) + ['spaa_version', 'spaa_tapconv_sizeof', 'spaa_tapconv_offsetof'])
 
 _lib = None
 
@@ -109,6 +110,9 @@ def load():
         fn.argtypes = argtypes
         fn.restype = C.c_int
     lib.spaa_version.restype = C.c_char_p
+    lib.spaa_tapconv_sizeof.restype = C.c_int
+    lib.spaa_tapconv_offsetof.argtypes = [C.c_int]
+    lib.spaa_tapconv_offsetof.restype = C.c_int
     _lib = lib
     return lib
 
@@ -141,11 +145,12 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-def check_dev(*tensors):
+def check_dev(*tensors, half_ok=False):
+    """Kernel operands: contiguous float32 GPU tensors (float16 as well where the caller runs in fp16-storage mode)."""
     for t in tensors:
         if t is None:
             continue
-        if not t.is_cuda or not t.is_contiguous() or t.dtype != torch.float32:
+        if not t.is_cuda or not t.is_contiguous() or not (t.dtype == torch.float32 or (half_ok and t.dtype == torch.float16)):
             raise ValueError('spaa_amd kernels need contiguous float32 tensors on the GPU '
                              f'(got device={t.device}, dtype={t.dtype}, contiguous={t.is_contiguous()})')
         _same_device(t)

@@ -31,7 +31,10 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               39: 'x6d16co_128x128', 40: 'x6d16co_128x64', 41: 'x6d16co_128x32',
               42: 'x6d16a3_128x64', 43: 'x6d16a3_128x32', 44: 'x6da3_128x64', 45: 'x6d16coa3_128x64', 46: 'x6d16coa3_128x32', 47: 'thinpatch16x2',
               48: 'x6d16p_128x128', 49: 'x6d16p_128x64', 50: 'x6d16a3p_128x64', 51: 'x6da3p_128x64', 52: 'x6d16p_256x128',
-              53: 'x6d16p_128x32', 54: 'x6dp_128x128'}
+              53: 'x6d16p_128x32', 54: 'x6dp_128x128',
+              60: 'h16_128x128', 61: 'h16_128x64', 62: 'h16_128x32', 63: 'h16_128x16'}
+STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 64))  # shared epilogue (epilogue.hpp)
+F16OUT_TILES = set(range(15, 25)) | {38} | set(range(60, 64))  # ... of which these may write fp16 (fp32 image in, fp16 activation out)
 DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
 DEBUG_TAPMAJOR = int(os.environ.get('SPAA_X6D_TAPMAJOR', '0'))      # 1: tap-major K order (A/B measurements only)
 DEBUG_PERSIST_CAP = int(os.environ.get('SPAA_X6D_PERSIST_CAP', '0'))  # > 0: persistent launches use this many workgroups
@@ -128,14 +131,33 @@ class ConvPlan:
         self.flops_per_pixel = 2 * sum(c['ntaps'] for c in self.cls) * cin * ngemm
         self.ntaps_total = sum(c['ntaps'] for c in self.cls)
         self._ws = None  # split-K workspace, allocated on first use
+        self._w_chunks, self._npad, self._dev = w_chunks, npad, device
+        self.w_half = None  # fp16 plane for the fp16-storage kernels, packed on first use (half_plane())
+
+    def half_plane(self):
+        """The weights rounded to fp16, per class [Npad][K rounded up to 64] (zero padded), classes back to back: the
+        operand of the fp16-storage kernels (csrc/tapconv_h16.hip)."""
+        if self.w_half is None:
+            parts = []
+            for c, wp in zip(self.cls, self._w_chunks):
+                k64 = _ceil(c['K'], 64)
+                wh = torch.zeros(self._npad, k64, dtype=torch.float16)
+                wh[:, :c['K']] = wp.view(self._npad, c['Kpad'])[:, :c['K']].to(torch.float16)
+                parts.append(wh.reshape(-1))
+            self.w_half = (torch.cat(parts) if parts else torch.zeros(8, dtype=torch.float16)).to(self._dev)
+        return self.w_half
 
     def run(self, inp, out, add=None, gate=None, gate_mode=_lib.GATE_POS, act=_lib.ACT_NONE, aux_out=None,
             gate2=None, in_coff=0, out_coff=0, add_coff=0, gate_coff=0, mask_out=None, gate_bits=None, gate2_bits=None):
         """inp: [B,Hin,Win,Cs_in], out: [B,Hout,Wout,Cs_out] NHWC float32 CUDA tensors.
         `mask_out` / `gate_bits` / `gate2_bits`: uint8 [B,Hout,Wout,Cs/4] ReLU-gate masks (one byte per 4 channels,
         include/spaa_hip.h): written for this launch's output resp. read instead of a float `gate` / `gate2`."""
-        _lib.check_dev(inp, out, add, gate, aux_out, gate2)
+        _lib.check_dev(inp, out, add, gate, aux_out, gate2, half_ok=True)
         _lib.check_mask(mask_out, gate_bits, gate2_bits)
+        in_f16, out_f16 = inp.dtype == torch.float16, out.dtype == torch.float16
+        for t in (add, gate, aux_out, gate2):
+            if t is not None and t.dtype != out.dtype:
+                raise ValueError(f'{self.name}: add / gate / aux_out / gate2 must have the storage type of `out` ({out.dtype})')
         b, hin, win, cs_in = inp.shape
         b2, hout, wout, cs_out = out.shape
         assert b == b2 and cs_in % 4 == 0 and in_coff % 4 == 0 and in_coff + self.cin_p <= cs_in
@@ -150,6 +172,11 @@ class ConvPlan:
             d.Hm, d.Wm = (hout + self.s_out - 1) // self.s_out, (wout + self.s_out - 1) // self.s_out
         d.s_in, d.s_out = self.s_in, self.s_out
         d.weights, d.taps = self.weights.data_ptr(), self.taps.data_ptr()
+        d.io_dtype = (_lib.IO_IN_F16 if in_f16 else 0) | (_lib.IO_OUT_F16 if out_f16 else 0)
+        if in_f16:
+            if self.cin_p % 32 or any(c['Kpad'] != c['K'] for c in self.cls):
+                raise ValueError(f'{self.name}: fp16-storage input needs Cin % 32 == 0 (got {self.cin_p})')
+            d.w_half = self.half_plane().data_ptr()
         d.w_split = self.w_split.data_ptr() if self.w_split is not None else None
         d.bias = self.bias.data_ptr() if self.bias is not None else None
         if add is not None:
@@ -193,11 +220,19 @@ class ConvPlan:
         tile = forced if forced else TUNE.get(key, -1)
         if tile < 0:
             tile = self._default_tile(b * d.Hm * d.Wm)
+        if in_f16:    # fp16 activations: the h16 kernels, N tile by the GEMM's width
+            ngemm = self.cout * self.nfold
+            tile = forced if 60 <= forced <= 63 else (60 if ngemm > 64 else 61 if ngemm > 32 else 62 if ngemm > 16 else 63)
+        elif out_f16:  # fp32 image in, fp16 activation out: any kernel built on the shared epilogue, without split-K
+            tile %= 100
+            if tile not in F16OUT_TILES:
+                tile = 38 if (len(self.cls) == 1 and self.cin_p in (4, 8) and self.cout <= 32 and self.ntaps_total <= 9
+                              and self.s_in <= 2) else (18 if self.cout > 32 else 16)
         # tune values >= 100 encode split-K: tile + 100 * ksplit (x6d tiles, one class, enough K-steps per split)
         ksplit, tile = (tile // 100, tile % 100) if tile >= 100 else (1, tile)
         if self.nfold > 1:  # only the DMA-staged kernels know the folded epilogue
             ksplit = 1
-            if not (25 <= tile <= 27 or 30 <= tile <= 37 or (39 <= tile <= 46 or 48 <= tile <= 54)):
+            if not (25 <= tile <= 27 or 30 <= tile <= 37 or (39 <= tile <= 46 or 48 <= tile <= 54) or 60 <= tile <= 63):
                 tile = 34
             d.nfold = self.nfold
         if ksplit == 9:  # stream-K (persistent x6d tiles, one class): workspace shared by all plans (one stream)
@@ -206,6 +241,8 @@ class ConvPlan:
             else:
                 d.splitk_ws, d.ksplit = _streamk_workspace(inp.device).data_ptr(), -1
                 ksplit = 1
+        if in_f16 or out_f16:
+            ksplit = 1
         if ksplit > 1:
             nk = self.cls[0]['Kpad'] // BK
             if len(self.cls) != 1 or nk < 2 * ksplit or not (25 <= tile <= 27 or 30 <= tile <= 37 or (39 <= tile <= 46 or 48 <= tile <= 54)) or self.cin_p % 32:
@@ -220,11 +257,11 @@ class ConvPlan:
             d.ksplit, d.splitk_ws = 0, None
             if tile < 25:
                 raise ValueError('GATE_MUL needs a layer shape served by the DMA-staged kernels')
-        if masked and not (15 <= tile <= 27 or 30 <= tile <= 46 or 48 <= tile <= 54):
+        if masked and tile not in STORE4_TILES:
             # byte masks live in the shared 4-channel epilogue (epilogue.hpp): thin / fp32-MFMA kernels do not have it
             tile = self._default_tile(b * d.Hm * d.Wm) % 100
             d.ksplit, d.splitk_ws = 0, None
-            if not (15 <= tile <= 27 or 30 <= tile <= 46 or 48 <= tile <= 54):
+            if tile not in STORE4_TILES:
                 raise ValueError(f'{self.name}: gate masks need a layer shape served by the bf16x6 / smallcin kernels')
         d.tile = tile
         d.reserved0 = DEBUG_TAPMAJOR | (DEBUG_PERSIST_CAP << 8)  # measurement / test switches of the x6d kernels

@@ -9,8 +9,43 @@ namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-// fused epilogue for 4 consecutive output channels n0..n0+3 of output pixel o
-__device__ __forceinline__ void store4(const spaa_tapconv_t& p, const size_t o, const int n0, float (&v)[4], const bool vec) {
+// 4 consecutive elements of a tensor stored as fp32 or as fp16 (fp16-STORAGE mode: spaa_tapconv_t.io_dtype)
+template <typename T>
+struct io4;
+template <>
+struct io4<float> {
+    static __device__ __forceinline__ f4 ld(const void* base, size_t idx) {
+        return *reinterpret_cast<const f4*>(reinterpret_cast<const float*>(base) + idx);
+    }
+    static __device__ __forceinline__ void st(void* base, size_t idx, f4 v) {
+        *reinterpret_cast<f4*>(reinterpret_cast<float*>(base) + idx) = v;
+    }
+    static __device__ __forceinline__ float ld1(const void* base, size_t idx) { return reinterpret_cast<const float*>(base)[idx]; }
+    static __device__ __forceinline__ void st1(void* base, size_t idx, float v) { reinterpret_cast<float*>(base)[idx] = v; }
+};
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+template <>
+struct io4<_Float16> {
+    static __device__ __forceinline__ f4 ld(const void* base, size_t idx) {
+        const h4 h = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(base) + idx);
+        return f4{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+    }
+    static __device__ __forceinline__ void st(void* base, size_t idx, f4 v) {
+        *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(base) + idx) =
+            h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    }
+    static __device__ __forceinline__ float ld1(const void* base, size_t idx) {
+        return (float)reinterpret_cast<const _Float16*>(base)[idx];
+    }
+    static __device__ __forceinline__ void st1(void* base, size_t idx, float v) {
+        reinterpret_cast<_Float16*>(base)[idx] = (_Float16)v;
+    }
+};
+
+// fused epilogue for 4 consecutive output channels n0..n0+3 of output pixel o; T = storage type of out / add / gate /
+// aux_out / gate2 (bias is always fp32).  The mask bits and the value handed back in `v` are those of the STORED value.
+template <typename T>
+__device__ __forceinline__ void store4_t(const spaa_tapconv_t& p, const size_t o, const int n0, float (&v)[4], const bool vec) {
     if (n0 >= p.Cout) return;
     if (vec) {
         if (p.bias != nullptr) {
@@ -18,18 +53,17 @@ __device__ __forceinline__ void store4(const spaa_tapconv_t& p, const size_t o, 
             v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
         }
         if (p.add != nullptr) {
-            const f4 aa = *reinterpret_cast<const f4*>(p.add + o * p.add_cstride + p.add_coff + n0);
+            const f4 aa = io4<T>::ld(p.add, o * p.add_cstride + p.add_coff + n0);
             v[0] += aa.x; v[1] += aa.y; v[2] += aa.z; v[3] += aa.w;
         }
-        float* outp = p.out + o * p.out_cstride + p.out_coff + n0;
+        const size_t oi = o * p.out_cstride + p.out_coff + n0;
         if (p.act == SPAA_ACT_RELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         } else if (p.act == SPAA_ACT_RELU_CLAMP1) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            if (p.aux_out != nullptr)
-                *reinterpret_cast<f4*>(p.aux_out + o * p.out_cstride + p.out_coff + n0) = f4{v[0], v[1], v[2], v[3]};
+            if (p.aux_out != nullptr) io4<T>::st(p.aux_out, oi, f4{v[0], v[1], v[2], v[3]});
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fminf(v[e], 1.f);
         } else if (p.act == SPAA_ACT_LEAKY01) {
@@ -37,7 +71,7 @@ __device__ __forceinline__ void store4(const spaa_tapconv_t& p, const size_t o, 
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.1f * v[e];
         }
         if (p.gate != nullptr) {
-            const f4 gg = *reinterpret_cast<const f4*>(p.gate + o * p.gate_cstride + p.gate_coff + n0);
+            const f4 gg = io4<T>::ld(p.gate, o * p.gate_cstride + p.gate_coff + n0);
             const float ga[4] = {gg.x, gg.y, gg.z, gg.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -49,18 +83,22 @@ __device__ __forceinline__ void store4(const spaa_tapconv_t& p, const size_t o, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ((mb >> e) & 1u) ? v[e] : 0.f;
         }
-        *reinterpret_cast<f4*>(outp) = f4{v[0], v[1], v[2], v[3]};
+        if (sizeof(T) == 2) {  // what is stored is the fp16 rounding: gate bits must describe that value
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (float)(_Float16)v[e];
+        }
+        io4<T>::st(p.out, oi, f4{v[0], v[1], v[2], v[3]});
         if (p.mask_out != nullptr)
             p.mask_out[(o * p.out_cstride + p.out_coff + n0) >> 2] =
                 (uint8_t)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
         if (p.gate2 != nullptr) {
-            const f4 gg = *reinterpret_cast<const f4*>(p.gate2 + o * p.gate2_cstride + p.gate2_coff + n0);
-            *reinterpret_cast<f4*>(p.aux_out + o * p.out_cstride + p.out_coff + n0) =
-                f4{gg.x > 0.f ? v[0] : 0.f, gg.y > 0.f ? v[1] : 0.f, gg.z > 0.f ? v[2] : 0.f, gg.w > 0.f ? v[3] : 0.f};
+            const f4 gg = io4<T>::ld(p.gate2, o * p.gate2_cstride + p.gate2_coff + n0);
+            io4<T>::st(p.aux_out, oi, f4{gg.x > 0.f ? v[0] : 0.f, gg.y > 0.f ? v[1] : 0.f, gg.z > 0.f ? v[2] : 0.f,
+                                        gg.w > 0.f ? v[3] : 0.f});
         } else if (p.gate2_bits != nullptr) {
             const unsigned int mb = p.gate2_bits[(o * p.gate2_cstride + p.gate2_coff + n0) >> 2];
-            *reinterpret_cast<f4*>(p.aux_out + o * p.out_cstride + p.out_coff + n0) =
-                f4{(mb & 1u) ? v[0] : 0.f, (mb & 2u) ? v[1] : 0.f, (mb & 4u) ? v[2] : 0.f, (mb & 8u) ? v[3] : 0.f};
+            io4<T>::st(p.aux_out, oi, f4{(mb & 1u) ? v[0] : 0.f, (mb & 2u) ? v[1] : 0.f, (mb & 4u) ? v[2] : 0.f,
+                                        (mb & 8u) ? v[3] : 0.f});
         }
     } else {
 #pragma unroll
@@ -68,28 +106,52 @@ __device__ __forceinline__ void store4(const spaa_tapconv_t& p, const size_t o, 
             const int n = n0 + e;
             if (n >= p.Cout) continue;
             float t = v[e] + (p.bias != nullptr ? p.bias[n] : 0.f);
-            if (p.add != nullptr) t += p.add[o * p.add_cstride + p.add_coff + n];
+            if (p.add != nullptr) t += io4<T>::ld1(p.add, o * p.add_cstride + p.add_coff + n);
+            const size_t oi = o * p.out_cstride + p.out_coff + n;
             if (p.act == SPAA_ACT_RELU) {
                 t = fmaxf(t, 0.f);
             } else if (p.act == SPAA_ACT_RELU_CLAMP1) {
                 t = fmaxf(t, 0.f);
-                if (p.aux_out != nullptr) p.aux_out[o * p.out_cstride + p.out_coff + n] = t;
+                if (p.aux_out != nullptr) io4<T>::st1(p.aux_out, oi, t);
                 t = fminf(t, 1.f);
             } else if (p.act == SPAA_ACT_LEAKY01) {
                 t = t > 0.f ? t : 0.1f * t;
             }
             if (p.gate != nullptr) {
-                const float gv = p.gate[o * p.gate_cstride + p.gate_coff + n];
+                const float gv = io4<T>::ld1(p.gate, o * p.gate_cstride + p.gate_coff + n);
                 const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (gv > 0.f && gv <= 1.f) : (gv > 0.f);
                 t = (p.gate_mode == SPAA_GATE_MUL) ? t * gv : (pass ? t : 0.f);
             }
-            p.out[o * p.out_cstride + p.out_coff + n] = t;
+            io4<T>::st1(p.out, oi, t);
             if (p.gate2 != nullptr) {
-                const float g2 = p.gate2[o * p.gate2_cstride + p.gate2_coff + n];
-                p.aux_out[o * p.out_cstride + p.out_coff + n] = (g2 > 0.f) ? t : 0.f;
+                const float g2 = io4<T>::ld1(p.gate2, o * p.gate2_cstride + p.gate2_coff + n);
+                io4<T>::st1(p.aux_out, oi, (g2 > 0.f) ? t : 0.f);
             }
         }
     }
+}
+
+// storage type chosen at run time (kernels that read fp32 IMAGES and may write fp16 activations: smallcin, x6v2/v3; the
+// fp32-only bf16x6 kernels call store4_t<float> directly and keep their register budget)
+__device__ __forceinline__ void store4(const spaa_tapconv_t& p, const size_t o, const int n0, float (&v)[4], const bool vec) {
+    if (p.io_dtype & SPAA_IO_OUT_F16) store4_t<_Float16>(p, o, n0, v, vec);
+    else store4_t<float>(p, o, n0, v, vec);
+}
+
+// N-folded stride-2 transposed convolution: GEMM row group n0 -> (parity class c, channel n) and the class's pixel
+template <typename T>
+__device__ __forceinline__ void store4_fold_t(const spaa_tapconv_t& p, const int m, const int M, const int HWm, const int n0,
+                                              float (&v)[4], const bool vec) {
+    if (m >= M) return;
+    const int c = n0 / p.Cout;
+    if (c >= p.nfold) return;
+    const int b = m / HWm;
+    const int rr = m - b * HWm;
+    const int y = rr / p.Wm;
+    const int x = rr - y * p.Wm;
+    const int oy = 2 * y + (c >> 1), ox = 2 * x + (c & 1);
+    if (oy >= p.Hout || ox >= p.Wout) return;
+    store4_t<T>(p, ((size_t)b * p.Hout + oy) * p.Wout + ox, n0 - c * p.Cout, v, vec);
 }
 
 // output pixel index of tile row m (class grid -> output grid); false when the pixel does not exist

@@ -78,21 +78,6 @@ __device__ __forceinline__ int swz_w(int n) {  // 64-byte rows, 4 chunks
     return SH == 32 ? (n >> 2) & 3 : ((n >> 3) & 1) << 1;
 }
 
-// N-folded stride-2 transposed convolution: GEMM row group n0 -> (parity class c, channel n) and the class's pixel
-__device__ __forceinline__ void store4_fold(const spaa_tapconv_t& p, const int m, const int M, const int HWm, const int n0,
-                                            float (&v)[4], const bool vec) {
-    if (m >= M) return;
-    const int c = n0 / p.Cout;
-    if (c >= p.nfold) return;
-    const int b = m / HWm;
-    const int rr = m - b * HWm;
-    const int y = rr / p.Wm;
-    const int x = rr - y * p.Wm;
-    const int oy = 2 * y + (c >> 1), ox = 2 * x + (c & 1);
-    if (oy >= p.Hout || ox >= p.Wout) return;
-    store4(p, ((size_t)b * p.Hout + oy) * p.Wout + ox, n0 - c * p.Cout, v, vec);
-}
-
 template <int NW, int BN, int SH, bool CO, int NA>
 __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapconv_t p, const int m_tiles,
                                                                  const int n_tiles) {
@@ -570,12 +555,12 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
                     if (p.nfold > 1) {
                         const int oy = 2 * py + (cfold >> 1), ox = 2 * px + (cfold & 1);
                         if (cfold < p.nfold && oy < p.Hout && ox < p.Wout)
-                            store4(p, ((size_t)pb * p.Hout + oy) * p.Wout + ox, n0 - cfold * p.Cout, v, vec);
+                            store4_t<float>(p, ((size_t)pb * p.Hout + oy) * p.Wout + ox, n0 - cfold * p.Cout, v, vec);
                     } else if (linear) {
-                        store4(p, (size_t)m, n0, v, vec);
+                        store4_t<float>(p, (size_t)m, n0, v, vec);
                     } else {
                         const int oy = cl.oy0 + py * p.s_out, ox = cl.ox0 + px * p.s_out;
-                        if (oy < p.Hout && ox < p.Wout) store4(p, ((size_t)pb * p.Hout + oy) * p.Wout + ox, n0, v, vec);
+                        if (oy < p.Hout && ox < p.Wout) store4_t<float>(p, ((size_t)pb * p.Hout + oy) * p.Wout + ox, n0, v, vec);
                     }
                 }
                 m += RPI;
@@ -601,7 +586,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc32[j][4 * g + e];
-                    store4_fold(p, m_blk_e + 32 * wave + (lane & 31), M, HWm, n_blk_e + 32 * j + 8 * g + 4 * (lane >> 5), v, vec);
+                    store4_fold_t<float>(p, m_blk_e + 32 * wave + (lane & 31), M, HWm, n_blk_e + 32 * j + 8 * g + 4 * (lane >> 5), v, vec);
                 }
         } else {
 #pragma unroll
@@ -609,7 +594,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
                     float v[4] = {acc16[ib][j][0], acc16[ib][j][1], acc16[ib][j][2], acc16[ib][j][3]};
-                    store4_fold(p, m_blk_e + 32 * wave + 16 * ib + (lane & 15), M, HWm, n_blk_e + 16 * j + 4 * (lane >> 4), v, vec);
+                    store4_fold_t<float>(p, m_blk_e + 32 * wave + 16 * ib + (lane & 15), M, HWm, n_blk_e + 16 * j + 4 * (lane >> 4), v, vec);
                 }
         }
         break;
@@ -626,7 +611,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc32[j][4 * g + e];
-                store4(p, o, n_blk_e + 32 * j + 8 * g + 4 * (lane >> 5), v, vec);
+                store4_t<float>(p, o, n_blk_e + 32 * j + 8 * g + 4 * (lane >> 5), v, vec);
             }
     } else {
         // D layout of a 16x16 tile: column (lane & 15) = pixel, rows 4*(lane>>4) + i = 4 consecutive output channels
@@ -637,7 +622,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 float v[4] = {acc16[ib][j][0], acc16[ib][j][1], acc16[ib][j][2], acc16[ib][j][3]};
-                store4(p, o, n_blk_e + 16 * j + 4 * (lane >> 4), v, vec);
+                store4_t<float>(p, o, n_blk_e + 16 * j + 4 * (lane >> 4), v, vec);
             }
         }
     }
@@ -676,7 +661,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const spaa_tapconv_t
                      (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
                      (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
     float v[4] = {sum.x, sum.y, sum.z, sum.w};
-    store4(p, o, n0, v, vec);
+    store4_t<float>(p, o, n0, v, vec);
 }
 
 // second pass of stream-K: tiles that were cut into segments are summed in segment order and finished.  Workgroup s
@@ -714,7 +699,7 @@ __global__ __launch_bounds__(256) void streamk_reduce_kernel(const spaa_tapconv_
                      (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
                      (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
     float v[4] = {sum.x, sum.y, sum.z, sum.w};
-    store4(p, o, n0, v, vec);
+    store4_t<float>(p, o, n0, v, vec);
 }
 
 constexpr int STREAMK_MAX_WG = 768;  // workspace contract: 2 * STREAMK_MAX_WG * 128 * 128 floats

@@ -42,6 +42,11 @@ def test_struct_layout_matches_c():
     assert ctypes.sizeof(_lib.TapClass) == 32
     assert _lib.TapConv.cls.offset % 8 == 0
     assert ctypes.sizeof(_lib.TapConv) == _lib.TapConv.cls.offset + 4 * 32
+    # the compiled struct itself (layout probes exported by the library)
+    lib = _lib.load()
+    assert lib.spaa_tapconv_sizeof() == ctypes.sizeof(_lib.TapConv)
+    for i, f in enumerate(('out', 'weights', 'taps', 'gate2', 'mask_out', 'tap_range', 'splitk_ws', 'io_dtype', 'nclass', 'cls')):
+        assert lib.spaa_tapconv_offsetof(i) == getattr(_lib.TapConv, f).offset, f
 
 
 def test_no_cpu_fallback():

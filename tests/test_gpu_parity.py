@@ -1226,3 +1226,80 @@ def test_engine_masks_match_activations(hip, golden_dir):
     for blk in body.blocks:
         assert torch.equal(blk['m_o1'], lib.pack_gate_mask(blk['o1'])) and torch.equal(blk['m_out'], lib.pack_gate_mask(blk['out']))
     assert torch.equal((body.mp_arg & 128) != 0, body.mp > 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fp16-STORAGE mode (BASELINE.json configs[4]: "fp16 with fp32 dE2000"): activations / gradients fp16 in HBM, fp16 weights,
+# fp32 accumulation.  Tolerances: the reference for a layer is the fp32 (fp64-accumulated) result on the SAME fp16-rounded
+# operands, so what is left is the accumulation order and the final fp16 rounding of the output (2^-11 = 4.9e-4 relative).
+def _h(x):
+    return x.half().float()
+
+
+@pytest.mark.parametrize('tile', [0, 60, 61, 62, 63])
+def test_tapconv_fp16_storage(hip, tile):
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(31 + tile)
+    try:
+        for ci, co, k, s, h, w, b in [(64, 96, 3, 1, 19, 23, 2), (32, 64, 3, 2, 22, 18, 3), (128, 40, 1, 1, 17, 9, 2),
+                                      (32, 3, 3, 1, 20, 24, 2), (96, 130, 3, 1, 7, 9, 1), (64, 64, 5, 1, 11, 10, 2)]:
+            x = _h(torch.randn(b, ci, h, w))
+            wt = _h(torch.randn(co, ci, k, k) / (ci * k * k) ** 0.5)
+            bias = torch.randn(co)
+            y = F.conv2d(x.double(), wt.double(), bias.double(), s, k // 2).float()
+            add = _h(torch.randn_like(y))
+            plan = cp.conv_fwd_plan(wt, bias, s, k // 2, DEV)
+            cs = (co + 3) // 4 * 4
+            ho, wo = y.shape[2:]
+            cp.FORCE_TILE = tile
+            # fp16 in -> fp16 out, residual + ReLU + byte mask
+            out = torch.zeros(b, ho, wo, cs, device=DEV, dtype=torch.float16)
+            mask = torch.zeros(b, ho, wo, cs // 4, dtype=torch.uint8, device=DEV) if co % 4 == 0 else None
+            plan.run(nhwc(x).half().to(DEV), out, add=nhwc(add, cs).half().to(DEV), act=lib.ACT_RELU, mask_out=mask)
+            want = F.relu(y + add)
+            got = nchw(out.float().cpu(), co)
+            assert rel_inf(got, want) < 1.5e-3, (tile, ci, co, k, s, rel_inf(got, want))
+            if mask is not None:
+                assert torch.equal(mask, lib.pack_gate_mask(out.float())), (tile, ci, co)
+            # fp16 in -> fp32 out (the image-side layers of the fp16 path), pre-clamp second output
+            out32, aux32 = torch.zeros(b, ho, wo, cs, device=DEV), torch.zeros(b, ho, wo, cs, device=DEV)
+            plan.run(nhwc(x).half().to(DEV), out32, act=lib.ACT_RELU_CLAMP1, aux_out=aux32)
+            assert rel_inf(nchw(out32.cpu(), co), F.relu(y).clamp(max=1)) < 2e-5 * max(1.0, float(F.relu(y).max()))
+            assert rel_inf(nchw(aux32.cpu(), co), F.relu(y)) < 2e-5
+            # input gradient: fp16 gradient in -> fp16 gradient out, gated by a byte mask
+            gy = _h(torch.randn(b, co, ho, wo))
+            gx_ref = torch.nn.grad.conv2d_input((b, ci, h, w), wt.double(), gy.double(), s, k // 2).float()
+            gate_act = torch.randn(b, h, w, ci, device=DEV)
+            dplan = cp.conv_dgrad_plan(wt, s, k // 2, DEV)
+            if dplan.cin_p % 32 == 0:
+                gx = torch.zeros(b, h, w, ci, device=DEV, dtype=torch.float16)
+                dplan.run(nhwc(gy, dplan.cin_p).half().to(DEV), gx, gate_bits=lib.pack_gate_mask(gate_act))
+                want_g = gx_ref * (nchw(gate_act.cpu(), ci) > 0)
+                assert rel_inf(nchw(gx.float().cpu(), ci), want_g) < 1.5e-3, (tile, 'dgrad', ci, co, k, s)
+            cp.FORCE_TILE = 0
+        # transposed convolutions: strided classes (k3) and folded classes (k2)
+        for kk, pad, op in [(3, 1, 1), (2, 0, 0)]:
+            xt = _h(torch.randn(2, 64, 11, 13))
+            wtt = _h(torch.randn(64, 32, kk, kk) / 16)
+            bt = torch.randn(32)
+            ref = F.relu(F.conv_transpose2d(xt.double(), wtt.double(), bt.double(), 2, pad, op).float())
+            tplan = cp.deconv_fwd_plan(wtt, bt, 2, pad, DEV)
+            outt = torch.zeros(2, ref.shape[2], ref.shape[3], 32, device=DEV, dtype=torch.float16)
+            cp.FORCE_TILE = tile
+            tplan.run(nhwc(xt).half().to(DEV), outt, act=lib.ACT_RELU)
+            cp.FORCE_TILE = 0
+            assert rel_inf(nchw(outt.float().cpu()), ref) < 1.5e-3, (tile, 'deconv', kk)
+        # fp32 image in -> fp16 activation out (first layers: the small-Cin kernels with the fp16 epilogue)
+        for ci, co, k, s in [(3, 32, 3, 2), (6, 32, 3, 2), (3, 64, 7, 2), (3, 64, 3, 1)]:
+            x = torch.rand(2, ci, 24, 28)
+            wt = torch.randn(co, ci, k, k) / (ci * k * k) ** 0.5
+            bias = torch.randn(co)
+            y = F.relu(F.conv2d(x, wt, bias, s, k // 2))
+            plan = cp.conv_fwd_plan(wt, bias, s, k // 2, DEV)
+            out = torch.zeros(2, y.shape[2], y.shape[3], co, device=DEV, dtype=torch.float16)
+            mask = torch.zeros(2, y.shape[2], y.shape[3], co // 4, dtype=torch.uint8, device=DEV)
+            plan.run(nhwc(x, plan.cin_p).to(DEV), out, act=lib.ACT_RELU, mask_out=mask)
+            assert rel_inf(nchw(out.float().cpu(), co), y) < 1e-3, ('image->f16', ci, co, k, s)
+            assert torch.equal(mask, lib.pack_gate_mask(out.float()))
+    finally:
+        cp.FORCE_TILE = 0
