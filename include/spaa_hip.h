@@ -209,6 +209,16 @@ int spaa_maxpool_fwd(const float* in, float* out, uint8_t* argmax, int B, int Hi
 int spaa_maxpool_bwd(const float* g_out, const uint8_t* argmax, int relu_gate, float* g_in, int B, int Hin,
                      int Win, int C, int Hout, int Wout, int k, int s, int p, int gout_cstride, int gout_coff,
                      spaa_stream_t stream);
+/* fp16-storage variants (activations and their gradients fp16; argmax bytes as above) */
+int spaa_maxpool_fwd_f16(const void* in, void* out, uint8_t* argmax, int B, int Hin, int Win, int C, int Hout, int Wout,
+                         int k, int s, int p, int out_cstride, int out_coff, spaa_stream_t stream);
+int spaa_maxpool_bwd_f16(const void* g_out, const uint8_t* argmax, int relu_gate, void* g_in, int B, int Hin, int Win,
+                         int C, int Hout, int Wout, int k, int s, int p, int gout_cstride, int gout_coff,
+                         spaa_stream_t stream);
+/* global average pool, fp16 activation in -> fp32 features out; backward fp32 feature gradient -> fp16 gradient, with the
+ * ReLU gate of `act` (fp16, may be NULL) */
+int spaa_avgpool_fwd_f16(const void* in, float* out, int B, int HW, int C, spaa_stream_t stream);
+int spaa_avgpool_bwd_f16(const float* g_out, const void* act, void* g_in, int B, int HW, int C, spaa_stream_t stream);
 /* avg_pool2d(k, s, p), count_include_pad=True */
 int spaa_avgpool2d_fwd(const float* in, float* out, int B, int Hin, int Win, int C, int Hout, int Wout, int k, int s,
                        int p, int out_cstride, int out_coff, spaa_stream_t stream);

@@ -77,6 +77,10 @@ _SIGNATURES = {
     'spaa_maxpool3s2_bwd': [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     'spaa_maxpool_fwd': [_p, _p, _p] + [_i] * 11 + [_p],
     'spaa_maxpool_bwd': [_p, _p, _i, _p] + [_i] * 11 + [_p],
+    'spaa_maxpool_fwd_f16': [_p, _p, _p] + [_i] * 11 + [_p],
+    'spaa_maxpool_bwd_f16': [_p, _p, _i, _p] + [_i] * 11 + [_p],
+    'spaa_avgpool_fwd_f16': [_p, _p, _i, _i, _i, _p],
+    'spaa_avgpool_bwd_f16': [_p, _p, _p, _i, _i, _i, _p],
     'spaa_avgpool2d_fwd': [_p, _p] + [_i] * 11 + [_p],
     'spaa_avgpool2d_bwd': [_p, _p] + [_i] * 11 + [_p],
     'spaa_adaptive_avgpool_fwd': [_p, _p] + [_i] * 6 + [_p],
@@ -142,6 +146,16 @@ def ptr(t):
     if t is None:
         return None
     _same_device(t)
+    return C.c_void_p(t.data_ptr())
+
+
+def hptr(t):
+    """Raw pointer of an activation tensor that is fp32 or, in fp16-storage mode, fp16."""
+    if t is None:
+        return None
+    _same_device(t)
+    if t.dtype not in (torch.float32, torch.float16) or not t.is_contiguous():
+        raise ValueError(f'expected a contiguous fp32/fp16 tensor, got {t.dtype}')
     return C.c_void_p(t.data_ptr())
 
 

@@ -42,17 +42,21 @@ def _strip(sd):
 class ResNet18Body:
     """torchvision.models.resnet18 (eval) forward + input-gradient on tapconv/maxpool/avgpool kernels."""
 
-    def __init__(self, sd, batch, in_hw, dev):
+    def __init__(self, sd, batch, in_hw, dev, storage='f32'):
         sd = _strip(sd)
-        self.B, self.dev = batch, dev
+        self.B, self.dev, self.storage = batch, dev, storage
+        hd = torch.float16 if storage == 'f16' else torch.float32   # activations / gradients; input image, features, logits fp32
         h, w = in_hw
 
         def folded(conv, bn):
             return cp.fold_bn(sd[conv + '.weight'], sd[bn + '.weight'], sd[bn + '.bias'], sd[bn + '.running_mean'],
                               sd[bn + '.running_var'])
 
-        def z(*shape):
+        def zf(*shape):
             return torch.zeros(*shape, device=dev)
+
+        def z(*shape):
+            return torch.zeros(*shape, device=dev, dtype=hd)
 
         def osz(n, k, s, p):
             return (n + 2 * p - k) // s + 1
@@ -97,16 +101,16 @@ class ResNet18Body:
                 self.blocks.append(blk)
                 x_buf, cin, hh, ww = blk['out'], cout, ho, wo
         self.feat_hw = hh * ww
-        self.feat = z(batch, 1, 1, 512)
+        self.feat = zf(batch, 1, 1, 512)
         ncls = sd['fc.weight'].shape[0]
         self.ncls = ncls
         self.fc_f = cp.linear_fwd_plan(sd['fc.weight'], sd['fc.bias'], dev, 'fc')
         self.fc_d = cp.linear_dgrad_plan(sd['fc.weight'], dev, 'fc_dgrad')
-        self.logits = z(batch, 1, 1, ncls)
-        self.g_feat = z(batch, 1, 1, 512)
+        self.logits = zf(batch, 1, 1, ncls)
+        self.g_feat = zf(batch, 1, 1, 512)
         self.g_last = z(batch, hh, ww, 512)
         self.g_c1 = z(batch, h1, w1, 64)
-        self.g_in = z(batch, h, w, 4)
+        self.g_in = zf(batch, h, w, 4)
 
     def forward(self, x4):
         R = _lib.ACT_RELU
@@ -114,18 +118,27 @@ class ResNet18Body:
         self.stem_f.run(x4, self.c1, act=R)
         _, h1, w1, _ = self.c1.shape
         _, h2, w2, _ = self.mp.shape
-        _lib.call('spaa_maxpool3s2_fwd', _lib.ptr(self.c1), _lib.ptr(self.mp), _lib.ptr(self.mp_arg), B, h1, w1, 64,
-                  h2, w2)
+        h16 = self.storage == 'f16'
+        if h16:
+            _lib.call('spaa_maxpool_fwd_f16', _lib.hptr(self.c1), _lib.hptr(self.mp), _lib.ptr(self.mp_arg), B, h1, w1, 64,
+                      h2, w2, 3, 2, 1, 64, 0)
+        else:
+            _lib.call('spaa_maxpool3s2_fwd', _lib.ptr(self.c1), _lib.ptr(self.mp), _lib.ptr(self.mp_arg), B, h1, w1, 64,
+                      h2, w2)
+        masks = USE_GATE_MASKS or h16
         for blk in self.blocks:
-            blk['f1'].run(blk['x'], blk['o1'], act=R, mask_out=blk['m_o1'] if USE_GATE_MASKS else None)
+            blk['f1'].run(blk['x'], blk['o1'], act=R, mask_out=blk['m_o1'] if masks else None)
             if 'fd' in blk:
                 blk['fd'].run(blk['x'], blk['idt'])
                 idt = blk['idt']
             else:
                 idt = blk['x']
-            blk['f2'].run(blk['o1'], blk['out'], add=idt, act=R, mask_out=blk['m_out'] if USE_GATE_MASKS else None)
+            blk['f2'].run(blk['o1'], blk['out'], add=idt, act=R, mask_out=blk['m_out'] if masks else None)
         last = self.blocks[-1]['out']
-        _lib.call('spaa_avgpool_fwd', _lib.ptr(last), _lib.ptr(self.feat), B, self.feat_hw, 512)
+        if h16:
+            _lib.call('spaa_avgpool_fwd_f16', _lib.hptr(last), _lib.ptr(self.feat), B, self.feat_hw, 512)
+        else:
+            _lib.call('spaa_avgpool_fwd', _lib.ptr(last), _lib.ptr(self.feat), B, self.feat_hw, 512)
         self.fc_f.run(self.feat, self.logits)
         return self.logits.view(B, self.ncls)
 
@@ -134,13 +147,18 @@ class ResNet18Body:
         B = self.B
         self.fc_d.run(g_logits.view(B, 1, 1, self.ncls), self.g_feat)
         last = self.blocks[-1]['out']
-        _lib.call('spaa_avgpool_bwd', _lib.ptr(self.g_feat), _lib.ptr(last), _lib.ptr(self.g_last), B, self.feat_hw,
-                  512)
+        h16 = self.storage == 'f16'
+        if h16:
+            _lib.call('spaa_avgpool_bwd_f16', _lib.ptr(self.g_feat), _lib.hptr(last), _lib.hptr(self.g_last), B,
+                      self.feat_hw, 512)
+        else:
+            _lib.call('spaa_avgpool_bwd', _lib.ptr(self.g_feat), _lib.ptr(last), _lib.ptr(self.g_last), B, self.feat_hw,
+                      512)
         gP = self.g_last
         for i in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[i]
             # the block's input is the previous block's output; block 0's is the max-pool output (gated in maxpool_bwd)
-            if USE_GATE_MASKS:
+            if USE_GATE_MASKS or h16:
                 kw2, kw1 = dict(gate_bits=blk['m_o1']), dict(gate_bits=self.blocks[i - 1]['m_out'] if i > 0 else None)
             else:
                 kw2, kw1 = dict(gate=blk['o1']), dict(gate=blk['x'] if i > 0 else None)
@@ -153,16 +171,20 @@ class ResNet18Body:
             gP = blk['g_x']
         _, h1, w1, _ = self.c1.shape
         _, h2, w2, _ = self.mp.shape
-        _lib.call('spaa_maxpool3s2_bwd', _lib.ptr(gP), _lib.ptr(self.mp_arg), 1, _lib.ptr(self.g_c1),
-                  B, h1, w1, 64, h2, w2)
+        if h16:
+            _lib.call('spaa_maxpool_bwd_f16', _lib.hptr(gP), _lib.ptr(self.mp_arg), 1, _lib.hptr(self.g_c1), B, h1, w1, 64,
+                      h2, w2, 3, 2, 1, 64, 0)
+        else:
+            _lib.call('spaa_maxpool3s2_bwd', _lib.ptr(gP), _lib.ptr(self.mp_arg), 1, _lib.ptr(self.g_c1),
+                      B, h1, w1, 64, h2, w2)
         self.stem_d.run(self.g_c1, self.g_in)
         return self.g_in
 
     def refresh_masks(self):
         """Recompute the gate masks from the activation buffers (after a test has overwritten the activations)."""
         for blk in self.blocks:
-            blk['m_o1'].copy_(_lib.pack_gate_mask(blk['o1']))
-            blk['m_out'].copy_(_lib.pack_gate_mask(blk['out']))
+            blk['m_o1'].copy_(_lib.pack_gate_mask(blk['o1'].float()))
+            blk['m_out'].copy_(_lib.pack_gate_mask(blk['out'].float()))
 
     def flops_fwd(self):
         h, w = self.in_hw
@@ -181,14 +203,18 @@ VGG16_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M',
 class VGG16Body:
     """torchvision.models.vgg16 (eval: dropout is the identity) forward + input-gradient."""
 
-    def __init__(self, sd, batch, in_hw, dev):
+    def __init__(self, sd, batch, in_hw, dev, storage='f32'):
         sd = _strip(sd)
-        self.B, self.dev = batch, dev
+        self.B, self.dev, self.storage = batch, dev, storage
+        hd = torch.float16 if storage == 'f16' else torch.float32   # activations / gradients; input image and logits fp32
         h, w = in_hw
         self.in_hw = (h, w)
 
-        def z(*shape):
+        def zf(*shape):
             return torch.zeros(*shape, device=dev)
+
+        def z(*shape):
+            return torch.zeros(*shape, device=dev, dtype=hd)
 
         self.ops = []
         cin, idx = 3, 0
@@ -204,7 +230,7 @@ class VGG16Body:
                 wt, bs = sd[f'features.{idx}.weight'], sd[f'features.{idx}.bias']
                 self.ops.append(dict(kind='conv', f=cp.conv_fwd_plan(wt, bs, 1, 1, dev, f'features.{idx}'),
                                      d=cp.conv_dgrad_plan(wt, 1, 1, dev, f'features.{idx}_dgrad'),
-                                     out=z(batch, h, w, v), g=z(batch, h, w, 4 if cin == 3 else cin)))
+                                     out=z(batch, h, w, v), g=zf(batch, h, w, 4) if cin == 3 else z(batch, h, w, cin)))
                 cin = v
                 idx += 2
         self.feat_hw = (h, w)
@@ -222,7 +248,7 @@ class VGG16Body:
         self.ncls = sd['classifier.6.weight'].shape[0]
         fcw = sd['classifier.0.weight'].shape[0]
         self.h1, self.h2 = z(batch, 1, 1, fcw), z(batch, 1, 1, fcw)
-        self.logits = z(batch, 1, 1, self.ncls)
+        self.logits = zf(batch, 1, 1, self.ncls)
         self.g_h1, self.g_h2 = z(batch, 1, 1, fcw), z(batch, 1, 1, fcw)
 
     def forward(self, x4):
@@ -232,12 +258,15 @@ class VGG16Body:
             if op['kind'] == 'conv':
                 op['f'].run(t, op['out'], act=R)
             else:
-                _lib.call('spaa_maxpool_fwd', _lib.ptr(t), _lib.ptr(op['out']), _lib.ptr(op['arg']), B, op['hin'],
-                          op['win'], op['c'], op['hin'] // 2, op['win'] // 2, 2, 2, 0, op['c'], 0)
+                _lib.call('spaa_maxpool_fwd_f16' if self.storage == 'f16' else 'spaa_maxpool_fwd', _lib.hptr(t),
+                          _lib.hptr(op['out']), _lib.ptr(op['arg']), B, op['hin'], op['win'], op['c'], op['hin'] // 2,
+                          op['win'] // 2, 2, 2, 0, op['c'], 0)
             op['inp'] = t
             t = op['out']
         fh, fw = self.feat_hw
         if (fh, fw) != (7, 7):
+            if self.storage == 'f16':
+                raise NotImplementedError('fp16-storage VGG-16 needs a 224x224 input (7x7 features: no adaptive pooling)')
             _lib.call('spaa_adaptive_avgpool_fwd', _lib.ptr(t), _lib.ptr(self.pool7), B, fh, fw, 512, 7, 7)
             t = self.pool7
         flat = t.view(B, 1, 1, 49 * 512)
@@ -261,8 +290,9 @@ class VGG16Body:
             op = self.ops[i]
             if op['kind'] == 'pool':
                 # input of a pool is a conv+ReLU output: gather + ReLU gate -> gradient w.r.t. that conv's pre-activation
-                _lib.call('spaa_maxpool_bwd', _lib.ptr(g), _lib.ptr(op['arg']), 1, _lib.ptr(op['g']),
-                          B, op['hin'], op['win'], op['c'], op['hin'] // 2, op['win'] // 2, 2, 2, 0, op['c'], 0)
+                _lib.call('spaa_maxpool_bwd_f16' if self.storage == 'f16' else 'spaa_maxpool_bwd', _lib.hptr(g),
+                          _lib.ptr(op['arg']), 1, _lib.hptr(op['g']), B, op['hin'], op['win'], op['c'], op['hin'] // 2,
+                          op['win'] // 2, 2, 2, 0, op['c'], 0)
             else:
                 prev = self.ops[i - 1] if i > 0 else None
                 gate = op['inp'] if (prev is not None and prev['kind'] == 'conv') else None
@@ -278,7 +308,9 @@ class VGG16Body:
         return t + sum(f.flops(self.B, 1, 1) for f, _ in self.fc)
 
 
-def _inception_body(sd, batch, in_hw, dev):
+def _inception_body(sd, batch, in_hw, dev, storage='f32'):
+    if storage != 'f32':
+        raise NotImplementedError('fp16-storage mode covers ResNet-18 and VGG-16 (BASELINE.json configs[4]); Inception-v3 runs in fp32')
     from .inception import InceptionV3Body
     return InceptionV3Body(sd, batch, in_hw, dev)
 
@@ -289,7 +321,8 @@ BODIES = {'resnet18': ResNet18Body, 'vgg16': VGG16Body, 'inception_v3': _incepti
 class ClassifierEngine:
     """crop -> area resize -> normalise -> net, forward and input-gradient, for a fixed batch/geometry."""
 
-    def __init__(self, name, state_dict, batch, im_hw, crop_sz, input_sz=None, device='cuda'):
+    def __init__(self, name, state_dict, batch, im_hw, crop_sz, input_sz=None, device='cuda', storage='f32'):
+        self.storage = storage
         if name not in BODIES:
             raise NotImplementedError(f'classifier body {name!r} is not implemented on HIP yet (have: {list(BODIES)})')
         self.name, self.B, self.dev = name, batch, torch.device(device)
@@ -297,7 +330,7 @@ class ClassifierEngine:
         self.ch, self.cw = crop_sz
         self.cy0, self.cx0 = center_crop_origin(self.H, self.W, crop_sz)
         self.oh, self.ow = tuple(input_sz) if input_sz is not None else INPUT_SZ[name]
-        self.body = BODIES[name](state_dict, batch, (self.oh, self.ow), self.dev)
+        self.body = BODIES[name](state_dict, batch, (self.oh, self.ow), self.dev, storage)
         self.pre = torch.zeros(batch, self.oh, self.ow, 4, device=self.dev)
         self.g_y = torch.zeros(batch, self.H, self.W, 4, device=self.dev)
         import ctypes as C
@@ -367,17 +400,17 @@ class Classifier(object):
         self.state_dict = {k: v.detach().float().cpu() for k, v in _strip(state_dict).items()}
         self._engines = {}
 
-    def engine(self, batch, im_hw, crop_sz, owner=None):
+    def engine(self, batch, im_hw, crop_sz, owner=None, storage='f32'):
         """Cached engine for a batch size / geometry; an engine leased to an `owner` (attack state) is not handed to
-        anyone else while the owner lives (see PCNet.engine)."""
-        key = (batch, tuple(im_hw), tuple(crop_sz))
+        anyone else while the owner lives (see PCNet.engine).  `storage`: 'f32' or 'f16' (fp16 activations in HBM)."""
+        key = (batch, tuple(im_hw), tuple(crop_sz), storage)
         pool = self._engines.setdefault(key, [])
         for e in pool:
             if e.owner is None or e.owner() is None:
                 break
         else:
             with _lib.on_device(self.device):
-                e = ClassifierEngine(self.name, self.state_dict, batch, im_hw, crop_sz, self.input_sz, self.device)
+                e = ClassifierEngine(self.name, self.state_dict, batch, im_hw, crop_sz, self.input_sz, self.device, storage)
             pool.append(e)
         e.owner = weakref.ref(owner) if owner is not None else None
         return e

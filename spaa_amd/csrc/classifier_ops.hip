@@ -127,7 +127,7 @@ __global__ void maxpool_bwd_kernel(const float4* __restrict__ g_out, const uchar
     const int iy = r % Hin;
     const int b = r / Hin;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const unsigned char need = relu_gate ? 0x80 : 0xff;  // relu_gate: only windows whose maximum is positive pass
+    const unsigned char need = relu_gate ? 0x80 : 0x00;  // relu_gate: only windows whose maximum is positive pass
     for (int ky = 0; ky < 3; ++ky) {
         const int t = iy + 1 - ky;
         if (t < 0 || (t & 1)) continue;
@@ -142,10 +142,10 @@ __global__ void maxpool_bwd_kernel(const float4* __restrict__ g_out, const uchar
             const uchar4 am = argmax[o];
             const float4 g = g_out[o];
             const unsigned char k = (unsigned char)(ky * 3 + kx);
-            if ((am.x & 0x7f) == k && (am.x & need)) acc.x += g.x;
-            if ((am.y & 0x7f) == k && (am.y & need)) acc.y += g.y;
-            if ((am.z & 0x7f) == k && (am.z & need)) acc.z += g.z;
-            if ((am.w & 0x7f) == k && (am.w & need)) acc.w += g.w;
+            if ((am.x & 0x7f) == k && (am.x & need) == need) acc.x += g.x;
+            if ((am.y & 0x7f) == k && (am.y & need) == need) acc.y += g.y;
+            if ((am.z & 0x7f) == k && (am.z & need) == need) acc.z += g.z;
+            if ((am.w & 0x7f) == k && (am.w & need) == need) acc.w += g.w;
         }
     }
     g_in[idx] = acc;
@@ -170,6 +170,27 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ g_out, const float*
     const int b = idx / (HW * C);
     const float g = g_out[(size_t)b * C + c] / (float)HW;
     g_in[idx] = (act == nullptr || act[idx] > 0.f) ? g : 0.f;
+}
+
+// fp16-storage variants of the two global-average-pool kernels: activations / their gradients fp16, pooled features fp32
+__global__ void avgpool_fwd_h_kernel(const _Float16* __restrict__ in, float* __restrict__ out, int B, int HW, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * C) return;
+    const int b = idx / C, c = idx - b * C;
+    const _Float16* p = in + (size_t)b * HW * C + c;
+    float a = 0.f;
+    for (int i = 0; i < HW; ++i) a += (float)p[(size_t)i * C];
+    out[idx] = a / (float)HW;
+}
+
+__global__ void avgpool_bwd_h_kernel(const float* __restrict__ g_out, const _Float16* __restrict__ act,
+                                     _Float16* __restrict__ g_in, int B, int HW, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * HW * C) return;
+    const int c = idx % C;
+    const int b = idx / (HW * C);
+    const float g = g_out[(size_t)b * C + c] / (float)HW;
+    g_in[idx] = (_Float16)((act == nullptr || (float)act[idx] > 0.f) ? g : 0.f);
 }
 
 inline int nblk(int64_t n) { return (int)((n + 255) / 256); }
@@ -229,6 +250,20 @@ int spaa_avgpool_fwd(const float* in, float* out, int B, int HW, int C, spaa_str
     if (!in || !out || B < 1 || HW < 1 || C < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(nblk((int64_t)B * C)), dim3(256), 0, (hipStream_t)stream, in, out, B,
                        HW, C);
+    return (int)hipGetLastError();
+}
+
+int spaa_avgpool_fwd_f16(const void* in, float* out, int B, int HW, int C, spaa_stream_t stream) {
+    if (!in || !out || B < 1 || HW < 1 || C < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(avgpool_fwd_h_kernel, dim3(nblk((int64_t)B * C)), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)in, out, B, HW, C);
+    return (int)hipGetLastError();
+}
+
+int spaa_avgpool_bwd_f16(const float* g_out, const void* act, void* g_in, int B, int HW, int C, spaa_stream_t stream) {
+    if (!g_out || !g_in || B < 1 || HW < 1 || C < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(avgpool_bwd_h_kernel, dim3(nblk((int64_t)B * HW * C)), dim3(256), 0, (hipStream_t)stream, g_out,
+                       (const _Float16*)act, (_Float16*)g_in, B, HW, C);
     return (int)hipGetLastError();
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/spaa_hip.h"
+#include "epilogue.hpp"  // io4<T>: 4 consecutive elements stored as fp32 or fp16
 
 namespace {
 
@@ -15,7 +16,8 @@ struct Geo {
 };
 
 // max_pool2d(k, s, p), first maximum in row-major window order wins (ATen CPU rule); 4 channels per thread
-__global__ void maxpool_fwd_kernel(const float4* __restrict__ in, float4* __restrict__ out,
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out,
                                    uchar4* __restrict__ argmax, Geo g, int out_c4stride, int out_c4off) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= g.B * g.Hout * g.Wout * g.C4) return;
@@ -33,7 +35,7 @@ __global__ void maxpool_fwd_kernel(const float4* __restrict__ in, float4* __rest
         for (int kx = 0; kx < g.k; ++kx) {
             const int ix = ox * g.s - g.p + kx;
             if ((unsigned)ix >= (unsigned)g.Win) continue;
-            const float4 v = in[(((size_t)b * g.Hin + iy) * g.Win + ix) * g.C4 + c];
+            const f4 v = io4<T>::ld(in, 4 * ((((size_t)b * g.Hin + iy) * g.Win + ix) * g.C4 + c));
             const unsigned char kk = (unsigned char)(ky * g.k + kx);
             if (v.x > best.x || v.x != v.x) { best.x = v.x; am.x = kk; }
             if (v.y > best.y || v.y != v.y) { best.y = v.y; am.y = kk; }
@@ -46,12 +48,14 @@ __global__ void maxpool_fwd_kernel(const float4* __restrict__ in, float4* __rest
     am.y |= best.y > 0.f ? 0x80 : 0;
     am.z |= best.z > 0.f ? 0x80 : 0;
     am.w |= best.w > 0.f ? 0x80 : 0;
-    out[(((size_t)b * g.Hout + oy) * g.Wout + ox) * out_c4stride + out_c4off + c] = best;
+    io4<T>::st(out, 4 * ((((size_t)b * g.Hout + oy) * g.Wout + ox) * out_c4stride + out_c4off + c),
+               f4{best.x, best.y, best.z, best.w});
     argmax[idx] = am;
 }
 
-__global__ void maxpool_bwd_kernel(const float4* __restrict__ g_out, const uchar4* __restrict__ argmax,
-                                   const int relu_gate, float4* __restrict__ g_in, Geo g,
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ g_out, const uchar4* __restrict__ argmax,
+                                   const int relu_gate, T* __restrict__ g_in, Geo g,
                                    int gout_c4stride, int gout_c4off) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= g.B * g.Hin * g.Win * g.C4) return;
@@ -62,7 +66,7 @@ __global__ void maxpool_bwd_kernel(const float4* __restrict__ g_out, const uchar
     const int iy = r % g.Hin;
     const int b = r / g.Hin;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const unsigned char need = relu_gate ? 0x80 : 0xff;  // relu_gate: only windows whose maximum is positive pass
+    const unsigned char need = relu_gate ? 0x80 : 0x00;  // relu_gate: only windows whose maximum is positive pass
     for (int ky = 0; ky < g.k; ++ky) {
         const int t = iy + g.p - ky;
         if (t < 0 || (t % g.s)) continue;
@@ -75,15 +79,15 @@ __global__ void maxpool_bwd_kernel(const float4* __restrict__ g_out, const uchar
             if (ox >= g.Wout) continue;
             const size_t opix = ((size_t)b * g.Hout + oy) * g.Wout + ox;
             const uchar4 am = argmax[opix * g.C4 + c];
-            const float4 go = g_out[opix * gout_c4stride + gout_c4off + c];
+            const f4 go = io4<T>::ld(g_out, 4 * (opix * gout_c4stride + gout_c4off + c));
             const unsigned char kk = (unsigned char)(ky * g.k + kx);
-            if ((am.x & 0x7f) == kk && (am.x & need)) acc.x += go.x;
-            if ((am.y & 0x7f) == kk && (am.y & need)) acc.y += go.y;
-            if ((am.z & 0x7f) == kk && (am.z & need)) acc.z += go.z;
-            if ((am.w & 0x7f) == kk && (am.w & need)) acc.w += go.w;
+            if ((am.x & 0x7f) == kk && (am.x & need) == need) acc.x += go.x;
+            if ((am.y & 0x7f) == kk && (am.y & need) == need) acc.y += go.y;
+            if ((am.z & 0x7f) == kk && (am.z & need) == need) acc.z += go.z;
+            if ((am.w & 0x7f) == kk && (am.w & need) == need) acc.w += go.w;
         }
     }
-    g_in[idx] = acc;
+    io4<T>::st(g_in, 4 * (size_t)idx, f4{acc.x, acc.y, acc.z, acc.w});
 }
 
 // avg_pool2d(k, s, p), count_include_pad=True (divisor k*k), optional output channel window of a concat buffer
@@ -216,8 +220,20 @@ int spaa_maxpool_fwd(const float* in, float* out, uint8_t* argmax, int B, int Hi
         out_coff + C > out_cstride)
         return hipErrorInvalidValue;
     Geo g{B, Hin, Win, C / 4, Hout, Wout, k, s, p};
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nb((int64_t)B * Hout * Wout * g.C4)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)in, (float4*)out, (uchar4*)argmax, g, out_cstride / 4, out_coff / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(nb((int64_t)B * Hout * Wout * g.C4)), dim3(256), 0, (hipStream_t)stream,
+                       in, out, (uchar4*)argmax, g, out_cstride / 4, out_coff / 4);
+    return (int)hipGetLastError();
+}
+
+int spaa_maxpool_fwd_f16(const void* in, void* out, uint8_t* argmax, int B, int Hin, int Win, int C, int Hout, int Wout,
+                         int k, int s, int p, int out_cstride, int out_coff, spaa_stream_t stream) {
+    if (!in || !out || !argmax || !geo_ok(B, Hin, Win, C, Hout, Wout, k, s, p) || (out_cstride & 3) || (out_coff & 3) ||
+        out_coff + C > out_cstride)
+        return hipErrorInvalidValue;
+    Geo g{B, Hin, Win, C / 4, Hout, Wout, k, s, p};
+    hipLaunchKernelGGL(maxpool_fwd_kernel<_Float16>, dim3(nb((int64_t)B * Hout * Wout * g.C4)), dim3(256), 0,
+                       (hipStream_t)stream, (const _Float16*)in, (_Float16*)out, (uchar4*)argmax, g, out_cstride / 4,
+                       out_coff / 4);
     return (int)hipGetLastError();
 }
 
@@ -228,8 +244,20 @@ int spaa_maxpool_bwd(const float* g_out, const uint8_t* argmax, int relu_gate, f
         (gout_coff & 3) || gout_coff + C > gout_cstride)
         return hipErrorInvalidValue;
     Geo g{B, Hin, Win, C / 4, Hout, Wout, k, s, p};
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nb((int64_t)B * Hin * Win * g.C4)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)g_out, (const uchar4*)argmax, relu_gate, (float4*)g_in, g,
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(nb((int64_t)B * Hin * Win * g.C4)), dim3(256), 0, (hipStream_t)stream,
+                       g_out, (const uchar4*)argmax, relu_gate, g_in, g, gout_cstride / 4, gout_coff / 4);
+    return (int)hipGetLastError();
+}
+
+int spaa_maxpool_bwd_f16(const void* g_out, const uint8_t* argmax, int relu_gate, void* g_in, int B, int Hin, int Win,
+                         int C, int Hout, int Wout, int k, int s, int p, int gout_cstride, int gout_coff,
+                         spaa_stream_t stream) {
+    if (!g_out || !argmax || !g_in || !geo_ok(B, Hin, Win, C, Hout, Wout, k, s, p) || (gout_cstride & 3) ||
+        (gout_coff & 3) || gout_coff + C > gout_cstride)
+        return hipErrorInvalidValue;
+    Geo g{B, Hin, Win, C / 4, Hout, Wout, k, s, p};
+    hipLaunchKernelGGL(maxpool_bwd_kernel<_Float16>, dim3(nb((int64_t)B * Hin * Win * g.C4)), dim3(256), 0,
+                       (hipStream_t)stream, (const _Float16*)g_out, (const uchar4*)argmax, relu_gate, (_Float16*)g_in, g,
                        gout_cstride / 4, gout_coff / 4);
     return (int)hipGetLastError();
 }

@@ -208,19 +208,20 @@ class PCNet(nn.Module):
         self._engines = {}
         return r
 
-    def engine(self, batch, prj_size, owner=None):
-        """Engine (packed weights + workspaces) for a batch size / projector size.  Engines are cached, but an engine
+    def engine(self, batch, prj_size, owner=None, storage='f32'):
+        """Engine (packed weights + workspaces) for a batch size / projector size; `storage` = 'f32' (default) or 'f16'
+        (fp16-storage mode, BASELINE.json configs[4]: activations and gradients fp16 in HBM, images and accumulation fp32).  Engines are cached, but an engine
         handed to an `owner` (an AttackState) is that owner's alone for as long as the owner lives: two attacks built
         from one PCNet never share activation workspaces.  Without an owner (the autograd path) any free engine is
         returned; `_PCNetFn.backward` detects a workspace that has been reused since its forward and recomputes it."""
-        key = (batch, tuple(prj_size), self.shading_net.conv1.weight.device)
+        key = (batch, tuple(prj_size), self.shading_net.conv1.weight.device, storage)
         pool = self._engines.setdefault(key, [])
         for e in pool:
             if e.owner is None or e.owner() is None:
                 break
         else:
             with _lib.on_device(key[2]):
-                e = PCNetEngine(self, batch, prj_size)
+                e = PCNetEngine(self, batch, prj_size, storage)
             pool.append(e)
         e.owner = weakref.ref(owner) if owner is not None else None
         return e
@@ -274,7 +275,11 @@ class PCNetEngine:
     """Packed weights, sampling grid and workspaces of one PCNet for a fixed batch size; HIP forward and
     input-gradient passes over NHWC4 tensors."""
 
-    def __init__(self, pcnet, batch, prj_size):
+    def __init__(self, pcnet, batch, prj_size, storage='f32'):
+        if storage not in ('f32', 'f16'):
+            raise ValueError("storage must be 'f32' or 'f16'")
+        self.storage = storage
+        hd = torch.float16 if storage == 'f16' else torch.float32   # activations / their gradients; images stay fp32
         wn, sn = pcnet.warping_net, pcnet.shading_net
         dev = sn.conv1.weight.device
         if dev.type != 'cuda':
@@ -317,12 +322,15 @@ class PCNetEngine:
         def z(*shape):
             return torch.zeros(*shape, device=dev)
 
+        def zh(*shape):
+            return torch.zeros(*shape, device=dev, dtype=hd)
+
         a = {}
         a['xw'], a['cat8'] = z(B, H, W, 4), z(B, H, W, 8)
-        a['S1'], a['S2'], a['S3'], a['S4'] = z(B, H2, W2, 32), z(B, H4, W4, 64), z(B, H4, W4, 128), z(B, H4, W4, 256)
-        a['X1'], a['R2'], a['X2'], a['R3'] = z(B, H2, W2, 32), z(B, H2, W2, 64), z(B, H4, W4, 64), z(B, H4, W4, 128)
-        a['X3'], a['X4'], a['X5'] = z(B, H4, W4, 128), z(B, H4, W4, 256), z(B, H4, W4, 128)
-        a['X6'], a['X7'] = z(B, H2, W2, 64), z(B, H, W, 32)
+        a['S1'], a['S2'], a['S3'], a['S4'] = zh(B, H2, W2, 32), zh(B, H4, W4, 64), zh(B, H4, W4, 128), zh(B, H4, W4, 256)
+        a['X1'], a['R2'], a['X2'], a['R3'] = zh(B, H2, W2, 32), zh(B, H2, W2, 64), zh(B, H4, W4, 64), zh(B, H4, W4, 128)
+        a['X3'], a['X4'], a['X5'] = zh(B, H4, W4, 128), zh(B, H4, W4, 256), zh(B, H4, W4, 128)
+        a['X6'], a['X7'] = zh(B, H2, W2, 64), zh(B, H, W, 32)
         a['Y'], a['Ypre'], a['R1'] = z(B, H, W, 4), z(B, H, W, 4), z(B, H, W, 4)
         self.a = a
         # ReLU gates of the activations, one byte per 4 channels (include/spaa_hip.h: mask_out / gate_bits): written by
@@ -331,10 +339,10 @@ class PCNetEngine:
         self.m = {k: torch.zeros(*a[k].shape[:3], a[k].shape[3] // 4, dtype=torch.uint8, device=dev)
                   for k in ('S1', 'S2', 'S3', 'S4', 'X1', 'X2', 'X3', 'X4', 'X5', 'X6', 'X7')}
         g = {}
-        g['P7'], g['P6'], g['P5'], g['P4'] = z(B, H, W, 32), z(B, H2, W2, 64), z(B, H4, W4, 128), z(B, H4, W4, 256)
-        g['S4'], g['P3'], g['t2'], g['P2'] = z(B, H4, W4, 256), z(B, H4, W4, 128), z(B, H4, W4, 64), z(B, H4, W4, 64)
-        g['t1'], g['P1'] = z(B, H2, W2, 32), z(B, H2, W2, 32)
-        g['S3'], g['S2'], g['S1'] = z(B, H4, W4, 128), z(B, H4, W4, 64), z(B, H2, W2, 32)
+        g['P7'], g['P6'], g['P5'], g['P4'] = zh(B, H, W, 32), zh(B, H2, W2, 64), zh(B, H4, W4, 128), zh(B, H4, W4, 256)
+        g['S4'], g['P3'], g['t2'], g['P2'] = zh(B, H4, W4, 256), zh(B, H4, W4, 128), zh(B, H4, W4, 64), zh(B, H4, W4, 64)
+        g['t1'], g['P1'] = zh(B, H2, W2, 32), zh(B, H2, W2, 32)
+        g['S3'], g['S2'], g['S1'] = zh(B, H4, W4, 128), zh(B, H4, W4, 64), zh(B, H2, W2, 32)
         g['xw'], g['xs'], g['x'] = z(B, H, W, 4), z(B, H, W, 4), z(B, self.Hp, self.Wp, 4)
         self.g = g
         self.scene = None
@@ -372,7 +380,7 @@ class PCNetEngine:
         R, N = _lib.ACT_RELU, _lib.ACT_NONE
         self.version += 1
         self.warp(x4, clamp01)
-        m = self.m if USE_GATE_MASKS else {k: None for k in self.m}
+        m = self.m if (USE_GATE_MASKS or self.storage == 'f16') else {k: None for k in self.m}
         f['conv1_s'].run(a['cat8'], a['S1'], act=R, mask_out=m['S1'])
         f['conv2_s'].run(a['S1'], a['S2'], act=R, mask_out=m['S2'])
         f['conv3_s'].run(a['S2'], a['S3'], act=R, mask_out=m['S3'])
@@ -392,7 +400,7 @@ class PCNetEngine:
     def backward(self, gP):
         """gP: gradient w.r.t. conv6's pre-activation (already gated by 0 < Ypre <= 1), [B,Hc,Wc,4].
         Returns the gradient w.r.t. the projector image x4 [B,Hp,Wp,4] (workspace)."""
-        if not USE_GATE_MASKS:
+        if not USE_GATE_MASKS and self.storage == 'f32':
             return self._backward_float_gates(gP)
         g, d, m = self.g, self.d, self.m
         d['conv6'].run(gP, g['P7'], gate_bits=m['X7'])
@@ -436,7 +444,7 @@ class PCNetEngine:
     def refresh_masks(self):
         """Recompute the gate masks from the activation buffers (after a test has overwritten the activations)."""
         for k, mk in self.m.items():
-            mk.copy_(_lib.pack_gate_mask(self.a[k]))
+            mk.copy_(_lib.pack_gate_mask(self.a[k].float()))
 
     def warp_backward(self, g_xw):
         """Adjoint of the masked grid_sample (models.py:184,340): deterministic gather over the transposed tap lists; the

@@ -28,7 +28,10 @@ def quantization(x):
 
 class PerC_AL:
     def __init__(self, max_iterations: int = 1000, alpha_l_init: float = 1., alpha_c_init: float = 0.5,
-                 confidence: float = 0, device=torch.device('cpu')) -> None:
+                 confidence: float = 0, device=torch.device('cpu'), storage: str = 'f32') -> None:
+        # storage = 'f16': BASELINE.json configs[4] ("fp16 with fp32 dE2000"): the classifier's activations and gradients
+        # are fp16 in HBM; the image, delta, dE2000 map, norms and all reductions stay fp32
+        self.storage = storage
         self.max_iterations = max_iterations
         self.alpha_l_init = alpha_l_init
         self.alpha_c_init = alpha_c_init
@@ -56,7 +59,7 @@ class PerC_AL:
         B, _, H, W = inputs.shape
         HW = H * W
         nblk = (HW + 255) // 256
-        clf = classifier.engine(B, (H, W), tuple(cp_sz))
+        clf = classifier.engine(B, (H, W), tuple(cp_sz), storage=self.storage)
         x_in = to_nhwc4(inputs.to(dev))
         lab_in = torch.zeros_like(x_in)
         _lib.call('spaa_rgb2lab', p(x_in), p(lab_in), B * HW)
@@ -74,7 +77,8 @@ class PerC_AL:
         stats = torch.zeros(B, 8, device=dev)
         stats[:, 5] = 100000.
         label = labels.to(dev).to(torch.int32).contiguous()
-        mult = -1.0 if targeted else 1.0
+        # (fp16 gradients: loss scale 64 at the logits; the step normalises the gradient, :193-195, so it cancels)
+        mult = (-1.0 if targeted else 1.0) * (64.0 if self.storage == 'f16' else 1.0)
         mode = 0 if targeted else (2 if self.confidence != 0 else 1)
         a_l_min, a_c_min = self.alpha_l_init / 100, self.alpha_c_init / 10
         n_it = self.max_iterations

@@ -26,8 +26,12 @@ def _unwrap(m):
 class AttackState:
     """Device-side state of one batched attack (everything the loop touches, allocated once)."""
 
-    def __init__(self, pcnet, classifier, target_idx, cam_scene, stealth_loss, setup_info, device):
+    def __init__(self, pcnet, classifier, target_idx, cam_scene, stealth_loss, setup_info, device, storage='f32'):
+        """`storage`: 'f32' (default; results identical to the reference to rounding) or 'f16' (fp16-storage mode of
+        BASELINE.json configs[4]: network activations and their gradients are fp16 in HBM, images / losses / dE2000 /
+        norms / accumulation fp32)."""
         dev = torch.device(device)
+        self.storage = storage
         if dev.type != 'cuda':
             raise RuntimeError('spaa_amd.spaa runs on the GPU only (no CPU fallback); got device=%s' % device)
         if dev.index is None:
@@ -50,11 +54,16 @@ class AttackState:
             cam_scene = cam_scene.expand(B, -1, -1, -1)
         if cam_scene.shape[0] != B:
             raise ValueError('cam_scene must hold 1 or len(target_idx) scenes')
-        self.eng = pcnet.engine(B, prj_sz, owner=self)
+        self.eng = pcnet.engine(B, prj_sz, owner=self, storage=self.storage)
         Hc, Wc = self.eng.Hc, self.eng.Wc
         if tuple(cam_scene.shape[-2:]) != (Hc, Wc):
             raise ValueError(f'cam_scene is {tuple(cam_scene.shape[-2:])} but PCNet outputs {(Hc, Wc)}')
-        self.clf = classifier.engine(B, (Hc, Wc), self.cp_sz, owner=self)
+        self.clf = classifier.engine(B, (Hc, Wc), self.cp_sz, owner=self, storage=self.storage)
+        # fp16 gradients need a loss scale (fp16's smallest normal is 6e-5; the per-pixel loss gradients are ~1/(B*H*W)).
+        # Each sample's gradient is normalised before the step (:307, :315), so a positive per-branch scale changes
+        # nothing but the fp16 rounding: stealth branch: 1/16 per pixel instead of 1/(B*H*W); adversarial branch: +-16
+        # at the target logit instead of 1/B.
+        self.gs_col, self.gs_adv = ((B * Hc * Wc) / 16.0, 16.0 * B) if self.storage == 'f16' else (1.0, 1.0)
         self.scene4 = to_nhwc4(cam_scene.contiguous().to(dev))
         self.eng.set_scene(self.scene4)
         self.scene_lab = torch.zeros_like(self.scene4)
@@ -105,10 +114,10 @@ class AttackState:
         if self.prjl2_w:
             _lib.call('spaa_prjl2_fwd', p(self.x), self.gray, p(self.prjl2), B, self.HWp)    # :275
         _lib.call('spaa_stealth_loss_fwd_bwd', p(y), p(self.scene4), p(self.scene_lab), self.caml2_w, self.camdE_w,
-                  1.0 / (B * self.HWc), p(self.g_col), None, p(self.partial_loss), B, self.HWc)    # :279-287 + backward
+                  self.gs_col / (B * self.HWc), p(self.g_col), None, p(self.partial_loss), B, self.HWc)   # :279-287 + bwd
         _lib.call('spaa_decide', p(logits), self.clf.ncls, p(self.target), int(bool(targeted)), p(self.partial_loss),
                   self.nblk_c, self.HWc, p(self.prjl2) if self.prjl2_w else None, self.prjl2_w, self.caml2_w,
-                  self.camdE_w, float(d_thr), float(p_thresh), adv_w / B, p(self.state), p(self.stats),
+                  self.camdE_w, float(d_thr), float(p_thresh), adv_w / B * self.gs_adv, p(self.state), p(self.stats),
                   p(self.g_logits), B)                                               # :269-272, :290-299, :318-320
         self._y = y
 
@@ -118,7 +127,7 @@ class AttackState:
         _lib.call('spaa_select_grad', p(g_adv), p(self.g_col), p(self.state), p(self.eng.a['Ypre']), p(self.gP), B,
                   self.HWc)
         gx = self.eng.backward(self.gP)                                              # :302 / :310 (PCNet part)
-        _lib.call('spaa_grad_sumsq', p(gx), p(self.x), self.gray, self.prjl2_w / (B * self.HWp), p(self.state),
+        _lib.call('spaa_grad_sumsq', p(gx), p(self.x), self.gray, self.prjl2_w / (B * self.HWp) * self.gs_col, p(self.state),
                   p(self.partial_ss), B, self.HWp)
         _lib.call('spaa_step_and_track', p(self.x), p(gx), p(self.partial_ss), p(self.state), float(adv_lr),
                   float(col_lr), p(self.x_best), p(y), p(self.cam_best), B, self.HWp, self.HWc)   # :307,315,323-328
@@ -129,7 +138,7 @@ class AttackState:
 
 
 def spaa(pcnet, classifier, imagenet_labels, target_idx, targeted, cam_scene, d_thr, stealth_loss, device, setup_info,
-         *, iters=50, adv_lr=2, col_lr=1, p_thresh=0.9, trace=None, verbose=False):
+         *, iters=50, adv_lr=2, col_lr=1, p_thresh=0.9, trace=None, verbose=False, storage='f32'):
     """Stealthy Projector-based Adversarial Attack (SPAA Algorithm 1) — see module docstring.
 
     :param pcnet: spaa_amd.PCNet (optionally wrapped in DataParallel-like `.module`)
@@ -152,7 +161,7 @@ def spaa(pcnet, classifier, imagenet_labels, target_idx, targeted, cam_scene, d_
             raise TypeError('classifier must be a spaa_amd.Classifier or a callable (im, crop_sz) -> (raw_score, p, idx)')
         return _spaa_foreign_classifier(pcnet, classifier, imagenet_labels, target_idx, targeted, cam_scene, d_thr,
                                         stealth_loss, device, setup_info, iters, adv_lr, col_lr, p_thresh, trace)
-    st = AttackState(pcnet, classifier, target_idx, cam_scene, stealth_loss, setup_info, device)
+    st = AttackState(pcnet, classifier, target_idx, cam_scene, stealth_loss, setup_info, device, storage=storage)
     for i in range(iters):
         st.iteration(targeted, d_thr, adv_lr, col_lr, p_thresh)
         if trace is not None:

@@ -70,6 +70,47 @@ def vgg16_pairs(body, cacts):
     return out
 
 
+class record_relu:
+    """Context manager: every F.relu output produced inside (the oracle's forward) is collected in call order."""
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self.F, self.orig, self.outs = F, F.relu, []
+
+        def relu(t, *a, **k):
+            o = self.orig(t, *a, **k)
+            self.outs.append(o.detach())
+            return o
+
+        F.relu = relu
+        return self.outs
+
+    def __exit__(self, *exc):
+        self.F.relu = self.orig
+        return False
+
+
+def inception_pairs(body, relu_outs):
+    """Inception-v3: the HIP body's 94 convolutions (every one followed by a ReLU) are matched with the oracle's recorded
+    ReLU outputs by shape and value (call orders differ inside the mixed blocks)."""
+    out, used = [], set()
+    for n, op in enumerate(o for o in body.ops if o['kind'] == 'conv'):
+        t = op['out']
+        hip = t.buf[..., t.coff:t.coff + t.c]
+        h = hip.detach().float().cpu()
+        best = None
+        for i, r in enumerate(relu_outs):
+            if i in used or r.ndim != 4 or (r.shape[0], r.shape[2], r.shape[3], r.shape[1]) != tuple(h.shape):
+                continue
+            e = float((r.permute(0, 2, 3, 1) - h).abs().max()) / (float(r.abs().max()) + 1e-30)
+            if best is None or e < best[1]:
+                best = (i, e)
+        assert best is not None and best[1] < 1e-3, (n, op.get('name'), best)
+        used.add(best[0])
+        out.append((f'inception.{op.get("name", n)}', 'relu', hip, _nhwc(relu_outs[best[0]])))
+    return out
+
+
 def count_flips(pairs, near_zero=2e-4, value_tol=2e-4):
     """Per-sample number of gates on which HIP and oracle disagree.  Asserts (a) the activations themselves agree to
     `value_tol` relative L-inf per layer, (b) every disagreeing ReLU/clamp unit is within `near_zero` x layer scale of the
@@ -105,7 +146,7 @@ def inject(pairs, engines=()):
     """Copy the oracle's activations / arg-maxes into the HIP engine's buffers (they agree to rounding: only the gates
     that sit within rounding of zero change), then let the engines rebuild the byte masks their backward passes read."""
     for name, kind, hip, orc in pairs:
-        hip.copy_(orc.to(hip.dtype).to(hip.device))
+        hip.copy_(orc.to(hip.dtype).to(hip.device))   # (`hip` may be a channel window of a concatenation buffer: a view)
     for e in engines:
         if hasattr(e, 'refresh_masks'):
             e.refresh_masks()

@@ -331,11 +331,16 @@ def _setup_case(hip, z):
 
 def _oracle_activations(sd, csd, x_prev, scene_b, cam_sz, crop, insz, body='resnet18'):
     """The oracle's forward for one teacher-forced iteration, with every gate-carrying activation (tests/gates.py)."""
+    import gates
     with torch.no_grad():
         xw = so.warp(sd, x_prev.clamp(0, 1), cam_sz) * sd['mask']
         y, acts = so.shading_net(sd, xw, (scene_b, xw * scene_b), return_all=True)
-        fwd = dict(resnet18=so.resnet18_forward, vgg16=so.vgg16_forward)[body]
-        _, cacts = fwd(csd, so.classifier_preprocess(y, crop, insz), return_all=True)
+        pre = so.classifier_preprocess(y, crop, insz)
+        if body == 'inception_v3':   # (no per-layer dump in the oracle: every ReLU output, in call order)
+            with gates.record_relu() as cacts:
+                so.inception_v3_forward(csd, pre)
+        else:
+            _, cacts = dict(resnet18=so.resnet18_forward, vgg16=so.vgg16_forward)[body](csd, pre, return_all=True)
     return acts, cacts
 
 
@@ -1056,7 +1061,7 @@ def _first_iteration_gate_aware(hip, body, csd, insz, im_sz, crop, targets, seed
         assert d < 5e-3
     st = A.AttackState(pc, clf, targets, scene, stealth, setup, DEV)
     x0 = torch.full((B, 3, *prj_sz), 0.5)
-    have_gates = body in ('resnet18', 'vgg16')
+    have_gates = True
     if have_gates:
         acts, cacts = _oracle_activations(sd, csd, x0, scene.expand(B, -1, -1, -1), im_sz, crop, insz, body)
     errs = {}
@@ -1065,7 +1070,8 @@ def _first_iteration_gate_aware(hip, body, csd, insz, im_sz, crop, targets, seed
         st.stats[:, 5] = 1e6
         st.forward_decide(targeted, d_thr, 0.9)
         if have_gates:
-            pairs = gates.pcnet_pairs(st.eng, acts) + (gates.vgg16_pairs if body == 'vgg16' else gates.resnet18_pairs)(st.clf.body, cacts)
+            pairs = gates.pcnet_pairs(st.eng, acts) + dict(vgg16=gates.vgg16_pairs, resnet18=gates.resnet18_pairs,
+                                                           inception_v3=gates.inception_pairs)[body](st.clf.body, cacts)
             if mode == 'plain':
                 flips, per_layer = gates.count_flips(pairs)
             else:
@@ -1185,9 +1191,9 @@ def test_gate_byte_masks(hip, tile):
             assert torch.equal(mask, lib.pack_gate_mask(out)), (tile, ci, co)
             # dgrad of a following layer whose output has `co` channels... use the transposed role: gradient w.r.t. this
             # layer's OUTPUT shape is what a later dgrad produces; gate it by this activation
-            wt2 = torch.randn(48, co, 3, 3) / (co * 9) ** 0.5
+            wt2 = torch.randn(64, co, 3, 3) / (co * 9) ** 0.5
             dplan = cp.conv_dgrad_plan(wt2, 1, 1, DEV)
-            gy = nhwc(torch.randn(b, 48, ho, wo)).to(DEV)
+            gy = nhwc(torch.randn(b, 64, ho, wo)).to(DEV)
             act2 = torch.randn(b, ho, wo, co, device=DEV)
             g_f, g_m = torch.zeros(b, ho, wo, co, device=DEV), torch.zeros(b, ho, wo, co, device=DEV)
             a_f, a_m = torch.zeros_like(g_f), torch.zeros_like(g_f)
@@ -1303,3 +1309,94 @@ def test_tapconv_fp16_storage(hip, tile):
             assert torch.equal(mask, lib.pack_gate_mask(out.float()))
     finally:
         cp.FORCE_TILE = 0
+
+
+def test_fp16_storage_pcnet_and_classifier(hip, golden_dir):
+    """fp16-storage engines vs the fp32 oracle on the reference's golden PCNet case: forward values to fp16 rounding
+    accumulated over the 14 layers, input gradients to a few percent (fp16-rounded activations flip more ReLU gates than
+    fp32 rounding does).  Stated tolerances = 3x the measured values (profiles/r02_parity.txt)."""
+    M = hip['models']
+    z = load(golden_dir, 'pcnet_64')
+    cam_sz = tuple(int(v) for v in z['cam_sz'])
+    sd = syn.pcnet_state_dict(int(z['seed']), cam_sz=cam_sz, mask=str(z['mask']))
+    pc = make_pcnet(hip, sd, cam_sz)
+    s = torch.from_numpy(z['s'])
+    x = syn.scenes(5, 2, cam_sz)
+    r = torch.from_numpy(z['r'])
+    xc = x.clone().requires_grad_(True)
+    yc = so.pcnet_forward(sd, xc, s)
+    (yc * r).sum().backward()
+    eng = pc.engine(2, cam_sz, storage='f16')
+    assert eng.a['X4'].dtype == torch.float16 and eng.a['Y'].dtype == torch.float32 and eng.g['P7'].dtype == torch.float16
+    eng.set_scene(M.to_nhwc4(s.to(DEV)))
+    y4 = eng.forward(M.to_nhwc4(x.to(DEV)), clamp01=False)
+    e_y = rel_inf(M.to_nchw(y4), yc)
+    gP = M.to_nhwc4((r * ((yc > 0) & (yc < 1))).to(DEV))          # cotangent at conv6's pre-activation, oracle's clamp gate
+    gx = M.to_nchw(eng.backward(gP)).cpu()
+    e_g = rel_l2(gx, xc.grad)
+    print(f'fp16-storage PCNet 64x64: forward rel Linf {e_y:.2e}, input-gradient rel L2 {e_g:.2e}')
+    assert e_y < 1.5e-2 and e_g < 1.5e-1
+    csd = syn.resnet18_state_dict(2, logit_gain=20.0)
+    for body, csd_, insz, tol_l, tol_g in (('resnet18', csd, (56, 56), 3e-2, 3e-1),
+                                           ('vgg16', syn.vgg16_state_dict(3, logit_gain=5.0, fc_width=512), (224, 224), 3e-2, 3e-1)):
+        hsz = 64 if body == 'resnet18' else 256
+        crop = (60, 60) if body == 'resnet18' else (240, 240)
+        im = syn.scenes(8, 2, (hsz, hsz))
+        imc = im.clone().requires_grad_(True)
+        raw, p, idx = so.OracleClassifier(body, csd_, input_sz=insz)(imc, crop)
+        q = torch.zeros(2, 1000)
+        q[0, int(idx[0, 1])] = -1.0
+        q[1, int(idx[1, 2])] = -1.0
+        (raw * q).sum().backward()
+        clf = hip['clf'].Classifier(body, DEV, state_dict=csd_, input_sz=insz)
+        ce = clf.engine(2, (hsz, hsz), crop, storage='f16')
+        logits = ce.forward(M.to_nhwc4(im.to(DEV)))
+        e_l = rel_inf(logits, raw)
+        g = M.to_nchw(ce.backward((q * 64).to(DEV).contiguous())).cpu() / 64
+        e_gc = rel_l2(g, imc.grad)
+        print(f'fp16-storage {body}: logits rel Linf {e_l:.2e}, input-gradient rel L2 {e_gc:.2e}, top-1 equal: '
+              f'{(logits.argmax(1).cpu().numpy() == idx[:, 0]).all()}')
+        assert e_l < tol_l and e_gc < tol_g and torch.isfinite(g).all()
+
+
+def test_fp16_storage_attack_loops(hip, golden_dir):
+    """BASELINE.json configs[4] in small: the SPAA loop and PerC_AL.adversary_projector (VGG-16) in fp16-storage mode, first
+    iteration from identical state vs the fp32 oracle; losses / dE2000 / norms are fp32 in this mode and must agree
+    tightly, the step direction to fp16 accuracy."""
+    from spaa_amd.perc_al import PerC_AL
+    A, M = hip['attack'], hip['models']
+    z = load(golden_dir, 'spaa_64_near')
+    sd, pc, clf, oclf, scene, setup = _setup_case(hip, z)
+    targets = [int(t) for t in z['targets']]
+    tr = []
+    so.spaa(sd, oclf, targets, True, scene, float(z['d_thr']), str(z['stealth']), setup, iters=1, trace=tr)
+    st = A.AttackState(pc, clf, targets, scene, str(z['stealth']), setup, DEV, storage='f16')
+    st.iteration(True, float(z['d_thr']), 2, 1, 0.9)
+    sts = st.stats.cpu().numpy()
+    assert np.allclose(sts[:, 1], tr[0]['caml2'], rtol=2e-2) and np.allclose(sts[:, 2], tr[0]['camdE'], rtol=2e-2)
+    assert (st.state[:, 3].cpu().numpy() == tr[0]['top1']).all()
+    x1, ref = M.to_nchw(st.x).cpu(), torch.from_numpy(tr[0]['prj_adv'])
+    e_step = rel_l2(x1 - 0.5, ref - 0.5)
+    step_len = (x1 - 0.5).flatten(1).norm(dim=1)
+    print(f'fp16-storage SPAA first iteration: step rel L2 vs fp32 oracle {e_step:.2e}; image rel Linf {rel_inf(x1, ref):.2e}')
+    assert e_step < 0.3 and torch.allclose(step_len, torch.full_like(step_len, 2.0), rtol=1e-3) and torch.isfinite(x1).all()
+    for _ in range(3):
+        st.iteration(True, float(z['d_thr']), 2, 1, 0.9)
+    cam, prj = st.results()
+    assert torch.isfinite(cam).all() and torch.isfinite(prj).all()
+    # PerC-AL + VGG-16 (the configs[4] pairing), 224-style geometry scaled to what the oracle finishes quickly
+    csd = syn.vgg16_state_dict(3, logit_gain=5.0, fc_width=256)
+    vclf = hip['clf'].Classifier('vgg16', DEV, state_dict=csd)
+    ov = so.OracleClassifier('vgg16', csd)
+    sc = syn.scenes(1, 1, (256, 256)).expand(2, -1, -1, -1).contiguous()
+    _, _, idx = ov(sc[:1], (240, 240))
+    labels = torch.tensor([int(i) for i in idx[0, 1:3]])
+    otr = []
+    so.perc_al_adversary_projector(ov, sc, labels, 2.0, True, (240, 240), 400, 1., 0.5, 0, stop_after=1, trace=otr)
+    ptr = []
+    att = PerC_AL(device=DEV, max_iterations=4, alpha_l_init=1, alpha_c_init=0.5, confidence=0, storage='f16')
+    out = att.adversary_projector(vclf, sc, labels, None, 2.0, True, (240, 240), trace=ptr)
+    e_d = rel_l2(ptr[0][2], otr[0]['delta'])
+    print(f'fp16-storage PerC-AL + VGG-16 at 256x256: delta rel L2 after iteration 0 vs fp32 oracle {e_d:.2e}')
+    assert e_d < 0.3 and out.min() >= 0 and out.max() <= 1 and (torch.round(out * 255) / 255 - out).abs().max() < 1e-6
+    assert np.allclose(ptr[0][1][:, 3].cpu().numpy(), otr[0]['color_dis'].numpy(), rtol=5e-2)
