@@ -36,7 +36,7 @@ MB_PER_SCENE_256 = {'warp_fwd': 1.57 + 2.36,    # grid_sample (read x, write x_w
                     'step_and_track': 3.9}     # read g, read/write x, conditional copies of x and cam_infer
 
 
-def build_attack(rank, batch, size, n_scenes, dev, classifier='resnet18'):
+def build_attack(rank, batch, size, n_scenes, dev, classifier='resnet18', storage='f32', attack='spaa'):
     from spaa_amd import synthetic as syn
     from spaa_amd.models import PCNet, WarpingNet
     from spaa_amd.classifier import Classifier
@@ -56,7 +56,22 @@ def build_attack(rank, batch, size, n_scenes, dev, classifier='resnet18'):
     targets = (syn.IMAGENET10_TARGETS * 8)[:per] * n_scenes
     crop = (size - 16, size - 16)
     setup = dict(classifier_crop_sz=crop, prj_brightness=0.5, prj_im_sz=sz)
-    st = AttackState(pc, clf, targets, scene_b, 'camdE_caml2', setup, dev)
+    if attack == 'perc_al':
+        # BASELINE.json configs[4]: PerC_AL.adversary_projector (400 iterations; alpha schedules of a 400-iteration run)
+        from spaa_amd.perc_al import PerC_AL, PerCALState
+        att = PerC_AL(device=torch.device(dev), max_iterations=400, alpha_l_init=1, alpha_c_init=0.5, confidence=0, storage=storage)
+        with torch.cuda.device(dev):
+            st = PerCALState(att, clf, scene_b, torch.tensor(targets), 5.0, True, crop)
+        it = [0]
+
+        def step():
+            st.iteration(it[0] % 400)
+            it[0] += 1
+        st.step, st.results = step, (lambda: (st.result(), st.result()))
+        return st, sd, csd, setup, scenes, targets
+    st = AttackState(pc, clf, targets, scene_b, 'camdE_caml2', setup, dev, storage=storage)
+    hp = dict(targeted=True, d_thr=5, adv_lr=2, col_lr=1, p_thresh=0.9)
+    st.step = lambda: st.iteration(**hp)
     return st, sd, csd, setup, scenes, targets
 
 
@@ -237,12 +252,12 @@ def rehearse_glue(args, world, rank, json_out):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def instrumented_pass(st, hp, args, n_prof=3):
+def instrumented_pass(st, args, n_prof=3):
     """Per-kernel event timing (HIP events on the launch stream): every tapconv launch, then every other entry point."""
     from spaa_amd import convplan, _lib
     convplan.PROFILE = []
     for _ in range(n_prof):
-        st.iteration(**hp)
+        st.step()
     torch.cuda.synchronize()
     conv_events = convplan.PROFILE
     convplan.PROFILE = None
@@ -271,7 +286,7 @@ def instrumented_pass(st, hp, args, n_prof=3):
     # second pass: the non-convolution entry points
     _lib.PROFILE = []
     for _ in range(n_prof):
-        st.iteration(**hp)
+        st.step()
     torch.cuda.synchronize()
     other = {}
     for name, e0, e1 in _lib.PROFILE:
@@ -293,6 +308,11 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--classifier', default='resnet18', choices=['resnet18', 'vgg16', 'inception_v3'],
                     help='BASELINE.json configs[1] is resnet18 (the bench line); the others are extra data points')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16s'],
+                    help='f32 (headline) or f16s = fp16 STORAGE of activations/gradients, fp32 accumulation / images / dE2000 '
+                         '(BASELINE.json configs[4]; an extra data point, never the headline)')
+    ap.add_argument('--attack', default='spaa', choices=['spaa', 'perc_al'],
+                    help='spaa (the bench line) or perc_al = PerC_AL.adversary_projector loop body (configs[4], with --classifier vgg16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-out', default=None, help='write the per-layer tapconv timing table (JSON) here')
     ap.add_argument('--rehearse-glue', action='store_true',
@@ -331,11 +351,11 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
 
     log('building attack state')
-    st, sd, csd, setup, scenes, targets = build_attack(rank, args.batch, args.size, 8, dev, args.classifier)
+    storage = 'f16' if args.dtype == 'f16s' else 'f32'
+    st, sd, csd, setup, scenes, targets = build_attack(rank, args.batch, args.size, 8, dev, args.classifier, storage, args.attack)
     torch.cuda.synchronize()
-    hp = dict(targeted=True, d_thr=5, adv_lr=2, col_lr=1, p_thresh=0.9)
     log('warmup + timed region')
-    dt_local = timed_steps(lambda: st.iteration(**hp), args.steps, args.warmup, dist, torch.cuda.synchronize)
+    dt_local = timed_steps(st.step, args.steps, args.warmup, dist, torch.cuda.synchronize)
     log(f'{args.steps} steps in {dt_local:.3f}s')
     dt, per_rank = reduce_times(dt_local, dist, world, dev)
 
@@ -348,12 +368,15 @@ def main():
     roof, table = None, {}
     if rank == 0:
         n_prof = 3
-        per_tile, per_layer, other, t_roof_x6, t_roof_f32 = instrumented_pass(st, hp, args, n_prof)
+        per_tile, per_layer, other, t_roof_x6, t_roof_f32 = instrumented_pass(st, args, n_prof)
         tot_ms = sum(v[1] for v in per_tile.values())
         dom = max(per_tile, key=lambda k: per_tile[k][1])
         f, ms, n, nb = per_tile[dom]
         ach = f / (ms * 1e-3) / 1e12
-        if dom.startswith('x6'):
+        if dom.startswith('h16'):
+            # fp16-storage kernels: one fp16 MFMA per product
+            peak, kname = PEAK_BF16_MFMA_TFLOPS, f'tapconv_{dom} (fp16 MFMA implicit-GEMM, fp16 storage, fp32 accumulation)'
+        elif dom.startswith('x6'):
             # fp32 emulated with six bf16 MFMAs per product group: the matrix-core ceiling for algorithmic fp32 FLOPs
             # is the dense bf16 peak / 6
             peak, kname = PEAK_BF16_MFMA_TFLOPS / 6.0, f'tapconv_{dom} (bf16x6-split MFMA implicit-GEMM, fp32-exact operands)'
@@ -410,9 +433,12 @@ def main():
             'metric': 'attack-iterations/sec (PCNet+classifier fwd/bwd), 256x256 batch=64',
             'value': round(value, 3), 'unit': 'attack-iterations/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.dtype == 'f32' else 'f16 storage (activations/gradients), f32 accumulation, images and dE2000',
+            'data': 'synthetic',
             'config': {'workload': f'{dict(resnet18="configs[1]", inception_v3="configs[2]", vgg16="configs[4] classifier, SPAA loop")[args.classifier]}: batch={args.batch} ({8} scenes x {args.batch // 8} targets) '
-                                   f'{args.size}x{args.size}, {args.classifier}, camdE_caml2, per GPU',
+                                   f'{args.size}x{args.size}, {args.classifier}, '
+                                   f'{"camdE_caml2" if args.attack == "spaa" else "PerC-AL adversary_projector loop body"}, per GPU',
                        'global_batch': args.batch * world, 'parallelism': f'dp{world} (independent shards)'},
             'scene_iterations_per_s': round(value * args.batch, 1),
             'per_rank_ms_per_step': [round(t / args.steps * 1e3, 3) for t in per_rank],
@@ -420,7 +446,7 @@ def main():
         }
         if gather_ms is not None:
             out['gather_ms'] = round(gather_ms, 3)
-        if world == 1 and not args.no_cpu_baseline and args.classifier == 'resnet18':
+        if world == 1 and not args.no_cpu_baseline and args.classifier == 'resnet18' and args.dtype == 'f32' and args.attack == 'spaa':
             log(f'cpu baseline on {usable_cores()} cores')
             out['cpu_baseline'] = cpu_baseline(sd, csd, setup, scenes)
         else:

@@ -279,9 +279,10 @@ class ConvPlan:
             e1.record()
             # algorithmic bytes: every operand read / result written once (logical channels, fp32)
             npx = b * hout * wout
-            nbytes = 4 * (b * hin * win * self.cin_p + npx * self.cout * (1 + (add is not None) + (gate is not None)
-                                                                         + (aux_out is not None) + (gate2 is not None))
-                          + self.ntaps_total * self.cin_p * self.cout)
+            bi, bo = (2 if in_f16 else 4), (2 if out_f16 else 4)   # bytes per element: fp16 storage or fp32
+            nbytes = (bi * b * hin * win * self.cin_p + bo * npx * self.cout * (1 + (add is not None) + (gate is not None)
+                                                                               + (aux_out is not None) + (gate2 is not None))
+                      + bi * self.ntaps_total * self.cin_p * self.cout)
             nbytes += npx * self.cout // 4 * ((mask_out is not None) + (gate_bits is not None) + (gate2_bits is not None))
             PROFILE.append((self.name, key, self.flops(b, hout, wout), e0, e1, d.tile + 100 * (d.ksplit if d.ksplit > 1 else (9 if d.ksplit == -1 else 0)), nbytes))
         return out

@@ -70,19 +70,22 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_h16_kernel(const spaa_tapc
 
     const uint32_t in_bytes = (uint32_t)p.B * (uint32_t)(p.Hin * p.Win) * (uint32_t)row_bytes;
     const uint64_t in_addr = reinterpret_cast<uint64_t>(p.in);
-    const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void*>(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(in_addr >> 32)) << 32) |
-                                __builtin_amdgcn_readfirstlane((uint32_t)in_addr)),
-        0, (int)__builtin_amdgcn_readfirstlane(in_bytes), 0x00020000);
+    // (readfirstlane returns a SIGNED int: keep the halves in uint32_t, or a low word with bit 31 set sign-extends into
+    // the high word of the base address)
+    const uint32_t in_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)in_addr);
+    const uint32_t in_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(in_addr >> 32));
+    const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)in_hi << 32) | in_lo), 0,
+                                                            (int)__builtin_amdgcn_readfirstlane(in_bytes), 0x00020000);
     const int K64 = (cl.K + 63) & ~63;
     const int npad = (p.Cout * (p.nfold > 1 ? p.nfold : 1) + 127) & ~127;
     uint64_t wh_off = 0;  // fp16 plane of class c: [npad][K64_c], classes back to back
     for (int c = 0; c < (int)blockIdx.y; ++c) wh_off += (uint64_t)npad * (uint64_t)((p.cls[c].K + 63) & ~63);
     const uint64_t w_addr = reinterpret_cast<uint64_t>(p.w_half) + wh_off * 2u;
+    const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)w_addr);
+    const uint32_t w_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(w_addr >> 32));
     const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void*>(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(w_addr >> 32)) << 32) |
-                                __builtin_amdgcn_readfirstlane((uint32_t)w_addr)),
-        0, (int)__builtin_amdgcn_readfirstlane((uint32_t)npad * (uint32_t)K64 * 2u), 0x00020000);
+        reinterpret_cast<void*>(((uint64_t)w_hi << 32) | w_lo), 0,
+        (int)__builtin_amdgcn_readfirstlane((uint32_t)npad * (uint32_t)K64 * 2u), 0x00020000);
 
     // ---- this wave's pixel rows: piece ib (16 rows) -> lane holds row 32 wave + 16 ib + (lane >> 2), physical chunk lane & 3
     int a_off[2];
