@@ -32,9 +32,9 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               42: 'x6d16a3_128x64', 43: 'x6d16a3_128x32', 44: 'x6da3_128x64', 45: 'x6d16coa3_128x64', 46: 'x6d16coa3_128x32', 47: 'thinpatch16x2',
               48: 'x6d16p_128x128', 49: 'x6d16p_128x64', 50: 'x6d16a3p_128x64', 51: 'x6da3p_128x64', 52: 'x6d16p_256x128',
               53: 'x6d16p_128x32', 54: 'x6dp_128x128',
-              60: 'h16_128x128', 61: 'h16_128x64', 62: 'h16_128x32', 63: 'h16_128x16'}
-STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 64))  # shared epilogue (epilogue.hpp)
-F16OUT_TILES = set(range(15, 25)) | {38} | set(range(60, 64))  # ... of which these may write fp16 (fp32 image in, fp16 activation out)
+              60: 'h16_128x128', 61: 'h16_128x64', 62: 'h16_128x32', 63: 'h16_128x16', 64: 'h16_256x128', 65: 'h16_256x256'}
+STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 66))  # shared epilogue (epilogue.hpp)
+F16OUT_TILES = set(range(15, 25)) | {38} | set(range(60, 66))  # ... of which these may write fp16 (fp32 image in, fp16 activation out)
 DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
 DEBUG_TAPMAJOR = int(os.environ.get('SPAA_X6D_TAPMAJOR', '0'))      # 1: tap-major K order (A/B measurements only)
 DEBUG_PERSIST_CAP = int(os.environ.get('SPAA_X6D_PERSIST_CAP', '0'))  # > 0: persistent launches use this many workgroups
@@ -222,7 +222,13 @@ class ConvPlan:
             tile = self._default_tile(b * d.Hm * d.Wm)
         if in_f16:    # fp16 activations: the h16 kernels, N tile by the GEMM's width
             ngemm = self.cout * self.nfold
-            tile = forced if 60 <= forced <= 63 else (60 if ngemm > 64 else 61 if ngemm > 32 else 62 if ngemm > 16 else 63)
+            if 60 <= forced <= 65:
+                tile = forced
+            else:
+                tile = 60 if ngemm > 64 else 61 if ngemm > 32 else 62 if ngemm > 16 else 63
+                m_all = b * d.Hm * d.Wm
+                if tile == 60 and m_all >= 256 * 512:   # enough pixels to fill the chip with 256-row tiles: less weight
+                    tile = 65 if ngemm > 128 else 64    # traffic per pixel (and one N tile for the 256-channel layers)
         elif out_f16:  # fp32 image in, fp16 activation out: any kernel built on the shared epilogue, without split-K
             tile %= 100
             if tile not in F16OUT_TILES:
@@ -232,7 +238,7 @@ class ConvPlan:
         ksplit, tile = (tile // 100, tile % 100) if tile >= 100 else (1, tile)
         if self.nfold > 1:  # only the DMA-staged kernels know the folded epilogue
             ksplit = 1
-            if not (25 <= tile <= 27 or 30 <= tile <= 37 or (39 <= tile <= 46 or 48 <= tile <= 54) or 60 <= tile <= 63):
+            if not (25 <= tile <= 27 or 30 <= tile <= 37 or (39 <= tile <= 46 or 48 <= tile <= 54) or 60 <= tile <= 65):
                 tile = 34
             d.nfold = self.nfold
         if ksplit == 9:  # stream-K (persistent x6d tiles, one class): workspace shared by all plans (one stream)

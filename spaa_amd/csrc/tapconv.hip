@@ -554,7 +554,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         // byte masks (1 byte per 4 channels): only the epilogues built on epilogue.hpp's store4 know them, and only in its
         // 4-channel-vector form
         const int t = d.tile;
-        if (!((t >= 15 && t <= 27) || (t >= 30 && t <= 46) || (t >= 48 && t <= 54) || (t >= 60 && t <= 63))) return hipErrorInvalidValue;
+        if (!((t >= 15 && t <= 27) || (t >= 30 && t <= 46) || (t >= 48 && t <= 54) || (t >= 60 && t <= 65))) return hipErrorInvalidValue;
         if ((d.Cout | d.out_cstride | d.out_coff) & 3) return hipErrorInvalidValue;
         if (d.add != nullptr && ((d.add_cstride | d.add_coff) & 3)) return hipErrorInvalidValue;
         if (d.gate_bits != nullptr && (d.gate != nullptr || ((d.gate_cstride | d.gate_coff) & 3))) return hipErrorInvalidValue;
@@ -577,13 +577,13 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         if ((int64_t)((d.Cout + 127) & ~127) * d.cls[c].Kpad * 4 >= (int64_t)1 << 31) return hipErrorInvalidValue;
     int tile = d.tile;
     // fp16-storage mode: fp16 inputs only through the h16 kernels; fp16 outputs only through the shared epilogue
-    if ((d.io_dtype & SPAA_IO_IN_F16) && !(tile >= 60 && tile <= 63)) return hipErrorInvalidValue;
+    if ((d.io_dtype & SPAA_IO_IN_F16) && !(tile >= 60 && tile <= 65)) return hipErrorInvalidValue;
     if (!(d.io_dtype & SPAA_IO_IN_F16) && tile >= 60 && tile <= 63) return hipErrorInvalidValue;
-    if ((d.io_dtype & SPAA_IO_OUT_F16) && !((tile >= 15 && tile <= 24) || tile == 38 || (tile >= 60 && tile <= 63)))
+    if ((d.io_dtype & SPAA_IO_OUT_F16) && !((tile >= 15 && tile <= 24) || tile == 38 || (tile >= 60 && tile <= 65)))
         return hipErrorInvalidValue;
     if ((d.io_dtype & SPAA_IO_OUT_F16) && (d.ksplit > 1 || d.ksplit < 0)) return hipErrorInvalidValue;  // (fp32 partial sums)
     if (d.gate != nullptr && d.gate_mode == SPAA_GATE_MUL && tile < 25) return hipErrorInvalidValue;
-    if (d.nfold > 1 && !((tile >= 25 && tile <= 27) || (tile >= 30 && tile <= 37) || (tile >= 39 && tile <= 46) || (tile >= 48 && tile <= 54) || (tile >= 60 && tile <= 63)))
+    if (d.nfold > 1 && !((tile >= 25 && tile <= 27) || (tile >= 30 && tile <= 37) || (tile >= 39 && tile <= 46) || (tile >= 48 && tile <= 54) || (tile >= 60 && tile <= 65)))
         return hipErrorInvalidValue;
     if (tile == 0) {  // heuristic: widest N tile that fits Cout; shrink M when the grid would not fill 256 CUs twice
         const int64_t M = (int64_t)d.B * d.Hm * d.Wm * d.nclass;
@@ -649,7 +649,9 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         case 60:
         case 61:
         case 62:
-        case 63: return spaa_launch_tapconv_h16(d, tile, stream);
+        case 63:
+        case 64:
+        case 65: return spaa_launch_tapconv_h16(d, tile, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -38,7 +38,7 @@ __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rsrc, unsigne
 __device__ __forceinline__ int swz64(int r) { return ((r >> 3) & 1) << 1; }
 
 template <int NW, int BN>
-__global__ __launch_bounds__(64 * NW, 2) void tapconv_h16_kernel(const spaa_tapconv_t p, const int m_tiles, const int n_tiles) {
+__global__ __launch_bounds__(64 * NW, NW > 4 ? 1 : 2) void tapconv_h16_kernel(const spaa_tapconv_t p, const int m_tiles, const int n_tiles) {
     constexpr int BM = 32 * NW;
     constexpr int TJ = BN / 16;
     constexpr int A_SUB = BM * 64;               // one sub-step's pixel rows
@@ -252,7 +252,7 @@ int launch_h16(const spaa_tapconv_t& d, hipStream_t stream) {
 
 }  // namespace
 
-// called by spaa_tapconv_f32 (tapconv.hip) for tiles 60..63 after the common shape checks
+// called by spaa_tapconv_f32 (tapconv.hip) for tiles 60..65 after the common shape checks
 int spaa_launch_tapconv_h16(const spaa_tapconv_t& d, int tile, hipStream_t stream) {
     if (!(d.io_dtype & SPAA_IO_IN_F16) || d.w_half == nullptr || (d.Cin % 32) != 0 || d.ksplit > 1 || d.ksplit < 0)
         return hipErrorInvalidValue;
@@ -268,6 +268,8 @@ int spaa_launch_tapconv_h16(const spaa_tapconv_t& d, int tile, hipStream_t strea
         case 61: return launch_h16<4, 64>(d, stream);
         case 62: return launch_h16<4, 32>(d, stream);
         case 63: return launch_h16<4, 16>(d, stream);
+        case 64: return launch_h16<8, 128>(d, stream);   // 256 x 128: half the weight traffic per pixel
+        case 65: return launch_h16<8, 256>(d, stream);   // 256 x 256: the 256-channel layers, one N tile
         default: return hipErrorInvalidValue;
     }
 }
