@@ -355,26 +355,25 @@ class ClassifierEngine:
         return self.g_y
 
 
-class _ClassifyFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, im, clf, crop_sz):
-        b, _, h, w = im.shape
-        with _lib.on_device(im.device):
-            eng = clf.engine(b, (h, w), crop_sz)
-            im4 = to_nhwc4(im)
-            logits = eng.forward(im4)
-            ctx.eng, ctx.version, ctx.im4 = eng, eng.version, im4
-            return logits.clone()
+def _classify_impl(clf, im, crop_sz):
+    """spaa::classify.  Returns (logits [B,ncls], saved)."""
+    b, _, h, w = im.shape
+    with _lib.on_device(im.device):
+        eng = clf.engine(b, (h, w), tuple(crop_sz))
+        im4 = to_nhwc4(im)
+        logits = eng.forward(im4).clone()
+        saved = dict(eng=eng, version=eng.version, im4=im4)
+        clf._last_saved = saved
+        return logits, saved
 
-    @staticmethod
-    def backward(ctx, g):
-        eng = ctx.eng
-        with _lib.on_device(g.device):
-            if eng.version != ctx.version:  # workspaces reused by a later forward: recompute this call's activations
-                eng.forward(ctx.im4)
-                ctx.version = eng.version
-            gy4 = eng.backward(g.detach().float().contiguous())
-            return to_nchw(gy4), None, None
+
+def _classify_backward_impl(saved, g):
+    eng = saved['eng']
+    with _lib.on_device(g.device):
+        if eng.version != saved['version']:  # workspaces reused by a later forward: recompute this call's activations
+            eng.forward(saved['im4'])
+            saved['version'] = eng.version
+        return to_nchw(eng.backward(g.detach().float().contiguous()))
 
 
 class Classifier(object):
@@ -422,7 +421,8 @@ class Classifier(object):
             im = im[None]
         if self.device.type != 'cuda':
             raise RuntimeError('spaa_amd.Classifier runs on the GPU only (no CPU fallback); got device=%s' % self.device)
-        raw_score = _ClassifyFn.apply(im.to(self.device), self, tuple(crop_sz))
+        from . import ops
+        raw_score = torch.ops.spaa.classify(im.to(self.device), ops.handle_of(self), int(crop_sz[0]), int(crop_sz[1]))
         # Compatibility outputs (classifier.py:64-72).  The fused attack loop does NOT use these: it takes top-1 and
         # its probability on device (spaa_decide); the full 1000-way sort is only done for API parity here.
         p = torch.softmax(raw_score.detach(), dim=1).cpu()

@@ -140,8 +140,10 @@ class WarpingNet(nn.Module):
         self.fine_grid = self.build_fine_grid(x.shape[-2:])[None, :, :, :2].contiguous()
 
     def forward(self, x):
-        """models.py:163-185: warp a [B,3,H,W] image (HIP grid_sample, differentiable w.r.t. x)."""
-        return _WarpFn.apply(x, self)
+        """models.py:163-185: warp a [B,3,H,W] image (HIP grid_sample, differentiable w.r.t. x): the registered custom op
+        `spaa::warp` (spaa_amd/ops.py)."""
+        from . import ops
+        return torch.ops.spaa.warp(x, ops.handle_of(self))
 
 
 class ShadingNetSPAA(nn.Module):
@@ -231,7 +233,9 @@ class PCNet(nn.Module):
         self._engines = {}
 
     def forward(self, x, s):
-        return _PCNetFn.apply(x, s, self)
+        """models.py:335-346 through the registered custom op `spaa::pcnet_forward` (differentiable w.r.t. x)."""
+        from . import ops
+        return torch.ops.spaa.pcnet_forward(x, s, ops.handle_of(self))
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -465,70 +469,67 @@ class PCNetEngine:
         return sum(self.f[k].flops(B, *v) for k, v in sizes.items())
 
 
-class _PCNetFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, s, pcnet):
-        b = x.shape[0]
-        with _lib.on_device(x.device):
-            eng = pcnet.engine(b, x.shape[-2:])
-            s4 = to_nhwc4(s.expand(b, -1, -1, -1) if s.shape[0] != b else s)
-            eng.set_scene(s4)
-            x4 = to_nhwc4(x)
-            y4 = eng.forward(x4, clamp01=False)
-            ctx.eng, ctx.version, ctx.x4, ctx.s4 = eng, eng.version, x4, s4
-            return to_nchw(y4)
-
-    @staticmethod
-    def backward(ctx, gy):
-        eng = ctx.eng
-        with _lib.on_device(gy.device):
-            if eng.version != ctx.version:
-                # the engine's workspaces were overwritten by a later forward (y1 = pcnet(x1, s); y2 = pcnet(x2, s);
-                # (l1 + l2).backward()): recompute this call's activations from its own saved inputs
-                eng.set_scene(ctx.s4)
-                eng.forward(ctx.x4, clamp01=False)
-                ctx.version = eng.version
-            g4 = to_nhwc4(gy)
-            gP = torch.zeros_like(g4)
-            state = torch.ones(eng.B, 4, dtype=torch.int32, device=g4.device)  # best_adv=1 -> take the 2nd argument
-            _lib.call('spaa_select_grad', _lib.ptr(g4), _lib.ptr(g4), _lib.ptr(state), _lib.ptr(eng.a['Ypre']),
-                      _lib.ptr(gP), eng.B, eng.Hc * eng.Wc)
-            gx4 = eng.backward(gP)
-            return to_nchw(gx4), None, None
+def _pcnet_forward_impl(pcnet, x, s):
+    """spaa::pcnet_forward.  Returns (y NCHW, saved) — `saved` is what the input-gradient pass needs."""
+    b = x.shape[0]
+    with _lib.on_device(x.device):
+        eng = pcnet.engine(b, x.shape[-2:])
+        s4 = to_nhwc4(s.expand(b, -1, -1, -1) if s.shape[0] != b else s)
+        eng.set_scene(s4)
+        x4 = to_nhwc4(x)
+        y4 = eng.forward(x4, clamp01=False)
+        saved = dict(eng=eng, version=eng.version, x4=x4, s4=s4)
+        pcnet._last_saved = saved
+        return to_nchw(y4), saved
 
 
-class _WarpFn(torch.autograd.Function):
-    """WarpingNet.forward (models.py:163-185) as a differentiable op; the backward is the same deterministic gather over
-    transposed tap lists that the attack loop uses (no float atomics)."""
+def _pcnet_backward_impl(saved, gy):
+    eng = saved['eng']
+    with _lib.on_device(gy.device):
+        if eng.version != saved['version']:
+            # the engine's workspaces were overwritten by a later forward (y1 = pcnet(x1, s); y2 = pcnet(x2, s);
+            # (l1 + l2).backward()): recompute this call's activations from its own saved inputs
+            eng.set_scene(saved['s4'])
+            eng.forward(saved['x4'], clamp01=False)
+            saved['version'] = eng.version
+        g4 = to_nhwc4(gy)
+        gP = torch.zeros_like(g4)
+        state = torch.ones(eng.B, 4, dtype=torch.int32, device=g4.device)  # best_adv=1 -> take the 2nd argument
+        _lib.call('spaa_select_grad', _lib.ptr(g4), _lib.ptr(g4), _lib.ptr(state), _lib.ptr(eng.a['Ypre']),
+                  _lib.ptr(gP), eng.B, eng.Hc * eng.Wc)
+        return to_nchw(eng.backward(gP))
 
-    @staticmethod
-    def forward(ctx, x, wn):
-        b = x.shape[0]
-        with _lib.on_device(x.device):
-            x4 = to_nhwc4(x)
-            if wn.fine_grid is None:
-                grid = wn.build_fine_grid(x.shape[-2:])
-            else:
-                grid = torch.zeros(*wn.out_size, 4, device=x.device)
-                grid[..., :2] = wn.fine_grid[0]
-            hc, wc = wn.out_size
-            xw = torch.zeros(b, hc, wc, 4, device=x.device)
-            _lib.call('spaa_warp_fwd', _lib.ptr(x4), _lib.ptr(grid), None, None, _lib.ptr(xw), None, b, x.shape[-2],
-                      x.shape[-1], hc, wc, 0)
-            ctx.x4, ctx.grid, ctx.cam = x4, grid, (hc, wc)
-            return to_nchw(xw)
 
-    @staticmethod
-    def backward(ctx, gy):
-        with _lib.on_device(gy.device):
-            g4 = to_nhwc4(gy)
-            b, hp, wp, _ = ctx.x4.shape
-            hc, wc = ctx.cam
-            off, order, wgt = transposed_taps(ctx.grid, (hp, wp), (hc, wc))
-            gx = torch.zeros_like(ctx.x4)
-            _lib.call('spaa_warp_bwd_gather', _lib.ptr(g4), None, _lib.ptr(ctx.x4), None, None, C_ptr(off), C_ptr(order),
-                      _lib.ptr(wgt), _lib.ptr(gx), b, hp, wp, hc, wc, 0)
-            return to_nchw(gx), None
+def _warp_forward_impl(wn, x):
+    """spaa::warp: WarpingNet.forward (models.py:163-185)."""
+    b = x.shape[0]
+    with _lib.on_device(x.device):
+        x4 = to_nhwc4(x)
+        if wn.fine_grid is None:
+            grid = wn.build_fine_grid(x.shape[-2:])
+        else:
+            grid = torch.zeros(*wn.out_size, 4, device=x.device)
+            grid[..., :2] = wn.fine_grid[0]
+        hc, wc = wn.out_size
+        xw = torch.zeros(b, hc, wc, 4, device=x.device)
+        _lib.call('spaa_warp_fwd', _lib.ptr(x4), _lib.ptr(grid), None, None, _lib.ptr(xw), None, b, x.shape[-2],
+                  x.shape[-1], hc, wc, 0)
+        saved = dict(x4=x4, grid=grid, cam=(hc, wc))
+        wn._last_saved = saved
+        return to_nchw(xw), saved
+
+
+def _warp_backward_impl(saved, gy):
+    """Deterministic gather over transposed tap lists, as in the attack loop (no float atomics)."""
+    with _lib.on_device(gy.device):
+        g4 = to_nhwc4(gy)
+        b, hp, wp, _ = saved['x4'].shape
+        hc, wc = saved['cam']
+        off, order, wgt = transposed_taps(saved['grid'], (hp, wp), (hc, wc))
+        gx = torch.zeros_like(saved['x4'])
+        _lib.call('spaa_warp_bwd_gather', _lib.ptr(g4), None, _lib.ptr(saved['x4']), None, None, C_ptr(off), C_ptr(order),
+                  _lib.ptr(wgt), _lib.ptr(gx), b, hp, wp, hc, wc, 0)
+        return to_nchw(gx)
 
 
 # ----------------------------------------------------------------------------------------------------------------

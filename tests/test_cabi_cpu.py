@@ -81,3 +81,25 @@ def test_shard_range_partitions():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_torch_library_ops_are_registered():
+    """The PyTorch-ROCm custom ops of namespace `spaa` (spaa_amd/ops.py): registered with schemas, CUDA(HIP)-only — a CPU
+    tensor is a dispatcher error, not a silent fallback — and with fake (meta) implementations for shape inference."""
+    from spaa_amd import ops
+    for n in ops.OPS:
+        assert hasattr(torch.ops.spaa, n), n
+    assert str(torch.ops.spaa.rgb2lab.default._schema) == 'spaa::rgb2lab(Tensor rgb4) -> Tensor'
+    assert 'Tensor lab1, Tensor lab2' in str(torch.ops.spaa.ciede2000.default._schema)
+    assert 'Int handle' in str(torch.ops.spaa.pcnet_forward.default._schema)
+    with pytest.raises(NotImplementedError):
+        torch.ops.spaa.rgb2lab(torch.zeros(1, 2, 2, 4))
+    with pytest.raises(NotImplementedError):
+        torch.ops.spaa.ciede2000(torch.zeros(1, 2, 2, 4), torch.zeros(1, 2, 2, 4))
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        x = torch.empty(2, 3, 8, 10, device='cuda')
+        x4 = torch.ops.spaa.nchw_to_nhwc4(x)
+        assert x4.shape == (2, 8, 10, 4)
+        assert torch.ops.spaa.ciede2000(x4, x4).shape == (2, 8, 10) and torch.ops.spaa.rgb2lab(x4).shape == x4.shape
+        assert torch.ops.spaa.nhwc4_to_nchw(x4).shape == (2, 3, 8, 10)
