@@ -111,6 +111,16 @@ typedef struct {
 } spaa_tapconv_t;
 
 int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream);
+/* Weight and bias gradients of the layer `desc` describes in its FORWARD form (same geometry / taps / packing fields;
+ * `in` = the layer's input activation; `out_cstride` / `out_coff` / Hout / Wout describe `gout`, the gradient w.r.t. the
+ * layer's pre-activation [B,Hout,Wout,out_cstride]); fp32 only, nfold <= 1.
+ *   dw_packed [sum_c Npad*Kpad_c]: dW in the layout of `weights` (spaa_tapclass_t.w_off), pad rows / columns zero
+ *   dbias [Cout] or NULL:          sum over output pixels of gout
+ *   workspace: nchunk * max(sum_c Npad*Kpad_c, Cout) floats; the pixel range is cut into `nchunk` parts that are summed in
+ *   a fixed order (deterministic).  Replaces aten::convolution_backward(weight, bias) in `train_loss_batch.backward()`
+ *   (train_network.py:316). */
+int spaa_tapconv_wgrad(const spaa_tapconv_t* desc, const float* gout, float* dw_packed, float* dbias, float* workspace,
+                       int nchunk, spaa_stream_t stream);
 /* layout probes for language bindings: sizeof(spaa_tapconv_t) and the byte offset of field # `field`
  * (0 out, 1 weights, 2 taps, 3 gate2, 4 mask_out, 5 tap_range, 6 splitk_ws, 7 io_dtype, 8 nclass, 9 cls; else -1) */
 int spaa_tapconv_sizeof(void);

@@ -49,6 +49,7 @@ _i, _f, _p, _l = C.c_int, C.c_float, C.c_void_p, C.c_int64
 # name -> argument types (all return int)
 _SIGNATURES = {
     'spaa_tapconv_f32': [C.POINTER(TapConv), _p],
+    'spaa_tapconv_wgrad': [C.POINTER(TapConv), _p, _p, _p, _p, _i, _p],
     'spaa_nchw_to_nhwc4': [_p, _p, _i, _i, _i, _i, _p],
     'spaa_nhwc4_to_nchw': [_p, _p, _i, _i, _i, _i, _p],
     'spaa_warp_coarse_grid': [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p],

@@ -96,7 +96,9 @@ class PerCALState:
         self.mode = 0 if targeted else (2 if attacker.confidence != 0 else 1)
         self.d_thr = float(d_thr)
 
-    def iteration(self, i):
+    def iteration(self, i, after_forward=None):
+        """One pass of the loop body (perc_al/__init__.py:179-245).  `after_forward(clf_engine)`: called between the first
+        classifier forward and its backward (the parity tests compare / exchange the ReLU gates there)."""
         att, p, B, HW, clf = self.att, _lib.ptr, self.B, self.HW, self.clf
         n_it = att.max_iterations
         a_l_min, a_c_min = att.alpha_l_init / 100, att.alpha_c_init / 10
@@ -106,6 +108,8 @@ class PerCALState:
         with torch.cuda.device(att.device):
             _lib.call('spaa_add_nhwc4', p(x_in), p(delta), p(x), B * HW)
             logits = clf.forward(x)                                                        # :181
+            if after_forward is not None:
+                after_forward(clf)
             _lib.call('spaa_ce_grad', p(logits), clf.ncls, p(self.label), self.mult, p(self.g_logits), B)  # :186-187
             g_a = clf.backward(self.g_logits)
             _lib.call('spaa_grad_sumsq', p(g_a), p(x), 0.0, 0.0, p(state), p(part1), B, HW)

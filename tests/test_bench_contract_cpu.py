@@ -3,12 +3,17 @@ carries every field of the measurement contract, and its numbers are mutually co
 import glob
 import json
 import os
+import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def latest_bench():
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench.json')), key=lambda f: int(f.split('_v')[-1].split('_')[0]))
+    def key(f):
+        m = re.search(r'r(\d+)_v(\d+)_bench', os.path.basename(f))
+        return (int(m.group(1)), int(m.group(2)))
+
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_v*_bench.json')), key=key)
     assert files, 'no committed bench line under profiles/'
     with open(files[-1]) as fh:
         return json.load(fh), files[-1]

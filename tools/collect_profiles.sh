@@ -2,7 +2,7 @@
 # Round-end evidence run on the GPU box: rocprofv3 kernel stats, PMC HBM traffic (separate passes), bench line.
 # usage (from the repo root on the GPU box): bash tools/collect_profiles.sh <tag>
 set -eo pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -16,7 +16,7 @@ rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o w --output-format csv -- python3 $
 echo "write pass done"
 cd $R
 python3 tools/pmc_traffic.py --fetch $O/pmc_fetch --write $O/pmc_write --out $O/pmc_traffic.json | tee $O/pmc_traffic.txt
-cp $O/pmc_traffic.json profiles/r01_pmc_traffic.json
+cp $O/pmc_traffic.json profiles/${TAG}_pmc_traffic.json
 python3 bench.py --profile-out $O/tapconv_layers.json > $O/bench.json 2> $O/bench.log
 cat $O/bench.json
 find $O -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
