@@ -162,6 +162,26 @@ int spaa_warp_bwd_gather(const float* g_xw, const float* g_xs, const float* x, c
                          const int32_t* off, const int32_t* order, const float* wgt, float* g_x, int B, int Hp, int Wp,
                          int Hc, int Wc, int clamp01, spaa_stream_t stream);
 
+/* ---- PCNet training step: WarpingNet parameter gradients and the optimiser (train_network.py:235-363) ------- */
+/* d loss / d fine_grid summed over the batch: grid_sampler_2d_backward w.r.t. the GRID (models.py:184 under autograd).
+ * g_xw: gradient w.r.t. the masked warped image [B,Hc,Wc,4]; x: the sampled image [B,Hp,Wp,4]; g_grid: [Hc,Wc,4] */
+int spaa_warp_bwd_grid(const float* g_xw, const float* x, const float* grid, const float* mask, float* g_grid, int B, int Hp,
+                       int Wp, int Hc, int Wc, spaa_stream_t stream);
+/* backward of spaa_warp_finish_grid: g_sum = gradient w.r.t. (refine + coarse) (clamp gate), g_r6 (optional) = gradient
+ * w.r.t. the refine net's last pre-activation (LeakyReLU 0.1) */
+int spaa_warp_finish_grid_bwd(const float* g_fine, const float* coarse, const float* refine, float* g_sum, float* g_r6,
+                              int npix, spaa_stream_t stream);
+/* backward of spaa_warp_coarse_grid: g_params [6 + 2 (T+2)] = (d/d affine_mat [2,3] row-major, d/d theta [(T+2),2]);
+ * partial: ceil(Hout*Wout/256) * (6 + 2 (T+2)) floats of scratch (block sums, added in order) */
+int spaa_warp_coarse_grid_bwd(const float* g_coarse, const float* affine6, const float* theta, const float* ctrl, int T, int Hin,
+                              int Win, int Hout, int Wout, float* partial, float* g_params, spaa_stream_t stream);
+/* ReLU backward as a stand-alone op: out = (act > 0) ? g : 0, n floats (n % 4 == 0, 16-byte aligned) */
+int spaa_relu_gate(const float* g, const float* act, float* out, int64_t n, spaa_stream_t stream);
+/* torch.optim.Adam step on one flat parameter tensor (train_network.py:252-254: betas (0.9, 0.999), eps 1e-8, L2 weight
+ * decay added to the gradient); `step` counts from 1 */
+int spaa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, spaa_stream_t stream);
+
 /* ---- stealthiness losses (projector_based_attack.py:275-287; perc_al/differential_color_functions.py) ----- */
 /* rgb [B,H,W,4] -> lab [B,H,W,4]  (rgb2lab_diff :39-64) */
 int spaa_rgb2lab(const float* rgb, float* lab, int npix, spaa_stream_t stream);
@@ -173,6 +193,14 @@ int spaa_ciede2000(const float* lab1, const float* lab2, float* de, int npix, sp
 int spaa_rgb2lab_bwd(const float* rgb, const float* g_lab, float* g_rgb, int npix, spaa_stream_t stream);
 int spaa_ciede2000_bwd(const float* lab1, const float* lab2, const float* g_de, float* g_lab1, float* g_lab2, int npix,
                        spaa_stream_t stream);
+/* PCNet training loss (train_network.py:367-392 compute_loss; pytorch_ssim/__init__.py:26-58), forward and gradient:
+ *   loss = l1_w * mean|infer - target| + ssim_w * (1 - mean SSIM(infer, target))      (means over B*3*H*W)
+ * infer, target, g_infer: NHWC4 [B,H,W,4]; window: the 11x11 Gaussian [121]; m_mu / m_11 / m_12: [B,H,W,4] scratch maps
+ * (needed when ssim_w != 0); partial [B * ceil(H/16) * ceil(W/16)][3] = block sums of (SSIM map, |d|, d^2): the host
+ * adds them in order (loss value and the MSE the reference logs).  g_infer = d loss / d infer. */
+int spaa_train_loss_fwd_bwd(const float* infer, const float* target, const float* window, float l1_w, float ssim_w,
+                            float* m_mu, float* m_11, float* m_12, float* partial, float* g_infer, int B, int H, int W,
+                            spaa_stream_t stream);
 /* Fused camera-side stealth loss + gradient (one launch replaces ~600 ATen ops):
  *   caml2_px = ||scene - y||_2 over rgb ; camdE_px = dE00(lab(y), scene_lab)
  *   g_y      = gscale * (caml2_w * d caml2_px/dy + camdE_w * d camdE_px/dy)      gscale = 1/(B*H*W)

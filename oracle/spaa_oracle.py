@@ -637,3 +637,61 @@ def calc_img_dists(x, y):
     de = ciede2000_diff(rgb2lab_diff(x), rgb2lab_diff(y)).mean().item()
     return (10 * math.log10(1 / mse), math.sqrt(mse.item() * 3), ssim(x, y), torch.norm(d, p=2, dim=1).mean().item() * 255,
             torch.norm(d, p=float('inf'), dim=1).mean().item() * 255, de)
+
+
+# --------------------------------------------------------------------------------------
+# train_network.py:235-363 (train_pcnet, one iteration) and :367-392 (compute_loss)
+# --------------------------------------------------------------------------------------
+def compute_loss(prj_infer, prj_train, loss_option):
+    """train_network.py:367-392 ('huber' omitted: not used for PCNet)."""
+    if loss_option == '':
+        raise TypeError('Loss type not specified')
+    train_loss = 0
+    if 'l1' in loss_option:
+        train_loss = train_loss + F.l1_loss(prj_infer, prj_train, reduction='mean')
+    l2_loss = F.mse_loss(prj_infer, prj_train, reduction='mean')
+    if 'l2' in loss_option:
+        train_loss = train_loss + l2_loss
+    if 'ssim' in loss_option:
+        train_loss = train_loss + 1 * (1 - ssim(prj_infer, prj_train))
+    return train_loss, l2_loss
+
+
+class PCNetTrainOracle:
+    """The reference's training iteration (train_network.py:247-265 optimisers / schedulers, :300-320 loop body) on a
+    PCNet state_dict, with torch.autograd and torch.optim on the CPU."""
+
+    def __init__(self, sd, cam_scene, batch_size, l2_reg=1e-4, lr_drop_ratio=0.2):
+        self.buffers = {k: v.clone() for k, v in sd.items() if k in ('mask', 'warping_net.ctrl_pts')}
+        self.p = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k not in self.buffers}
+        aff = [self.p['warping_net.affine_mat'], self.p['warping_net.theta']]
+        ref = [v for k, v in self.p.items() if 'warping_net.grid_refine_net' in k]
+        shd = [v for k, v in self.p.items() if 'warping_net' not in k]
+        self.opts = [torch.optim.Adam([{'params': aff}], lr=1e-2, weight_decay=0),
+                     torch.optim.Adam([{'params': ref}], lr=5e-3, weight_decay=0),
+                     torch.optim.Adam([{'params': shd}], lr=1e-3, weight_decay=l2_reg)]
+        self.scheds = [torch.optim.lr_scheduler.MultiStepLR(o, milestones=[m], gamma=lr_drop_ratio)
+                       for o, m in zip(self.opts, (100, 1200, 1800))]
+        self.scene = expand_4d(cam_scene).expand(batch_size, -1, -1, -1)
+        self.iters = 0
+
+    def sd(self):
+        d = dict(self.p)
+        d.update(self.buffers)
+        return d
+
+    def step(self, prj, cam, loss=None):
+        if loss is None:
+            loss = 'l1' if self.iters <= 400 else 'l1+ssim'
+        infer = pcnet_forward(self.sd(), prj, self.scene, per_batch_grid=True)
+        train_loss, l2 = compute_loss(infer, cam, loss)
+        for o in self.opts:
+            o.zero_grad()
+        train_loss.backward()
+        self.grads = {k: v.grad.detach().clone() for k, v in self.p.items()}
+        for o in self.opts:
+            o.step()
+        for s in self.scheds:
+            s.step()
+        self.iters += 1
+        return float(train_loss.detach()), float(l2.detach())

@@ -58,12 +58,18 @@ _SIGNATURES = {
     'spaa_warp_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'spaa_warp_taps': [_p, _i, _i, _i, _i, _p, _p, _p],
     'spaa_warp_bwd_gather': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'spaa_warp_bwd_grid': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    'spaa_warp_finish_grid_bwd': [_p, _p, _p, _p, _p, _i, _p],
+    'spaa_warp_coarse_grid_bwd': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
+    'spaa_relu_gate': [_p, _p, _p, _l, _p],
+    'spaa_adam_step': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p],
     'spaa_rgb2lab': [_p, _p, _i, _p],
     'spaa_ciede2000': [_p, _p, _p, _i, _p],
     'spaa_rgb2lab_bwd': [_p, _p, _p, _i, _p],
     'spaa_ciede2000_bwd': [_p, _p, _p, _p, _p, _i, _p],
     'spaa_stealth_loss_fwd_bwd': [_p, _p, _p, _f, _f, _f, _p, _p, _p, _i, _i, _p],
     'spaa_img_dists': [_p, _p, _p, _i, _p],
+    'spaa_train_loss_fwd_bwd': [_p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     'spaa_ssim': [_p, _p, _p, _p, _i, _i, _i, _p],
     'spaa_add_nhwc4': [_p, _p, _p, _i, _p],
     'spaa_ce_grad': [_p, _i, _p, _f, _p, _i, _p],

@@ -293,6 +293,66 @@ class ConvPlan:
             PROFILE.append((self.name, key, self.flops(b, hout, wout), e0, e1, d.tile + 100 * (d.ksplit if d.ksplit > 1 else (9 if d.ksplit == -1 else 0)), nbytes))
         return out
 
+    def wgrad(self, inp, gout, dbias=True, nchunk=None, out_coff=0, in_coff=0):
+        """Weight (and bias) gradient of this layer in its forward form (csrc/tapconv_wgrad.hip): `inp` = the layer's input
+        activation [B,Hin,Win,Cs], `gout` = gradient w.r.t. its pre-activation [B,Hout,Wout,Cs'].  Returns (dW in the packed
+        layout of `self.weights`, dbias [cout] or None); `unpack_grad` maps dW back to the parameter's shape."""
+        _lib.check_dev(inp, gout)
+        assert self.nfold == 1, 'weight gradients use the unfolded transposed-convolution plan'
+        b, hin, win, cs_in = inp.shape
+        b2, hout, wout, cs_out = gout.shape
+        assert b == b2 and in_coff + self.cin_p <= cs_in and out_coff + self.cout <= cs_out
+        d = _lib.TapConv()
+        d.inp, d.Hin, d.Win, d.Cin, d.in_cstride, d.in_coff = inp.data_ptr(), hin, win, self.cin_p, cs_in, in_coff
+        d.Hout, d.Wout, d.Cout, d.out_cstride, d.out_coff = hout, wout, self.cout, cs_out, out_coff
+        d.B = b
+        if self.s_out == 1:
+            d.Hm, d.Wm = hout, wout
+        else:
+            d.Hm, d.Wm = (hout + self.s_out - 1) // self.s_out, (wout + self.s_out - 1) // self.s_out
+        d.s_in, d.s_out = self.s_in, self.s_out
+        d.taps = self.taps.data_ptr()
+        d.nclass = len(self.cls)
+        for i, c in enumerate(self.cls):
+            for k, v in c.items():
+                setattr(d.cls[i], k, v)
+        m = b * d.Hm * d.Wm
+        if nchunk is None:   # enough waves to fill the chip: (taps x n tiles x c groups) x chunks ~ 4096
+            blocks = self.ntaps_total * ((self.cout + 31) // 32) * ((self.cin_p + 127) // 128)
+            nchunk = max(1, min(1024, (4096 + blocks - 1) // blocks, max(1, m // 64)))
+        wtotal = self.weights.numel()
+        need = nchunk * max(wtotal, self.cout)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, device=inp.device, dtype=torch.float32)
+        dw = torch.empty(wtotal, device=inp.device)
+        db = torch.empty(self.cout, device=inp.device) if dbias else None
+        _lib.call('spaa_tapconv_wgrad', C.byref(d), _lib.ptr(gout), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(self._ws), int(nchunk))
+        return dw, db
+
+    def refresh(self, weight, bias=None):
+        """Re-pack a parameter that has changed (training): fp32 matrix and, for the bf16x6 kernels, its three bf16
+        planes — on the device (needs the maps of `attach_maps`).  Exactly what the constructor does on the host."""
+        w = weight.detach().float().reshape(-1)
+        self.weights[self.repack_pos] = w[self.repack_src]
+        if self.w_split is not None:
+            parts = []
+            for c in self.cls:
+                wp = self.weights[c['w_off']:c['w_off'] + self._npad * c['Kpad']]
+                h = wp.to(torch.bfloat16)
+                r1 = wp - h.float()
+                m = r1.to(torch.bfloat16)
+                lo = (r1 - m.float()).to(torch.bfloat16)
+                parts.append(torch.stack([h, m, lo]).view(torch.int16).reshape(-1))
+            self.w_split.copy_(torch.cat(parts))
+        self.w_half = None
+        if bias is not None:
+            self.bias.copy_(bias.detach().float())
+
+    def unpack_grad(self, dw_packed):
+        """Packed dW -> gradient in the shape of the parameter this plan was built from (needs `unpack_idx`, attached by
+        `attach_unpack`)."""
+        return dw_packed[self.unpack_idx].view(self.param_shape)
+
     def _default_tile(self, m):
         """Kernel choice for a layer shape that tools/autotune.py has not measured: the family that wins for the
         measured shapes of the same kind."""
@@ -379,8 +439,9 @@ def conv_dgrad_plan(weight, stride, pad, device='cuda', name='', in_ch=None):
     return ConvPlan(_fractional_classes(wsel, kh, kw, pad), co, hi - lo, 1, 2, None, device, name)
 
 
-def deconv_fwd_plan(weight, bias, stride, pad, device='cuda', name=''):
-    """nn.ConvTranspose2d forward (stride 2). weight [ci, co, kh, kw]."""
+def deconv_fwd_plan(weight, bias, stride, pad, device='cuda', name='', fold=None):
+    """nn.ConvTranspose2d forward (stride 2). weight [ci, co, kh, kw].  `fold=False`: keep the four parity classes
+    separate (the training path: weight gradients are taken per class)."""
     assert stride == 2
     w = _w2(weight)
     ci, co, kh, kw = w.shape
@@ -388,7 +449,7 @@ def deconv_fwd_plan(weight, bias, stride, pad, device='cuda', name=''):
     def wsel(ky, kx):
         return w[:, :, ky, kx].t().contiguous()
 
-    if FOLD_DECONV and kh == 2 and kw == 2 and pad == 0 and ci % 32 == 0 and co % 4 == 0 and ENABLE_X6:
+    if (FOLD_DECONV if fold is None else fold) and kh == 2 and kw == 2 and pad == 0 and ci % 32 == 0 and co % 4 == 0 and ENABLE_X6:
         # the four output-parity classes share the tap (0, 0): fold them into the GEMM rows (row c*co + n, c = 2 dy + dx)
         c = TapClassSpec(0, 0)
         c.add(0, 0, torch.cat([wsel(dy, dx) for dy in (0, 1) for dx in (0, 1)], 0))
@@ -405,6 +466,36 @@ def deconv_dgrad_plan(weight, stride, pad, device='cuda', name=''):
         for kx in range(kw):
             c.add(ky - pad, kx - pad, w[:, :, ky, kx].contiguous())
     return ConvPlan([c], co, ci, stride, 1, None, device, name)
+
+
+def attach_maps(plan, builder, weight):
+    """Index plumbing for training: where does each element of the parameter tensor sit in the packed weight matrix?
+    `builder(w)` is the plan constructor that built `plan` (as a function of the weight alone); it is run once more on a
+    tensor of element indices.  Keeps on the device
+      repack_pos / repack_src : packed[repack_pos] = param.flatten()[repack_src]   (every used packed position;
+                                `ConvPlan.refresh` re-packs a CHANGED parameter with it, no host round trip)
+      unpack_idx              : param_grad.flatten() = dW_packed[unpack_idx]       (only when every element is used once,
+                                i.e. for forward plans)."""
+    n = weight.numel()
+    assert n < (1 << 24)   # indices travel through the fp32 packing exactly
+    idx_w = (torch.arange(n, dtype=torch.float32) + 1).view(weight.shape)
+    global ENABLE_X6
+    saved, ENABLE_X6 = ENABLE_X6, False
+    try:
+        ip = builder(idx_w)
+    finally:
+        ENABLE_X6 = saved
+    packed = ip.weights.cpu().round().long()
+    assert packed.numel() == plan.weights.numel()
+    pos = torch.nonzero(packed, as_tuple=False).view(-1)
+    dev = plan.weights.device
+    plan.repack_pos, plan.repack_src = pos.to(dev), (packed[pos] - 1).to(dev)
+    plan.param_shape = tuple(weight.shape)
+    if pos.numel() == n and torch.unique(packed[pos]).numel() == n:
+        unpack = torch.empty(n, dtype=torch.long)
+        unpack[packed[pos] - 1] = pos
+        plan.unpack_idx = unpack.to(dev)
+    return plan
 
 
 def linear_fwd_plan(weight, bias, device='cuda', name=''):

@@ -457,9 +457,158 @@ __global__ __launch_bounds__(256) void ssim_kernel(const float4* __restrict__ x,
     if (threadIdx.x == 0) partial[((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Training loss of PCNet (train_network.py:367-392 compute_loss): l1 [+ (1 - SSIM)], with its gradient w.r.t. the inferred
+// image, and the MSE the reference logs.  SSIM as pytorch_ssim/__init__.py:26-58 (11x11 Gaussian, replicate padding).
+//   S = A1 A2 / (B1 B2),  A1 = 2 mu1 mu2 + C1, A2 = 2 (e12 - mu1 mu2) + C2, B1 = mu1^2 + mu2^2 + C1, B2 = e11 - mu1^2 + e22 - mu2^2 + C2
+// pass 1 (per output pixel p): S and its partials w.r.t. the three window statistics that depend on y:
+//   Mmu = dS/dmu1, M11 = dS/de11, M12 = dS/de12        (mu1 = sum w y, e11 = sum w y^2, e12 = sum w y t)
+// pass 2 (per image pixel q): g[q] = sign(y-t)/N - (1/N) sum_{q' -> q} sum_p w(p - q') [Mmu(p) + 2 y[q] M11(p) + t[q] M12(p)]
+//   where q' runs over the replicate-padded positions that read pixel q (q itself, plus the pad cells beside an edge pixel).
+__global__ __launch_bounds__(256) void train_loss_stats_kernel(const float4* __restrict__ x, const float4* __restrict__ y,
+                                                               const float* __restrict__ window, float4* __restrict__ Mmu,
+                                                               float4* __restrict__ M11, float4* __restrict__ M12,
+                                                               float* __restrict__ partial, int H, int W, int use_ssim) {
+    __shared__ float4 sx[SS_P * SS_P], sy[SS_P * SS_P];
+    __shared__ float sw[121];
+    __shared__ float red[4];
+    const int b = blockIdx.z, y0 = blockIdx.y * SS_T, x0 = blockIdx.x * SS_T;
+    const size_t base = (size_t)b * H * W;
+    for (int i = threadIdx.x; i < SS_P * SS_P; i += 256) {
+        const int py = i / SS_P, px = i - py * SS_P;
+        const int iy = min(max(y0 + py - SS_R, 0), H - 1), ix = min(max(x0 + px - SS_R, 0), W - 1);  // replicate
+        sx[i] = x[base + (size_t)iy * W + ix];
+        sy[i] = y[base + (size_t)iy * W + ix];
+    }
+    if (threadIdx.x < 121) sw[threadIdx.x] = window[threadIdx.x];
+    __syncthreads();
+    const int ly = threadIdx.x / SS_T, lx = threadIdx.x - ly * SS_T;
+    const bool inside = y0 + ly < H && x0 + lx < W;
+    float s_sum = 0.f, l1 = 0.f, l2 = 0.f;
+    float mmu[3] = {0, 0, 0}, m11[3] = {0, 0, 0}, m12[3] = {0, 0, 0};
+    if (inside) {
+        const float4 a0 = sx[(ly + SS_R) * SS_P + lx + SS_R], c0 = sy[(ly + SS_R) * SS_P + lx + SS_R];
+        const float d[3] = {a0.x - c0.x, a0.y - c0.y, a0.z - c0.z};
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            l1 += fabsf(d[ch]);
+            l2 += d[ch] * d[ch];
+        }
+    }
+    if (use_ssim) {
+        float mu1[3] = {0, 0, 0}, mu2[3] = {0, 0, 0}, e11[3] = {0, 0, 0}, e22[3] = {0, 0, 0}, e12[3] = {0, 0, 0};
+        for (int ky = 0; ky < 11; ++ky)
+            for (int kx = 0; kx < 11; ++kx) {
+                const float w = sw[ky * 11 + kx];
+                const float4 a = sx[(ly + ky) * SS_P + lx + kx], c = sy[(ly + ky) * SS_P + lx + kx];
+                const float av[3] = {a.x, a.y, a.z}, cv[3] = {c.x, c.y, c.z};
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    mu1[ch] = fmaf(w, av[ch], mu1[ch]);
+                    mu2[ch] = fmaf(w, cv[ch], mu2[ch]);
+                    e11[ch] = fmaf(w, av[ch] * av[ch], e11[ch]);
+                    e22[ch] = fmaf(w, cv[ch] * cv[ch], e22[ch]);
+                    e12[ch] = fmaf(w, av[ch] * cv[ch], e12[ch]);
+                }
+            }
+        if (inside) {
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float m11s = mu1[ch] * mu1[ch], m22s = mu2[ch] * mu2[ch], m12s = mu1[ch] * mu2[ch];
+                const float A1 = 2.f * m12s + C1, A2 = 2.f * (e12[ch] - m12s) + C2;
+                const float B1 = m11s + m22s + C1, B2 = (e11[ch] - m11s) + (e22[ch] - m22s) + C2;
+                const float S = (A1 * A2) / (B1 * B2);
+                s_sum += S;
+                mmu[ch] = (2.f * mu2[ch] * (A2 - A1)) / (B1 * B2) - S * (2.f * mu1[ch] / B1 - 2.f * mu1[ch] / B2);
+                m11[ch] = -S / B2;
+                m12[ch] = 2.f * A1 / (B1 * B2);
+            }
+        }
+        if (inside) {
+            const size_t o = base + (size_t)(y0 + ly) * W + x0 + lx;
+            Mmu[o] = make_float4(mmu[0], mmu[1], mmu[2], 0.f);
+            M11[o] = make_float4(m11[0], m11[1], m11[2], 0.f);
+            M12[o] = make_float4(m12[0], m12[1], m12[2], 0.f);
+        }
+    }
+    const float r0 = block_sum_256(s_sum, red), r1 = block_sum_256(l1, red), r2 = block_sum_256(l2, red);
+    if (threadIdx.x == 0) {
+        float* pp = partial + 3 * (((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        pp[0] = r0;
+        pp[1] = r1;
+        pp[2] = r2;
+    }
+}
+
+__global__ __launch_bounds__(256) void train_loss_grad_kernel(const float4* __restrict__ x, const float4* __restrict__ y,
+                                                              const float* __restrict__ window, const float4* __restrict__ Mmu,
+                                                              const float4* __restrict__ M11, const float4* __restrict__ M12,
+                                                              float4* __restrict__ g, int B, int H, int W, float l1_w,
+                                                              float ssim_w, float inv_n) {
+    __shared__ float sw[121];
+    if (threadIdx.x < 121) sw[threadIdx.x] = window[threadIdx.x];
+    __syncthreads();
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * H * W) return;
+    const int b = idx / (H * W);
+    const int r = idx - b * H * W;
+    const int qy = r / W, qx = r - qy * W;
+    const float4 xv = x[idx], yv = y[idx];
+    const float xa[3] = {xv.x, xv.y, xv.z}, ya[3] = {yv.x, yv.y, yv.z};
+    float gout[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float d = xa[ch] - ya[ch];
+        gout[ch] = l1_w * inv_n * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+    }
+    if (ssim_w != 0.f) {
+        // padded positions (q'y, q'x) whose replicate-clamped source is this pixel
+        const int ylo = qy == 0 ? -SS_R : qy, yhi = qy == H - 1 ? H - 1 + SS_R : qy;
+        const int xlo = qx == 0 ? -SS_R : qx, xhi = qx == W - 1 ? W - 1 + SS_R : qx;
+        float acc[3] = {0, 0, 0};
+        const size_t base = (size_t)b * H * W;
+        for (int py = ylo; py <= yhi; ++py)
+            for (int px = xlo; px <= xhi; ++px)
+                // output pixels p whose 11x11 window covers the padded position: p = q' - k + R, k = 0..10
+                for (int ky = 0; ky < 11; ++ky) {
+                    const int oy = py - ky + SS_R;
+                    if ((unsigned)oy >= (unsigned)H) continue;
+                    for (int kx = 0; kx < 11; ++kx) {
+                        const int ox = px - kx + SS_R;
+                        if ((unsigned)ox >= (unsigned)W) continue;
+                        const float w = sw[ky * 11 + kx];
+                        const size_t o = base + (size_t)oy * W + ox;
+                        const float4 a = Mmu[o], c = M11[o], e = M12[o];
+                        acc[0] += w * (a.x + 2.f * xa[0] * c.x + ya[0] * e.x);
+                        acc[1] += w * (a.y + 2.f * xa[1] * c.y + ya[1] * e.y);
+                        acc[2] += w * (a.z + 2.f * xa[2] * c.z + ya[2] * e.z);
+                    }
+                }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) gout[ch] -= ssim_w * inv_n * acc[ch];
+    }
+    g[idx] = make_float4(gout[0], gout[1], gout[2], 0.f);
+}
+
 }  // namespace
 
 extern "C" {
+
+int spaa_train_loss_fwd_bwd(const float* infer, const float* target, const float* window, float l1_w, float ssim_w,
+                            float* m_mu, float* m_11, float* m_12, float* partial, float* g_infer, int B, int H, int W,
+                            spaa_stream_t stream) {
+    if (!infer || !target || !window || !partial || !g_infer || B < 1 || H < 1 || W < 1 || B > 65535) return hipErrorInvalidValue;
+    if (ssim_w != 0.f && (!m_mu || !m_11 || !m_12)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(train_loss_stats_kernel, dim3((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, B), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)infer, (const float4*)target, window, (float4*)m_mu, (float4*)m_11,
+                       (float4*)m_12, partial, H, W, ssim_w != 0.f ? 1 : 0);
+    const float inv_n = 1.f / (3.f * (float)B * (float)H * (float)W);
+    hipLaunchKernelGGL(train_loss_grad_kernel, dim3((B * H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)infer, (const float4*)target, window, (const float4*)m_mu, (const float4*)m_11,
+                       (const float4*)m_12, (float4*)g_infer, B, H, W, l1_w, ssim_w, inv_n);
+    return (int)hipGetLastError();
+}
 
 int spaa_img_dists(const float* x, const float* y, float* partial, int npix, spaa_stream_t stream) {
     if (!x || !y || !partial || npix < 1) return hipErrorInvalidValue;

@@ -1424,3 +1424,107 @@ def test_fp16_storage_attack_loops(hip, golden_dir):
     print(f'fp16-storage PerC-AL + VGG-16 at 256x256: delta rel L2 after iteration 0 vs fp32 oracle {e_d:.2e}')
     assert e_d < 0.3 and out.min() >= 0 and out.max() <= 1 and (torch.round(out * 255) / 255 - out).abs().max() < 1e-6
     assert np.allclose(ptr[0][1][:, 3].cpu().numpy(), otr[0]['color_dis'].numpy(), rtol=5e-2)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the PCNet training step (train_network.py:235-363, compute_loss :367-392)
+def test_tapconv_weight_gradients(hip):
+    """spaa_tapconv_wgrad (weight and bias gradients, exact fp32 MFMA, fixed-order pixel chunks) vs torch.autograd:
+    convolutions (stride 1/2, 1x1/3x3/7x7, thin channel counts), transposed convolutions (k2 and k3, unfolded classes)."""
+    cp = hip['cp']
+    torch.manual_seed(3)
+    for ci, co, k, s, h, w, b in [(32, 64, 3, 2, 22, 18, 3), (3, 32, 3, 2, 16, 20, 2), (64, 3, 3, 1, 12, 14, 2),
+                                  (6, 32, 3, 2, 16, 16, 2), (128, 256, 3, 1, 9, 8, 2), (32, 64, 1, 1, 10, 10, 2), (3, 3, 1, 1, 9, 7, 2)]:
+        x = torch.randn(b, ci, h, w)
+        wt = (torch.randn(co, ci, k, k) / (ci * k * k) ** 0.5).requires_grad_(True)
+        bias = torch.randn(co, requires_grad=True)
+        y = F.conv2d(x, wt, bias, s, k // 2)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        builder = lambda wv, s=s, k=k: cp.conv_fwd_plan(wv, None, s, k // 2, 'cpu')
+        pl = builder(wt.detach())
+        pl.weights, pl.taps, pl.w_split = pl.weights.to(DEV), pl.taps.to(DEV), None
+        cp.attach_maps(pl, builder, wt.detach())
+        for nchunk in (None, 1, 7):
+            dw, db = pl.wgrad(nhwc(x, pl.cin_p).to(DEV), nhwc(gy, (co + 3) // 4 * 4).to(DEV), nchunk=nchunk)
+            assert rel_inf(pl.unpack_grad(dw), wt.grad) < 2e-5, (ci, co, k, s, nchunk)
+            assert rel_inf(db, bias.grad) < 2e-5, (ci, co, k, s, nchunk)
+    for ci, co, k, pad, op, h, w in [(64, 32, 2, 0, 0, 9, 7), (128, 64, 3, 1, 1, 8, 8), (32, 2, 2, 0, 0, 8, 10)]:
+        x = torch.randn(2, ci, h, w)
+        wt = (torch.randn(ci, co, k, k) / (ci * k * k) ** 0.5).requires_grad_(True)
+        bias = torch.randn(co, requires_grad=True)
+        y = F.conv_transpose2d(x, wt, bias, 2, pad, op)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        builder = lambda wv, pad=pad: cp.deconv_fwd_plan(wv, None, 2, pad, 'cpu', fold=False)
+        pl = builder(wt.detach())
+        pl.weights, pl.taps, pl.w_split = pl.weights.to(DEV), pl.taps.to(DEV), None
+        cp.attach_maps(pl, builder, wt.detach())
+        dw, db = pl.wgrad(nhwc(x).to(DEV), nhwc(gy, (co + 3) // 4 * 4).to(DEV))
+        assert rel_inf(pl.unpack_grad(dw), wt.grad) < 2e-5, ('deconv', ci, co, k)
+        assert rel_inf(db, bias.grad) < 2e-5
+
+
+def test_training_loss_and_gradient(hip):
+    """compute_loss 'l1' / 'l1+ssim' (train_network.py:367-392; SSIM with replicate padding, pytorch_ssim/__init__.py:26-58):
+    value and gradient w.r.t. the inferred image vs the oracle, on sizes that are not multiples of the 16x16 tile."""
+    lib, M = hip['lib'], hip['models']
+    from spaa_amd import train_network as tn
+    torch.manual_seed(8)
+    for (b, h, w) in [(2, 37, 53), (3, 64, 64), (1, 16, 12)]:
+        t = syn.scenes(3, b, (h, w))
+        y = (t + 0.08 * torch.randn(b, 3, h, w)).clamp(0, 1)
+        for opt in ('l1', 'l1+ssim'):
+            yc = y.clone().requires_grad_(True)
+            loss, l2 = so.compute_loss(yc, t, opt)
+            loss.backward()
+            y4, t4 = M.to_nhwc4(y.to(DEV)), M.to_nhwc4(t.to(DEV))
+            nblk = ((h + 15) // 16) * ((w + 15) // 16)
+            ws = [torch.zeros_like(y4) for _ in range(4)]
+            part = torch.zeros(b * nblk, 3, device=DEV)
+            lib.call('spaa_train_loss_fwd_bwd', lib.ptr(y4), lib.ptr(t4), lib.ptr(tn._window().to(DEV)), 1.0,
+                     1.0 if 'ssim' in opt else 0.0, lib.ptr(ws[0]), lib.ptr(ws[1]), lib.ptr(ws[2]), lib.ptr(part), lib.ptr(ws[3]), b, h, w)
+            s = part.sum(dim=0).cpu() / (3.0 * b * h * w)
+            val = float(s[1]) + ((1 - float(s[0])) if 'ssim' in opt else 0.0)
+            assert abs(val - float(loss)) < 1e-5 * max(1.0, abs(float(loss))) and abs(float(s[2]) - float(l2)) < 1e-6
+            assert rel_inf(M.to_nchw(ws[3]), yc.grad) < 1e-4, (b, h, w, opt)
+            got, _ = tn.compute_loss(y.to(DEV), t, opt)
+            assert abs(float(got) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+
+
+def test_pcnet_training_step(hip):
+    """Two iterations of the reference's PCNet training loop body (forward with the current WarpingNet parameters, l1+ssim
+    resp. l1 loss, gradients of all 44 parameter tensors, three Adam optimisers) on HIP vs the oracle (torch.autograd +
+    torch.optim on the CPU): loss values, every gradient, every updated parameter."""
+    from spaa_amd.train_network import PCNetTrainer
+    sz = (64, 64)
+    sd = syn.pcnet_state_dict(0, cam_sz=sz, mask='rect')
+    pc = make_pcnet(hip, sd, sz)
+    scene = syn.scenes(1, 1, sz)
+    B = 4
+    prj = [syn.scenes(20 + i, B, sz) for i in range(2)]
+    cam = [syn.scenes(30 + i, B, sz) * 0.8 + 0.05 for i in range(2)]
+    orc = so.PCNetTrainOracle(sd, scene, B)
+    tr = PCNetTrainer(pc, scene, B, device=DEV)
+    for it, opt in enumerate(('l1+ssim', 'l1')):
+        lo, l2o = orc.step(prj[it], cam[it], opt)
+        lh, l2h = tr.step(prj[it], cam[it], opt)
+        assert abs(lh - lo) < 2e-5 * max(1.0, abs(lo)) and abs(l2h - l2o) < 1e-6, (it, lh, lo)
+        worst = ('', 0.0)
+        for name, g_ref in orc.grads.items():
+            g = tr.grads[name].reshape(g_ref.shape)
+            e = rel_l2(g, g_ref)
+            if e > worst[1]:
+                worst = (name, e)
+            # (ReLU gates within rounding of zero: sparse differences, DESIGN.md section 4; a wrong kernel gives O(1))
+            assert e < 2e-3, (it, name, e)
+        print(f'training step {it} ({opt}): loss {lh:.6f} vs oracle {lo:.6f}; worst gradient rel L2 {worst[1]:.2e} ({worst[0]})')
+        hp = dict(pc.named_parameters())
+        for name, p_ref in orc.p.items():
+            d = (hp[name].detach().cpu() - p_ref.detach())
+            lr = 1e-2 if name in ('warping_net.affine_mat', 'warping_net.theta') else (5e-3 if 'grid_refine_net' in name else 1e-3)
+            # Adam's first steps move every element by ~lr * sign(g): elements whose gradient is rounding noise may go either way
+            sig = orc.grads[name].abs() > 1e-4 * orc.grads[name].abs().max()
+            assert float(d[sig].abs().max()) < 0.02 * lr, (it, name, float(d[sig].abs().max()), lr)
+            assert float(d.abs().max()) <= 2.01 * lr * (it + 1), (it, name)
+    assert tr.iters == 2
