@@ -615,7 +615,13 @@ def ssim_window(window_size=11, sigma=1.5, channel=3):
 
 
 def ssim(x, y, window_size=11):
-    """pytorch_ssim.ssim (:98-107) -> _ssim (:26-58): replicate padding, grouped 11x11 Gaussian, mean of the map."""
+    """The metric as utils.py uses it: a Python float."""
+    return ssim_tensor(x, y, window_size).item()
+
+
+def ssim_tensor(x, y, window_size=11):
+    """pytorch_ssim.ssim (:98-107) -> _ssim (:26-58): replicate padding, grouped 11x11 Gaussian, mean of the map
+    (differentiable: the training loss uses pytorch_ssim.SSIM(), same arithmetic)."""
     c = x.shape[1]
     w = ssim_window(window_size, 1.5, c)
     pad = window_size // 2
@@ -626,7 +632,7 @@ def ssim(x, y, window_size=11):
     s2 = F.conv2d(y * y, w, groups=c) - mu2_sq
     s12 = F.conv2d(x * y, w, groups=c) - mu12
     c1, c2 = 0.01 ** 2, 0.03 ** 2
-    return (((2 * mu12 + c1) * (2 * s12 + c2)) / ((mu1_sq + mu2_sq + c1) * (s1 + s2 + c2))).mean().item()
+    return (((2 * mu12 + c1) * (2 * s12 + c2)) / ((mu1_sq + mu2_sq + c1) * (s1 + s2 + c2))).mean()
 
 
 def calc_img_dists(x, y):
@@ -653,7 +659,7 @@ def compute_loss(prj_infer, prj_train, loss_option):
     if 'l2' in loss_option:
         train_loss = train_loss + l2_loss
     if 'ssim' in loss_option:
-        train_loss = train_loss + 1 * (1 - ssim(prj_infer, prj_train))
+        train_loss = train_loss + 1 * (1 - ssim_tensor(prj_infer, prj_train))
     return train_loss, l2_loss
 
 
