@@ -479,12 +479,7 @@ def attach_maps(plan, builder, weight):
     n = weight.numel()
     assert n < (1 << 24)   # indices travel through the fp32 packing exactly
     idx_w = (torch.arange(n, dtype=torch.float32) + 1).view(weight.shape)
-    global ENABLE_X6
-    saved, ENABLE_X6 = ENABLE_X6, False
-    try:
-        ip = builder(idx_w)
-    finally:
-        ENABLE_X6 = saved
+    ip = builder(idx_w)
     packed = ip.weights.cpu().round().long()
     assert packed.numel() == plan.weights.numel()
     pos = torch.nonzero(packed, as_tuple=False).view(-1)
