@@ -315,7 +315,59 @@ def gen_io(name):
     print(f'  {name}: {rgb.shape} mean {rgb.reshape(-1, 3).mean(0)}')
 
 
+def gen_train(ref, name, sz, bsz, seed):
+    """8f-4: the reference's PCNet training iteration.  train_network.py cannot be imported (visdom / Qt at import), so
+    `compute_loss` (:367-392) is exec'd from its source with the reference's own pytorch_ssim.SSIM() as `ssim_fun`, and the
+    loop body (:306-320) runs on the reference's PCNet module with the optimisers / schedulers of :252-265."""
+    import importlib.util
+    import torch.nn.functional as F
+    spec = importlib.util.spec_from_file_location('ref_pytorch_ssim', os.path.join(ref_shims.REF_ROOT, 'pytorch_ssim', '__init__.py'))
+    ref_ssim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_ssim)
+    ns = _exec_defs(os.path.join(ref_shims.REF_ROOT, 'train_network.py'), ('compute_loss',), dict(F=F, ssim_fun=ref_ssim.SSIM()))
+    sd = syn.pcnet_state_dict(seed, cam_sz=sz, mask='rect')
+    wn = ref.models.WarpingNet(out_size=tuple(sz))
+    sn = ref.models.ShadingNetSPAA()
+    holder = types.SimpleNamespace
+    model = ref.models.PCNet(sd['mask'], holder(module=wn), holder(module=sn))
+    model.load_state_dict(sd)
+    named = [('module.' + k, v) for k, v in model.named_parameters()]       # (the reference wraps the model in DataParallel)
+    aff = [v for k, v in named if k in ['module.warping_net.affine_mat', 'module.warping_net.theta']]
+    refine = [v for k, v in named if 'module.warping_net.grid_refine_net' in k]
+    shading = [v for k, v in named if 'module.warping_net' not in k]
+    opts = [torch.optim.Adam([{'params': aff}], lr=1e-2, weight_decay=0), torch.optim.Adam([{'params': refine}], lr=5e-3, weight_decay=0),
+            torch.optim.Adam([{'params': shading}], lr=1e-3, weight_decay=1e-4)]
+    scene = syn.scenes(seed + 1, 1, sz)
+    scene_b = scene.expand(bsz, -1, -1, -1)
+    orc = so.PCNetTrainOracle(sd, scene, bsz, l2_reg=1e-4, lr_drop_ratio=0.2)
+    out, diff = {}, 0.0
+    for it, opt in enumerate(('l1+ssim', 'l1')):
+        prj = syn.scenes(seed + 20 + it, bsz, sz)
+        cam = syn.scenes(seed + 30 + it, bsz, sz) * 0.8 + 0.05
+        model.train()
+        infer = model(prj, scene_b)
+        loss, l2 = ns['compute_loss'](infer, cam, opt)
+        for o in opts:
+            o.zero_grad()
+        loss.backward()
+        grads = {k: v.grad.detach().clone() for k, v in model.named_parameters()}
+        for o in opts:
+            o.step()
+        lo, l2o = orc.step(prj, cam, opt)
+        diff = max(diff, abs(lo - float(loss)), abs(l2o - float(l2)), max(float((orc.grads[k] - g).abs().max()) for k, g in grads.items()),
+                   max(float((orc.p[k] - v).abs().max()) for k, v in model.named_parameters()))
+        out[f'loss{it}'], out[f'l2_{it}'] = float(loss), float(l2)
+        for k in ('warping_net.affine_mat', 'warping_net.theta', 'warping_net.grid_refine_net.6.bias', 'shading_net.conv6.weight',
+                  'shading_net.conv1_s.bias', 'shading_net.skipConv1.0.weight', 'shading_net.transConv2.bias'):
+            out[f'grad{it}.{k}'] = grads[k].numpy()
+            out[f'param{it}.{k}'] = dict(model.named_parameters())[k].detach().numpy().copy()
+        out[f'gradnorm{it}'] = np.array([float(grads[k].double().norm()) for k in sorted(grads)])
+    print(f'  {name}: oracle maxdiff {diff:.3e}; losses {out["loss0"]:.6f} {out["loss1"]:.6f}')
+    save(name, seed=seed, sz=sz, bsz=bsz, names=np.array(sorted(grads)), wsum=weights_checksum(sd), oracle_maxdiff=diff, **out)
+
+
 CASES = {
+    'train_32': lambda r: gen_train(r, 'train_32', (32, 32), 3, 0),
     'preproc_240_224': lambda r: gen_preproc('preproc_240_224', (256, 256), (240, 240), (224, 224), 41),
     'preproc_240_299': lambda r: gen_preproc('preproc_240_299', (256, 256), (240, 240), (299, 299), 42),
     'preproc_nonsq_small': lambda r: gen_preproc('preproc_nonsq_small', (60, 84), (56, 56), (48, 48), 43, bsz=3),

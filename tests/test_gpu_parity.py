@@ -1539,3 +1539,23 @@ def test_pcnet_training_step(hip):
             sig = orc.grads[name].abs() > 1e-2 * orc.grads[name].abs().max()
             assert float((hp[name].detach().cpu() - orc.p[name].detach())[sig].abs().max()) < 0.05 * lr, (it, name)
     assert tr.iters == 2
+
+
+def test_training_iteration_vs_reference_fixture(hip, golden_dir):
+    """The HIP training step against what the REFERENCE's own modules produced (tests/golden/make_golden.py gen_train):
+    first-iteration loss and gradients."""
+    from spaa_amd.train_network import PCNetTrainer
+    z = load(golden_dir, 'train_32')
+    sz, bsz, seed = tuple(int(v) for v in z['sz']), int(z['bsz']), int(z['seed'])
+    sd = syn.pcnet_state_dict(seed, cam_sz=sz, mask='rect')
+    pc = make_pcnet(hip, sd, sz)
+    tr = PCNetTrainer(pc, syn.scenes(seed + 1, 1, sz), bsz, l2_reg=1e-4, lr_drop_ratio=0.2, device=DEV)
+    lh, l2h = tr.step(syn.scenes(seed + 20, bsz, sz), syn.scenes(seed + 30, bsz, sz) * 0.8 + 0.05, 'l1+ssim')
+    assert abs(lh - float(z['loss0'])) < 2e-5 and abs(l2h - float(z['l2_0'])) < 1e-6
+    names = [str(n) for n in z['names']]
+    gn = np.array([float(tr.grads[k].double().norm()) for k in names])
+    assert np.allclose(gn, z['gradnorm0'], rtol=2e-3), np.abs(gn / z['gradnorm0'] - 1).max()
+    for key in z.files:
+        if key.startswith('grad0.'):
+            k = key[len('grad0.'):]
+            assert rel_l2(tr.grads[k].reshape(z[key].shape), torch.from_numpy(z[key])) < 2e-3, key

@@ -151,3 +151,26 @@ def test_classifier_wrapper_and_preprocessing(golden_dir, name):
     raw8, _, idx8 = oc((im[0] * 255).to(torch.uint8), crop)  # 3-D uint8 (classifier.py:56-57, img_proc.py:110-114)
     assert np.abs(raw8.detach().numpy() - z['raw_score_u8']).max() <= 1e-4 * np.abs(z['raw_score_u8']).max()
     assert (idx8[:, :5] == z['idx5_u8']).all()
+
+
+def test_training_iteration_vs_reference(golden_dir):
+    """two iterations of the reference's PCNet training loop body (reference PCNet module, its compute_loss and
+    pytorch_ssim.SSIM, torch.optim.Adam as configured at train_network.py:252-265) — losses, gradients, updated parameters."""
+    z = load(golden_dir, 'train_32')
+    sz, bsz, seed = tuple(int(v) for v in z['sz']), int(z['bsz']), int(z['seed'])
+    sd = syn.pcnet_state_dict(seed, cam_sz=sz, mask='rect')
+    assert np.allclose(checksum(sd), z['wsum'], rtol=1e-9)
+    orc = so.PCNetTrainOracle(sd, syn.scenes(seed + 1, 1, sz), bsz, l2_reg=1e-4, lr_drop_ratio=0.2)
+    names = [str(n) for n in z['names']]
+    for it, opt in enumerate(('l1+ssim', 'l1')):
+        lo, l2 = orc.step(syn.scenes(seed + 20 + it, bsz, sz), syn.scenes(seed + 30 + it, bsz, sz) * 0.8 + 0.05, opt)
+        assert abs(lo - float(z[f'loss{it}'])) < 1e-6 and abs(l2 - float(z[f'l2_{it}'])) < 1e-7
+        gn = np.array([float(orc.grads[k].double().norm()) for k in names])
+        assert np.allclose(gn, z[f'gradnorm{it}'], rtol=1e-4)
+        for key in z.files:
+            if key.startswith(f'grad{it}.'):
+                k = key[len(f'grad{it}.'):]
+                assert np.abs(orc.grads[k].numpy() - z[key]).max() <= 1e-5 * max(np.abs(z[key]).max(), 1e-12), key
+            if key.startswith(f'param{it}.'):
+                k = key[len(f'param{it}.'):]
+                assert np.abs(orc.p[k].detach().numpy() - z[key]).max() <= 1e-5, key
