@@ -32,14 +32,16 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               42: 'x6d16a3_128x64', 43: 'x6d16a3_128x32', 44: 'x6da3_128x64', 45: 'x6d16coa3_128x64', 46: 'x6d16coa3_128x32', 47: 'thinpatch16x2',
               48: 'x6d16p_128x128', 49: 'x6d16p_128x64', 50: 'x6d16a3p_128x64', 51: 'x6da3p_128x64', 52: 'x6d16p_256x128',
               53: 'x6d16p_128x32', 54: 'x6dp_128x128',
-              60: 'h16_128x128', 61: 'h16_128x64', 62: 'h16_128x32', 63: 'h16_128x16', 64: 'h16_256x128', 65: 'h16_256x256'}
-STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 66))  # shared epilogue (epilogue.hpp)
+              60: 'h16_128x128', 61: 'h16_128x64', 62: 'h16_128x32', 63: 'h16_128x16', 64: 'h16_256x128', 65: 'h16_256x256',
+              70: 'wino_x6_16x32x128'}
+STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 66)) | {70}  # shared epilogue (epilogue.hpp)
 F16OUT_TILES = set(range(15, 25)) | {38} | set(range(60, 66))  # ... of which these may write fp16 (fp32 image in, fp16 activation out)
 DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
 DEBUG_TAPMAJOR = int(os.environ.get('SPAA_X6D_TAPMAJOR', '0'))      # 1: tap-major K order (A/B measurements only)
 DEBUG_PERSIST_CAP = int(os.environ.get('SPAA_X6D_PERSIST_CAP', '0'))  # > 0: persistent launches use this many workgroups
 FOLD_DECONV = True  # k2/s2 transposed convs: parity classes folded into GEMM rows (one read of the input)
 ENABLE_X6 = True  # build the split-bf16 weight planes (needed by tiles 12-14)
+WINOGRAD = os.environ.get('SPAA_WINOGRAD', '1') != '0'  # 3x3/s1 layers: allow the Winograd F(2x2,3x3) kernel (tile 70)
 
 
 def _load_tune():
@@ -83,7 +85,7 @@ class TapClassSpec:
 class ConvPlan:
     """Packed weights + launch template for spaa_tapconv_f32."""
 
-    def __init__(self, classes, cin, cout, s_in, s_out, bias=None, device='cuda', name='', nfold=1):
+    def __init__(self, classes, cin, cout, s_in, s_out, bias=None, device='cuda', name='', nfold=1, kpad_extra=0):
         assert 1 <= len(classes) <= _lib.MAX_CLASSES
         assert nfold == 1 or (nfold == 4 and len(classes) == 1 and s_out == 2 and cout % 4 == 0 and cin % 32 == 0)
         self.nfold = nfold                  # 4: the parity classes of a k2/s2 deconv folded into GEMM rows
@@ -100,7 +102,7 @@ class ConvPlan:
             nt = len(c.taps)
             assert nt <= _lib.MAX_TAPS
             k = nt * self.cin_p
-            kpad = _ceil(k, BK)
+            kpad = _ceil(k, BK) + kpad_extra   # (extra: de-tune the row stride from the L2 channel interleave)
             wp = torch.zeros(npad, kpad, dtype=torch.float32)
             for t, (dy, dx, w) in enumerate(c.taps):
                 assert w.shape == (ngemm, cin), (w.shape, ngemm, cin)
@@ -133,6 +135,9 @@ class ConvPlan:
         self._ws = None  # split-K workspace, allocated on first use
         self._w_chunks, self._npad, self._dev = w_chunks, npad, device
         self.w_half = None  # fp16 plane for the fp16-storage kernels, packed on first use (half_plane())
+        self.wino = None    # the same layer in Winograd F(2x2,3x3) form (attach_winograd), run as tile 70
+        self.fixed_tile = 0
+        self.alg_taps = self.ntaps_total
 
     def half_plane(self):
         """The weights rounded to fp16, per class [Npad][K rounded up to 64] (zero padded), classes back to back: the
@@ -220,6 +225,11 @@ class ConvPlan:
         tile = forced if forced else TUNE.get(key, -1)
         if tile < 0:
             tile = self._default_tile(b * d.Hm * d.Wm)
+        if tile == 70:   # Winograd form of a 3x3 / stride-1 layer (csrc/tapconv_wino.hip): fp32 storage, same-size output
+            if self.wino is not None and WINOGRAD and not (in_f16 or out_f16) and (hin, win) == (hout, wout):
+                return self.wino.run(inp, out, add, gate, gate_mode, act, aux_out, gate2, in_coff, out_coff, add_coff, gate_coff,
+                                     mask_out, gate_bits, gate2_bits)
+            tile = 0 if forced else self._default_tile(b * d.Hm * d.Wm, winograd=False)
         if in_f16:    # fp16 activations: the h16 kernels, N tile by the GEMM's width
             ngemm = self.cout * self.nfold
             if 60 <= forced <= 65:
@@ -269,6 +279,8 @@ class ConvPlan:
             d.ksplit, d.splitk_ws = 0, None
             if tile not in STORE4_TILES:
                 raise ValueError(f'{self.name}: gate masks need a layer shape served by the bf16x6 / smallcin kernels')
+        if self.fixed_tile:
+            tile, d.ksplit, d.splitk_ws = self.fixed_tile, 0, None
         d.tile = tile
         d.reserved0 = DEBUG_TAPMAJOR | (DEBUG_PERSIST_CAP << 8)  # measurement / test switches of the x6d kernels
         d.nclass = len(self.cls)
@@ -288,7 +300,7 @@ class ConvPlan:
             bi, bo = (2 if in_f16 else 4), (2 if out_f16 else 4)   # bytes per element: fp16 storage or fp32
             nbytes = (bi * b * hin * win * self.cin_p + bo * npx * self.cout * (1 + (add is not None) + (gate is not None)
                                                                                + (aux_out is not None) + (gate2 is not None))
-                      + bi * self.ntaps_total * self.cin_p * self.cout)
+                      + bi * self.alg_taps * self.cin_p * self.cout)
             nbytes += npx * self.cout // 4 * ((mask_out is not None) + (gate_bits is not None) + (gate2_bits is not None))
             PROFILE.append((self.name, key, self.flops(b, hout, wout), e0, e1, d.tile + 100 * (d.ksplit if d.ksplit > 1 else (9 if d.ksplit == -1 else 0)), nbytes))
         return out
@@ -345,6 +357,8 @@ class ConvPlan:
                 parts.append(torch.stack([h, m, lo]).view(torch.int16).reshape(-1))
             self.w_split.copy_(torch.cat(parts))
         self.w_half = None
+        if self.wino is not None:
+            _winograd_weights(self, self.wino)
         if bias is not None:
             self.bias.copy_(bias.detach().float())
 
@@ -353,11 +367,13 @@ class ConvPlan:
         `attach_unpack`)."""
         return dw_packed[self.unpack_idx].view(self.param_shape)
 
-    def _default_tile(self, m):
+    def _default_tile(self, m, winograd=True):
         """Kernel choice for a layer shape that tools/autotune.py has not measured: the family that wins for the
         measured shapes of the same kind."""
         one = len(self.cls) == 1
         off = DEFAULT_DISABLE  # debugging aid: families to leave out of the default choice
+        if winograd and self.wino is not None and 'wino' not in off and self.cout >= 128 and m >= 256 * 512:
+            return 70                                                   # big 3x3 / s1 layer: Winograd F(2x2,3x3)
         if 'thin' not in off and self.cout <= 4 and self.s_in == 1 and self.cin_p % 16 == 0:
             return 29                                                   # thin output: patch-staged VALU kernel
         if 'smallcin' not in off and one and self.cin_p in (4, 8) and self.cout <= 32 and self.ntaps_total <= 9 and self.s_in <= 2:
@@ -380,6 +396,57 @@ class ConvPlan:
         return b * hm * wm * self.flops_per_pixel
 
 
+_WINO_G = torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]], dtype=torch.float64)
+
+
+def _winograd_weights(plan, wino):
+    """U = G g G^T of every (output, input) channel pair of `plan` (fp64 on the device, rounded once to fp32) into `wino`'s
+    packed 16-'tap' matrix W[n][pos * Cin + c] and its three bf16 planes."""
+    c = plan.cls[0]
+    g = plan.weights[:plan._npad * c['Kpad']].view(plan._npad, c['Kpad'])[:, :9 * plan.cin_p]
+    g = g.reshape(plan._npad, 9, plan.cin_p).double()
+    u = torch.einsum('pt,ntc->npc', wino._wino_t.to(g.device), g).float().reshape(plan._npad, -1)
+    u = torch.nn.functional.pad(u, (0, wino.cls[0]['Kpad'] - u.shape[1])).reshape(-1)
+    wino.weights.copy_(u)
+    h = u.to(torch.bfloat16)
+    r1 = u - h.float()
+    m = r1.to(torch.bfloat16)
+    lo = (r1 - m.float()).to(torch.bfloat16)
+    wino.w_split.copy_(torch.stack([h, m, lo]).view(torch.int16).reshape(-1))
+
+
+def attach_winograd(plan):
+    """Give a 3x3 / stride-1 / pad-1 convolution plan (forward or input gradient) its Winograd F(2x2,3x3) form: the filter
+    transform U = G g G^T as a 16-'tap' ConvPlan run by csrc/tapconv_wino.hip (tile 70).  Returns the plan; plans of any other
+    shape are returned untouched."""
+    if (len(plan.cls) != 1 or plan.ntaps_total != 9 or plan.s_in != 1 or plan.s_out != 1 or plan.nfold != 1
+            or plan.cin_p % 32 or plan.cin != plan.cin_p or plan.w_split is None):
+        return plan
+    taps = [(dy, dx) for dy, dx, _ in plan.classes_host[0].taps]
+    if sorted(taps) != [(dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]:
+        return plan
+    t = torch.zeros(16, 9, dtype=torch.float64)  # U[pos] = sum_t T[pos, t] g_t,  g_t = the tap at offset (dy, dx)
+    for i, (dy, dx) in enumerate(taps):
+        for xi in range(4):
+            for nu in range(4):
+                t[4 * xi + nu, i] = _WINO_G[xi, dy + 1] * _WINO_G[nu, dx + 1]
+    c = TapClassSpec(0, 0)
+    zero = torch.zeros(plan.cout, plan.cin)
+    for xi in range(4):
+        for nu in range(4):
+            c.add(xi, nu, zero)
+    # rows of 16 * Cin bf16 are a multiple of 4 KiB apart for Cin = 128, 256: every row of a DMA piece would hit the same L2
+    # channel (measured 16x slower); 128 extra elements (256 B) walk the channels
+    wino = ConvPlan([c], plan.cin, plan.cout, 1, 1, None, plan._dev, plan.name, kpad_extra=128)
+    wino.bias = plan.bias            # (shared tensor: refresh() updates both)
+    wino._wino_t = t
+    wino.fixed_tile = 70
+    wino.flops_per_pixel, wino.alg_taps = plan.flops_per_pixel, 9   # algorithmic work = the direct convolution's
+    _winograd_weights(plan, wino)
+    plan.wino = wino
+    return plan
+
+
 def _w2(w):
     return w.detach().float().cpu()
 
@@ -393,7 +460,7 @@ def conv_fwd_plan(weight, bias, stride, pad, device='cuda', name=''):
     for ky in range(kh):
         for kx in range(kw):
             c.add(ky - ph, kx - pw, w[:, :, ky, kx])
-    return ConvPlan([c], ci, co, stride, 1, bias, device, name)
+    return attach_winograd(ConvPlan([c], ci, co, stride, 1, bias, device, name))
 
 
 def _pair(p):
@@ -434,7 +501,7 @@ def conv_dgrad_plan(weight, stride, pad, device='cuda', name='', in_ch=None):
         for ky in range(kh):
             for kx in range(kw):
                 c.add(ph - ky, pw - kx, wsel(ky, kx))
-        return ConvPlan([c], co, hi - lo, 1, 1, None, device, name)
+        return attach_winograd(ConvPlan([c], co, hi - lo, 1, 1, None, device, name))
     assert stride == 2
     return ConvPlan(_fractional_classes(wsel, kh, kw, pad), co, hi - lo, 1, 2, None, device, name)
 

@@ -174,6 +174,70 @@ def test_tapconv_x6_is_fp32_accurate(hip, tile):
         cp.FORCE_TILE = 0
 
 
+@pytest.mark.parametrize('ci,co,h,w,b', [(128, 256, 64, 64, 2), (256, 128, 30, 44, 3), (64, 128, 17, 35, 2), (32, 192, 16, 32, 1)])
+def test_winograd_is_fp32_accurate(hip, ci, co, h, w, b):
+    """3x3 / s1 / p1 layers through Winograd F(2x2,3x3) on the bf16x6 arithmetic (csrc/tapconv_wino.hip): forward and input
+    gradient against fp64.  The transforms add roundings: the bound is 3x the exact-fp32 MFMA kernel's error (measured ~2x)."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(ci + co)
+    x = torch.relu(torch.randn(b, ci, h, w)) * (1 + 3 * torch.rand(b, ci, 1, 1))
+    wt = torch.randn(co, ci, 3, 3) / (ci * 9) ** 0.5
+    bias = torch.randn(co)
+    truth = F.conv2d(x.double(), wt.double(), bias.double(), 1, 1)
+    gy = torch.randn(b, co, h, w)
+    g_truth = torch.nn.grad.conv2d_input(x.shape, wt.double(), gy.double(), 1, 1)
+    fplan, dplan = cp.conv_fwd_plan(wt, bias, 1, 1, DEV), cp.conv_dgrad_plan(wt, 1, 1, DEV)
+    assert fplan.wino is not None and dplan.wino is not None
+    errs = {}
+    try:
+        for t in (6, 34, 70):
+            out = torch.zeros(b, h, w, co, device=DEV)
+            gx = torch.zeros(b, h, w, ci, device=DEV)
+            cp.FORCE_TILE = t
+            fplan.run(nhwc(x, ci).to(DEV), out)
+            dplan.run(nhwc(gy, co).to(DEV), gx)
+            cp.FORCE_TILE = 0
+            errs[t] = ((nchw(out.cpu(), co).double() - truth).abs().max().item() / truth.abs().max().item(),
+                       (nchw(gx.cpu(), ci).double() - g_truth).abs().max().item() / g_truth.abs().max().item())
+    finally:
+        cp.FORCE_TILE = 0
+    print(f'ci={ci} co={co} {h}x{w}: rel err vs fp64 fp32-MFMA {errs[6][0]:.1e}/{errs[6][1]:.1e}  bf16x6 {errs[34][0]:.1e}/{errs[34][1]:.1e}  '
+          f'winograd {errs[70][0]:.1e}/{errs[70][1]:.1e}')
+    assert errs[70][0] < max(3 * errs[6][0], 6e-7) and errs[70][1] < max(3 * errs[6][1], 6e-7)
+
+
+def test_winograd_epilogues_and_masks(hip):
+    """The Winograd kernel shares the epilogue of the other bf16x6 kernels: bias, residual, ReLU, byte gate masks."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(5)
+    b, ci, co, h, w = 2, 64, 128, 20, 38
+    x, wt, bias = torch.randn(b, ci, h, w), torch.randn(co, ci, 3, 3) / 24, torch.randn(co)
+    add, gate = torch.randn(b, co, h, w), torch.randn(b, co, h, w)
+    plan = cp.conv_fwd_plan(wt, bias, 1, 1, DEV)
+    try:
+        cp.FORCE_TILE = 70
+        out, aux = torch.zeros(b, h, w, co, device=DEV), torch.zeros(b, h, w, co, device=DEV)
+        mask = torch.zeros(b, h, w, co // 4, dtype=torch.uint8, device=DEV)
+        plan.run(nhwc(x).to(DEV), out, add=nhwc(add).to(DEV), act=lib.ACT_RELU, mask_out=mask)
+        ref = F.relu(F.conv2d(x, wt, bias, 1, 1) + add)
+        assert rel_inf(nchw(out.cpu()), ref) < 1e-5
+        assert torch.equal(mask, lib.pack_gate_mask(out))
+        gbits = lib.pack_gate_mask(nhwc(gate).to(DEV))
+        plan.run(nhwc(x).to(DEV), out, gate_bits=gbits)
+        assert rel_inf(nchw(out.cpu()), F.conv2d(x, wt, bias, 1, 1) * (gate > 0)) < 1e-5
+        plan.run(nhwc(x).to(DEV), out, act=lib.ACT_RELU_CLAMP1, aux_out=aux)
+        pre = F.relu(F.conv2d(x, wt, bias, 1, 1))
+        assert rel_inf(nchw(out.cpu()), pre.clamp(max=1)) < 1e-5 and rel_inf(nchw(aux.cpu()), pre) < 1e-5
+        # a sub-range of a wider buffer (channel offsets), as the engine's concatenated buffers use
+        wide_in = torch.randn(b, h, w, ci + 32, device=DEV)
+        wide_out = torch.zeros(b, h, w, co + 64, device=DEV)
+        plan.run(wide_in, wide_out, in_coff=32, out_coff=64)
+        ref2 = F.conv2d(nchw(wide_in.cpu())[:, 32:], wt, bias, 1, 1)
+        assert rel_inf(nchw(wide_out.cpu())[:, 64:], ref2) < 1e-5 and (wide_out[..., :64] == 0).all()
+    finally:
+        cp.FORCE_TILE = 0
+
+
 @pytest.mark.parametrize('tile', [0, 6, 18, 34, 36, 39, 40, 41, 42, 44, 45, 46, 48, 50, 51, 52])
 def test_tapconv_epilogues(hip, tile):
     cp, lib = hip['cp'], hip['lib']
