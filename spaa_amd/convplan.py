@@ -39,6 +39,7 @@ F16OUT_TILES = set(range(15, 25)) | {38} | set(range(60, 66))  # ... of which th
 DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
 DEBUG_TAPMAJOR = int(os.environ.get('SPAA_X6D_TAPMAJOR', '0'))      # 1: tap-major K order (A/B measurements only)
 DEBUG_PERSIST_CAP = int(os.environ.get('SPAA_X6D_PERSIST_CAP', '0'))  # > 0: persistent launches use this many workgroups
+DEBUG_WINO = int(os.environ.get('SPAA_WINO_DBG', '0'))              # timing experiments of the Winograd kernel
 FOLD_DECONV = True  # k2/s2 transposed convs: parity classes folded into GEMM rows (one read of the input)
 ENABLE_X6 = True  # build the split-bf16 weight planes (needed by tiles 12-14)
 WINOGRAD = os.environ.get('SPAA_WINOGRAD', '1') != '0'  # 3x3/s1 layers: allow the Winograd F(2x2,3x3) kernel (tile 70)
@@ -282,7 +283,7 @@ class ConvPlan:
         if self.fixed_tile:
             tile, d.ksplit, d.splitk_ws = self.fixed_tile, 0, None
         d.tile = tile
-        d.reserved0 = DEBUG_TAPMAJOR | (DEBUG_PERSIST_CAP << 8)  # measurement / test switches of the x6d kernels
+        d.reserved0 = DEBUG_TAPMAJOR | (DEBUG_PERSIST_CAP << 8) | (DEBUG_WINO << 16)  # measurement / test switches of the x6d kernels
         d.nclass = len(self.cls)
         d.tap_range[:] = self.tap_range
         for i, c in enumerate(self.cls):

@@ -64,8 +64,9 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& h, bf16x8& m
 constexpr int TY = 8, TX = 16;                 // Winograd tiles per workgroup (rows x columns): 16 x 32 output pixels
 constexpr int PH = 2 * TY + 2, PW = 2 * TX + 2;  // input patch 18 x 34 pixels
 constexpr int NPX = PH * PW;                   // 612
-constexpr int NPIECE = (NPX + 7) / 8;          // 1-KiB pieces of 8 pixels x 32 channels (fp32)
-constexpr int PATCH_BYTES = NPIECE * 1024;     // 78848
+constexpr int NPIECE = (NPX + 7) / 8;          // 1-KiB pieces of 8 pixels x 32 channels (fp32): 77
+constexpr int PPW = (NPIECE + 7) / 8;          // pieces per wave (8 waves): 10
+constexpr int PATCH_BYTES = PPW * 8 * 1024;    // 81920 (pieces 77..79: pad)
 
 // 64-byte weight rows (32 bf16), chunk swizzle as tapconv_x6d.hip swz_w<16>
 __device__ __forceinline__ int swz_w16(int n) { return ((n >> 3) & 1) << 1; }
@@ -119,19 +120,9 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
     //   slot of patch pixel p = row * PW + column:  p ^ ((p >> 1) & 1)   (neighbouring pixel pairs alternate their order, so
     //   pixels 2 apart alternate between the two 128-byte halves of the 64 banks);
     //   16-byte chunk L of the pixel's 32 channels sits at chunk  L ^ ((column >> 2) & 7).
-    constexpr int PPW = (NPIECE + NW - 1) / NW;  // pieces per wave
-    int pa_off[PPW];                             // source byte offset without the channel block (or the OOB sentinel)
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int piece = wave + NW * i;
-        const int slot = piece * 8 + (lane >> 3);
-        const int pix = slot ^ ((slot >> 1) & 1);
-        const int pr = pix / PW, pc = pix - pr * PW;
-        const int c = (lane & 7) ^ ((pc >> 2) & 7);
-        const int iy = oy0 - 1 + pr, ix = ox0 - 1 + pc;
-        const bool ok = piece < NPIECE && pix < NPX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        pa_off[i] = ok ? ((img * H + iy) * W + ix) * row_bytes + p.in_coff * 4 + c * 16 : (int)0x80000000;
-    }
+    // Every wave issues exactly PPW DMAs per block (s_waitcnt counts): pieces past the patch read the out-of-range offset
+    // into the pad at the end of the patch buffer.
+    const int pa_base = p.in_coff * 4 + (lane & 7) * 16;   // (chunk swizzle applied per pixel below)
     // ---- weight staging (as tapconv_x6d.hip): piece q = wave + 8 i -> (plane, 16-row block); lane -> (row, physical chunk)
     int w_goff[WPW];
 #pragma unroll
@@ -162,117 +153,179 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
         _Pragma("unroll") for (int i = 0; i < WPW; ++i) if (W_PIECES % NW == 0 || wave + NW * i < W_PIECES)        \
             dma16(rsrc_w, wsm + (st) * WS_BYTES + (wave + NW * i) * 1024, w_goff[i], soff_);                       \
     }
-    WINO_DMA_W(0, 0)
-    for (int kb = 0; kb < nkb; ++kb) {
-        // ---- stage the patch of this channel block (everybody is past the previous block's reads)
-        __syncthreads();
+    // pipeline: weight stages three deep (the DMA of step t+2 is issued at step t); the patch of the next channel block is
+    // requested as soon as the last reads of the current one (the row combination of xi = 3) are done.
+    // Waves w and w+4 share a SIMD: waves 0-3 form V(t) at the START of step t, waves 4-7 form V(t+1) at the END of step t, so
+    // that one wave's transform (VALU) runs under its partner's MFMAs.
+#define WINO_DMA_PATCH(kb_)                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                                \
+        const int slot_ = (wave + NW * i) * 8 + (lane >> 3);                                                         \
+        const int pix_ = slot_ ^ ((slot_ >> 1) & 1);                                                                 \
+        const int pr_ = pix_ / PW, pc_ = pix_ - pr_ * PW;                                                            \
+        const int iy_ = oy0 - 1 + pr_, ix_ = ox0 - 1 + pc_;                                                          \
+        const bool ok_ = pix_ < NPX && (unsigned)iy_ < (unsigned)H && (unsigned)ix_ < (unsigned)W;                   \
+        const int u_ = pc_ >> 1;                                                                                     \
+        const int lc_ = ((((lane & 7) >> 1) - 2 * (u_ >> 2)) & 3) * 2 + ((lane & 1) ^ ((u_ >> 1) & 1));               \
+        const int off_ = ok_ ? ((img * H + iy_) * W + ix_) * row_bytes + p.in_coff * 4 + lc_ * 16 + (kb_) * 128      \
+                             : (int)0x80000000;                                                                      \
+        dma16(rsrc_in, smem + (wave + NW * i) * 1024, off_, 0);                                                      \
+    }
+    const bool late = wave >= 4;
+    float rc[4][8];   // s1 * d[a1][b] + s2 * d[a2][b] for the four patch columns b of the current xi
+    bf16x8 pf[3];     // V(xi, nu) of the current step, split
+    // rows of B^T for xi: 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+    auto combine_rows = [&](const int xi) {
+        const int a1 = xi == 0 ? 0 : 1, a2 = xi == 3 ? 3 : 2;
+        const float s1 = xi == 2 ? -1.f : 1.f, s2 = (xi == 1 || xi == 2) ? 1.f : -1.f;
 #pragma unroll
-        for (int i = 0; i < PPW; ++i)
-            if (wave + NW * i < NPIECE)
-                dma16(rsrc_in, smem + (wave + NW * i) * 1024, pa_off[i] == (int)0x80000000 ? pa_off[i] : pa_off[i] + kb * 128, 0);
+        for (int b = 0; b < 4; ++b) {
+            // pixel (row 2 wave + a, column 2 tx + b): p = row * PW + column, (p >> 1) & 1 = (a + u) & 1 with u = column >> 1
+            const int u = tx + (b >> 1);
+            const int p1 = (2 * wave + a1) * PW + 2 * tx + b, p2 = (2 * wave + a2) * PW + 2 * tx + b;
+            const int o1 = (p1 ^ ((a1 + u) & 1)) << 7, o2 = (p2 ^ ((a2 + u) & 1)) << 7;
+            const int pair = ((q8 + 2 * (u >> 2)) & 3) << 5, hb = ((u >> 1) & 1) << 4;   // chunk 2 pair + (h ^ bit)
+            const f32x4 d1l = *reinterpret_cast<const f32x4*>(smem + o1 + pair + hb);
+            const f32x4 d1h = *reinterpret_cast<const f32x4*>(smem + o1 + pair + (hb ^ 16));
+            const f32x4 d2l = *reinterpret_cast<const f32x4*>(smem + o2 + pair + hb);
+            const f32x4 d2h = *reinterpret_cast<const f32x4*>(smem + o2 + pair + (hb ^ 16));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {   // (+-1 coefficients: the products are exact, one rounding per addition)
+                rc[b][e] = __builtin_fmaf(d2l[e], s2, d1l[e] * s1);
+                rc[b][4 + e] = __builtin_fmaf(d2h[e], s2, d1h[e] * s1);
+            }
+        }
+    };
+    // row nu of B^T over the four row-combined columns: 0: c0 - c2, 1: c1 + c2, 2: c2 - c1, 3: c1 - c3 (nu is a constant
+    // wherever this is expanded)
+    auto form_v = [&](const int nu) {
+        float vv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            vv[e] = nu == 0 ? rc[0][e] - rc[2][e] : (nu == 1 ? rc[1][e] + rc[2][e] : (nu == 2 ? rc[2][e] - rc[1][e] : rc[1][e] - rc[3][e]));
+        split8(vv, pf[0], pf[1], pf[2]);
+    };
+    WINO_DMA_PATCH(0)
+    WINO_DMA_W(0, 0)
+    if (nsteps > 1) WINO_DMA_W(1, 1)
+    int st = 0;   // weight stage of the current step
+    for (int kb = 0; kb < nkb; ++kb) {
 #pragma unroll 1
-        for (int pos = 0; pos < 16; ++pos) {
-            const int step = kb * 16 + pos;
-            const int xi = pos >> 2, nu = pos & 3;
-            // B^T rows: 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3  ->  s1 * d[a1] + s2 * d[a2]
-            const int a1 = xi == 0 ? 0 : 1, a2 = xi == 3 ? 3 : 2;
-            const float s1 = xi == 2 ? -1.f : 1.f, s2 = (xi == 1 || xi == 2) ? 1.f : -1.f;
-            const int b1 = nu == 0 ? 0 : 1, b2 = nu == 3 ? 3 : 2;
-            const float t1 = nu == 2 ? -1.f : 1.f, t2 = (nu == 1 || nu == 2) ? 1.f : -1.f;
+        for (int xi = 0; xi < 4; ++xi) {
             // A^T = [[1,1,1,0],[0,1,-1,-1]]: coefficient of M(xi, nu) in output (i, j) = At[i][xi] * At[j][nu]
             const float ci0 = xi < 3 ? 1.f : 0.f, ci1 = xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f);
-            const float cj0 = nu < 3 ? 1.f : 0.f, cj1 = nu == 0 ? 0.f : (nu == 1 ? 1.f : -1.f);
-            const float c00 = ci0 * cj0, c01 = ci0 * cj1, c10 = ci1 * cj0, c11 = ci1 * cj1;
-            // own DMAs (patch pieces, weight pieces of this step) have landed; everybody's have after the barrier; every wave is
-            // also past its reads of the other weight stage
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (step + 1 < nsteps) WINO_DMA_W((step + 1) & 1, step + 1)
-            float vv[8];
-            {
-                // pixel (row 2 wave + a, column 2 tx + b): p = row * PW + column, (p >> 1) & 1 = (a + tx + (b >> 1)) & 1 (PW / 2 is odd)
-                const int u1 = tx + (b1 >> 1), u2 = tx + (b2 >> 1);
-                const int p11 = (2 * wave + a1) * PW + 2 * tx + b1, p12 = (2 * wave + a1) * PW + 2 * tx + b2;
-                const int p21 = (2 * wave + a2) * PW + 2 * tx + b1, p22 = (2 * wave + a2) * PW + 2 * tx + b2;
-                const int o11 = (p11 ^ ((a1 + u1) & 1)) << 7, o12 = (p12 ^ ((a1 + u2) & 1)) << 7;
-                const int o21 = (p21 ^ ((a2 + u1) & 1)) << 7, o22 = (p22 ^ ((a2 + u2) & 1)) << 7;
-                const int z1 = (u1 >> 1) & 7, z2 = (u2 >> 1) & 7;
-                const int h0a = ((2 * q8) ^ z1) << 4, h1a = ((2 * q8 + 1) ^ z1) << 4;
-                const int h0b = ((2 * q8) ^ z2) << 4, h1b = ((2 * q8 + 1) ^ z2) << 4;
-                const f32x4 d11l = *reinterpret_cast<const f32x4*>(smem + o11 + h0a);
-                const f32x4 d11h = *reinterpret_cast<const f32x4*>(smem + o11 + h1a);
-                const f32x4 d12l = *reinterpret_cast<const f32x4*>(smem + o12 + h0b);
-                const f32x4 d12h = *reinterpret_cast<const f32x4*>(smem + o12 + h1b);
-                const f32x4 d21l = *reinterpret_cast<const f32x4*>(smem + o21 + h0a);
-                const f32x4 d21h = *reinterpret_cast<const f32x4*>(smem + o21 + h1a);
-                const f32x4 d22l = *reinterpret_cast<const f32x4*>(smem + o22 + h0b);
-                const f32x4 d22h = *reinterpret_cast<const f32x4*>(smem + o22 + h1b);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    // (+-1 coefficients: every product is exact, each line rounds once per addition)
-                    const float ra = __builtin_fmaf(d12l[e], t2, d11l[e] * t1), rb = __builtin_fmaf(d22l[e], t2, d21l[e] * t1);
-                    vv[e] = __builtin_fmaf(rb, s2, ra * s1);
-                    const float rc = __builtin_fmaf(d12h[e], t2, d11h[e] * t1), rd = __builtin_fmaf(d22h[e], t2, d21h[e] * t1);
-                    vv[4 + e] = __builtin_fmaf(rd, s2, rc * s1);
+            for (int nu = 0; nu < 4; ++nu) {
+                const int step = kb * 16 + xi * 4 + nu;
+                // this step's weight pieces have landed; after the barrier everybody's have, and every wave is past its reads of
+                // the stage that the DMA issued below overwrites.  Loads complete in order; issued after this step's weights:
+                // the next step's WPW pieces and, on the two steps that follow the request of the next block's patch, its PPW
+                if (step + 1 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (xi == 3 && (nu == 1 || nu == 2) && kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
+                __syncthreads();
+                const int st2 = st >= 1 ? st - 1 : 2;   // (st + 2) % 3
+                if (step + 2 < nsteps) WINO_DMA_W(st2, step + 2)
+                if (!late || step == 0) {   // (step 0: every wave)
+                    if (nu == 0) combine_rows(xi);
+                    form_v(nu);
                 }
-            }
-            bf16x8 pf[3];
-            split8(vv, pf[0], pf[1], pf[2]);
-            const unsigned char* wc = wsm + (step & 1) * WS_BYTES + w_addr_l;
-#pragma unroll
-            for (int jq = 0; jq < TJ; jq += 2) {
-                f32x4 m[2];
-                bf16x8 w0[2], w1[2], w2[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    w0[u] = *reinterpret_cast<const bf16x8*>(wc + (jq + u) * 1024);
-                    w1[u] = *reinterpret_cast<const bf16x8*>(wc + (jq + u) * 1024 + W_PLANE);
-                    w2[u] = *reinterpret_cast<const bf16x8*>(wc + (jq + u) * 1024 + 2 * W_PLANE);
-                    m[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (nu == 0 && xi == 3 && kb + 1 < nkb) {   // (uniform) the patch is free: request the next channel block
+                    __syncthreads();
+                    WINO_DMA_PATCH(kb + 1)
                 }
-                // weights = A operand (rows = output channels), tiles = B operand (columns); small terms first; two independent
-                // chains interleaved
+                const float cj1 = nu == 1 ? 1.f : -1.f;   // (nu 0 adds nothing to output column 1, nu 3 nothing to column 0)
+                const float c01 = ci0 * cj1, c11 = ci1 * cj1;
+                const unsigned char* wc = wsm + st * WS_BYTES + w_addr_l;
+                // weights = A operand (rows = output channels), tiles = B operand (columns); small terms first.  The fragments
+                // of block j+1 are requested before block j's MFMAs, block j-1's result is folded into Y between them.
+                bf16x8 wf[2][3];
+                f32x4 mp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int u = 0; u < 2; ++u) m[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[u], pf[0], m[u], 0, 0, 0);
+                for (int k = 0; k < 3; ++k) wf[0][k] = *reinterpret_cast<const bf16x8*>(wc + k * W_PLANE);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) m[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[u], pf[2], m[u], 0, 0, 0);
+                for (int j = 0; j <= TJ; ++j) {
+                    f32x4 m = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (j < TJ) {
+                        if (j + 1 < TJ) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) m[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[u], pf[1], m[u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) m[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[u], pf[0], m[u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) m[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[u], pf[1], m[u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) m[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[u], pf[0], m[u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        Y[0][jq + u][e] = __builtin_fmaf(m[u][e], c00, Y[0][jq + u][e]);
-                        Y[1][jq + u][e] = __builtin_fmaf(m[u][e], c01, Y[1][jq + u][e]);
-                        Y[2][jq + u][e] = __builtin_fmaf(m[u][e], c10, Y[2][jq + u][e]);
-                        Y[3][jq + u][e] = __builtin_fmaf(m[u][e], c11, Y[3][jq + u][e]);
+                            for (int k = 0; k < 3; ++k)
+                                wf[(j + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(wc + (j + 1) * 1024 + k * W_PLANE);
+                        }
+                        const bf16x8 w0 = wf[j & 1][0], w1 = wf[j & 1][1], w2 = wf[j & 1][2];
+                        m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, pf[0], m, 0, 0, 0);
+                        m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, pf[2], m, 0, 0, 0);
+                        m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, pf[1], m, 0, 0, 0);
+                        m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, pf[0], m, 0, 0, 0);
+                        m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, pf[1], m, 0, 0, 0);
+                        m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, pf[0], m, 0, 0, 0);
                     }
-                __builtin_amdgcn_sched_barrier(0);
+                    if (j > 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (nu < 3) {
+                                Y[0][j - 1][e] = __builtin_fmaf(mp[e], ci0, Y[0][j - 1][e]);
+                                Y[2][j - 1][e] = __builtin_fmaf(mp[e], ci1, Y[2][j - 1][e]);
+                            }
+                            if (nu > 0) {
+                                Y[1][j - 1][e] = __builtin_fmaf(mp[e], c01, Y[1][j - 1][e]);
+                                Y[3][j - 1][e] = __builtin_fmaf(mp[e], c11, Y[3][j - 1][e]);
+                            }
+                        }
+                        // (pins the fold here: without a use inside this scheduling region the optimiser sinks it to the loop's end)
+                        asm volatile("" : "+v"(Y[0][j - 1]), "+v"(Y[1][j - 1]), "+v"(Y[2][j - 1]), "+v"(Y[3][j - 1]));
+                    }
+                    if (j < TJ) {
+                        // order: the fragment reads first, then the MFMAs with the fold's VALU work in their shadows
+                        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+                        for (int g = 0; g < 6; ++g) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mp = m;
+                }
+                if (late && step + 1 < nsteps) {   // V of the next step (its patch has landed: see the wait of step 15)
+                    if (nu == 3) combine_rows((xi + 1) & 3);
+                    form_v((nu + 1) & 3);
+                }
+                st = st == 2 ? 0 : st + 1;
             }
         }
     }
+#undef WINO_DMA_PATCH
 #undef WINO_DMA_W
 
-    // ---- epilogue: D layout of a 16x16 block: column (lane & 15) = tile, rows 4 (lane >> 4) + e = 4 consecutive channels
+    // ---- epilogue.  D layout of a 16x16 block: column (lane & 15) = tile, rows 4 (lane >> 4) + e = 4 consecutive channels:
+    // stored straight from the accumulators a wave-instruction would write 16 pixels x 64 B, 2 KiB apart.  Through LDS
+    // (free now) it writes 2 pixels x 512 B: tile row 0 of every tile, then tile row 1 (256 pixels x 128 channels each).
+    //   LDS image: pixel pl = 32 wave + 2 tx + (i & 1), 16-byte chunk c of its 128 channels at chunk c ^ (tx & 15)
     const bool vec = !((p.Cout | p.out_cstride | p.out_coff) & 3) &&
                      (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
                      (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
                      (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int oy = oy0 + 2 * wave + (i >> 1), ox = ox0 + 2 * tx + (i & 1);
-        if (oy < p.Hout && ox < p.Wout) {
-            const size_t o = ((size_t)img * p.Hout + oy) * p.Wout + ox;
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();   // the main loop's (resp. the previous half's) LDS reads are done
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                float v[4] = {Y[i][j][0], Y[i][j][1], Y[i][j][2], Y[i][j][3]};
-                store4_t<float>(p, o, n_blk + 16 * j + 4 * q8, v, vec);
+        for (int c = 0; c < 2; ++c) {
+            const int pl = 32 * wave + 2 * tx + c;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                *reinterpret_cast<f32x4*>(smem + pl * 512 + (((4 * j + q8) ^ tx) << 4)) = Y[2 * half + c][j];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int pl = 2 * (16 * wave + it) + (lane >> 5);
+            const int pc = lane & 31;                       // physical chunk
+            const int lc = pc ^ ((pl & 31) >> 1);           // logical chunk: channels 4 lc .. 4 lc + 3 of this n tile
+            const f32x4 y = *reinterpret_cast<const f32x4*>(smem + pl * 512 + (pc << 4));
+            const int oy = oy0 + 2 * (pl >> 5) + half, ox = ox0 + (pl & 31);
+            if (oy < p.Hout && ox < p.Wout) {
+                float v[4] = {y[0], y[1], y[2], y[3]};
+                store4_t<float>(p, ((size_t)img * p.Hout + oy) * p.Wout + ox, n_blk + 4 * lc, v, vec);
             }
         }
     }
@@ -294,7 +347,7 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     const int n_tiles = (d.Cout + BN - 1) / BN;
     const int64_t nwg = (int64_t)d.B * wg_y * wg_x * n_tiles;
     if (nwg > 0x7fffffff) return hipErrorInvalidValue;
-    const size_t smem = (size_t)PATCH_BYTES + 2 * (size_t)(3 * BN * 64);
+    const size_t smem = (size_t)PATCH_BYTES + 3 * (size_t)(3 * BN * 64);
     static bool attr_set[SPAA_MAX_DEVICES] = {};
     {
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<BN>), (int)smem, attr_set);
