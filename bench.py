@@ -376,6 +376,12 @@ def main():
         if dom.startswith('h16'):
             # fp16-storage kernels: one fp16 MFMA per product
             peak, kname = PEAK_BF16_MFMA_TFLOPS, f'tapconv_{dom} (fp16 MFMA implicit-GEMM, fp16 storage, fp32 accumulation)'
+        elif dom.startswith('wino'):
+            # Winograd F(2x2,3x3) on the bf16x6 arithmetic: `achieved` counts the ALGORITHMIC FLOPs of the 3x3 convolution
+            # (2 x 9 x Cin x Cout per pixel) against the same matrix-core ceiling as the direct bf16x6 kernels; the
+            # kernel itself issues 16/36 of those products (+ the transforms on the VALU), reported as `executed_tflops`
+            peak, kname = PEAK_BF16_MFMA_TFLOPS / 6.0, (f'tapconv_{dom} (Winograd F(2x2,3x3), bf16x6-split MFMA, fp32-exact '
+                                                         'operands)')
         elif dom.startswith('x6'):
             # fp32 emulated with six bf16 MFMAs per product group: the matrix-core ceiling for algorithmic fp32 FLOPs
             # is the dense bf16 peak / 6
@@ -407,6 +413,7 @@ def main():
                              '157.3 TF for the fp32-MFMA kernels',
                 'avg_launch_us': round(ms * 1e3 / n, 2), 'launches_per_step': n // n_prof,
                 'flop_per_launch': f / n, 'share_of_conv_time': round(ms / tot_ms, 3),
+                **({'executed_tflops': round(ach * 16 / 36, 2)} if dom.startswith('wino') else {}),
                 'all_tapconv_tflops': round(sum(v[0] for v in per_tile.values()) / (tot_ms * 1e-3) / 1e12, 2),
                 'conv_ms_per_step': round(tot_ms / n_prof, 3),
                 'other_kernels_ms_per_step': round(other_ms, 3),

@@ -373,7 +373,7 @@ class ConvPlan:
         measured shapes of the same kind."""
         one = len(self.cls) == 1
         off = DEFAULT_DISABLE  # debugging aid: families to leave out of the default choice
-        if winograd and self.wino is not None and 'wino' not in off and self.cout >= 128 and m >= 256 * 512:
+        if winograd and self.wino is not None and 'wino' not in off and self.cout >= 128 and m >= 50176 and m * self.cout >= 50176 * 256:
             return 70                                                   # big 3x3 / s1 layer: Winograd F(2x2,3x3)
         if 'thin' not in off and self.cout <= 4 and self.s_in == 1 and self.cin_p % 16 == 0:
             return 29                                                   # thin output: patch-staged VALU kernel
