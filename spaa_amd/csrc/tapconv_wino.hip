@@ -71,7 +71,7 @@ constexpr int PATCH_BYTES = PPW * 8 * 1024;    // 81920 (pieces 77..79: pad)
 // 64-byte weight rows (32 bf16), chunk swizzle as tapconv_x6d.hip swz_w<16>
 __device__ __forceinline__ int swz_w16(int n) { return ((n >> 3) & 1) << 1; }
 
-template <int BN>
+template <int BN, bool LATE>
 __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p, const int wg_y, const int wg_x, const int n_tiles) {
     constexpr int TJ = BN / 16;
     constexpr int W_PLANE = BN * 64;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                              : (int)0x80000000;                                                                      \
         dma16(rsrc_in, smem + (wave + NW * i) * 1024, off_, 0);                                                      \
     }
-    const bool late = wave >= 4;
+    const bool late = LATE && wave >= 4;
     float rc[4][8];   // s1 * d[a1][b] + s2 * d[a2][b] for the four patch columns b of the current xi
     bf16x8 pf[3];     // V(xi, nu) of the current step, split
     // rows of B^T for xi: 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
@@ -350,9 +350,15 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     const size_t smem = (size_t)PATCH_BYTES + 3 * (size_t)(3 * BN * 64);
     static bool attr_set[SPAA_MAX_DEVICES] = {};
     {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<BN>), (int)smem, attr_set);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<BN, true>), (int)smem, attr_set);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((wino_x6_kernel<BN>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles);
+    if ((d.reserved0 >> 16) & 1) {   // (A/B measurement switch)
+        static bool attr_set2[SPAA_MAX_DEVICES] = {};
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<BN, false>), (int)smem, attr_set2);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((wino_x6_kernel<BN, false>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles);
+    } else
+        hipLaunchKernelGGL((wino_x6_kernel<BN, true>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles);
     return (int)hipGetLastError();
 }
