@@ -71,7 +71,7 @@ constexpr int PATCH_BYTES = PPW * 8 * 1024;    // 81920 (pieces 77..79: pad)
 // 64-byte weight rows (32 bf16), chunk swizzle as tapconv_x6d.hip swz_w<16>
 __device__ __forceinline__ int swz_w16(int n) { return ((n >> 3) & 1) << 1; }
 
-template <int BN, bool LATE>
+template <int BN, int VAR>
 __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p, const int wg_y, const int wg_x, const int n_tiles) {
     constexpr int TJ = BN / 16;
     constexpr int W_PLANE = BN * 64;
@@ -170,13 +170,15 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                              : (int)0x80000000;                                                                      \
         dma16(rsrc_in, smem + (wave + NW * i) * 1024, off_, 0);                                                      \
     }
+    constexpr bool LATE = VAR & 1, TWOCHAIN = (VAR >> 1) & 1;   // measurement variants (default 0)
     const bool late = LATE && wave >= 4;
-    float rc[4][8];   // s1 * d[a1][b] + s2 * d[a2][b] for the four patch columns b of the current xi
+    f32x4 rc[4][2];   // s1 * d[a1][b] + s2 * d[a2][b] for the four patch columns b of the current xi (8 channels: two vectors)
     bf16x8 pf[3];     // V(xi, nu) of the current step, split
     // rows of B^T for xi: 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
     auto combine_rows = [&](const int xi) {
         const int a1 = xi == 0 ? 0 : 1, a2 = xi == 3 ? 3 : 2;
         const float s1 = xi == 2 ? -1.f : 1.f, s2 = (xi == 1 || xi == 2) ? 1.f : -1.f;
+        const f32x4 s1v = {s1, s1, s1, s1}, s2v = {s2, s2, s2, s2};
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             // pixel (row 2 wave + a, column 2 tx + b): p = row * PW + column, (p >> 1) & 1 = (a + u) & 1 with u = column >> 1
@@ -188,20 +190,20 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
             const f32x4 d1h = *reinterpret_cast<const f32x4*>(smem + o1 + pair + (hb ^ 16));
             const f32x4 d2l = *reinterpret_cast<const f32x4*>(smem + o2 + pair + hb);
             const f32x4 d2h = *reinterpret_cast<const f32x4*>(smem + o2 + pair + (hb ^ 16));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {   // (+-1 coefficients: the products are exact, one rounding per addition)
-                rc[b][e] = __builtin_fmaf(d2l[e], s2, d1l[e] * s1);
-                rc[b][4 + e] = __builtin_fmaf(d2h[e], s2, d1h[e] * s1);
-            }
+            // (+-1 coefficients: the products are exact, one rounding per addition)
+            rc[b][0] = __builtin_elementwise_fma(d2l, s2v, d1l * s1v);
+            rc[b][1] = __builtin_elementwise_fma(d2h, s2v, d1h * s1v);
         }
     };
     // row nu of B^T over the four row-combined columns: 0: c0 - c2, 1: c1 + c2, 2: c2 - c1, 3: c1 - c3 (nu is a constant
     // wherever this is expanded)
     auto form_v = [&](const int nu) {
-        float vv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            vv[e] = nu == 0 ? rc[0][e] - rc[2][e] : (nu == 1 ? rc[1][e] + rc[2][e] : (nu == 2 ? rc[2][e] - rc[1][e] : rc[1][e] - rc[3][e]));
+        f32x4 v0, v1;
+        if (nu == 0) { v0 = rc[0][0] - rc[2][0]; v1 = rc[0][1] - rc[2][1]; }
+        else if (nu == 1) { v0 = rc[1][0] + rc[2][0]; v1 = rc[1][1] + rc[2][1]; }
+        else if (nu == 2) { v0 = rc[2][0] - rc[1][0]; v1 = rc[2][1] - rc[1][1]; }
+        else { v0 = rc[1][0] - rc[3][0]; v1 = rc[1][1] - rc[3][1]; }
+        const float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         split8(vv, pf[0], pf[1], pf[2]);
     };
     WINO_DMA_PATCH(0)
@@ -239,12 +241,11 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                 // weights = A operand (rows = output channels), tiles = B operand (columns); small terms first.  The fragments
                 // of block j+1 are requested before block j's MFMAs, block j-1's result is folded into Y between them.
                 bf16x8 wf[2][3];
-                f32x4 mp = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 mm[2];   // product of block j in mm[j & 1]
 #pragma unroll
                 for (int k = 0; k < 3; ++k) wf[0][k] = *reinterpret_cast<const bf16x8*>(wc + k * W_PLANE);
 #pragma unroll
                 for (int j = 0; j <= TJ; ++j) {
-                    f32x4 m = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (j < TJ) {
                         if (j + 1 < TJ) {
 #pragma unroll
@@ -252,27 +253,46 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                                 wf[(j + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(wc + (j + 1) * 1024 + k * W_PLANE);
                         }
                         const bf16x8 w0 = wf[j & 1][0], w1 = wf[j & 1][1], w2 = wf[j & 1][2];
-                        m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, pf[0], m, 0, 0, 0);
-                        m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, pf[2], m, 0, 0, 0);
-                        m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, pf[1], m, 0, 0, 0);
-                        m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, pf[0], m, 0, 0, 0);
-                        m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, pf[1], m, 0, 0, 0);
-                        m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, pf[0], m, 0, 0, 0);
+                        const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (TWOCHAIN) {   // the three small terms and the three large ones in separate chains, added at the end
+                            f32x4 ms = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, pf[0], zero, 0, 0, 0);
+                            f32x4 ml = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, pf[0], zero, 0, 0, 0);
+                            ms = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, pf[2], ms, 0, 0, 0);
+                            ml = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, pf[1], ml, 0, 0, 0);
+                            ms = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, pf[1], ms, 0, 0, 0);
+                            ml = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, pf[0], ml, 0, 0, 0);
+                            mm[j & 1] = ml + ms;
+                        } else {
+                            f32x4 m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, pf[0], zero, 0, 0, 0);
+                            m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, pf[2], m, 0, 0, 0);
+                            m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, pf[1], m, 0, 0, 0);
+                            m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, pf[0], m, 0, 0, 0);
+                            m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, pf[1], m, 0, 0, 0);
+                            mm[j & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, pf[0], m, 0, 0, 0);
+                        }
                     }
                     if (j > 0) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (nu < 3) {
-                                Y[0][j - 1][e] = __builtin_fmaf(mp[e], ci0, Y[0][j - 1][e]);
-                                Y[2][j - 1][e] = __builtin_fmaf(mp[e], ci1, Y[2][j - 1][e]);
-                            }
-                            if (nu > 0) {
-                                Y[1][j - 1][e] = __builtin_fmaf(mp[e], c01, Y[1][j - 1][e]);
-                                Y[3][j - 1][e] = __builtin_fmaf(mp[e], c11, Y[3][j - 1][e]);
-                            }
+                        const f32x4 mp = mm[(j - 1) & 1];
+                        if (nu < 3) {
+                            Y[0][j - 1] = __builtin_elementwise_fma(mp, f32x4{ci0, ci0, ci0, ci0}, Y[0][j - 1]);
+                            Y[2][j - 1] = __builtin_elementwise_fma(mp, f32x4{ci1, ci1, ci1, ci1}, Y[2][j - 1]);
+                        }
+                        if (nu > 0) {
+                            Y[1][j - 1] = __builtin_elementwise_fma(mp, f32x4{c01, c01, c01, c01}, Y[1][j - 1]);
+                            Y[3][j - 1] = __builtin_elementwise_fma(mp, f32x4{c11, c11, c11, c11}, Y[3][j - 1]);
                         }
                         // (pins the fold here: without a use inside this scheduling region the optimiser sinks it to the loop's end)
-                        asm volatile("" : "+v"(Y[0][j - 1]), "+v"(Y[1][j - 1]), "+v"(Y[2][j - 1]), "+v"(Y[3][j - 1]));
+                        // ... in fixed registers (Y[i][j] = v[32 i + 4 j ..]): in-place updates, no copies around the loop
+                        switch (j - 1) {
+                            case 0: asm volatile("" : "+{v[0:3]}"(Y[0][0]), "+{v[32:35]}"(Y[1][0]), "+{v[64:67]}"(Y[2][0]), "+{v[96:99]}"(Y[3][0])); break;
+                            case 1: asm volatile("" : "+{v[4:7]}"(Y[0][1]), "+{v[36:39]}"(Y[1][1]), "+{v[68:71]}"(Y[2][1]), "+{v[100:103]}"(Y[3][1])); break;
+                            case 2: asm volatile("" : "+{v[8:11]}"(Y[0][2]), "+{v[40:43]}"(Y[1][2]), "+{v[72:75]}"(Y[2][2]), "+{v[104:107]}"(Y[3][2])); break;
+                            case 3: asm volatile("" : "+{v[12:15]}"(Y[0][3]), "+{v[44:47]}"(Y[1][3]), "+{v[76:79]}"(Y[2][3]), "+{v[108:111]}"(Y[3][3])); break;
+                            case 4: asm volatile("" : "+{v[16:19]}"(Y[0][4]), "+{v[48:51]}"(Y[1][4]), "+{v[80:83]}"(Y[2][4]), "+{v[112:115]}"(Y[3][4])); break;
+                            case 5: asm volatile("" : "+{v[20:23]}"(Y[0][5]), "+{v[52:55]}"(Y[1][5]), "+{v[84:87]}"(Y[2][5]), "+{v[116:119]}"(Y[3][5])); break;
+                            case 6: asm volatile("" : "+{v[24:27]}"(Y[0][6]), "+{v[56:59]}"(Y[1][6]), "+{v[88:91]}"(Y[2][6]), "+{v[120:123]}"(Y[3][6])); break;
+                            case 7: asm volatile("" : "+{v[28:31]}"(Y[0][7]), "+{v[60:63]}"(Y[1][7]), "+{v[92:95]}"(Y[2][7]), "+{v[124:127]}"(Y[3][7])); break;
+                        }
                     }
                     if (j < TJ) {
                         // order: the fragment reads first, then the MFMAs with the fold's VALU work in their shadows
@@ -284,7 +304,6 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    mp = m;
                 }
                 if (late && step + 1 < nsteps) {   // V of the next step (its patch has landed: see the wait of step 15)
                     if (nu == 3) combine_rows((xi + 1) & 3);
@@ -348,17 +367,15 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     const int64_t nwg = (int64_t)d.B * wg_y * wg_x * n_tiles;
     if (nwg > 0x7fffffff) return hipErrorInvalidValue;
     const size_t smem = (size_t)PATCH_BYTES + 3 * (size_t)(3 * BN * 64);
-    static bool attr_set[SPAA_MAX_DEVICES] = {};
-    {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<BN, true>), (int)smem, attr_set);
-        if (e != hipSuccess) return (int)e;
+    static bool attr_set[4][SPAA_MAX_DEVICES] = {};
+    const int var = (d.reserved0 >> 16) & 3;   // measurement variants of the kernel (0 = default)
+#define WINO_LAUNCH(V)                                                                                                    \
+    {                                                                                                                     \
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<BN, V>), (int)smem, attr_set[V]); \
+        if (e != hipSuccess) return (int)e;                                                                               \
+        hipLaunchKernelGGL((wino_x6_kernel<BN, V>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles); \
     }
-    if ((d.reserved0 >> 16) & 1) {   // (A/B measurement switch)
-        static bool attr_set2[SPAA_MAX_DEVICES] = {};
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<BN, false>), (int)smem, attr_set2);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((wino_x6_kernel<BN, false>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles);
-    } else
-        hipLaunchKernelGGL((wino_x6_kernel<BN, true>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles);
+    if (var == 0) WINO_LAUNCH(0) else if (var == 1) WINO_LAUNCH(1) else if (var == 2) WINO_LAUNCH(2) else WINO_LAUNCH(3)
+#undef WINO_LAUNCH
     return (int)hipGetLastError();
 }

@@ -9,7 +9,7 @@ for ci, co in [(128, 256), (256, 128)]:
     x = torch.relu(torch.randn(64, 64, 64, ci, device=DEV))
     out = torch.zeros(64, 64, 64, co, device=DEV)
     cp.FORCE_TILE = 70
-    for dbg in [0, 1, 0, 1]:
+    for dbg in [0, 1, 2, 3, 0, 1, 2, 3, 0, 1, 2, 3]:
         cp.DEBUG_WINO = dbg
         for _ in range(3):
             plan.run(x, out)
