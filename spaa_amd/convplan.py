@@ -48,7 +48,7 @@ WINOGRAD = os.environ.get('SPAA_WINOGRAD', '1') != '0'  # 3x3/s1 layers: allow t
 def _load_tune():
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tapconv_tune.json')
+    path = os.environ.get('SPAA_TUNE_FILE') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tapconv_tune.json')
     if os.path.exists(path):
         with open(path) as fh:
             return {k: int(v) for k, v in json.load(fh).items()}
@@ -208,7 +208,7 @@ class ConvPlan:
         if gate2_bits is not None:
             assert gate2 is None and aux_out is not None and gate2_bits.shape[:3] == out.shape[:3] and self.cout <= 4 * gate2_bits.shape[3]
             d.gate2_bits, d.gate2_cstride, d.gate2_coff = gate2_bits.data_ptr(), 4 * gate2_bits.shape[3], 0
-        key = f'{self.cin_p}_{self.cout}_{self.ntaps_total}_{self.s_in}_{self.s_out}_{b * d.Hm * d.Wm}' + ('_fold' if self.nfold > 1 else '')
+        key = f'{self.cin_p}_{self.cout}_{self.alg_taps}_{self.s_in}_{self.s_out}_{b * d.Hm * d.Wm}' + ('_fold' if self.nfold > 1 else '')
         forced = FORCE_TILE
         if forced == 9 and self.cout > 4:
             forced = 0
@@ -270,13 +270,13 @@ class ConvPlan:
                 self._ws = torch.empty(need, device=inp.device, dtype=torch.float32)
             d.splitk_ws, d.ksplit = self._ws.data_ptr(), ksplit
         if gate is not None and gate_mode == _lib.GATE_MUL and tile < 25:  # multiplicative gate: newer epilogues only
-            tile = self._default_tile(b * d.Hm * d.Wm) % 100
+            tile = self._default_tile(b * d.Hm * d.Wm, winograd=False) % 100
             d.ksplit, d.splitk_ws = 0, None
             if tile < 25:
                 raise ValueError('GATE_MUL needs a layer shape served by the DMA-staged kernels')
         if masked and tile not in STORE4_TILES:
             # byte masks live in the shared 4-channel epilogue (epilogue.hpp): thin / fp32-MFMA kernels do not have it
-            tile = self._default_tile(b * d.Hm * d.Wm) % 100
+            tile = self._default_tile(b * d.Hm * d.Wm, winograd=False) % 100
             d.ksplit, d.splitk_ws = 0, None
             if tile not in STORE4_TILES:
                 raise ValueError(f'{self.name}: gate masks need a layer shape served by the bf16x6 / smallcin kernels')
@@ -421,7 +421,7 @@ def attach_winograd(plan):
     transform U = G g G^T as a 16-'tap' ConvPlan run by csrc/tapconv_wino.hip (tile 70).  Returns the plan; plans of any other
     shape are returned untouched."""
     if (len(plan.cls) != 1 or plan.ntaps_total != 9 or plan.s_in != 1 or plan.s_out != 1 or plan.nfold != 1
-            or plan.cin_p % 32 or plan.cin != plan.cin_p or plan.w_split is None):
+            or plan.cin_p % 32 or plan.cin != plan.cin_p or plan.w_split is None or plan.cout < 64):
         return plan
     taps = [(dy, dx) for dy, dx, _ in plan.classes_host[0].taps]
     if sorted(taps) != [(dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]:

@@ -21,7 +21,7 @@ def main():
     torch.cuda.synchronize()
     res = {}
     names = {}
-    tiles = [int(t) for t in os.environ.get('SPAA_TUNE_TILES', '').split(',') if t] or (list(range(1, 55)) + [s * 100 + t for s in (2, 4, 8) for t in (25, 27, 31, 34, 35, 36, 42, 48, 50, 52)] + [900 + t for t in (48, 49, 50, 51, 52, 53, 54)])
+    tiles = [int(t) for t in os.environ.get('SPAA_TUNE_TILES', '').split(',') if t] or (list(range(1, 55)) + [70] + [s * 100 + t for s in (2, 4, 8) for t in (25, 27, 31, 34, 35, 36, 42, 48, 50, 52)] + [900 + t for t in (48, 49, 50, 51, 52, 53, 54)])
     for tile in tiles:
         convplan.FORCE_TILE = tile
         st.iteration(**hp)  # warm (sets the LDS attribute of a new instantiation)
