@@ -175,6 +175,22 @@ int spaa_warp_finish_grid_bwd(const float* g_fine, const float* coarse, const fl
  * partial: ceil(Hout*Wout/256) * (6 + 2 (T+2)) floats of scratch (block sums, added in order) */
 int spaa_warp_coarse_grid_bwd(const float* g_coarse, const float* affine6, const float* theta, const float* ctrl, int T, int Hin,
                               int Win, int Hout, int Wout, float* partial, float* g_params, spaa_stream_t stream);
+/* ---- fused tail / head of ShadingNetSPAA (/root/reference/src/python/models.py:296-300) --------------------------
+ * forward:   Ypre = relu(conv6(relu(transConv2(X6) + bias2)) + bias6 + res1),  Y = min(Ypre, 1); the activation between
+ *            the two layers (X7, 32 channels at camera resolution) stays in LDS, only its ReLU gate bytes reach HBM.
+ *   x6 [B,H2,W2,64] fp32; w2_split [3][128][64] bf16: the three planes (w == h + m + l) of W[n][k] =
+ *   transConv2.weight[k][c][py][px], n = 32 (2 py + px) + c; bias2 [32]; w6 [3][9][32]: w6[o][3 ky + kx][c] =
+ *   conv6.weight[o][c][ky][kx]; bias6 [3]; res1, y, ypre [B,2 H2,2 W2,4]; mask7 [B,2 H2,2 W2,8] gate bytes of X7
+ *   (bit e of byte q = channel 4 q + e > 0, as `mask_out` of spaa_tapconv_t).
+ * backward:  P6 = gate6 . transConv2^T( gate7 . conv6^T(gP) ): gp [B,2 H2,2 W2,4] (gradient w.r.t. Ypre, channel 3
+ *   ignored); w6t [27][32]: w6t[3 t + o][c] = conv6.weight[o][c][2 - t / 3][2 - t % 3]; w2t_split [3][64][128] bf16 planes
+ *   of W[n][k] = transConv2.weight[n][c][py][px], k = 32 (2 py + px) + c; mask7 as above, mask6 [B,H2,W2,16] gate bytes
+ *   of X6; p6 [B,H2,W2,64]. */
+int spaa_shading_tail_fwd(const float* x6, const uint16_t* w2_split, const float* bias2, const float* w6, const float* bias6,
+                          const float* res1, float* y, float* ypre, uint8_t* mask7, int B, int H2, int W2, spaa_stream_t stream);
+int spaa_shading_head_bwd(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7,
+                          const uint8_t* mask6, float* p6, int B, int H2, int W2, spaa_stream_t stream);
+
 /* ReLU backward as a stand-alone op: out = (act > 0) ? g : 0, n floats (n % 4 == 0, 16-byte aligned) */
 int spaa_relu_gate(const float* g, const float* act, float* out, int64_t n, spaa_stream_t stream);
 /* torch.optim.Adam step on one flat parameter tensor (train_network.py:252-254: betas (0.9, 0.999), eps 1e-8, L2 weight

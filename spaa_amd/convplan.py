@@ -448,6 +448,16 @@ def attach_winograd(plan):
     return plan
 
 
+def split_planes(w):
+    """fp32 matrix -> int16 tensor [3, *w.shape]: the bf16 planes h, m, l with w == h + m + l exactly."""
+    w = w.detach().float().contiguous()
+    h = w.to(torch.bfloat16)
+    r1 = w - h.float()
+    m = r1.to(torch.bfloat16)
+    lo = (r1 - m.float()).to(torch.bfloat16)
+    return torch.stack([h, m, lo]).view(torch.int16).contiguous()
+
+
 def _w2(w):
     return w.detach().float().cpu()
 

@@ -1,0 +1,384 @@
+// shading_tail.hip — the tail of ShadingNetSPAA.forward and the head of its backward pass as ONE kernel each
+// (/root/reference/src/python/models.py:296-300:  x = relu(transConv2(x));  x = clamp(relu(conv6(x) + res1), max=1)).
+//
+// At the benchmark size the activation between the two layers (X7: 64 x 256 x 256 x 32 fp32 = 537 MB) is the largest
+// tensor of the network and exists only to be read once by the next layer: forward, transConv2 writes it and conv6 reads
+// it; backward, conv6's input gradient writes its gradient (P7) and transConv2's input gradient reads it.  Here a
+// workgroup keeps its tile of X7 (resp. P7) in LDS:
+//   forward   X6 tile (8 x 16 pixels, 64 ch) --bf16x6 MFMA, K = 64, N = 4 parities x 32--> X7 tile (16 x 32 px, 32 ch) in LDS
+//             --3x3 taps on the VALU (packed FMAs, scalar weights), + res1, ReLU, clamp--> Y, Ypre for the 14 x 30 interior;
+//             HBM sees X6, res1, Y, Ypre and the ReLU gate bytes of X7 (1 byte per 4 channels) only;
+//   backward  gP tile (16 x 32 px + halo, 3 ch) --3x3 taps on the VALU, gated by X7's bytes--> P7 tile in LDS as the GEMM's
+//             pixel operand (K = 4 parities x 32) --bf16x6 MFMA, N = 64, gated by X6's bytes--> P6 tile (8 x 16 px, 64 ch).
+// The arithmetic is that of the separate kernels: fp32 operands split exactly into three bf16 planes, six of the nine
+// partial products, fp32 accumulation (tapconv_x6d.hip); fp32 FMAs for the thin 3x3 layer (thinpatch.hip).
+// Persistent: one workgroup (8 waves) per CU walks the tiles; the transposed convolution's weight planes stay in LDS.
+#include <hip/hip_runtime.h>
+#include "launch_util.hpp"
+#include <stdint.h>
+#include "../../include/spaa_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(4))) f16v* cf16_ptr;
+
+__device__ __forceinline__ unsigned int cvt2(float a, float b) {
+    f2 v = {a, b};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float lo_f(unsigned int p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float hi_f(unsigned int p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// 8 fp32 -> three bf16x8 with x == h + m + l exactly
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& h, bf16x8& m, bf16x8& l) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    u4 hh, mm, ll;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned int ph = cvt2(x[2 * i], x[2 * i + 1]);
+        const float r0 = x[2 * i] - lo_f(ph), r1 = x[2 * i + 1] - hi_f(ph);
+        const unsigned int pm = cvt2(r0, r1);
+        const float s0 = r0 - lo_f(pm), s1 = r1 - hi_f(pm);
+        hh[i] = ph;
+        mm[i] = pm;
+        ll[i] = cvt2(s0, s1);
+    }
+    h = __builtin_bit_cast(bf16x8, hh);
+    m = __builtin_bit_cast(bf16x8, mm);
+    l = __builtin_bit_cast(bf16x8, ll);
+}
+
+// six of the nine partial products of (w0 + w1 + w2) . (p0 + p1 + p2), small terms first
+__device__ __forceinline__ f32x4 mfma6(const bf16x8 w0, const bf16x8 w1, const bf16x8 w2, const bf16x8 p0, const bf16x8 p1,
+                                       const bf16x8 p2, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, p0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, p2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, p1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, p0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, p1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, p0, acc, 0, 0, 0);
+    return acc;
+}
+
+constexpr int C6 = 64, C7 = 32;        // channels of X6 and X7 (models.py:167-168)
+constexpr int RY = 8, RX = 16;         // X6 pixels of a tile
+constexpr int TY = 2 * RY, TX = 2 * RX;  // X7 pixels of a tile (16 x 32), of which the interior 14 x 30 is owned
+constexpr int OY = TY - 2, OX = TX - 2;
+constexpr int W_BYTES = 3 * 128 * 128;   // weight planes: [plane][128 rows][64 bf16]
+constexpr int T_BYTES = TY * TX * 128;   // X7 / P7 tile: 32 fp32 per pixel
+
+// stage [3][128][64] bf16 weight planes (rows of 128 B) into LDS; 16-byte chunk c of row r sits at chunk c ^ ((r >> 1) & 7)
+__device__ __forceinline__ void stage_planes(const uint16_t* w, unsigned char* dst, const int wave, const int lane) {
+    const uint64_t addr = reinterpret_cast<uint64_t>(w);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)addr);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, W_BYTES, 0x00020000);
+    for (int piece = wave; piece < W_BYTES / 1024; piece += 8) {   // 8 rows per piece
+        const int r = piece * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + piece * 1024), 16, r * 128 + c * 16, 0, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward tail
+__global__ __launch_bounds__(512, 1) void shading_tail_fwd_kernel(const float* __restrict__ x6, const uint16_t* __restrict__ w2s,
+                                                                  const float* __restrict__ bias2, const float* __restrict__ w6,
+                                                                  const float* __restrict__ bias6, const float* __restrict__ r1,
+                                                                  float* __restrict__ y, float* __restrict__ ypre,
+                                                                  uint8_t* __restrict__ mask7, const int B, const int H2,
+                                                                  const int W2, const int tiles_y, const int tiles_x) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char* wl = smem;             // weight planes
+    unsigned char* tl = smem + W_BYTES;   // X7 tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = 2 * H2, W = 2 * W2;
+    stage_planes(w2s, wl, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int rx = lane & 15, g = lane >> 4;
+    const int ntiles = B * tiles_y * tiles_x;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx_ = tile % tiles_x, ty_ = (tile / tiles_x) % tiles_y, img = tile / (tiles_x * tiles_y);
+        // owned output rows [OY ty - 1, OY ty + OY - 1), X7 rows [OY ty - 2, + TY), X6 rows [RY' = (OY/2) ty - 1, + RY)
+        const int a0 = (OY / 2) * ty_ - 1, b0 = (OX / 2) * tx_ - 1;   // first X6 row / column of the tile
+        // ---- phase 1: X7 tile = relu(transConv2(X6) + bias); wave = X6 row, lane = (X6 column, 8-channel chunk)
+        {
+            const int ay = a0 + wave, ax = b0 + rx;
+            const bool in6 = (unsigned)ay < (unsigned)H2 && (unsigned)ax < (unsigned)W2;
+            const float* src = x6 + (((size_t)img * H2 + (in6 ? ay : 0)) * W2 + (in6 ? ax : 0)) * C6 + g * 8;
+            bf16x8 pf[2][3];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f};
+                if (in6) {
+                    u0 = *reinterpret_cast<const f32x4*>(src + s * 32);
+                    u1 = *reinterpret_cast<const f32x4*>(src + s * 32 + 4);
+                }
+                split8(u0, u1, pf[s][0], pf[s][1], pf[s][2]);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    // A operand: row n = 16 nb + (lane & 15), k chunk 4 s + (lane >> 4)
+                    const int r = 16 * nb + rx;
+                    const unsigned char* wp = wl + r * 128 + (((4 * s + g) ^ ((r >> 1) & 7)) << 4);
+                    const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wp);
+                    const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wp + 128 * 128);
+                    const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wp + 2 * 128 * 128);
+                    acc = mfma6(w0, w1, w2, pf[s][0], pf[s][1], pf[s][2], acc);
+                }
+                // D: column = X6 pixel (lane & 15), rows n = 16 nb + 4 g + e: parity nb >> 1, channels 16 (nb & 1) + 4 g + e
+                const int par = nb >> 1, c0 = 16 * (nb & 1) + 4 * g;
+                const int py = 2 * wave + (par >> 1), px = 2 * rx + (par & 1);           // X7 pixel in the tile
+                const int gy = 2 * a0 + py, gx = 2 * b0 + px;                           // ... in the image
+                const bool in7 = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias2 + c0);
+                f32x4 v;
+                unsigned int bits = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = acc[e] + bv[e];
+                    v[e] = in7 ? fmaxf(t, 0.f) : 0.f;   // (outside the image: conv6's zero padding)
+                    bits |= (t > 0.f ? 1u : 0u) << e;
+                }
+                const int q = py * TX + px;
+                *reinterpret_cast<f32x4*>(tl + q * 128 + ((((c0 >> 2)) ^ ((q >> 1) & 7)) << 4)) = v;
+                const bool own = py >= 1 && py <= OY && px >= 1 && px <= OX;
+                if (in7 && own) mask7[(((size_t)img * H + gy) * W + gx) * (C7 / 4) + (c0 >> 2)] = (uint8_t)bits;
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: conv6 (3x3, 32 -> 3) + res1, ReLU, clamp for the owned interior; thread = pixel
+        if (tid < OY * OX) {
+            const int oy_l = tid / OX, ox_l = tid - oy_l * OX;
+            const int gy = 2 * a0 + 1 + oy_l, gx = 2 * b0 + 1 + ox_l;
+            f2 acc[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll 1
+            for (int t = 0; t < 9; ++t) {   // (not unrolled: 48 weight SGPRs per half-tap is what the scalar file holds)
+                const int q = (oy_l + t / 3) * TX + ox_l + t % 3;
+                const unsigned char* pp = tl + q * 128;
+                const int sw = (q >> 1) & 7;
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) {   // 16 channels at a time: one s_load_dwordx16 per output channel
+                    f16v w[3];
+#pragma unroll
+                    for (int n = 0; n < 3; ++n) w[n] = *(cf16_ptr)(uintptr_t)(w6 + (n * 9 + t) * C7 + 16 * h);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(pp + (((4 * h + u) ^ sw) << 4));
+                        const f2 a01 = {a[0], a[1]}, a23 = {a[2], a[3]};
+#pragma unroll
+                        for (int n = 0; n < 3; ++n) {
+                            const f2 w01 = {w[n][4 * u], w[n][4 * u + 1]}, w23 = {w[n][4 * u + 2], w[n][4 * u + 3]};
+                            acc[n] = __builtin_elementwise_fma(a01, w01, acc[n]);
+                            acc[n] = __builtin_elementwise_fma(a23, w23, acc[n]);
+                        }
+                    }
+                }
+            }
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const size_t o = (((size_t)img * H + gy) * W + gx) * 4;
+                const f32x4 rv = *reinterpret_cast<const f32x4*>(r1 + o);
+                f32x4 outv = {0.f, 0.f, 0.f, 0.f}, prev = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+                    const float t = fmaxf(acc[n][0] + acc[n][1] + bias6[n] + rv[n], 0.f);
+                    prev[n] = t;
+                    outv[n] = fminf(t, 1.f);
+                }
+                *reinterpret_cast<f32x4*>(y + o) = outv;
+                *reinterpret_cast<f32x4*>(ypre + o) = prev;
+            }
+        }
+        __syncthreads();   // the tile is free for the next one
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward head:  P7 = gate7 . conv6^T(gP)  (3 -> 32, 3x3),  P6 = gate6 . transConv2^T(P7)  (K = 4 parities x 32, N = 64)
+// tile = 8 x 16 pixels of X6 = 16 x 32 pixels of X7 (no halo on P7; the gP tile carries a 1-pixel halo).
+// LDS: weight planes [3][128 rows: 64 used][128 bf16]... see stage below; P7 tile as the GEMM's pixel operand:
+//   row = X6 pixel m = 16 ry + rx (128 rows), 128 fp32 columns k = 32 parity + c  (512 B per row)
+constexpr int GP_W = TX + 2, GP_H = TY + 2;   // gP tile with halo: 18 x 34 pixels x 16 B
+constexpr int WB_BYTES = 3 * 64 * 256;        // backward weight planes: [plane][64 rows n][128 bf16 k] (256 B per row)
+constexpr int P7_BYTES = 128 * 512;           // 64 KB
+constexpr int GP_BYTES = GP_W * GP_H * 16;    // 9792 B
+
+__global__ __launch_bounds__(512, 1) void shading_head_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ w6t,
+                                                                  const uint16_t* __restrict__ w2ts,
+                                                                  const uint8_t* __restrict__ mask7,
+                                                                  const uint8_t* __restrict__ mask6, float* __restrict__ p6,
+                                                                  const int B, const int H2, const int W2, const int tiles_y,
+                                                                  const int tiles_x) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char* wl = smem;                       // weight planes
+    unsigned char* pl = smem + WB_BYTES;            // P7 tile
+    unsigned char* gl = smem + WB_BYTES + P7_BYTES;  // gP tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = 2 * H2, W = 2 * W2;
+    {   // stage [3][64][128] bf16 planes: rows of 256 B, 16 chunks; chunk c of row r at chunk c ^ (r & 15)
+        const uint64_t addr = reinterpret_cast<uint64_t>(w2ts);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)addr);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, WB_BYTES, 0x00020000);
+        for (int piece = wave; piece < WB_BYTES / 1024; piece += 8) {   // 4 rows per piece
+            const int r = piece * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (r & 15);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(wl + piece * 1024), 16, r * 256 + c * 16, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const int rx = lane & 15, g = lane >> 4;
+    const int ntiles = B * tiles_y * tiles_x;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx_ = tile % tiles_x, ty_ = (tile / tiles_x) % tiles_y, img = tile / (tiles_x * tiles_y);
+        const int a0 = RY * ty_, b0 = RX * tx_;   // first X6 row / column
+        // ---- phase 0: gP tile with halo (out-of-image pixels: zeros = conv6's zero padding seen from the gradient)
+        for (int i = tid; i < GP_W * GP_H; i += 512) {
+            const int py = i / GP_W, px = i - py * GP_W;
+            const int gy = 2 * a0 - 1 + py, gx = 2 * b0 - 1 + px;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                v = *reinterpret_cast<const f32x4*>(gp + (((size_t)img * H + gy) * W + gx) * 4);
+            *reinterpret_cast<f32x4*>(gl + i * 16) = v;
+        }
+        __syncthreads();
+        // ---- phase 1: P7[pixel][32] = gate7 . sum_{taps, 3 ch} gP[pixel + d] w6t[tap][ch][32]; thread = X7 pixel of the tile
+        {
+            const int py = tid >> 5, px = tid & 31;   // 16 x 32
+            const int gy = 2 * a0 + py, gx = 2 * b0 + px;
+            const bool in7 = gy < H && gx < W;
+            uint64_t mbits = 0;   // 8 gate bytes of this pixel
+            if (in7) mbits = *reinterpret_cast<const uint64_t*>(mask7 + (((size_t)img * H + gy) * W + gx) * (C7 / 4));
+            f32x4 acc[8];
+#pragma unroll
+            for (int c4 = 0; c4 < 8; ++c4) acc[c4] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int i = 0; i < 27; ++i) {   // input (tap t = i / 3, channel o = i % 3): 32 wave-uniform weights (scalar loads)
+                const int t = i / 3, o = i - 3 * t;
+                const float gv = *reinterpret_cast<const float*>(gl + ((py + t / 3) * GP_W + px + t % 3) * 16 + 4 * o);
+                const f16v wa = *(cf16_ptr)(uintptr_t)(w6t + i * C7), wb = *(cf16_ptr)(uintptr_t)(w6t + i * C7 + 16);
+                const f32x4 g4 = {gv, gv, gv, gv};
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    acc[c4] = __builtin_elementwise_fma(g4, f32x4{wa[4 * c4], wa[4 * c4 + 1], wa[4 * c4 + 2], wa[4 * c4 + 3]}, acc[c4]);
+                    acc[4 + c4] = __builtin_elementwise_fma(g4, f32x4{wb[4 * c4], wb[4 * c4 + 1], wb[4 * c4 + 2], wb[4 * c4 + 3]}, acc[4 + c4]);
+                }
+            }
+            // GEMM operand row m = 16 (py >> 1) + (px >> 1), columns k = 32 (2 (py & 1) + (px & 1)) + c
+            const int m = 16 * (py >> 1) + (px >> 1), kb = 32 * (2 * (py & 1) + (px & 1));
+#pragma unroll
+            for (int c4 = 0; c4 < 8; ++c4) {
+                const unsigned int nib = (unsigned int)(mbits >> (8 * c4)) & 15u;
+                f32x4 v = acc[c4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ((nib >> e) & 1u) ? v[e] : 0.f;
+                // 16-byte chunk (kb + 4 c4) / 4 of row m at chunk ^ (m & 31)
+                const int ch = (kb >> 2) + c4;
+                *reinterpret_cast<f32x4*>(pl + m * 512 + ((ch ^ (m & 31)) << 4)) = v;
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: P6[m][n] = gate6 . sum_k P7[m][k] W[n][k];  wave = X6 row of the tile, lane = (column, k chunk)
+        {
+            const int m = 16 * wave + rx;
+            bf16x8 pf[4][3];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {   // k step s: columns 32 s + 8 g .. + 7 = chunks 8 s + 2 g, + 1
+                const f32x4 u0 = *reinterpret_cast<const f32x4*>(pl + m * 512 + (((8 * s + 2 * g) ^ (m & 31)) << 4));
+                const f32x4 u1 = *reinterpret_cast<const f32x4*>(pl + m * 512 + (((8 * s + 2 * g + 1) ^ (m & 31)) << 4));
+                split8(u0, u1, pf[s][0], pf[s][1], pf[s][2]);
+            }
+            const int ay = a0 + wave, ax = b0 + rx;
+            const bool in6 = ay < H2 && ax < W2;
+            uint64_t g6lo = 0, g6hi = 0;   // 16 gate bytes of this X6 pixel
+            if (in6) {
+                const uint64_t* mp = reinterpret_cast<const uint64_t*>(mask6 + (((size_t)img * H2 + ay) * W2 + ax) * (C6 / 4));
+                g6lo = mp[0];
+                g6hi = mp[1];
+            }
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int r = 16 * nb + rx;   // weight row n
+                    const unsigned char* wp = wl + r * 256 + (((4 * s + g) ^ (r & 15)) << 4);
+                    const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wp);
+                    const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wp + 64 * 256);
+                    const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wp + 2 * 64 * 256);
+                    acc = mfma6(w0, w1, w2, pf[s][0], pf[s][1], pf[s][2], acc);
+                }
+                // D: column = X6 pixel (lane & 15), rows n = 16 nb + 4 g + e
+                const int n0 = 16 * nb + 4 * g;
+                const unsigned int nib = (unsigned int)((n0 < 32 ? g6lo >> (2 * n0) : g6hi >> (2 * (n0 - 32)))) & 15u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = ((nib >> e) & 1u) ? acc[e] : 0.f;
+                if (in6) *reinterpret_cast<f32x4*>(p6 + (((size_t)img * H2 + ay) * W2 + ax) * C6 + n0) = acc;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int spaa_shading_tail_fwd(const float* x6, const uint16_t* w2_split, const float* bias2, const float* w6, const float* bias6,
+                          const float* res1, float* y, float* ypre, uint8_t* mask7, int B, int H2, int W2, spaa_stream_t stream_) {
+    if (!x6 || !w2_split || !bias2 || !w6 || !bias6 || !res1 || !y || !ypre || !mask7 || B <= 0 || H2 <= 0 || W2 <= 0)
+        return hipErrorInvalidValue;
+    if ((int64_t)B * H2 * W2 * 4 * C7 * 4 >= (int64_t)1 << 40) return hipErrorInvalidValue;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int H = 2 * H2, W = 2 * W2;
+    const int tiles_y = (H + 1 + OY - 1) / OY, tiles_x = (W + 1 + OX - 1) / OX;   // owned rows start at -1
+    const int64_t ntiles = (int64_t)B * tiles_y * tiles_x;
+    if (ntiles > 0x7fffffff) return hipErrorInvalidValue;
+    const size_t smem = (size_t)W_BYTES + T_BYTES;
+    static bool attr_set[SPAA_MAX_DEVICES] = {};
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&shading_tail_fwd_kernel), (int)smem, attr_set);
+    if (e != hipSuccess) return (int)e;
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);
+    hipLaunchKernelGGL(shading_tail_fwd_kernel, dim3(grid), dim3(512), smem, stream, x6, w2_split, bias2, w6, bias6, res1, y, ypre,
+                       mask7, B, H2, W2, tiles_y, tiles_x);
+    return (int)hipGetLastError();
+}
+
+int spaa_shading_head_bwd(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6,
+                          float* p6, int B, int H2, int W2, spaa_stream_t stream_) {
+    if (!gp || !w6t || !w2t_split || !mask7 || !mask6 || !p6 || B <= 0 || H2 <= 0 || W2 <= 0) return hipErrorInvalidValue;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int tiles_y = (H2 + RY - 1) / RY, tiles_x = (W2 + RX - 1) / RX;
+    const int64_t ntiles = (int64_t)B * tiles_y * tiles_x;
+    if (ntiles > 0x7fffffff) return hipErrorInvalidValue;
+    const size_t smem = (size_t)WB_BYTES + P7_BYTES + GP_BYTES;
+    static bool attr_set[SPAA_MAX_DEVICES] = {};
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&shading_head_bwd_kernel), (int)smem, attr_set);
+    if (e != hipSuccess) return (int)e;
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);
+    hipLaunchKernelGGL(shading_head_bwd_kernel, dim3(grid), dim3(512), smem, stream, gp, w6t, w2t_split, mask7, mask6, p6, B, H2, W2,
+                       tiles_y, tiles_x);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

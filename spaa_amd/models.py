@@ -22,6 +22,7 @@ from .synthetic import uniform_ctrl_pts
 
 
 USE_GATE_MASKS = os.environ.get('SPAA_GATE_MASKS', '1') != '0'   # 0: fp32 activations as ReLU gates (A/B measurements)
+FUSE_TAIL = os.environ.get('SPAA_FUSE_TAIL', '1') != '0'         # 0: transConv2 / conv6 as separate launches (A/B measurements)
 
 
 def C_ptr(t):
@@ -275,6 +276,19 @@ def transposed_taps(grid, prj_size, cam_size, mask=None):
     return bounds.to(torch.int32).contiguous(), order.to(torch.int32).contiguous(), tap_wm
 
 
+class _Activations(dict):
+    """The engine's activation workspaces by name; 'X7' is recomputed on demand when the fused tail kept it in LDS."""
+
+    def __init__(self, eng):
+        super().__init__()
+        self._eng = eng
+
+    def __getitem__(self, k):
+        if k == 'X7':
+            self._eng._materialize_x7()
+        return dict.__getitem__(self, k)
+
+
 class PCNetEngine:
     """Packed weights, sampling grid and workspaces of one PCNet for a fixed batch size; HIP forward and
     input-gradient passes over NHWC4 tensors."""
@@ -329,7 +343,7 @@ class PCNetEngine:
         def zh(*shape):
             return torch.zeros(*shape, device=dev, dtype=hd)
 
-        a = {}
+        a = _Activations(self)
         a['xw'], a['cat8'] = z(B, H, W, 4), z(B, H, W, 8)
         a['S1'], a['S2'], a['S3'], a['S4'] = zh(B, H2, W2, 32), zh(B, H4, W4, 64), zh(B, H4, W4, 128), zh(B, H4, W4, 256)
         a['X1'], a['R2'], a['X2'], a['R3'] = zh(B, H2, W2, 32), zh(B, H2, W2, 64), zh(B, H4, W4, 64), zh(B, H4, W4, 128)
@@ -352,6 +366,18 @@ class PCNetEngine:
         self.scene = None
         self._x = None
         self._clamp = 1
+        # tail / head fusion (csrc/shading_tail.hip): X7 and its gradient never reach HBM.  Needs the byte gate masks; the
+        # training step (weight gradients read X7 and P7) switches it off
+        self.fuse_tail = FUSE_TAIL and USE_GATE_MASKS and storage == 'f32' and H % 2 == 0 and W % 2 == 0
+        self._x7_version = -1    # `version` for which a['X7'] holds the activation
+        wt, w6 = sn.transConv2.weight.detach().float().cpu(), sn.conv6.weight.detach().float().cpu()
+        assert wt.shape == (64, 32, 2, 2) and w6.shape == (3, 32, 3, 3)
+        self.tail = dict(
+            w2s=cp.split_planes(wt.permute(2, 3, 1, 0).reshape(128, 64)).to(dev),      # [3][32 (2 py + px) + c][k]
+            w2ts=cp.split_planes(wt.permute(0, 2, 3, 1).reshape(64, 128)).to(dev),     # [3][n][32 (2 py + px) + c]
+            w6=w6.permute(0, 2, 3, 1).reshape(3, 9, 32).contiguous().to(dev),          # [o][3 ky + kx][c]
+            w6t=w6.flip(2, 3).permute(2, 3, 0, 1).reshape(27, 32).contiguous().to(dev),  # [3 t + o][c], taps mirrored
+            b2=sn.transConv2.bias.detach().float().contiguous().to(dev), b6=sn.conv6.bias.detach().float().contiguous().to(dev))
         self.owner = None    # weakref to the AttackState this engine is leased to (PCNet.engine)
         self.version = 0     # bumped whenever the activation workspaces are overwritten (set_scene / forward)
 
@@ -397,8 +423,16 @@ class PCNetEngine:
         f['conv4'].run(a['X3'], a['X4'], add=a['S4'], act=R, mask_out=m['X4'])
         f['conv5'].run(a['X4'], a['X5'], add=a['R3'], act=R, mask_out=m['X5'])
         f['transConv1'].run(a['X5'], a['X6'], add=a['R2'], act=R, mask_out=m['X6'])
-        f['transConv2'].run(a['X6'], a['X7'], act=R, mask_out=m['X7'])
-        f['conv6'].run(a['X7'], a['Y'], add=a['R1'], act=_lib.ACT_RELU_CLAMP1, aux_out=a['Ypre'])
+        if self.fuse_tail:
+            t = self.tail
+            _lib.call('spaa_shading_tail_fwd', _lib.ptr(a['X6']), _lib.ptr(t['w2s']), _lib.ptr(t['b2']), _lib.ptr(t['w6']),
+                      _lib.ptr(t['b6']), _lib.ptr(a['R1']), _lib.ptr(a['Y']), _lib.ptr(a['Ypre']), _lib.ptr(m['X7']), self.B,
+                      self.Hc // 2, self.Wc // 2)
+            return a['Y']
+        x7 = dict.__getitem__(a, 'X7')
+        f['transConv2'].run(a['X6'], x7, act=R, mask_out=m['X7'])
+        f['conv6'].run(x7, a['Y'], add=a['R1'], act=_lib.ACT_RELU_CLAMP1, aux_out=a['Ypre'])
+        self._x7_version = self.version
         return a['Y']
 
     def backward(self, gP):
@@ -407,8 +441,15 @@ class PCNetEngine:
         if not USE_GATE_MASKS and self.storage == 'f32':
             return self._backward_float_gates(gP)
         g, d, m = self.g, self.d, self.m
-        d['conv6'].run(gP, g['P7'], gate_bits=m['X7'])
-        d['transConv2'].run(g['P7'], g['P6'], gate_bits=m['X6'])
+        if self.fuse_tail and self.storage == 'f32':
+            t = self.tail
+            _lib.check_dev(gP)
+            assert gP.shape == (self.B, self.Hc, self.Wc, 4) and gP.dtype == torch.float32
+            _lib.call('spaa_shading_head_bwd', _lib.ptr(gP), _lib.ptr(t['w6t']), _lib.ptr(t['w2ts']), _lib.ptr(m['X7']),
+                      _lib.ptr(m['X6']), _lib.ptr(g['P6']), self.B, self.Hc // 2, self.Wc // 2)
+        else:
+            d['conv6'].run(gP, g['P7'], gate_bits=m['X7'])
+            d['transConv2'].run(g['P7'], g['P6'], gate_bits=m['X6'])
         d['transConv1'].run(g['P6'], g['P5'], gate_bits=m['X5'])
         d['conv5'].run(g['P5'], g['P4'], gate_bits=m['X4'], aux_out=g['S4'], gate2_bits=m['S4'])
         d['conv4'].run(g['P4'], g['P3'], gate_bits=m['X3'])
@@ -449,6 +490,13 @@ class PCNetEngine:
         """Recompute the gate masks from the activation buffers (after a test has overwritten the activations)."""
         for k, mk in self.m.items():
             mk.copy_(_lib.pack_gate_mask(self.a[k].float()))
+
+    def _materialize_x7(self):
+        """With the fused tail X7 lives in LDS only; whoever asks for a['X7'] (parity tests, tools) gets it recomputed from X6
+        by the stand-alone transConv2 launch."""
+        if getattr(self, 'fuse_tail', False) and self._x7_version != self.version and self.scene is not None:
+            self.f['transConv2'].run(dict.__getitem__(self.a, 'X6'), dict.__getitem__(self.a, 'X7'), act=_lib.ACT_RELU)
+            self._x7_version = self.version
 
     def warp_backward(self, g_xw):
         """Adjoint of the masked grid_sample (models.py:184,340): deterministic gather over the transposed tap lists; the

@@ -80,6 +80,7 @@ class PCNetTrainer:
         wn, sn = self.pc.warping_net, self.pc.shading_net
         dev = self.dev
         eng = PCNetEngine(self.pc, self.B, prj_size)
+        eng.fuse_tail = False   # the weight gradients of conv6 / transConv2 read X7 and its gradient
         self.maps = []   # (plan, parameter, bias parameter or None)
 
         def reg(plan, builder, mod, with_bias):

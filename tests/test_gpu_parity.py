@@ -1315,11 +1315,57 @@ def test_engine_masks_match_activations(hip, golden_dir):
     st.forward_decide(True, 5, 0.9)
     lib = hip['lib']
     for k, m in st.eng.m.items():
-        assert torch.equal(m, lib.pack_gate_mask(st.eng.a[k])), k
+        want = lib.pack_gate_mask(st.eng.a[k])
+        if k == 'X7' and st.eng.fuse_tail:
+            # the fused tail wrote X7's gates; a['X7'] is recomputed on demand by the stand-alone launch (another summation
+            # order): the two may disagree on units within rounding of zero, nowhere else
+            bad = (m != want)
+            assert bad.float().mean() < 1e-4
+            if bad.any():
+                assert st.eng.a[k].view(*m.shape, 4)[bad].abs().max() < 1e-5 * st.eng.a[k].abs().max()
+        else:
+            assert torch.equal(m, want), k
     body = st.clf.body
     for blk in body.blocks:
         assert torch.equal(blk['m_o1'], lib.pack_gate_mask(blk['o1'])) and torch.equal(blk['m_out'], lib.pack_gate_mask(blk['out']))
     assert torch.equal((body.mp_arg & 128) != 0, body.mp > 0)
+
+
+@pytest.mark.parametrize('cam_sz,b', [((64, 96), 2), ((72, 100), 3), ((256, 256), 1)])
+def test_fused_shading_tail_and_head(hip, cam_sz, b):
+    """csrc/shading_tail.hip: transConv2 + conv6 forward and their input gradients as one kernel each (X7 and its gradient stay
+    in LDS) against the separate launches on the same engine: outputs, gate bytes and the gradient handed to transConv1."""
+    lib, m_ = hip['lib'], hip['models']
+    torch.manual_seed(cam_sz[0] + b)
+    sd = syn.pcnet_state_dict(4, cam_sz=cam_sz, mask='ones')
+    pc = make_pcnet(hip, sd, cam_sz)
+    eng = m_.PCNetEngine(pc, b, cam_sz)
+    assert eng.fuse_tail
+    x = torch.rand(b, cam_sz[0], cam_sz[1], 4, device=DEV)
+    x[..., 3] = 0
+    scene = torch.rand(b, cam_sz[0], cam_sz[1], 4, device=DEV)
+    scene[..., 3] = 0
+    eng.set_scene(scene)
+    y_f = eng.forward(x).clone()
+    ypre_f, m7_f = eng.a['Ypre'].clone(), eng.m['X7'].clone()
+    gP = torch.randn(b, cam_sz[0], cam_sz[1], 4, device=DEV)
+    gP[..., 3] = 0
+    eng.backward(gP)
+    p6_f = eng.g['P6'].clone()
+    eng.fuse_tail = False
+    y_s = eng.forward(x).clone()
+    ypre_s, m7_s = eng.a['Ypre'].clone(), eng.m['X7'].clone()
+    assert rel_inf(y_f, y_s) < 2e-6 and rel_inf(ypre_f, ypre_s) < 2e-6
+    bad = m7_f != m7_s
+    assert bad.float().mean() < 1e-4      # (units within rounding of zero may fall on either side)
+    if bad.any():
+        assert eng.a['X7'].view(*m7_s.shape, 4)[bad].abs().max() < 1e-5 * eng.a['X7'].abs().max()
+    eng.m['X7'].copy_(m7_f)               # the same gates for both backward passes
+    eng.backward(gP)
+    print(f'{cam_sz} b={b}: Y {rel_inf(y_f, y_s):.1e}  Ypre {rel_inf(ypre_f, ypre_s):.1e}  gate bytes differing {int(bad.sum())}  '
+          f'P6 {rel_inf(p6_f, eng.g["P6"]):.1e}')
+    assert rel_inf(p6_f, eng.g['P6']) < 2e-6
+    eng.fuse_tail = True
 
 
 # ---------------------------------------------------------------------------------------------------------------
