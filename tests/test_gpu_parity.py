@@ -174,7 +174,7 @@ def test_tapconv_x6_is_fp32_accurate(hip, tile):
         cp.FORCE_TILE = 0
 
 
-@pytest.mark.parametrize('ci,co,h,w,b', [(128, 256, 64, 64, 2), (256, 128, 30, 44, 3), (64, 128, 17, 35, 2), (32, 192, 16, 32, 1)])
+@pytest.mark.parametrize('ci,co,h,w,b', [(128, 256, 64, 64, 2), (256, 128, 30, 44, 3), (64, 128, 17, 35, 2), (64, 192, 16, 32, 1)])
 def test_winograd_is_fp32_accurate(hip, ci, co, h, w, b):
     """3x3 / s1 / p1 layers through Winograd F(2x2,3x3) on the bf16x6 arithmetic (csrc/tapconv_wino.hip): forward and input
     gradient against fp64.  The transforms add roundings: the bound is 3x the exact-fp32 MFMA kernel's error (measured ~2x)."""
