@@ -145,14 +145,17 @@ def pmc_traffic(tile):
     if path is None:
         return None, None
     m = re.match(r'(x6d(?:16)?(?:co)?(?:a3)?|x6v\d|x6)_(\d+)x(\d+)(?:g(\d))?', tile)
-    if not m:
+    if tile.startswith('wino'):
+        want = 'wino_x6_kernel<128, 0>'       # (template arguments: N tile, measurement variant)
+    elif not m:
         return None, None
-    fam, bm, bn, g = m.groups()
-    if fam.startswith('x6d'):  # tapconv_x6d_kernel<waves, BN, MFMA shape, coalesced epilogue, pixel stages>
-        want = (f'tapconv_x6d_kernel<{int(bm) // 32}, {bn}, {16 if "16" in fam else 32}, '
-                f'{"true" if "co" in fam else "false"}, {3 if fam.endswith("a3") else 2}>')
     else:
-        want = f'tapconv_{fam}_kernel<{bm}, {bn}' + (f', {g}>' if g else '>')
+        fam, bm, bn, g = m.groups()
+        if fam.startswith('x6d'):  # tapconv_x6d_kernel<waves, BN, MFMA shape, coalesced epilogue, pixel stages>
+            want = (f'tapconv_x6d_kernel<{int(bm) // 32}, {bn}, {16 if "16" in fam else 32}, '
+                    f'{"true" if "co" in fam else "false"}, {3 if fam.endswith("a3") else 2}>')
+        else:
+            want = f'tapconv_{fam}_kernel<{bm}, {bn}' + (f', {g}>' if g else '>')
     with open(path) as fh:
         for k, e in json.load(fh)['kernels'].items():
             if k.startswith(want):
