@@ -75,10 +75,10 @@ template <int BN, int VAR>
 __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p, const int wg_y, const int wg_x, const int n_tiles) {
     constexpr int TJ = BN / 16;
     constexpr int W_PLANE = BN * 64;
-    constexpr int WS_BYTES = 3 * W_PLANE;
-    constexpr int W_PIECES = 3 * BN / 16;
     constexpr int NW = 8;
+    constexpr int W_PIECES = 3 * BN / 16;
     constexpr int WPW = (W_PIECES + NW - 1) / NW;
+    constexpr int WS_BYTES = WPW * NW * 1024;   // (every wave issues WPW DMAs per step: pieces past the planes land in the pad)
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* wsm = smem + PATCH_BYTES;
 
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
         const int pl = q / (BN / 16), rb = q % (BN / 16);
         const int n = 16 * rb + (lane >> 2);
         const int c = (lane & 3) ^ swz_w16(n);
-        w_goff[i] = pl * plane_bytes + (n_blk + n) * cl.Kpad * 2 + c * 16;
+        w_goff[i] = q < W_PIECES ? pl * plane_bytes + (n_blk + n) * cl.Kpad * 2 + c * 16 : (int)0x80000000;
     }
     const int w_addr_l = (lane & 15) * 64 + (((lane >> 4) ^ swz_w16(lane & 15)) * 16);
 
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
     {                                                                                                              \
         const int kb_ = (step) >> 4, pos_ = (step) & 15;                                                           \
         const int soff_ = (pos_ * Cin + kb_ * 32) * 2;                                                             \
-        _Pragma("unroll") for (int i = 0; i < WPW; ++i) if (W_PIECES % NW == 0 || wave + NW * i < W_PIECES)        \
+        _Pragma("unroll") for (int i = 0; i < WPW; ++i)                                                             \
             dma16(rsrc_w, wsm + (st) * WS_BYTES + (wave + NW * i) * 1024, w_goff[i], soff_);                       \
     }
     // pipeline: weight stages three deep (the DMA of step t+2 is issued at step t); the patch of the next channel block is
@@ -324,6 +324,9 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                      (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
                      (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
                      (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
+    constexpr int ROWB = BN * 4;          // bytes of a pixel's BN channels in the LDS image
+    constexpr int LPP = BN / 4;           // lanes (16-byte chunks) per pixel: 32 or 16
+    constexpr int PPI = 64 / LPP;         // pixels per wave store instruction
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         __syncthreads();   // the main loop's (resp. the previous half's) LDS reads are done
@@ -332,15 +335,15 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
             const int pl = 32 * wave + 2 * tx + c;
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
-                *reinterpret_cast<f32x4*>(smem + pl * 512 + (((4 * j + q8) ^ tx) << 4)) = Y[2 * half + c][j];
+                *reinterpret_cast<f32x4*>(smem + pl * ROWB + (((4 * j + q8) ^ tx) << 4)) = Y[2 * half + c][j];
         }
         __syncthreads();
 #pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int pl = 2 * (16 * wave + it) + (lane >> 5);
-            const int pc = lane & 31;                       // physical chunk
+        for (int it = 0; it < 32 / PPI; ++it) {   // 256 pixels / 8 waves / PPI
+            const int pl = PPI * ((32 / PPI) * wave + it) + lane / LPP;
+            const int pc = lane & (LPP - 1);                // physical chunk
             const int lc = pc ^ ((pl & 31) >> 1);           // logical chunk: channels 4 lc .. 4 lc + 3 of this n tile
-            const f32x4 y = *reinterpret_cast<const f32x4*>(smem + pl * 512 + (pc << 4));
+            const f32x4 y = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + (pc << 4));
             const int oy = oy0 + 2 * (pl >> 5) + half, ox = ox0 + (pl & 31);
             if (oy < p.Hout && ox < p.Wout) {
                 float v[4] = {y[0], y[1], y[2], y[3]};
@@ -356,26 +359,27 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
 // Winograd form: ONE class with 16 "taps" = the positions of U = G g G^T (tap entries unused), s_in = s_out = 1, same input and
 // output size, Cin % 32 == 0.
 int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
-    constexpr int BN = 128;
     if (d.w_split == nullptr || (d.Cin % 32) != 0 || d.nclass != 1 || d.cls[0].ntaps != 16 || d.cls[0].K != 16 * d.Cin || d.cls[0].Kpad < d.cls[0].K || (d.cls[0].Kpad & 7) ||
         d.s_in != 1 || d.s_out != 1 || d.Hin != d.Hout || d.Win != d.Wout || d.Hm != d.Hout || d.Wm != d.Wout || d.nfold > 1 ||
         d.ksplit > 1 || d.ksplit < 0 || d.io_dtype != 0)
         return hipErrorInvalidValue;
     if ((int64_t)((d.Cout + 127) & ~127) * d.cls[0].Kpad * 6 >= (int64_t)1 << 31) return hipErrorInvalidValue;
+    const int BN = d.Cout <= 64 ? 64 : 128;   // N tile: the 64-wide instantiation for layers with at most 64 output channels
     const int wg_y = (d.Hout + 2 * TY - 1) / (2 * TY), wg_x = (d.Wout + 2 * TX - 1) / (2 * TX);
     const int n_tiles = (d.Cout + BN - 1) / BN;
     const int64_t nwg = (int64_t)d.B * wg_y * wg_x * n_tiles;
     if (nwg > 0x7fffffff) return hipErrorInvalidValue;
-    const size_t smem = (size_t)PATCH_BYTES + 3 * (size_t)(3 * BN * 64);
-    static bool attr_set[4][SPAA_MAX_DEVICES] = {};
+    static bool attr_set[5][SPAA_MAX_DEVICES] = {};
     const int var = (d.reserved0 >> 16) & 3;   // measurement variants of the kernel (0 = default)
-#define WINO_LAUNCH(V)                                                                                                    \
+#define WINO_LAUNCH(N, V, SLOT)                                                                                           \
     {                                                                                                                     \
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<BN, V>), (int)smem, attr_set[V]); \
+        const size_t smem = (size_t)PATCH_BYTES + 3 * (size_t)(((3 * N / 16 + 7) / 8) * 8 * 1024);                        \
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<N, V>), (int)smem, attr_set[SLOT]); \
         if (e != hipSuccess) return (int)e;                                                                               \
-        hipLaunchKernelGGL((wino_x6_kernel<BN, V>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles); \
+        hipLaunchKernelGGL((wino_x6_kernel<N, V>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles); \
     }
-    if (var == 0) WINO_LAUNCH(0) else if (var == 1) WINO_LAUNCH(1) else if (var == 2) WINO_LAUNCH(2) else WINO_LAUNCH(3)
+    if (BN == 64) WINO_LAUNCH(64, 0, 4)
+    else if (var == 0) WINO_LAUNCH(128, 0, 0) else if (var == 1) WINO_LAUNCH(128, 1, 1) else if (var == 2) WINO_LAUNCH(128, 2, 2) else WINO_LAUNCH(128, 3, 3)
 #undef WINO_LAUNCH
     return (int)hipGetLastError();
 }

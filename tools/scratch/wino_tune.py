@@ -11,7 +11,7 @@ for k, v in sorted(t.items()):
     if not (p[2] == '9' and p[3] == '1' and p[4] == '1' and 'fold' not in k):
         continue
     ci, co, m = int(p[0]), int(p[1]), int(p[5])
-    if ci % 32 or co < 96:
+    if ci % 32 or co < 64:
         continue
     hw = int(round(math.sqrt(m / 64)))
     if 64 * hw * hw != m:
