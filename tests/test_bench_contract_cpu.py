@@ -48,11 +48,14 @@ def test_rocprof_summary_agrees_with_bench_roofline():
     stats = path.replace('_bench.json', '_rocprofv3_kernel_stats.csv')
     assert os.path.exists(stats), stats
     kern = b['roofline']['kernel']
-    m = re.match(r'tapconv_(x6d(?:16)?(?:co)?(?:a3)?)_(\d+)x(\d+)', kern)
-    assert m, kern
-    fam, bm, bn = m.groups()
-    want = (f'tapconv_x6d_kernel<{int(bm) // 32}, {bn}, {16 if "16" in fam else 32}, {"true" if "co" in fam else "false"}, '
-            f'{3 if fam.endswith("a3") else 2}>')
+    if kern.startswith('tapconv_wino'):
+        want = 'wino_x6_kernel<128, 0>'
+    else:
+        m = re.match(r'tapconv_(x6d(?:16)?(?:co)?(?:a3)?)_(\d+)x(\d+)', kern)
+        assert m, kern
+        fam, bm, bn = m.groups()
+        want = (f'tapconv_x6d_kernel<{int(bm) // 32}, {bn}, {16 if "16" in fam else 32}, {"true" if "co" in fam else "false"}, '
+                f'{3 if fam.endswith("a3") else 2}>')
     with open(stats) as fh:
         rows = [r for r in csv.DictReader(fh) if want in r['Name']]
     assert len(rows) == 1, (want, len(rows))
