@@ -275,6 +275,8 @@ def instrumented_pass(st, args, n_prof=3):
         if kern == 70 and int(key.split('_')[1]) <= 64:   # the 64-wide instantiation is a kernel of its own for rocprofv3
             base = 'wino_x6_16x32x64'
         tile = convplan.TILE_NAMES.get(tile_id % 100, 'auto') + (('_streamk' if tile_id // 100 == 9 else f'_splitk{tile_id // 100}') if tile_id >= 100 else '')
+        if base == 'wino_x6_16x32x64':
+            tile = base
         a = per_tile.setdefault(base, [0.0, 0.0, 0, 0.0])
         a[0] += flops
         a[1] += ms

@@ -131,6 +131,78 @@ __device__ __forceinline__ void store4_t(const spaa_tapconv_t& p, const size_t o
     }
 }
 
+// The same epilogue in two steps, so that a kernel can have the operand loads of several pixels in flight before it
+// finishes (and stores) any of them: epi_load() fetches what the vector path of store4_t reads besides the accumulators
+// (residual, gates), store4_pre() is store4_t's vector path on those values.
+struct epi_pre_t {
+    f4 add, gate, gate2;
+    unsigned int gbits, g2bits;
+};
+
+template <typename T>
+__device__ __forceinline__ epi_pre_t epi_load(const spaa_tapconv_t& p, const size_t o, const int n0) {
+    epi_pre_t r;
+    r.add = r.gate = r.gate2 = f4{0.f, 0.f, 0.f, 0.f};
+    r.gbits = r.g2bits = 0;
+    if (n0 >= p.Cout) return r;
+    if (p.add != nullptr) r.add = io4<T>::ld(p.add, o * p.add_cstride + p.add_coff + n0);
+    if (p.gate != nullptr) r.gate = io4<T>::ld(p.gate, o * p.gate_cstride + p.gate_coff + n0);
+    else if (p.gate_bits != nullptr) r.gbits = p.gate_bits[(o * p.gate_cstride + p.gate_coff + n0) >> 2];
+    if (p.gate2 != nullptr) r.gate2 = io4<T>::ld(p.gate2, o * p.gate2_cstride + p.gate2_coff + n0);
+    else if (p.gate2_bits != nullptr) r.g2bits = p.gate2_bits[(o * p.gate2_cstride + p.gate2_coff + n0) >> 2];
+    return r;
+}
+
+template <typename T>
+__device__ __forceinline__ void store4_pre(const spaa_tapconv_t& p, const size_t o, const int n0, float (&v)[4], const epi_pre_t& r) {
+    if (n0 >= p.Cout) return;
+    if (p.bias != nullptr) {
+        const f4 bb = *reinterpret_cast<const f4*>(p.bias + n0);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+    }
+    if (p.add != nullptr) { v[0] += r.add.x; v[1] += r.add.y; v[2] += r.add.z; v[3] += r.add.w; }
+    const size_t oi = o * p.out_cstride + p.out_coff + n0;
+    if (p.act == SPAA_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (p.act == SPAA_ACT_RELU_CLAMP1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        if (p.aux_out != nullptr) io4<T>::st(p.aux_out, oi, f4{v[0], v[1], v[2], v[3]});
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fminf(v[e], 1.f);
+    } else if (p.act == SPAA_ACT_LEAKY01) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.1f * v[e];
+    }
+    if (p.gate != nullptr) {
+        const float ga[4] = {r.gate.x, r.gate.y, r.gate.z, r.gate.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool pass = (p.gate_mode == SPAA_GATE_POS_LE1) ? (ga[e] > 0.f && ga[e] <= 1.f) : (ga[e] > 0.f);
+            v[e] = (p.gate_mode == SPAA_GATE_MUL) ? v[e] * ga[e] : (pass ? v[e] : 0.f);
+        }
+    } else if (p.gate_bits != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ((r.gbits >> e) & 1u) ? v[e] : 0.f;
+    }
+    if (sizeof(T) == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (float)(_Float16)v[e];
+    }
+    io4<T>::st(p.out, oi, f4{v[0], v[1], v[2], v[3]});
+    if (p.mask_out != nullptr)
+        p.mask_out[(o * p.out_cstride + p.out_coff + n0) >> 2] =
+            (uint8_t)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
+    if (p.gate2 != nullptr) {
+        io4<T>::st(p.aux_out, oi, f4{r.gate2.x > 0.f ? v[0] : 0.f, r.gate2.y > 0.f ? v[1] : 0.f, r.gate2.z > 0.f ? v[2] : 0.f,
+                                    r.gate2.w > 0.f ? v[3] : 0.f});
+    } else if (p.gate2_bits != nullptr) {
+        io4<T>::st(p.aux_out, oi, f4{(r.g2bits & 1u) ? v[0] : 0.f, (r.g2bits & 2u) ? v[1] : 0.f, (r.g2bits & 4u) ? v[2] : 0.f,
+                                    (r.g2bits & 8u) ? v[3] : 0.f});
+    }
+}
+
 // storage type chosen at run time (kernels that read fp32 IMAGES and may write fp16 activations: smallcin, x6v2/v3; the
 // fp32-only bf16x6 kernels call store4_t<float> directly and keep their register budget)
 __device__ __forceinline__ void store4(const spaa_tapconv_t& p, const size_t o, const int n0, float (&v)[4], const bool vec) {

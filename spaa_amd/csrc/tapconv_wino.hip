@@ -338,16 +338,33 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                 *reinterpret_cast<f32x4*>(smem + pl * ROWB + (((4 * j + q8) ^ tx) << 4)) = Y[2 * half + c][j];
         }
         __syncthreads();
-#pragma unroll 4
-        for (int it = 0; it < 32 / PPI; ++it) {   // 256 pixels / 8 waves / PPI
-            const int pl = PPI * ((32 / PPI) * wave + it) + lane / LPP;
-            const int pc = lane & (LPP - 1);                // physical chunk
-            const int lc = pc ^ ((pl & 31) >> 1);           // logical chunk: channels 4 lc .. 4 lc + 3 of this n tile
-            const f32x4 y = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + (pc << 4));
-            const int oy = oy0 + 2 * (pl >> 5) + half, ox = ox0 + (pl & 31);
-            if (oy < p.Hout && ox < p.Wout) {
-                float v[4] = {y[0], y[1], y[2], y[3]};
-                store4_t<float>(p, ((size_t)img * p.Hout + oy) * p.Wout + ox, n_blk + 4 * lc, v, vec);
+        // the residual / gate operands of EB pixels are requested before any of them is finished: EB loads in flight per lane
+        constexpr int EB = 8;
+#pragma unroll 1
+        for (int it0 = 0; it0 < 32 / PPI; it0 += EB) {   // 256 pixels / 8 waves / PPI per wave
+            epi_pre_t pre[EB];
+            size_t oo[EB];
+            bool ok[EB];
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const int pl = PPI * ((32 / PPI) * wave + it0 + u) + lane / LPP;
+                const int lc = (lane & (LPP - 1)) ^ ((pl & 31) >> 1);
+                const int oy = oy0 + 2 * (pl >> 5) + half, ox = ox0 + (pl & 31);
+                ok[u] = oy < p.Hout && ox < p.Wout;
+                oo[u] = ((size_t)img * p.Hout + (ok[u] ? oy : 0)) * p.Wout + (ok[u] ? ox : 0);
+                if (vec && ok[u]) pre[u] = epi_load<float>(p, oo[u], n_blk + 4 * lc);
+            }
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const int pl = PPI * ((32 / PPI) * wave + it0 + u) + lane / LPP;
+                const int pc = lane & (LPP - 1);                // physical chunk
+                const int lc = pc ^ ((pl & 31) >> 1);           // logical chunk: channels 4 lc .. 4 lc + 3 of this n tile
+                const f32x4 y = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + (pc << 4));
+                if (ok[u]) {
+                    float v[4] = {y[0], y[1], y[2], y[3]};
+                    if (vec) store4_pre<float>(p, oo[u], n_blk + 4 * lc, v, pre[u]);
+                    else store4_t<float>(p, oo[u], n_blk + 4 * lc, v, vec);
+                }
             }
         }
     }
