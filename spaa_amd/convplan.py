@@ -40,6 +40,8 @@ DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
 DEBUG_TAPMAJOR = int(os.environ.get('SPAA_X6D_TAPMAJOR', '0'))      # 1: tap-major K order (A/B measurements only)
 DEBUG_PERSIST_CAP = int(os.environ.get('SPAA_X6D_PERSIST_CAP', '0'))  # > 0: persistent launches use this many workgroups
 DEBUG_WINO = int(os.environ.get('SPAA_WINO_DBG', '0'))              # timing experiments of the Winograd kernel
+FOLD_K3S2 = os.environ.get('SPAA_FOLD_K3S2', '1') != '0'   # 3x3 / s2 input gradients with few output channels: classes folded
+FOLD_K3S2_MAX_COUT = 32
 FOLD_DECONV = True  # k2/s2 transposed convs: parity classes folded into GEMM rows (one read of the input)
 ENABLE_X6 = True  # build the split-bf16 weight planes (needed by tiles 12-14)
 WINOGRAD = os.environ.get('SPAA_WINOGRAD', '1') != '0'  # 3x3/s1 layers: allow the Winograd F(2x2,3x3) kernel (tile 70)
@@ -496,7 +498,24 @@ def _fractional_classes(wsel, kh, kw, pad):
     return classes
 
 
-def conv_dgrad_plan(weight, stride, pad, device='cuda', name='', in_ch=None):
+def _fold_classes(classes, cout, cin):
+    """Four output-parity classes of a stride-2 fractional layer as ONE class over the union of their taps, the classes stacked
+    in the GEMM rows (row c * cout + n, c = 2 py + px); a class without a tap gets zero weights there (3x3 / s2: 9 of the 16
+    (class, tap) pairs are real).  One pass over the input instead of four, N = 4 cout."""
+    by_par = {(c.oy0, c.ox0): c for c in classes}
+    taps = sorted({(dy, dx) for c in classes for dy, dx, _ in c.taps})
+    zero = torch.zeros(cout, cin)
+    f = TapClassSpec(0, 0)
+    for dy, dx in taps:
+        rows = []
+        for par in ((0, 0), (0, 1), (1, 0), (1, 1)):
+            w = [w_ for dy_, dx_, w_ in by_par[par].taps if (dy_, dx_) == (dy, dx)]
+            rows.append(w[0] if w else zero)
+        f.add(dy, dx, torch.cat(rows, 0))
+    return f
+
+
+def conv_dgrad_plan(weight, stride, pad, device='cuda', name='', in_ch=None, fold=None):
     """Input gradient of nn.Conv2d: consumes grad_out [.., co], produces grad_in [.., ci].
     `in_ch=(lo, hi)` restricts the produced input channels (used for conv1_s, whose first 3 inputs are constant)."""
     w = _w2(weight)
@@ -514,7 +533,10 @@ def conv_dgrad_plan(weight, stride, pad, device='cuda', name='', in_ch=None):
                 c.add(ph - ky, pw - kx, wsel(ky, kx))
         return attach_winograd(ConvPlan([c], co, hi - lo, 1, 1, None, device, name))
     assert stride == 2
-    return ConvPlan(_fractional_classes(wsel, kh, kw, pad), co, hi - lo, 1, 2, None, device, name)
+    classes = _fractional_classes(wsel, kh, kw, pad)
+    if (FOLD_K3S2 if fold is None else fold) and kh == 3 and kw == 3 and co % 32 == 0 and (hi - lo) % 4 == 0 and ENABLE_X6 and (fold or hi - lo <= FOLD_K3S2_MAX_COUT):
+        return ConvPlan([_fold_classes(classes, hi - lo, co)], co, hi - lo, 1, 2, None, device, name, nfold=4)
+    return ConvPlan(classes, co, hi - lo, 1, 2, None, device, name)
 
 
 def deconv_fwd_plan(weight, bias, stride, pad, device='cuda', name='', fold=None):
@@ -532,7 +554,10 @@ def deconv_fwd_plan(weight, bias, stride, pad, device='cuda', name='', fold=None
         c = TapClassSpec(0, 0)
         c.add(0, 0, torch.cat([wsel(dy, dx) for dy in (0, 1) for dx in (0, 1)], 0))
         return ConvPlan([c], ci, co, 1, 2, bias, device, name, nfold=4)
-    return ConvPlan(_fractional_classes(wsel, kh, kw, pad), ci, co, 1, 2, bias, device, name)
+    classes = _fractional_classes(wsel, kh, kw, pad)
+    if fold and kh == 3 and kw == 3 and ci % 32 == 0 and co % 4 == 0 and ENABLE_X6:   # (measured slower for transConv1: opt-in)
+        return ConvPlan([_fold_classes(classes, co, ci)], ci, co, 1, 2, bias, device, name, nfold=4)
+    return ConvPlan(classes, ci, co, 1, 2, bias, device, name)
 
 
 def deconv_dgrad_plan(weight, stride, pad, device='cuda', name=''):

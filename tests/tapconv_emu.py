@@ -11,11 +11,17 @@ def emulate(plan, inp, hout, wout):
     out = torch.zeros(b, hout, wout, plan.cout)
     if getattr(plan, 'nfold', 1) > 1:
         # spaa_tapconv_t.nfold: GEMM row c*Cout + n -> output pixel (2y + c//2, 2x + c%2), channel n
-        (dy, dx, w), = plan.classes_host[0].taps
-        assert (dy, dx) == (0, 0) and plan.s_in == 1 and plan.s_out == 2
-        acc = inp[..., :cin] @ w.t()                      # [b, hin, win, 4*cout]
+        # (k2/s2: the one tap (0, 0); k3/s2: the 2x2 neighbourhood, zero weights where a class has no tap)
+        assert plan.s_in == 1 and plan.s_out == 2
+        hm, wm = (hout + 1) // 2, (wout + 1) // 2
+        acc = torch.zeros(b, hm, wm, 4 * plan.cout)
+        for dy, dx, w in plan.classes_host[0].taps:
+            iy, ix = torch.arange(hm) + dy, torch.arange(wm) + dx
+            vy, vx = (iy >= 0) & (iy < hin), (ix >= 0) & (ix < win)
+            g = inp[:, iy.clamp(0, hin - 1)][:, :, ix.clamp(0, win - 1)][..., :cin]
+            acc += (g * (vy.view(1, -1, 1, 1) & vx.view(1, 1, -1, 1))) @ w.t()
         for c in range(4):
-            oy, ox = 2 * torch.arange(hin) + c // 2, 2 * torch.arange(win) + c % 2
+            oy, ox = 2 * torch.arange(hm) + c // 2, 2 * torch.arange(wm) + c % 2
             ky, kx = oy < hout, ox < wout
             out[:, oy[ky][:, None], ox[kx][None, :]] = acc[:, ky][:, :, kx][..., c * plan.cout:(c + 1) * plan.cout]
         return out + plan.bias.cpu() if plan.bias is not None else out

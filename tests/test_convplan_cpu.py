@@ -26,6 +26,27 @@ def test_conv_fwd_and_dgrad(ci, co, k, s, p, h, w):
     assert torch.allclose(nchw(gx), x.grad, atol=1e-4)
 
 
+@pytest.mark.parametrize('ci,co,h,w', [(8, 32, 12, 10), (4, 64, 9, 7)])
+def test_k3s2_classes_folded_into_gemm_rows(ci, co, h, w):
+    """3x3 / stride-2 input gradient and transposed convolution with the four parity classes folded into the GEMM rows (zero
+    weights where a class has no tap): the same result as the four separate classes."""
+    x = torch.randn(2, ci, h, w, requires_grad=True)
+    wt = torch.randn(co, ci, 3, 3)
+    y = F.conv2d(x, wt, None, 2, 1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    dplan = cp.conv_dgrad_plan(wt, 2, 1, device='cpu', fold=True)
+    assert dplan.nfold == 4 and dplan.ntaps_total == 4
+    gx = emulate(dplan, nhwc(gy, dplan.cin_p), h, w)
+    assert torch.allclose(nchw(gx), x.grad, atol=1e-4)
+    xt = torch.randn(2, co, h, w)
+    wtt = torch.randn(co, ci, 3, 3)
+    yt = F.conv_transpose2d(xt, wtt, None, 2, 1, 1)
+    tplan = cp.deconv_fwd_plan(wtt, None, 2, 1, device='cpu', fold=True)
+    assert tplan.nfold == 4
+    assert torch.allclose(nchw(emulate(tplan, nhwc(xt), yt.shape[2], yt.shape[3])), yt, atol=1e-4)
+
+
 def test_conv_dgrad_channel_subset():
     x = torch.randn(1, 6, 8, 8, requires_grad=True)
     wt = torch.randn(5, 6, 3, 3)
