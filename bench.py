@@ -146,7 +146,7 @@ def pmc_traffic(tile):
         return None, None
     m = re.match(r'(x6d(?:16)?(?:co)?(?:a3)?|x6v\d|x6)_(\d+)x(\d+)(?:g(\d))?', tile)
     if tile.startswith('wino'):
-        want = f'wino_x6_kernel<{64 if tile.endswith("x64") else 128}, 0>'   # (template arguments: N tile, measurement variant)
+        want = 'wino_x6_kernel<64, 2>' if tile.endswith('x64') else 'wino_x6_kernel<128, 3>'   # (template arguments: N tile, kernel variant)
     elif not m:
         return None, None
     else:

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                              : (int)0x80000000;                                                                      \
         dma16(rsrc_in, smem + (wave + NW * i) * 1024, off_, 0);                                                      \
     }
-    constexpr bool LATE = VAR & 1, TWOCHAIN = (VAR >> 1) & 1;   // measurement variants (default 0)
+    constexpr bool LATE = VAR & 1, XIU = (VAR >> 1) & 1;   // measurement variants (default 0)
     const bool late = LATE && wave >= 4;
     f32x4 rc[4][2];   // s1 * d[a1][b] + s2 * d[a2][b] for the four patch columns b of the current xi (8 channels: two vectors)
     bf16x8 pf[3];     // V(xi, nu) of the current step, split
@@ -210,9 +210,10 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
     WINO_DMA_W(0, 0)
     if (nsteps > 1) WINO_DMA_W(1, 1)
     int st = 0;   // weight stage of the current step
-    for (int kb = 0; kb < nkb; ++kb) {
-#pragma unroll 1
-        for (int xi = 0; xi < 4; ++xi) {
+    // one xi group (four positions = four steps).  XIU: expanded for each xi (coefficients and row choices become immediates:
+    // no multiplications by 0 / +-1 in the fold and the row combination), else one body with run-time xi
+    auto xi_group = [&](const int kb, const int xi) __attribute__((always_inline)) {
+        {
             // A^T = [[1,1,1,0],[0,1,-1,-1]]: coefficient of M(xi, nu) in output (i, j) = At[i][xi] * At[j][nu]
             const float ci0 = xi < 3 ? 1.f : 0.f, ci1 = xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f);
 #pragma unroll
@@ -254,15 +255,7 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                         }
                         const bf16x8 w0 = wf[j & 1][0], w1 = wf[j & 1][1], w2 = wf[j & 1][2];
                         const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (TWOCHAIN) {   // the three small terms and the three large ones in separate chains, added at the end
-                            f32x4 ms = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, pf[0], zero, 0, 0, 0);
-                            f32x4 ml = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, pf[0], zero, 0, 0, 0);
-                            ms = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, pf[2], ms, 0, 0, 0);
-                            ml = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, pf[1], ml, 0, 0, 0);
-                            ms = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, pf[1], ms, 0, 0, 0);
-                            ml = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, pf[0], ml, 0, 0, 0);
-                            mm[j & 1] = ml + ms;
-                        } else {
+                        {
                             f32x4 m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, pf[0], zero, 0, 0, 0);
                             m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, pf[2], m, 0, 0, 0);
                             m = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, pf[1], m, 0, 0, 0);
@@ -273,13 +266,27 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                     }
                     if (j > 0) {
                         const f32x4 mp = mm[(j - 1) & 1];
-                        if (nu < 3) {
-                            Y[0][j - 1] = __builtin_elementwise_fma(mp, f32x4{ci0, ci0, ci0, ci0}, Y[0][j - 1]);
-                            Y[2][j - 1] = __builtin_elementwise_fma(mp, f32x4{ci1, ci1, ci1, ci1}, Y[2][j - 1]);
-                        }
-                        if (nu > 0) {
-                            Y[1][j - 1] = __builtin_elementwise_fma(mp, f32x4{c01, c01, c01, c01}, Y[1][j - 1]);
-                            Y[3][j - 1] = __builtin_elementwise_fma(mp, f32x4{c11, c11, c11, c11}, Y[3][j - 1]);
+                        if constexpr (XIU) {   // (xi is a constant here: additions / subtractions, nothing for a zero coefficient)
+                            if (nu < 3) {
+                                if (xi < 3) Y[0][j - 1] += mp;
+                                if (xi == 1) Y[2][j - 1] += mp;
+                                if (xi >= 2) Y[2][j - 1] -= mp;
+                            }
+                            if (nu > 0) {
+                                const bool neg = nu != 1;   // cj1 = -1
+                                if (xi < 3) Y[1][j - 1] = neg ? Y[1][j - 1] - mp : Y[1][j - 1] + mp;
+                                if (xi == 1) Y[3][j - 1] = neg ? Y[3][j - 1] - mp : Y[3][j - 1] + mp;
+                                if (xi >= 2) Y[3][j - 1] = neg ? Y[3][j - 1] + mp : Y[3][j - 1] - mp;
+                            }
+                        } else {
+                            if (nu < 3) {
+                                Y[0][j - 1] = __builtin_elementwise_fma(mp, f32x4{ci0, ci0, ci0, ci0}, Y[0][j - 1]);
+                                Y[2][j - 1] = __builtin_elementwise_fma(mp, f32x4{ci1, ci1, ci1, ci1}, Y[2][j - 1]);
+                            }
+                            if (nu > 0) {
+                                Y[1][j - 1] = __builtin_elementwise_fma(mp, f32x4{c01, c01, c01, c01}, Y[1][j - 1]);
+                                Y[3][j - 1] = __builtin_elementwise_fma(mp, f32x4{c11, c11, c11, c11}, Y[3][j - 1]);
+                            }
                         }
                         // (pins the fold here: without a use inside this scheduling region the optimiser sinks it to the loop's end)
                         // ... in fixed registers (Y[i][j] = v[32 i + 4 j ..]): in-place updates, no copies around the loop
@@ -311,6 +318,17 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                 }
                 st = st == 2 ? 0 : st + 1;
             }
+        }
+    };
+    for (int kb = 0; kb < nkb; ++kb) {
+        if constexpr (XIU) {
+            xi_group(kb, 0);
+            xi_group(kb, 1);
+            xi_group(kb, 2);
+            xi_group(kb, 3);
+        } else {
+#pragma unroll 1
+            for (int xi = 0; xi < 4; ++xi) xi_group(kb, xi);
         }
     }
 #undef WINO_DMA_PATCH
@@ -386,8 +404,10 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     const int n_tiles = (d.Cout + BN - 1) / BN;
     const int64_t nwg = (int64_t)d.B * wg_y * wg_x * n_tiles;
     if (nwg > 0x7fffffff) return hipErrorInvalidValue;
-    static bool attr_set[5][SPAA_MAX_DEVICES] = {};
-    const int var = (d.reserved0 >> 16) & 3;   // measurement variants of the kernel (0 = default)
+    static bool attr_set[8][SPAA_MAX_DEVICES] = {};
+    // kernel variant: bit 0 = late V (waves 4-7 transform one step ahead), bit 1 = xi groups expanded.  Default 3 / 2 (measured:
+    // conv4 500 -> 462 us, conv5 461 -> 415 us against variant 0); `reserved0` bits 16-17 flip bits for A/B measurements
+    const int var = (BN == 64 ? 2 : 3) ^ ((d.reserved0 >> 16) & 3);   // (64-wide tile: late V does not pay: 168 / 167 / 159 us for 0 / 3 / 2)
 #define WINO_LAUNCH(N, V, SLOT)                                                                                           \
     {                                                                                                                     \
         const size_t smem = (size_t)PATCH_BYTES + 3 * (size_t)(((3 * N / 16 + 7) / 8) * 8 * 1024);                        \
@@ -395,8 +415,9 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;                                                                               \
         hipLaunchKernelGGL((wino_x6_kernel<N, V>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles); \
     }
-    if (BN == 64) WINO_LAUNCH(64, 0, 4)
-    else if (var == 0) WINO_LAUNCH(128, 0, 0) else if (var == 1) WINO_LAUNCH(128, 1, 1) else if (var == 2) WINO_LAUNCH(128, 2, 2) else WINO_LAUNCH(128, 3, 3)
+    if (BN == 64) {
+        if (var == 3) WINO_LAUNCH(64, 3, 4) else if (var == 2) WINO_LAUNCH(64, 2, 5) else if (var == 1) WINO_LAUNCH(64, 1, 6) else WINO_LAUNCH(64, 0, 7)
+    } else if (var == 3) WINO_LAUNCH(128, 3, 3) else if (var == 2) WINO_LAUNCH(128, 2, 2) else if (var == 1) WINO_LAUNCH(128, 1, 1) else WINO_LAUNCH(128, 0, 0)
 #undef WINO_LAUNCH
     return (int)hipGetLastError();
 }
