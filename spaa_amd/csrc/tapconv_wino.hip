@@ -5,18 +5,24 @@
 // PCNet's MACs, /root/reference/src/python/models.py:286-298) sit at the chip's power wall in the direct form (DESIGN.md
 // section 3): fewer products is the only lever left there.
 //     Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A        g: 3x3 filter, d: 4x4 input patch (stride 2), Y: 2x2 outputs
-//   * U = G g G^T is computed on the host in fp64, rounded ONCE to fp32 and split exactly into three bf16 planes, packed like
-//     a 16-tap weight matrix  W[n][pos * Cin + c],  pos = 4 xi + nu  (spaa_amd/convplan.py: wino_*_plan);
+//   * U = G g G^T is computed in fp64, rounded ONCE to fp32 and split exactly into three bf16 planes, packed like a 16-tap
+//     weight matrix  W[n][pos * Cin + c],  pos = 4 xi + nu  (spaa_amd/convplan.py: attach_winograd); its rows are de-tuned by
+//     256 B: rows a multiple of 4 KiB apart all map to one L2 channel (measured: 16x slower);
 //   * V = B^T d B (entries are sums / differences of four inputs: +-1 coefficients, fp32 adds) is formed in registers from a
 //     patch of the input staged ONCE per 32-channel block in LDS by LDS-DMA (out-of-image pixels: the out-of-range offset,
-//     zeros = the convolution's zero padding), split into three bf16 fragments like every other activation operand;
+//     zeros = the convolution's zero padding; pixel-pair / chunk swizzle: conflict-free reads), split into three bf16
+//     fragments like every other activation operand;
 //   * per position one 32-deep product  M_pos = U_pos . V_pos  (6 bf16 MFMAs per 16x16 block, fp32 accumulation) is folded
-//     into the four output accumulators with A^T . A's +-1 coefficients:  16 + 4x16 accumulator registers per 16 channels;
-//   * a workgroup (8 waves) owns 8 x 16 Winograd tiles (16 x 32 output pixels) of one image x 128 output channels; wave w owns
-//     tile row w (16 tiles = the 16 columns of the MFMA's B operand); the U planes of a (position, channel block) are shared
-//     by the workgroup: 24 KB per step, two LDS stages, one barrier per step, DMA of step t+1 under step t's MFMAs.
-// Accuracy: measured against fp64 the error is ~2x that of the direct fp32 sum (the transforms add roundings); gated by
-// tests/test_gpu_parity.py::test_winograd_*.
+//     into the four output accumulators with A^T . A's +-1 coefficients, in place between the MFMAs of the next block (the
+//     accumulators are pinned to fixed registers; the xi / nu loops are expanded so that the coefficients are immediates);
+//   * a workgroup (8 waves) owns 8 x 16 Winograd tiles (16 x 32 output pixels) of one image x BN = 128 or 64 output channels;
+//     wave w owns tile row w (16 tiles = the 16 columns of the MFMA's B operand); the U planes of a (position, channel block)
+//     are shared by the workgroup: 24 KB per step, THREE LDS stages (DMA two steps ahead), one barrier per step; the next
+//     block's patch is requested as soon as the last row combination of the current one has been read;
+//   * epilogue through LDS (a store instruction writes whole 512-byte channel rows) and the shared store4 (bias, residual,
+//     activation, gates, byte masks), the residual / gate operands of eight pixels in flight.
+// Accuracy: measured against fp64 the error is BELOW that of the direct kernels (2.6e-7 vs 1.0e-6 relative L-inf on conv4: 128
+// instead of 1152 terms per fp32 accumulation chain); gated by tests/test_gpu_parity.py::test_winograd_*.
 #include <hip/hip_runtime.h>
 #include "launch_util.hpp"
 #include <stdint.h>
