@@ -405,8 +405,14 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
         d.ksplit > 1 || d.ksplit < 0 || d.io_dtype != 0)
         return hipErrorInvalidValue;
     if ((int64_t)((d.Cout + 127) & ~127) * d.cls[0].Kpad * 6 >= (int64_t)1 << 31) return hipErrorInvalidValue;
-    const int BN = d.Cout <= 64 ? 64 : 128;   // N tile: the 64-wide instantiation for layers with at most 64 output channels
     const int wg_y = (d.Hout + 2 * TY - 1) / (2 * TY), wg_x = (d.Wout + 2 * TX - 1) / (2 * TX);
+    // N tile: the 64-wide instantiation for layers with at most 64 output channels, and where the 128-wide grid would leave
+    // compute units without a workgroup (one workgroup per CU: ResNet layer2, 28 x 28 images)
+    static int ncu[SPAA_MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SPAA_MAX_DEVICES) return hipErrorInvalidValue;
+    if (ncu[dev] == 0 && hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu[dev] = 256;
+    const int BN = (d.Cout <= 64 || (int64_t)d.B * wg_y * wg_x * ((d.Cout + 127) / 128) < ncu[dev]) ? 64 : 128;
     const int n_tiles = (d.Cout + BN - 1) / BN;
     const int64_t nwg = (int64_t)d.B * wg_y * wg_x * n_tiles;
     if (nwg > 0x7fffffff) return hipErrorInvalidValue;
