@@ -272,11 +272,7 @@ def instrumented_pass(st, args, n_prof=3):
         # (persistent launches 48..54 run the same instantiations as 34, 36, 42, 44, 35, 37, 25)
         kern = {48: 34, 49: 36, 50: 42, 51: 44, 52: 35, 53: 37, 54: 25}.get(tile_id % 100, tile_id % 100)
         base = convplan.TILE_NAMES.get(kern, 'auto')
-        if kern == 70 and int(key.split('_')[1]) <= 64:   # the 64-wide instantiation is a kernel of its own for rocprofv3
-            base = 'wino_x6_16x32x64'
         tile = convplan.TILE_NAMES.get(tile_id % 100, 'auto') + (('_streamk' if tile_id // 100 == 9 else f'_splitk{tile_id // 100}') if tile_id >= 100 else '')
-        if base == 'wino_x6_16x32x64':
-            tile = base
         a = per_tile.setdefault(base, [0.0, 0.0, 0, 0.0])
         a[0] += flops
         a[1] += ms

@@ -33,7 +33,7 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               48: 'x6d16p_128x128', 49: 'x6d16p_128x64', 50: 'x6d16a3p_128x64', 51: 'x6da3p_128x64', 52: 'x6d16p_256x128',
               53: 'x6d16p_128x32', 54: 'x6dp_128x128',
               60: 'h16_128x128', 61: 'h16_128x64', 62: 'h16_128x32', 63: 'h16_128x16', 64: 'h16_256x128', 65: 'h16_256x256',
-              70: 'wino_x6_16x32x128'}
+              70: 'wino_x6_16x32x128', 71: 'wino_x6_16x32x64'}   # (71: reporting only: tile 70 run by its 64-wide instantiation)
 STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 66)) | {70}  # shared epilogue (epilogue.hpp)
 F16OUT_TILES = set(range(15, 25)) | {38} | set(range(60, 66))  # ... of which these may write fp16 (fp32 image in, fp16 activation out)
 DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
@@ -305,7 +305,12 @@ class ConvPlan:
                                                                                + (aux_out is not None) + (gate2 is not None))
                       + bi * self.alg_taps * self.cin_p * self.cout)
             nbytes += npx * self.cout // 4 * ((mask_out is not None) + (gate_bits is not None) + (gate2_bits is not None))
-            PROFILE.append((self.name, key, self.flops(b, hout, wout), e0, e1, d.tile + 100 * (d.ksplit if d.ksplit > 1 else (9 if d.ksplit == -1 else 0)), nbytes))
+            tid = d.tile + 100 * (d.ksplit if d.ksplit > 1 else (9 if d.ksplit == -1 else 0))
+            if d.tile == 70:   # the launcher's choice of the N tile (csrc/tapconv_wino.hip): a kernel of its own for rocprofv3
+                ncu = torch.cuda.get_device_properties(inp.device).multi_processor_count
+                if self.cout <= 64 or b * ((hout + 15) // 16) * ((wout + 31) // 32) * ((self.cout + 127) // 128) < ncu:
+                    tid = 71
+            PROFILE.append((self.name, key, self.flops(b, hout, wout), e0, e1, tid, nbytes))
         return out
 
     def wgrad(self, inp, gout, dbias=True, nchunk=None, out_coff=0, in_coff=0):

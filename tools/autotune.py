@@ -30,7 +30,7 @@ def main():
             st.iteration(**hp)
         torch.cuda.synchronize()
         for name, key, flops, e0, e1, used, _nbytes in convplan.PROFILE:
-            if used != tile:
+            if (70 if used == 71 else used) != tile:   # (71 = tile 70 run by its 64-wide instantiation)
                 continue  # this tile is not valid for the layer (ConvPlan.run fell back)
             res.setdefault(key, {}).setdefault(tile, []).append(e0.elapsed_time(e1))
             names.setdefault(key, set()).add(name)
