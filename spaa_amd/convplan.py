@@ -20,6 +20,7 @@ from . import _lib
 BK = 32
 NPAD = 128
 PROFILE = None  # set to a list by bench.py to time every tapconv launch with HIP events
+PROFILE_ONLY = None  # ... or only the launches of these reported tile ids (events inside bench.py's timed region)
 FORCE_TILE = 0  # tools/autotune.py: force one workgroup tile for every launch
 TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32', 6: '64x64', 7: '64x128', 8: '128x64b',
               9: 'direct4', 10: 'direct32', 11: 'thin4', 12: 'x6_64x64', 13: 'x6_128x32', 14: 'x6_32x128',
@@ -291,7 +292,14 @@ class ConvPlan:
         for i, c in enumerate(self.cls):
             for k, v in c.items():
                 setattr(d.cls[i], k, v)
-        if PROFILE is None:
+        tid = 0
+        if PROFILE is not None:
+            tid = d.tile + 100 * (d.ksplit if d.ksplit > 1 else (9 if d.ksplit == -1 else 0))
+            if d.tile == 70:   # the launcher's choice of the N tile (csrc/tapconv_wino.hip): a kernel of its own for rocprofv3
+                ncu = torch.cuda.get_device_properties(inp.device).multi_processor_count
+                if self.cout <= 64 or b * ((hout + 15) // 16) * ((wout + 31) // 32) * ((self.cout + 127) // 128) < ncu:
+                    tid = 71
+        if PROFILE is None or (PROFILE_ONLY is not None and tid not in PROFILE_ONLY):
             _lib.call('spaa_tapconv_f32', C.byref(d))
         else:  # bench.py's instrumented pass: HIP events on the launch stream around this one kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -305,11 +313,6 @@ class ConvPlan:
                                                                                + (aux_out is not None) + (gate2 is not None))
                       + bi * self.alg_taps * self.cin_p * self.cout)
             nbytes += npx * self.cout // 4 * ((mask_out is not None) + (gate_bits is not None) + (gate2_bits is not None))
-            tid = d.tile + 100 * (d.ksplit if d.ksplit > 1 else (9 if d.ksplit == -1 else 0))
-            if d.tile == 70:   # the launcher's choice of the N tile (csrc/tapconv_wino.hip): a kernel of its own for rocprofv3
-                ncu = torch.cuda.get_device_properties(inp.device).multi_processor_count
-                if self.cout <= 64 or b * ((hout + 15) // 16) * ((wout + 31) // 32) * ((self.cout + 127) // 128) < ncu:
-                    tid = 71
             PROFILE.append((self.name, key, self.flops(b, hout, wout), e0, e1, tid, nbytes))
         return out
 
