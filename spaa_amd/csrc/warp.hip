@@ -191,40 +191,57 @@ __global__ void warp_taps_kernel(const float4* __restrict__ grid, int Hp, int Wp
 
 // g_x[b, s] = clampgate(x) * sum_{e in list(s)} w_e * ((g_xw + g_xs * scene) * mask)[b, campix_e]
 // order[e] = 4*campix + tap (entries sorted by source pixel, ties in camera-pixel order), off[s]..off[s+1] the list of s.
+// A thread owns source pixel s of GB consecutive images: the tap list (identical for every image of the batch) is read once
+// for them, and the GB gathers of an entry are independent loads in flight.
+constexpr int GB = 4;
 __global__ void warp_bwd_gather_kernel(const float4* __restrict__ g_xw, const float4* __restrict__ g_xs,
                                        const float4* __restrict__ x, const float* __restrict__ mask,
                                        const float4* __restrict__ s, const int32_t* __restrict__ off,
                                        const int32_t* __restrict__ order, const float* __restrict__ wgt,
                                        float4* __restrict__ g_x, int B, int HWp, int HWc, int clamp) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * HWp) return;
-    const int b = idx / HWp, sp = idx - b * HWp;
+    const int nbg = (B + GB - 1) / GB;
+    if (idx >= nbg * HWp) return;
+    const int bg = idx / HWp, sp = idx - bg * HWp;
+    const int b0 = bg * GB;
     const int e0 = off[sp], e1 = off[sp + 1];
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    float a0[GB], a1[GB], a2[GB];
+#pragma unroll
+    for (int k = 0; k < GB; ++k) a0[k] = a1[k] = a2[k] = 0.f;
     for (int e = e0; e < e1; ++e) {
         const int ent = order[e];
         const int cp = ent >> 2;
-        const size_t ci = (size_t)b * HWc + cp;
-        float4 g = g_xw[ci];
-        if (g_xs != nullptr) {
-            const float4 gs = g_xs[ci];
-            const float4 sv = s[ci];
-            g.x += gs.x * sv.x;
-            g.y += gs.y * sv.y;
-            g.z += gs.z * sv.z;
-        }
         const float w = wgt[ent] * ((mask != nullptr) ? mask[cp] : 1.f);
-        a0 += g.x * w;
-        a1 += g.y * w;
-        a2 += g.z * w;
+#pragma unroll
+        for (int k = 0; k < GB; ++k) {
+            if (b0 + k >= B) break;
+            const size_t ci = (size_t)(b0 + k) * HWc + cp;
+            float4 g = g_xw[ci];
+            if (g_xs != nullptr) {
+                const float4 gs = g_xs[ci];
+                const float4 sv = s[ci];
+                g.x += gs.x * sv.x;
+                g.y += gs.y * sv.y;
+                g.z += gs.z * sv.z;
+            }
+            a0[k] += g.x * w;
+            a1[k] += g.y * w;
+            a2[k] += g.z * w;
+        }
     }
-    if (clamp) {
-        const float4 v = x[idx];
-        a0 = (v.x >= 0.f && v.x <= 1.f) ? a0 : 0.f;
-        a1 = (v.y >= 0.f && v.y <= 1.f) ? a1 : 0.f;
-        a2 = (v.z >= 0.f && v.z <= 1.f) ? a2 : 0.f;
+#pragma unroll
+    for (int k = 0; k < GB; ++k) {
+        if (b0 + k >= B) break;
+        const size_t o = (size_t)(b0 + k) * HWp + sp;
+        float r0 = a0[k], r1 = a1[k], r2 = a2[k];
+        if (clamp) {
+            const float4 v = x[o];
+            r0 = (v.x >= 0.f && v.x <= 1.f) ? r0 : 0.f;
+            r1 = (v.y >= 0.f && v.y <= 1.f) ? r1 : 0.f;
+            r2 = (v.z >= 0.f && v.z <= 1.f) ? r2 : 0.f;
+        }
+        g_x[o] = make_float4(r0, r1, r2, 0.f);
     }
-    g_x[idx] = make_float4(a0, a1, a2, 0.f);
 }
 
 __global__ void nchw_to_nhwc4_kernel(const float* __restrict__ src, float4* __restrict__ dst, int B, int HW,
@@ -317,7 +334,7 @@ int spaa_warp_bwd_gather(const float* g_xw, const float* g_xs, const float* x, c
         return hipErrorInvalidValue;
     if ((int64_t)B * Hp * Wp >= ((int64_t)1 << 31) || (int64_t)B * Hc * Wc >= ((int64_t)1 << 31))
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(warp_bwd_gather_kernel, dim3(blocks_for((int64_t)B * Hp * Wp, 256)), dim3(256), 0,
+    hipLaunchKernelGGL(warp_bwd_gather_kernel, dim3(blocks_for((int64_t)((B + GB - 1) / GB) * Hp * Wp, 256)), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)g_xw, (const float4*)g_xs, (const float4*)x, mask,
                        (const float4*)s, off, order, wgt, (float4*)g_x, B, Hp * Wp, Hc * Wc, clamp);
     return (int)hipGetLastError();
