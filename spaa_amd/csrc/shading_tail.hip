@@ -73,7 +73,8 @@ constexpr int RY = 8, RX = 16;         // X6 pixels of a tile
 constexpr int TY = 2 * RY, TX = 2 * RX;  // X7 pixels of a tile (16 x 32), of which the interior 14 x 30 is owned
 constexpr int OY = TY - 2, OX = TX - 2;
 constexpr int W_BYTES = 3 * 128 * 128;   // weight planes: [plane][128 rows][64 bf16]
-constexpr int T_BYTES = TY * TX * 128;   // X7 / P7 tile: 32 fp32 per pixel
+constexpr int PLANE = TY * TX * 16;      // X7 tile, chunk-planar: [8 chunks of 4 channels][512 pixels][16 B]
+constexpr int T_BYTES = 8 * PLANE;
 
 // stage [3][128][64] bf16 weight planes (rows of 128 B) into LDS; 16-byte chunk c of row r sits at chunk c ^ ((r >> 1) & 7)
 __device__ __forceinline__ void stage_planes(const uint16_t* w, unsigned char* dst, const int wave, const int lane) {
@@ -90,45 +91,87 @@ __device__ __forceinline__ void stage_planes(const uint16_t* w, unsigned char* d
 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward tail
-__global__ __launch_bounds__(512, 1) void shading_tail_fwd_kernel(const float* __restrict__ x6, const uint16_t* __restrict__ w2s,
-                                                                  const float* __restrict__ bias2, const float* __restrict__ w6,
-                                                                  const float* __restrict__ bias6, const float* __restrict__ r1,
-                                                                  float* __restrict__ y, float* __restrict__ ypre,
-                                                                  uint8_t* __restrict__ mask7, const int B, const int H2,
-                                                                  const int W2, const int tiles_y, const int tiles_x) {
+// 16 waves per workgroup (one workgroup per CU): phase 1 gives wave w the X6 row w & 7 and the N half w >> 3 (four of the eight
+// 16-channel blocks); phase 2 gives it 64 pixels and ONE half of the 32 channels (waves 0-6: channels 0-15, waves 7-13:
+// 16-31; the weights stay wave-uniform = scalar loads), the halves meet through LDS.  Twice the waves of the 8-wave form hide the
+// scalar-load and LDS latencies of the VALU phase.
+constexpr int FWD_WAVES = 16;
+constexpr int PW2 = (OY * OX + 63) / 64;            // waves per channel half in phase 2 (7)
+constexpr int RED_BYTES = PW2 * 64 * 16;            // partial sums of the second half
+
+__global__ __launch_bounds__(64 * FWD_WAVES, 1) void shading_tail_fwd_kernel(
+    const float* __restrict__ x6, const uint16_t* __restrict__ w2s, const float* __restrict__ bias2, const float* __restrict__ w6,
+    const float* __restrict__ bias6, const float* __restrict__ r1, float* __restrict__ y, float* __restrict__ ypre,
+    uint8_t* __restrict__ mask7, const int B, const int H2, const int W2, const int tiles_y, const int tiles_x) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    unsigned char* wl = smem;             // weight planes
-    unsigned char* tl = smem + W_BYTES;   // X7 tile
+    unsigned char* wl = smem;                       // weight planes
+    unsigned char* tl = smem + W_BYTES;             // X7 tile
+    unsigned char* rl = smem + W_BYTES + T_BYTES;   // phase-2 partial sums
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = 2 * H2, W = 2 * W2;
-    stage_planes(w2s, wl, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {   // weight planes (rows of 128 B; chunk c of row r at chunk c ^ ((r >> 1) & 7)): 48 pieces over 16 waves
+        const uint64_t addr = reinterpret_cast<uint64_t>(w2s);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)addr);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, W_BYTES, 0x00020000);
+        for (int piece = wave; piece < W_BYTES / 1024; piece += FWD_WAVES) {
+            const int r = piece * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(wl + piece * 1024), 16, r * 128 + c * 16, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
     const int rx = lane & 15, g = lane >> 4;
+    const int row = wave & 7, nh = wave >> 3;       // phase 1: X6 row and N half of this wave
+    const int ph = wave >= PW2 ? 1 : 0;             // phase 2: channel half (waves 14, 15: idle)
+    const int pix = (wave - ph * PW2) * 64 + lane;  // ... and pixel of the owned interior
+    const bool p2 = wave < 2 * PW2 && pix < OY * OX;
+    const int oy_l = p2 ? pix / OX : 0, ox_l = p2 ? pix - oy_l * OX : 0;
+    const unsigned char* p2base = tl + 4 * ph * PLANE + (oy_l * TX + ox_l) * 16;
+    // per-lane constants of the phase-1 epilogue: LDS address and bias of its four 16-channel blocks
+    int wofs[4];
+    f32x4 bq[4];
+#pragma unroll
+    for (int nq = 0; nq < 4; ++nq) {
+        const int nb = 4 * nh + nq, par = nb >> 1, c0 = 16 * (nb & 1) + 4 * g;
+        wofs[nq] = (c0 >> 2) * PLANE + ((2 * row + (par >> 1)) * TX + 2 * rx + (par & 1)) * 16;
+        bq[nq] = *reinterpret_cast<const f32x4*>(bias2 + c0);
+    }
     const int ntiles = B * tiles_y * tiles_x;
+    // X6 operands of a tile (this wave's row; lane = (column, 8-channel chunk)), loaded one tile ahead
+    f32x4 xin[4];
+    auto load_x6 = [&](const int tile_) {
+        const int tx_ = tile_ % tiles_x, ty_ = (tile_ / tiles_x) % tiles_y, img = tile_ / (tiles_x * tiles_y);
+        const int ay = (OY / 2) * ty_ - 1 + row, ax = (OX / 2) * tx_ - 1 + rx;
+        const bool in6 = tile_ < ntiles && (unsigned)ay < (unsigned)H2 && (unsigned)ax < (unsigned)W2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (in6) {
+            const float* src = x6 + (((size_t)img * H2 + ay) * W2 + ax) * C6 + g * 8;
+            xin[0] = *reinterpret_cast<const f32x4*>(src);
+            xin[1] = *reinterpret_cast<const f32x4*>(src + 4);
+            xin[2] = *reinterpret_cast<const f32x4*>(src + 32);
+            xin[3] = *reinterpret_cast<const f32x4*>(src + 36);
+        }
+    };
+    load_x6(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx_ = tile % tiles_x, ty_ = (tile / tiles_x) % tiles_y, img = tile / (tiles_x * tiles_y);
-        // owned output rows [OY ty - 1, OY ty + OY - 1), X7 rows [OY ty - 2, + TY), X6 rows [RY' = (OY/2) ty - 1, + RY)
+        // owned output rows [OY ty - 1, OY ty + OY - 1), X7 rows [OY ty - 2, + TY), X6 rows [(OY/2) ty - 1, + RY)
         const int a0 = (OY / 2) * ty_ - 1, b0 = (OX / 2) * tx_ - 1;   // first X6 row / column of the tile
-        // ---- phase 1: X7 tile = relu(transConv2(X6) + bias); wave = X6 row, lane = (X6 column, 8-channel chunk)
+        const bool interior = a0 >= 0 && 2 * a0 + TY <= H && b0 >= 0 && 2 * b0 + TX <= W;
+        // ---- phase 1: X7 tile = relu(transConv2(X6) + bias); lane = (X6 column, 8-channel chunk)
         {
-            const int ay = a0 + wave, ax = b0 + rx;
-            const bool in6 = (unsigned)ay < (unsigned)H2 && (unsigned)ax < (unsigned)W2;
-            const float* src = x6 + (((size_t)img * H2 + (in6 ? ay : 0)) * W2 + (in6 ? ax : 0)) * C6 + g * 8;
             bf16x8 pf[2][3];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f};
-                if (in6) {
-                    u0 = *reinterpret_cast<const f32x4*>(src + s * 32);
-                    u1 = *reinterpret_cast<const f32x4*>(src + s * 32 + 4);
-                }
-                split8(u0, u1, pf[s][0], pf[s][1], pf[s][2]);
-            }
+            for (int s = 0; s < 2; ++s) split8(xin[2 * s], xin[2 * s + 1], pf[s][0], pf[s][1], pf[s][2]);
+            load_x6(tile + gridDim.x);   // the next tile's operands fly during this tile's arithmetic
 #pragma unroll
-            for (int nb = 0; nb < 8; ++nb) {
+            for (int nq = 0; nq < 4; ++nq) {
+                const int nb = 4 * nh + nq;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -141,69 +184,70 @@ __global__ __launch_bounds__(512, 1) void shading_tail_fwd_kernel(const float* _
                     acc = mfma6(w0, w1, w2, pf[s][0], pf[s][1], pf[s][2], acc);
                 }
                 // D: column = X6 pixel (lane & 15), rows n = 16 nb + 4 g + e: parity nb >> 1, channels 16 (nb & 1) + 4 g + e
-                const int par = nb >> 1, c0 = 16 * (nb & 1) + 4 * g;
-                const int py = 2 * wave + (par >> 1), px = 2 * rx + (par & 1);           // X7 pixel in the tile
-                const int gy = 2 * a0 + py, gx = 2 * b0 + px;                           // ... in the image
-                const bool in7 = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias2 + c0);
                 f32x4 v;
-                unsigned int bits = 0;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = acc[e] + bv[e];
-                    v[e] = in7 ? fmaxf(t, 0.f) : 0.f;   // (outside the image: conv6's zero padding)
-                    bits |= (t > 0.f ? 1u : 0u) << e;
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[e] + bq[nq][e], 0.f);
+                if (!interior) {   // (uniform) a tile at the image border: pixels outside are conv6's zero padding
+                    const int par = nb >> 1;
+                    const int gy = 2 * a0 + 2 * row + (par >> 1), gx = 2 * b0 + 2 * rx + (par & 1);
+                    if (!((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                const int q = py * TX + px;
-                *reinterpret_cast<f32x4*>(tl + q * 128 + ((((c0 >> 2)) ^ ((q >> 1) & 7)) << 4)) = v;
-                const bool own = py >= 1 && py <= OY && px >= 1 && px <= OX;
-                if (in7 && own) mask7[(((size_t)img * H + gy) * W + gx) * (C7 / 4) + (c0 >> 2)] = (uint8_t)bits;
+                *reinterpret_cast<f32x4*>(tl + wofs[nq]) = v;
             }
         }
         __syncthreads();
-        // ---- phase 2: conv6 (3x3, 32 -> 3) + res1, ReLU, clamp for the owned interior; thread = pixel
-        if (tid < OY * OX) {
-            const int oy_l = tid / OX, ox_l = tid - oy_l * OX;
-            const int gy = 2 * a0 + 1 + oy_l, gx = 2 * b0 + 1 + ox_l;
-            f2 acc[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        // ---- phase 2: conv6 (3x3, 32 -> 3) over this wave's 16 channels; X7's gate bytes from the centre tap (relu(t) > 0 <=> t > 0)
+        f2 acc[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        const int gy = 2 * a0 + 1 + oy_l, gx = 2 * b0 + 1 + ox_l;
+        const bool ok = p2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const size_t o = ((size_t)img * H + (ok ? gy : 0)) * W + (ok ? gx : 0);
+        f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+        if (ok && ph == 0) rv = *reinterpret_cast<const f32x4*>(r1 + o * 4);   // (requested early: used after the taps)
+        if (p2) {
+            unsigned int bits = 0;
 #pragma unroll 1
-            for (int t = 0; t < 9; ++t) {   // (not unrolled: 48 weight SGPRs per half-tap is what the scalar file holds)
-                const int q = (oy_l + t / 3) * TX + ox_l + t % 3;
-                const unsigned char* pp = tl + q * 128;
-                const int sw = (q >> 1) & 7;
-#pragma unroll 1
-                for (int h = 0; h < 2; ++h) {   // 16 channels at a time: one s_load_dwordx16 per output channel
-                    f16v w[3];
+            for (int t = 0; t < 9; ++t) {   // (not unrolled: 48 weight SGPRs per tap is what the scalar file holds)
+                // (chunk-planar tile: the four reads of a tap are one address + immediates, neighbouring lanes 16 bytes apart)
+                const unsigned char* pp = p2base + ((t / 3) * TX + t % 3) * 16;
+                f16v w[3];                  // 16 channels x 3 outputs of this tap: one s_load_dwordx16 per output channel
 #pragma unroll
-                    for (int n = 0; n < 3; ++n) w[n] = *(cf16_ptr)(uintptr_t)(w6 + (n * 9 + t) * C7 + 16 * h);
+                for (int n = 0; n < 3; ++n) w[n] = *(cf16_ptr)(uintptr_t)(w6 + (n * 9 + t) * C7 + 16 * ph);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const f32x4 a = *reinterpret_cast<const f32x4*>(pp + (((4 * h + u) ^ sw) << 4));
-                        const f2 a01 = {a[0], a[1]}, a23 = {a[2], a[3]};
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(pp + u * PLANE);
+                    const f2 a01 = {a[0], a[1]}, a23 = {a[2], a[3]};
 #pragma unroll
-                        for (int n = 0; n < 3; ++n) {
-                            const f2 w01 = {w[n][4 * u], w[n][4 * u + 1]}, w23 = {w[n][4 * u + 2], w[n][4 * u + 3]};
-                            acc[n] = __builtin_elementwise_fma(a01, w01, acc[n]);
-                            acc[n] = __builtin_elementwise_fma(a23, w23, acc[n]);
-                        }
+                    for (int n = 0; n < 3; ++n) {
+                        const f2 w01 = {w[n][4 * u], w[n][4 * u + 1]}, w23 = {w[n][4 * u + 2], w[n][4 * u + 3]};
+                        acc[n] = __builtin_elementwise_fma(a01, w01, acc[n]);
+                        acc[n] = __builtin_elementwise_fma(a23, w23, acc[n]);
                     }
                 }
             }
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const size_t o = (((size_t)img * H + gy) * W + gx) * 4;
-                const f32x4 rv = *reinterpret_cast<const f32x4*>(r1 + o);
-                f32x4 outv = {0.f, 0.f, 0.f, 0.f}, prev = {0.f, 0.f, 0.f, 0.f};
+            // X7's gate bytes of this pixel (its own four reads of the centre tap: the tap loop above stays branch-free)
 #pragma unroll
-                for (int n = 0; n < 3; ++n) {
-                    const float t = fmaxf(acc[n][0] + acc[n][1] + bias6[n] + rv[n], 0.f);
-                    prev[n] = t;
-                    outv[n] = fminf(t, 1.f);
-                }
-                *reinterpret_cast<f32x4*>(y + o) = outv;
-                *reinterpret_cast<f32x4*>(ypre + o) = prev;
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(p2base + (TX + 1) * 16 + u * PLANE);
+                bits |= ((a[0] > 0.f ? 1u : 0u) | (a[1] > 0.f ? 2u : 0u) | (a[2] > 0.f ? 4u : 0u) | (a[3] > 0.f ? 8u : 0u)) << (8 * u);
             }
+            if (ok) *reinterpret_cast<uint32_t*>(mask7 + o * (C7 / 4) + 4 * ph) = bits;
+            if (ph == 1) *reinterpret_cast<f32x4*>(rl + pix * 16) = f32x4{acc[0][0] + acc[0][1], acc[1][0] + acc[1][1], acc[2][0] + acc[2][1], 0.f};
         }
-        __syncthreads();   // the tile is free for the next one
+        __syncthreads();   // the second half's sums are in LDS; the tile is free for the next one
+        if (ok && ph == 0) {
+            const f32x4 other = *reinterpret_cast<const f32x4*>(rl + pix * 16);
+            f32x4 outv = {0.f, 0.f, 0.f, 0.f}, prev = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const float t = fmaxf((acc[n][0] + acc[n][1]) + other[n] + bias6[n] + rv[n], 0.f);
+                prev[n] = t;
+                outv[n] = fminf(t, 1.f);
+            }
+            *reinterpret_cast<f32x4*>(y + o * 4) = outv;
+            *reinterpret_cast<f32x4*>(ypre + o * 4) = prev;
+        }
+        // (the next tile's phase 1 writes `tl` only; `rl` is rewritten after its barrier: no third barrier needed, since the
+        // first-half waves read `rl` before they reach that barrier)
     }
 }
 
@@ -350,14 +394,14 @@ int spaa_shading_tail_fwd(const float* x6, const uint16_t* w2_split, const float
     const int tiles_y = (H + 1 + OY - 1) / OY, tiles_x = (W + 1 + OX - 1) / OX;   // owned rows start at -1
     const int64_t ntiles = (int64_t)B * tiles_y * tiles_x;
     if (ntiles > 0x7fffffff) return hipErrorInvalidValue;
-    const size_t smem = (size_t)W_BYTES + T_BYTES;
+    const size_t smem = (size_t)W_BYTES + T_BYTES + RED_BYTES;
     static bool attr_set[SPAA_MAX_DEVICES] = {};
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&shading_tail_fwd_kernel), (int)smem, attr_set);
     if (e != hipSuccess) return (int)e;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);
-    hipLaunchKernelGGL(shading_tail_fwd_kernel, dim3(grid), dim3(512), smem, stream, x6, w2_split, bias2, w6, bias6, res1, y, ypre,
+    hipLaunchKernelGGL(shading_tail_fwd_kernel, dim3(grid), dim3(64 * FWD_WAVES), smem, stream, x6, w2_split, bias2, w6, bias6, res1, y, ypre,
                        mask7, B, H2, W2, tiles_y, tiles_x);
     return (int)hipGetLastError();
 }
