@@ -261,12 +261,15 @@ constexpr int WB_BYTES = 3 * 64 * 256;        // backward weight planes: [plane]
 constexpr int P7_BYTES = 128 * 512;           // 64 KB
 constexpr int GP_BYTES = GP_W * GP_H * 16;    // 9792 B
 
-__global__ __launch_bounds__(512, 1) void shading_head_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ w6t,
-                                                                  const uint16_t* __restrict__ w2ts,
-                                                                  const uint8_t* __restrict__ mask7,
-                                                                  const uint8_t* __restrict__ mask6, float* __restrict__ p6,
-                                                                  const int B, const int H2, const int W2, const int tiles_y,
-                                                                  const int tiles_x) {
+// 16 waves per workgroup: phase 1 gives a thread one X7 pixel of the tile and ONE half of P7's 32 channels (waves 0-7: channels
+// 0-15, waves 8-15: 16-31; per tap 3 inputs x 16 weights = three scalar loads feeding 24 packed FMAs); phase 2 gives wave w the X6
+// row w & 7 and the N half w >> 3 (two of the four 16-channel blocks of P6).
+__global__ __launch_bounds__(1024, 1) void shading_head_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ w6t,
+                                                                   const uint16_t* __restrict__ w2ts,
+                                                                   const uint8_t* __restrict__ mask7,
+                                                                   const uint8_t* __restrict__ mask6, float* __restrict__ p6,
+                                                                   const int B, const int H2, const int W2, const int tiles_y,
+                                                                   const int tiles_x) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* wl = smem;                       // weight planes
     unsigned char* pl = smem + WB_BYTES;            // P7 tile
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(512, 1) void shading_head_bwd_kernel(const float* _
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)addr);
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, WB_BYTES, 0x00020000);
-        for (int piece = wave; piece < WB_BYTES / 1024; piece += 8) {   // 4 rows per piece
+        for (int piece = wave; piece < WB_BYTES / 1024; piece += 16) {   // 4 rows per piece
             const int r = piece * 4 + (lane >> 4);
             const int c = (lane & 15) ^ (r & 15);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(wl + piece * 1024), 16, r * 256 + c * 16, 0, 0, 0);
@@ -288,59 +291,62 @@ __global__ __launch_bounds__(512, 1) void shading_head_bwd_kernel(const float* _
     }
     __syncthreads();
     const int rx = lane & 15, g = lane >> 4;
+    const int row = wave & 7, nh = wave >> 3;        // phase 2: X6 row and N half; phase 1: nh = channel half
+    const int pix = (tid & 511);                     // phase 1: X7 pixel of the 16 x 32 tile
+    const int py = pix >> 5, px = pix & 31;
+    // GEMM operand row m = 16 (py >> 1) + (px >> 1), columns k = 32 (2 (py & 1) + (px & 1)) + 16 nh + ...
+    const int m1 = 16 * (py >> 1) + (px >> 1), ch1 = 8 * (2 * (py & 1) + (px & 1)) + 4 * nh;
     const int ntiles = B * tiles_y * tiles_x;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx_ = tile % tiles_x, ty_ = (tile / tiles_x) % tiles_y, img = tile / (tiles_x * tiles_y);
         const int a0 = RY * ty_, b0 = RX * tx_;   // first X6 row / column
         // ---- phase 0: gP tile with halo (out-of-image pixels: zeros = conv6's zero padding seen from the gradient)
-        for (int i = tid; i < GP_W * GP_H; i += 512) {
-            const int py = i / GP_W, px = i - py * GP_W;
-            const int gy = 2 * a0 - 1 + py, gx = 2 * b0 - 1 + px;
+        if (tid < GP_W * GP_H) {
+            const int qy = tid / GP_W, qx = tid - qy * GP_W;
+            const int gy = 2 * a0 - 1 + qy, gx = 2 * b0 - 1 + qx;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
                 v = *reinterpret_cast<const f32x4*>(gp + (((size_t)img * H + gy) * W + gx) * 4);
-            *reinterpret_cast<f32x4*>(gl + i * 16) = v;
+            *reinterpret_cast<f32x4*>(gl + tid * 16) = v;
         }
+        // this pixel's gate bytes of the thread's channel half (requested before the barrier)
+        const int gy7 = 2 * a0 + py, gx7 = 2 * b0 + px;
+        uint32_t mbits = 0;
+        if (gy7 < H && gx7 < W) mbits = *reinterpret_cast<const uint32_t*>(mask7 + (((size_t)img * H + gy7) * W + gx7) * (C7 / 4) + 4 * nh);
         __syncthreads();
-        // ---- phase 1: P7[pixel][32] = gate7 . sum_{taps, 3 ch} gP[pixel + d] w6t[tap][ch][32]; thread = X7 pixel of the tile
+        // ---- phase 1: P7[pixel][16 nh ..] = gate7 . sum_{taps, 3 ch} gP[pixel + d] w6t[tap][ch][16 nh ..]
         {
-            const int py = tid >> 5, px = tid & 31;   // 16 x 32
-            const int gy = 2 * a0 + py, gx = 2 * b0 + px;
-            const bool in7 = gy < H && gx < W;
-            uint64_t mbits = 0;   // 8 gate bytes of this pixel
-            if (in7) mbits = *reinterpret_cast<const uint64_t*>(mask7 + (((size_t)img * H + gy) * W + gx) * (C7 / 4));
-            f32x4 acc[8];
+            f32x4 acc[4];
 #pragma unroll
-            for (int c4 = 0; c4 < 8; ++c4) acc[c4] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int c4 = 0; c4 < 4; ++c4) acc[c4] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-            for (int i = 0; i < 27; ++i) {   // input (tap t = i / 3, channel o = i % 3): 32 wave-uniform weights (scalar loads)
-                const int t = i / 3, o = i - 3 * t;
-                const float gv = *reinterpret_cast<const float*>(gl + ((py + t / 3) * GP_W + px + t % 3) * 16 + 4 * o);
-                const f16v wa = *(cf16_ptr)(uintptr_t)(w6t + i * C7), wb = *(cf16_ptr)(uintptr_t)(w6t + i * C7 + 16);
-                const f32x4 g4 = {gv, gv, gv, gv};
+            for (int t = 0; t < 9; ++t) {   // (not unrolled: 48 weight SGPRs per tap)
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(gl + ((py + t / 3) * GP_W + px + t % 3) * 16);
+                f16v w[3];
 #pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    acc[c4] = __builtin_elementwise_fma(g4, f32x4{wa[4 * c4], wa[4 * c4 + 1], wa[4 * c4 + 2], wa[4 * c4 + 3]}, acc[c4]);
-                    acc[4 + c4] = __builtin_elementwise_fma(g4, f32x4{wb[4 * c4], wb[4 * c4 + 1], wb[4 * c4 + 2], wb[4 * c4 + 3]}, acc[4 + c4]);
+                for (int o = 0; o < 3; ++o) w[o] = *(cf16_ptr)(uintptr_t)(w6t + (3 * t + o) * C7 + 16 * nh);
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    const f32x4 g4 = {gv[o], gv[o], gv[o], gv[o]};
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4)
+                        acc[c4] = __builtin_elementwise_fma(g4, f32x4{w[o][4 * c4], w[o][4 * c4 + 1], w[o][4 * c4 + 2], w[o][4 * c4 + 3]}, acc[c4]);
                 }
             }
-            // GEMM operand row m = 16 (py >> 1) + (px >> 1), columns k = 32 (2 (py & 1) + (px & 1)) + c
-            const int m = 16 * (py >> 1) + (px >> 1), kb = 32 * (2 * (py & 1) + (px & 1));
 #pragma unroll
-            for (int c4 = 0; c4 < 8; ++c4) {
-                const unsigned int nib = (unsigned int)(mbits >> (8 * c4)) & 15u;
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const unsigned int nib = (mbits >> (8 * c4)) & 15u;
                 f32x4 v = acc[c4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = ((nib >> e) & 1u) ? v[e] : 0.f;
-                // 16-byte chunk (kb + 4 c4) / 4 of row m at chunk ^ (m & 31)
-                const int ch = (kb >> 2) + c4;
-                *reinterpret_cast<f32x4*>(pl + m * 512 + ((ch ^ (m & 31)) << 4)) = v;
+                // 16-byte chunk ch1 + c4 of row m1 at chunk ^ (m1 & 31)
+                *reinterpret_cast<f32x4*>(pl + m1 * 512 + (((ch1 + c4) ^ (m1 & 31)) << 4)) = v;
             }
         }
         __syncthreads();
-        // ---- phase 2: P6[m][n] = gate6 . sum_k P7[m][k] W[n][k];  wave = X6 row of the tile, lane = (column, k chunk)
+        // ---- phase 2: P6[m][n] = gate6 . sum_k P7[m][k] W[n][k];  lane = (X6 column, k chunk)
         {
-            const int m = 16 * wave + rx;
+            const int m = 16 * row + rx;
             bf16x8 pf[4][3];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {   // k step s: columns 32 s + 8 g .. + 7 = chunks 8 s + 2 g, + 1
@@ -348,16 +354,13 @@ __global__ __launch_bounds__(512, 1) void shading_head_bwd_kernel(const float* _
                 const f32x4 u1 = *reinterpret_cast<const f32x4*>(pl + m * 512 + (((8 * s + 2 * g + 1) ^ (m & 31)) << 4));
                 split8(u0, u1, pf[s][0], pf[s][1], pf[s][2]);
             }
-            const int ay = a0 + wave, ax = b0 + rx;
+            const int ay = a0 + row, ax = b0 + rx;
             const bool in6 = ay < H2 && ax < W2;
-            uint64_t g6lo = 0, g6hi = 0;   // 16 gate bytes of this X6 pixel
-            if (in6) {
-                const uint64_t* mp = reinterpret_cast<const uint64_t*>(mask6 + (((size_t)img * H2 + ay) * W2 + ax) * (C6 / 4));
-                g6lo = mp[0];
-                g6hi = mp[1];
-            }
+            uint64_t g6 = 0;   // the 8 gate bytes of this X6 pixel's channel half
+            if (in6) g6 = *reinterpret_cast<const uint64_t*>(mask6 + (((size_t)img * H2 + ay) * W2 + ax) * (C6 / 4) + 8 * nh);
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
+            for (int nq = 0; nq < 2; ++nq) {
+                const int nb = 2 * nh + nq;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -368,9 +371,9 @@ __global__ __launch_bounds__(512, 1) void shading_head_bwd_kernel(const float* _
                     const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wp + 2 * 64 * 256);
                     acc = mfma6(w0, w1, w2, pf[s][0], pf[s][1], pf[s][2], acc);
                 }
-                // D: column = X6 pixel (lane & 15), rows n = 16 nb + 4 g + e
+                // D: column = X6 pixel (lane & 15), rows n = 16 nb + 4 g + e: byte 4 nq + g of this half's gate bytes
                 const int n0 = 16 * nb + 4 * g;
-                const unsigned int nib = (unsigned int)((n0 < 32 ? g6lo >> (2 * n0) : g6hi >> (2 * (n0 - 32)))) & 15u;
+                const unsigned int nib = (unsigned int)(g6 >> (8 * (4 * nq + g))) & 15u;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] = ((nib >> e) & 1u) ? acc[e] : 0.f;
                 if (in6) *reinterpret_cast<f32x4*>(p6 + (((size_t)img * H2 + ay) * W2 + ax) * C6 + n0) = acc;
@@ -420,7 +423,7 @@ int spaa_shading_head_bwd(const float* gp, const float* w6t, const uint16_t* w2t
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);
-    hipLaunchKernelGGL(shading_head_bwd_kernel, dim3(grid), dim3(512), smem, stream, gp, w6t, w2t_split, mask7, mask6, p6, B, H2, W2,
+    hipLaunchKernelGGL(shading_head_bwd_kernel, dim3(grid), dim3(1024), smem, stream, gp, w6t, w2t_split, mask7, mask6, p6, B, H2, W2,
                        tiles_y, tiles_x);
     return (int)hipGetLastError();
 }
