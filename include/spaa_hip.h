@@ -190,6 +190,12 @@ int spaa_shading_tail_fwd(const float* x6, const uint16_t* w2_split, const float
                           const float* res1, float* y, float* ypre, uint8_t* mask7, int B, int H2, int W2, spaa_stream_t stream);
 int spaa_shading_head_bwd(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7,
                           const uint8_t* mask6, float* p6, int B, int H2, int W2, spaa_stream_t stream);
+/* the same two kernels in fp16-storage mode (BASELINE.json configs[4]): x6 resp. p6 are fp16 [B,H2,W2,64]; images, res1, gp, the
+ * activation kept in LDS and all arithmetic stay fp32 (the fp16 values are split exactly) */
+int spaa_shading_tail_fwd_f16(const void* x6, const uint16_t* w2_split, const float* bias2, const float* w6, const float* bias6,
+                              const float* res1, float* y, float* ypre, uint8_t* mask7, int B, int H2, int W2, spaa_stream_t stream);
+int spaa_shading_head_bwd_f16(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7,
+                              const uint8_t* mask6, void* p6, int B, int H2, int W2, spaa_stream_t stream);
 
 /* ReLU backward as a stand-alone op: out = (act > 0) ? g : 0, n floats (n % 4 == 0, 16-byte aligned) */
 int spaa_relu_gate(const float* g, const float* act, float* out, int64_t n, spaa_stream_t stream);

@@ -24,6 +24,8 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -99,8 +101,9 @@ constexpr int FWD_WAVES = 16;
 constexpr int PW2 = (OY * OX + 63) / 64;            // waves per channel half in phase 2 (7)
 constexpr int RED_BYTES = PW2 * 64 * 16;            // partial sums of the second half
 
+template <typename T6>   // storage type of X6: float, or _Float16 in fp16-storage mode (the arithmetic is the same: exact operands)
 __global__ __launch_bounds__(64 * FWD_WAVES, 1) void shading_tail_fwd_kernel(
-    const float* __restrict__ x6, const uint16_t* __restrict__ w2s, const float* __restrict__ bias2, const float* __restrict__ w6,
+    const T6* __restrict__ x6, const uint16_t* __restrict__ w2s, const float* __restrict__ bias2, const float* __restrict__ w6,
     const float* __restrict__ bias6, const float* __restrict__ r1, float* __restrict__ y, float* __restrict__ ypre,
     uint8_t* __restrict__ mask7, const int B, const int H2, const int W2, const int tiles_y, const int tiles_x) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -150,11 +153,19 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void shading_tail_fwd_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) xin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (in6) {
-            const float* src = x6 + (((size_t)img * H2 + ay) * W2 + ax) * C6 + g * 8;
-            xin[0] = *reinterpret_cast<const f32x4*>(src);
-            xin[1] = *reinterpret_cast<const f32x4*>(src + 4);
-            xin[2] = *reinterpret_cast<const f32x4*>(src + 32);
-            xin[3] = *reinterpret_cast<const f32x4*>(src + 36);
+            const T6* src = x6 + (((size_t)img * H2 + ay) * W2 + ax) * C6 + g * 8;
+            if constexpr (sizeof(T6) == 4) {
+                xin[0] = *reinterpret_cast<const f32x4*>(src);
+                xin[1] = *reinterpret_cast<const f32x4*>(src + 4);
+                xin[2] = *reinterpret_cast<const f32x4*>(src + 32);
+                xin[3] = *reinterpret_cast<const f32x4*>(src + 36);
+            } else {
+                const h8 a = *reinterpret_cast<const h8*>(src), b = *reinterpret_cast<const h8*>(src + 32);
+                xin[0] = f32x4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
+                xin[1] = f32x4{(float)a[4], (float)a[5], (float)a[6], (float)a[7]};
+                xin[2] = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                xin[3] = f32x4{(float)b[4], (float)b[5], (float)b[6], (float)b[7]};
+            }
         }
     };
     load_x6(blockIdx.x);
@@ -264,10 +275,11 @@ constexpr int GP_BYTES = GP_W * GP_H * 16;    // 9792 B
 // 16 waves per workgroup: phase 1 gives a thread one X7 pixel of the tile and ONE half of P7's 32 channels (waves 0-7: channels
 // 0-15, waves 8-15: 16-31; per tap 3 inputs x 16 weights = three scalar loads feeding 24 packed FMAs); phase 2 gives wave w the X6
 // row w & 7 and the N half w >> 3 (two of the four 16-channel blocks of P6).
+template <typename T6>   // storage type of P6 (float / _Float16)
 __global__ __launch_bounds__(1024, 1) void shading_head_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ w6t,
                                                                    const uint16_t* __restrict__ w2ts,
                                                                    const uint8_t* __restrict__ mask7,
-                                                                   const uint8_t* __restrict__ mask6, float* __restrict__ p6,
+                                                                   const uint8_t* __restrict__ mask6, T6* __restrict__ p6,
                                                                    const int B, const int H2, const int W2, const int tiles_y,
                                                                    const int tiles_x) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -376,7 +388,11 @@ __global__ __launch_bounds__(1024, 1) void shading_head_bwd_kernel(const float* 
                 const unsigned int nib = (unsigned int)(g6 >> (8 * (4 * nq + g))) & 15u;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] = ((nib >> e) & 1u) ? acc[e] : 0.f;
-                if (in6) *reinterpret_cast<f32x4*>(p6 + (((size_t)img * H2 + ay) * W2 + ax) * C6 + n0) = acc;
+                if (in6) {
+                    T6* dst = p6 + (((size_t)img * H2 + ay) * W2 + ax) * C6 + n0;
+                    if constexpr (sizeof(T6) == 4) *reinterpret_cast<f32x4*>(dst) = acc;
+                    else *reinterpret_cast<h4*>(dst) = h4{(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};
+                }
             }
         }
         __syncthreads();
@@ -385,10 +401,9 @@ __global__ __launch_bounds__(1024, 1) void shading_head_bwd_kernel(const float* 
 
 }  // namespace
 
-extern "C" {
-
-int spaa_shading_tail_fwd(const float* x6, const uint16_t* w2_split, const float* bias2, const float* w6, const float* bias6,
-                          const float* res1, float* y, float* ypre, uint8_t* mask7, int B, int H2, int W2, spaa_stream_t stream_) {
+template <typename T6>
+static int launch_tail_fwd(const T6* x6, const uint16_t* w2_split, const float* bias2, const float* w6, const float* bias6,
+                           const float* res1, float* y, float* ypre, uint8_t* mask7, int B, int H2, int W2, spaa_stream_t stream_) {
     if (!x6 || !w2_split || !bias2 || !w6 || !bias6 || !res1 || !y || !ypre || !mask7 || B <= 0 || H2 <= 0 || W2 <= 0)
         return hipErrorInvalidValue;
     if ((int64_t)B * H2 * W2 * 4 * C7 * 4 >= (int64_t)1 << 40) return hipErrorInvalidValue;
@@ -399,18 +414,19 @@ int spaa_shading_tail_fwd(const float* x6, const uint16_t* w2_split, const float
     if (ntiles > 0x7fffffff) return hipErrorInvalidValue;
     const size_t smem = (size_t)W_BYTES + T_BYTES + RED_BYTES;
     static bool attr_set[SPAA_MAX_DEVICES] = {};
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&shading_tail_fwd_kernel), (int)smem, attr_set);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&shading_tail_fwd_kernel<T6>), (int)smem, attr_set);
     if (e != hipSuccess) return (int)e;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);
-    hipLaunchKernelGGL(shading_tail_fwd_kernel, dim3(grid), dim3(64 * FWD_WAVES), smem, stream, x6, w2_split, bias2, w6, bias6, res1, y, ypre,
-                       mask7, B, H2, W2, tiles_y, tiles_x);
+    hipLaunchKernelGGL(shading_tail_fwd_kernel<T6>, dim3(grid), dim3(64 * FWD_WAVES), smem, stream, x6, w2_split, bias2, w6, bias6, res1,
+                       y, ypre, mask7, B, H2, W2, tiles_y, tiles_x);
     return (int)hipGetLastError();
 }
 
-int spaa_shading_head_bwd(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6,
-                          float* p6, int B, int H2, int W2, spaa_stream_t stream_) {
+template <typename T6>
+static int launch_head_bwd(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6,
+                           T6* p6, int B, int H2, int W2, spaa_stream_t stream_) {
     if (!gp || !w6t || !w2t_split || !mask7 || !mask6 || !p6 || B <= 0 || H2 <= 0 || W2 <= 0) return hipErrorInvalidValue;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const int tiles_y = (H2 + RY - 1) / RY, tiles_x = (W2 + RX - 1) / RX;
@@ -418,14 +434,34 @@ int spaa_shading_head_bwd(const float* gp, const float* w6t, const uint16_t* w2t
     if (ntiles > 0x7fffffff) return hipErrorInvalidValue;
     const size_t smem = (size_t)WB_BYTES + P7_BYTES + GP_BYTES;
     static bool attr_set[SPAA_MAX_DEVICES] = {};
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&shading_head_bwd_kernel), (int)smem, attr_set);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&shading_head_bwd_kernel<T6>), (int)smem, attr_set);
     if (e != hipSuccess) return (int)e;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);
-    hipLaunchKernelGGL(shading_head_bwd_kernel, dim3(grid), dim3(1024), smem, stream, gp, w6t, w2t_split, mask7, mask6, p6, B, H2, W2,
+    hipLaunchKernelGGL(shading_head_bwd_kernel<T6>, dim3(grid), dim3(1024), smem, stream, gp, w6t, w2t_split, mask7, mask6, p6, B, H2, W2,
                        tiles_y, tiles_x);
     return (int)hipGetLastError();
+}
+
+extern "C" {
+
+int spaa_shading_tail_fwd(const float* x6, const uint16_t* w2_split, const float* bias2, const float* w6, const float* bias6,
+                          const float* res1, float* y, float* ypre, uint8_t* mask7, int B, int H2, int W2, spaa_stream_t stream) {
+    return launch_tail_fwd<float>(x6, w2_split, bias2, w6, bias6, res1, y, ypre, mask7, B, H2, W2, stream);
+}
+int spaa_shading_tail_fwd_f16(const void* x6, const uint16_t* w2_split, const float* bias2, const float* w6, const float* bias6,
+                              const float* res1, float* y, float* ypre, uint8_t* mask7, int B, int H2, int W2, spaa_stream_t stream) {
+    return launch_tail_fwd<_Float16>(reinterpret_cast<const _Float16*>(x6), w2_split, bias2, w6, bias6, res1, y, ypre, mask7, B, H2, W2,
+                                     stream);
+}
+int spaa_shading_head_bwd(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6,
+                          float* p6, int B, int H2, int W2, spaa_stream_t stream) {
+    return launch_head_bwd<float>(gp, w6t, w2t_split, mask7, mask6, p6, B, H2, W2, stream);
+}
+int spaa_shading_head_bwd_f16(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6,
+                              void* p6, int B, int H2, int W2, spaa_stream_t stream) {
+    return launch_head_bwd<_Float16>(gp, w6t, w2t_split, mask7, mask6, reinterpret_cast<_Float16*>(p6), B, H2, W2, stream);
 }
 
 }  // extern "C"

@@ -368,7 +368,7 @@ class PCNetEngine:
         self._clamp = 1
         # tail / head fusion (csrc/shading_tail.hip): X7 and its gradient never reach HBM.  Needs the byte gate masks; the
         # training step (weight gradients read X7 and P7) switches it off
-        self.fuse_tail = FUSE_TAIL and USE_GATE_MASKS and storage == 'f32' and H % 2 == 0 and W % 2 == 0
+        self.fuse_tail = FUSE_TAIL and (USE_GATE_MASKS or storage == 'f16') and H % 2 == 0 and W % 2 == 0
         self._x7_version = -1    # `version` for which a['X7'] holds the activation
         wt, w6 = sn.transConv2.weight.detach().float().cpu(), sn.conv6.weight.detach().float().cpu()
         assert wt.shape == (64, 32, 2, 2) and w6.shape == (3, 32, 3, 3)
@@ -425,9 +425,10 @@ class PCNetEngine:
         f['transConv1'].run(a['X5'], a['X6'], add=a['R2'], act=R, mask_out=m['X6'])
         if self.fuse_tail:
             t = self.tail
-            _lib.call('spaa_shading_tail_fwd', _lib.ptr(a['X6']), _lib.ptr(t['w2s']), _lib.ptr(t['b2']), _lib.ptr(t['w6']),
-                      _lib.ptr(t['b6']), _lib.ptr(a['R1']), _lib.ptr(a['Y']), _lib.ptr(a['Ypre']), _lib.ptr(m['X7']), self.B,
-                      self.Hc // 2, self.Wc // 2)
+            f16 = self.storage == 'f16'   # (X6 fp16 in HBM; the activation kept in LDS and the arithmetic stay fp32)
+            _lib.call('spaa_shading_tail_fwd_f16' if f16 else 'spaa_shading_tail_fwd', _lib.hptr(a['X6']) if f16 else _lib.ptr(a['X6']),
+                      _lib.ptr(t['w2s']), _lib.ptr(t['b2']), _lib.ptr(t['w6']), _lib.ptr(t['b6']), _lib.ptr(a['R1']), _lib.ptr(a['Y']),
+                      _lib.ptr(a['Ypre']), _lib.ptr(m['X7']), self.B, self.Hc // 2, self.Wc // 2)
             return a['Y']
         x7 = dict.__getitem__(a, 'X7')
         f['transConv2'].run(a['X6'], x7, act=R, mask_out=m['X7'])
@@ -441,12 +442,13 @@ class PCNetEngine:
         if not USE_GATE_MASKS and self.storage == 'f32':
             return self._backward_float_gates(gP)
         g, d, m = self.g, self.d, self.m
-        if self.fuse_tail and self.storage == 'f32':
+        if self.fuse_tail:
             t = self.tail
             _lib.check_dev(gP)
             assert gP.shape == (self.B, self.Hc, self.Wc, 4) and gP.dtype == torch.float32
-            _lib.call('spaa_shading_head_bwd', _lib.ptr(gP), _lib.ptr(t['w6t']), _lib.ptr(t['w2ts']), _lib.ptr(m['X7']),
-                      _lib.ptr(m['X6']), _lib.ptr(g['P6']), self.B, self.Hc // 2, self.Wc // 2)
+            _lib.call('spaa_shading_head_bwd' if self.storage == 'f32' else 'spaa_shading_head_bwd_f16', _lib.ptr(gP), _lib.ptr(t['w6t']),
+                      _lib.ptr(t['w2ts']), _lib.ptr(m['X7']), _lib.ptr(m['X6']),
+                      _lib.hptr(g['P6']) if self.storage == 'f16' else _lib.ptr(g['P6']), self.B, self.Hc // 2, self.Wc // 2)
         else:
             d['conv6'].run(gP, g['P7'], gate_bits=m['X7'])
             d['transConv2'].run(g['P7'], g['P6'], gate_bits=m['X6'])
