@@ -77,7 +77,20 @@ constexpr int PATCH_BYTES = PPW * 8 * 1024;    // 81920 (pieces 77..79: pad)
 // 64-byte weight rows (32 bf16), chunk swizzle as tapconv_x6d.hip swz_w<16>
 __device__ __forceinline__ int swz_w16(int n) { return ((n >> 3) & 1) << 1; }
 
-template <int BN, int VAR>
+// workgroup barrier that leaves LDS-DMA in flight: __syncthreads() drains vmcnt to 0 while a buffer_load ... lds is pending
+// (cdna_hip_programming.md section 5, "Pipelining across barriers"), which defeats the counted waits of the weight pipeline
+template <bool RAW>
+__device__ __forceinline__ void wg_barrier() {
+    if constexpr (RAW) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int BN, int VAR, int DBG = 0>   // DBG: timing-only ablations (wrong results): 1 no epilogue, 2 no fold, 4 no V, 8 no barrier, 16 no DMA; 32: raw barrier
 __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p, const int wg_y, const int wg_x, const int n_tiles) {
     constexpr int TJ = BN / 16;
     constexpr int W_PLANE = BN * 64;
@@ -231,15 +244,15 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                 if (step + 1 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (xi == 3 && (nu == 1 || nu == 2) && kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + PPW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
-                __syncthreads();
+                if constexpr (!(DBG & 8)) wg_barrier<(DBG & 32) != 0>();
                 const int st2 = st >= 1 ? st - 1 : 2;   // (st + 2) % 3
-                if (step + 2 < nsteps) WINO_DMA_W(st2, step + 2)
-                if (!late || step == 0) {   // (step 0: every wave)
+                if (step + 2 < nsteps && !(DBG & 16)) WINO_DMA_W(st2, step + 2)
+                if ((!late || step == 0) && (!(DBG & 4) || step == 0)) {   // (step 0: every wave)
                     if (nu == 0) combine_rows(xi);
                     form_v(nu);
                 }
-                if (nu == 0 && xi == 3 && kb + 1 < nkb) {   // (uniform) the patch is free: request the next channel block
-                    __syncthreads();
+                if (nu == 0 && xi == 3 && kb + 1 < nkb && !(DBG & 16)) {   // (uniform) the patch is free: request the next channel block
+                    if constexpr (!(DBG & 8)) wg_barrier<(DBG & 32) != 0>();
                     WINO_DMA_PATCH(kb + 1)
                 }
                 const float cj1 = nu == 1 ? 1.f : -1.f;   // (nu 0 adds nothing to output column 1, nu 3 nothing to column 0)
@@ -272,7 +285,9 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                     }
                     if (j > 0) {
                         const f32x4 mp = mm[(j - 1) & 1];
-                        if constexpr (XIU) {   // (xi is a constant here: additions / subtractions, nothing for a zero coefficient)
+                        if constexpr (DBG & 2) {
+                            asm volatile("" ::"v"(mp));
+                        } else if constexpr (XIU) {   // (xi is a constant here: additions / subtractions, nothing for a zero coefficient)
                             if (nu < 3) {
                                 if (xi < 3) Y[0][j - 1] += mp;
                                 if (xi == 1) Y[2][j - 1] += mp;
@@ -318,7 +333,7 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (late && step + 1 < nsteps) {   // V of the next step (its patch has landed: see the wait of step 15)
+                if (late && step + 1 < nsteps && !(DBG & 4)) {   // V of the next step (its patch has landed: see the wait of step 15)
                     if (nu == 3) combine_rows((xi + 1) & 3);
                     form_v((nu + 1) & 3);
                 }
@@ -348,12 +363,19 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                      (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
                      (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
                      (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
+    if constexpr (DBG & 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) asm volatile("" ::"v"(Y[i][j]));
+        return;
+    }
     constexpr int ROWB = BN * 4;          // bytes of a pixel's BN channels in the LDS image
     constexpr int LPP = BN / 4;           // lanes (16-byte chunks) per pixel: 32 or 16
     constexpr int PPI = 64 / LPP;         // pixels per wave store instruction
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        __syncthreads();   // the main loop's (resp. the previous half's) LDS reads are done
+        wg_barrier<(DBG & 64) != 0>();   // the main loop's (resp. the previous half's) LDS reads are done (raw: the stores stay in flight)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int pl = 32 * wave + 2 * tx + c;
@@ -361,7 +383,7 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
             for (int j = 0; j < TJ; ++j)
                 *reinterpret_cast<f32x4*>(smem + pl * ROWB + (((4 * j + q8) ^ tx) << 4)) = Y[2 * half + c][j];
         }
-        __syncthreads();
+        wg_barrier<(DBG & 64) != 0>();
         // the residual / gate operands of EB pixels are requested before any of them is finished: EB loads in flight per lane
         constexpr int EB = 8;
 #pragma unroll 1
@@ -427,6 +449,22 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;                                                                               \
         hipLaunchKernelGGL((wino_x6_kernel<N, V>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles); \
     }
+#ifdef SPAA_WINO_ABLATE
+    const int dbg = (d.reserved0 >> 18) & 127;
+#define WINO_LAUNCH_DBG(D)                                                                                                \
+    if (dbg == D) {                                                                                                       \
+        static bool as_[SPAA_MAX_DEVICES] = {};                                                                           \
+        const size_t smem = (size_t)PATCH_BYTES + 3 * (size_t)(((3 * 128 / 16 + 7) / 8) * 8 * 1024);                      \
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<128, 3, D>), (int)smem, as_);     \
+        if (e != hipSuccess) return (int)e;                                                                               \
+        hipLaunchKernelGGL((wino_x6_kernel<128, 3, D>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles); \
+        return (int)hipGetLastError();                                                                                    \
+    }
+    if (BN == 128) {
+        WINO_LAUNCH_DBG(1) WINO_LAUNCH_DBG(3) WINO_LAUNCH_DBG(5) WINO_LAUNCH_DBG(7) WINO_LAUNCH_DBG(15) WINO_LAUNCH_DBG(31) WINO_LAUNCH_DBG(2) WINO_LAUNCH_DBG(4) WINO_LAUNCH_DBG(8) WINO_LAUNCH_DBG(32) WINO_LAUNCH_DBG(33) WINO_LAUNCH_DBG(64) WINO_LAUNCH_DBG(96)
+    }
+#undef WINO_LAUNCH_DBG
+#endif
     if (BN == 64) {
         if (var == 3) WINO_LAUNCH(64, 3, 4) else if (var == 2) WINO_LAUNCH(64, 2, 5) else if (var == 1) WINO_LAUNCH(64, 1, 6) else WINO_LAUNCH(64, 0, 7)
     } else if (var == 3) WINO_LAUNCH(128, 3, 3) else if (var == 2) WINO_LAUNCH(128, 2, 2) else if (var == 1) WINO_LAUNCH(128, 1, 1) else WINO_LAUNCH(128, 0, 0)

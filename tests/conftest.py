@@ -30,3 +30,11 @@ def built_library():
             import __graft_entry__
             __graft_entry__.build()
     return lib
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """GPU sessions: the largest gate-bookkeeping quantities seen (tests/gates.py: MEASURED), so that its tolerances can be
+    stated as a multiple of what is measured."""
+    gates = sys.modules.get('gates')
+    if gates is not None and any(gates.MEASURED.values()):
+        print('\n[gates] largest over this session: ' + ', '.join(f'{k} {v:.3e}' for k, v in gates.MEASURED.items()))

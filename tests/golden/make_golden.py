@@ -208,6 +208,55 @@ def gen_spaa(ref, name, sz, targeted, targets, d_thr, stealth, seed=0, mask='rec
          wsum=weights_checksum(sd), oracle_maxdiff=diff)
 
 
+def gen_sensitivity(ref, name, sz=(64, 64)):
+    """How far does the UNMODIFIED reference move its own 50-iteration output under changes that are pure rounding?  Same
+    case as spaa_64_near (8 targets, camdE_caml2, d_thr 5); three runs of `spaa()`: (a) 8 CPU threads, (b) 1 thread (another
+    summation order inside the convolutions), (c) 8 threads with the start image one ulp above 0.5.  The fixture is what
+    DESIGN.md section 4 and the docstrings of tests/test_gpu_parity.py cite; tests/test_oracle_golden.py re-measures the
+    thread-count part with the oracle (== reference bit for bit) on the machine that runs the tests."""
+    t0 = time.time()
+    sd = syn.pcnet_state_dict(0, cam_sz=sz, mask='rect')
+    csd = syn.resnet18_state_dict(2, logit_gain=GAIN)
+    in_sz, cp = (sz[0] - 8, sz[1] - 8), (sz[0] - 4, sz[1] - 4)
+    clf = so.OracleClassifier('resnet18', csd, input_sz=in_sz)
+    scene = syn.scenes(1, 1, sz)
+    targets = near_targets(clf, scene, cp, 8)
+    nthr = torch.get_num_threads()
+
+    def run(threads, brightness):
+        torch.set_num_threads(threads)
+        pc = ref_shims.make_reference_pcnet(ref, sd, sz, sz)
+        setup = dict(classifier_crop_sz=cp, prj_brightness=brightness, prj_im_sz=sz)
+        rec = Recorder(clf)
+        with contextlib.redirect_stdout(io.StringIO()):
+            cam, prj = ref.attack.spaa(pc, rec, LABELS, targets, True, scene[0], 5, 'camdE_caml2', 'cpu', setup)
+        torch.set_num_threads(nthr)
+        return cam.detach(), prj.detach(), np.stack(rec.top1)
+
+    ulp = float(np.nextafter(np.float32(0.5), np.float32(1.0)))
+    cam8, prj8, top8 = run(8, 0.5)
+    cam1, prj1, top1 = run(1, 0.5)
+    camu, prju, topu = run(8, ulp)
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max())
+
+    # growth of a 1e-7 perturbation of the start, per iteration (oracle == reference; its trace has every iterate)
+    tra, trb = [], []
+    setup = dict(classifier_crop_sz=cp, prj_brightness=0.5, prj_im_sz=sz)
+    so.spaa(sd, clf, targets, True, scene, 5, 'camdE_caml2', setup, iters=8, trace=tra)
+    so.spaa(sd, clf, targets, True, scene, 5, 'camdE_caml2', dict(setup, prj_brightness=0.5 + 1e-7), iters=8, trace=trb)
+    growth = np.array([np.abs(a['prj_adv'] - b['prj_adv']).max() / np.abs(a['prj_adv']).max() for a, b in zip(tra, trb)])
+    first_div = lambda ta, tb: int(np.argmax((ta != tb).any(axis=1))) if (ta != tb).any() else -1
+    print(f'  {name}: prj_adv_best rel Linf  8 vs 1 threads {rel(prj1, prj8):.3f}, one-ulp start {rel(prju, prj8):.3f}; cam_infer_best '
+          f'{rel(cam1, cam8):.3f} / {rel(camu, cam8):.3f}; first iteration with another top-1: {first_div(top1, top8)} / '
+          f'{first_div(topu, top8)}; growth of 1e-7: {growth} ({time.time() - t0:.0f}s)')
+    save(name, sz=sz, targets=np.array(targets), ulp_start=ulp, prj_threads=rel(prj1, prj8), prj_ulp=rel(prju, prj8),
+         cam_threads=rel(cam1, cam8), cam_ulp=rel(camu, cam8), top1_div_threads=first_div(top1, top8),
+         top1_div_ulp=first_div(topu, top8), growth_1e7=growth,
+         mean_prj_threads=float((prj1 - prj8).abs().mean()), mean_prj_ulp=float((prju - prj8).abs().mean()))
+
+
 def gen_percal(ref, name, sz, targeted, d_thr, confidence):
     csd = syn.resnet18_state_dict(2, logit_gain=GAIN)
     cp, in_sz = (sz[0] - 4, sz[1] - 4), (sz[0] - 8, sz[1] - 8)
@@ -391,6 +440,7 @@ CASES = {
     'img_dists': lambda r: gen_metrics(r, 'img_dists'),
     'percal_64_targeted': lambda r: gen_percal(r, 'percal_64_targeted', (64, 64), True, 2, 0),
     'percal_64_untargeted': lambda r: gen_percal(r, 'percal_64_untargeted', (64, 64), False, 2, 40),
+    'sensitivity_64': lambda r: gen_sensitivity(r, 'sensitivity_64'),
 }
 
 if __name__ == '__main__':

@@ -3,7 +3,8 @@
 Tolerances.  north_star asks for 1e-4 relative L-inf on the produced projection image.  The SPAA loop is a chaotic,
 discontinuous map (normalised-gradient steps of length 1-2 through ReLU networks, hard masks): the REFERENCE ITSELF
 changes its 50-iteration output by ~2e-1 relative L-inf when run with 1 instead of 8 CPU threads or when the
-initial image is perturbed by one ulp (`test_reference_sensitivity_envelope` re-measures it).
+initial image is perturbed by one ulp (fixture tests/golden/sensitivity_64.npz, produced by the unmodified reference;
+tests/test_oracle_golden.py::test_reference_sensitivity_envelope checks it and re-measures it with the oracle).
 So parity is asserted where it is well defined:
   * every forward quantity                                        <= 1e-4 (typically 1e-6) relative L-inf
   * gradients                                                     <= 1e-4 relative L2 (ReLU-gate flips of
@@ -567,6 +568,56 @@ def test_free_running_drift_vs_fp64_oracle(hip, golden_dir):
     assert abs(d_ours - d_ref) / d_ref < 0.05
 
 
+FIFTY = ['spaa_64_untargeted', 'spaa_64_imagenet10', 'spaa_64_near', 'spaa_64_caml2_dthr', 'spaa_64_prjl2', 'spaa_64_camdE',
+         'spaa_256_untargeted', 'spaa_256_near']
+
+
+@pytest.mark.parametrize('name', FIFTY)
+def test_spaa_fifty_iterations_statistics(hip, golden_dir, name):
+    """All eight 50-iteration runs of the unmodified reference (fixtures spaa_*): the free-running HIP attack must reach the same
+    OUTCOME.  Element-wise equality of the produced images is not defined for this loop (the reference moves its own output by
+    0.17-0.24 relative L-inf under a thread-count change / a one-ulp start: fixture sensitivity_64), so what is compared is
+    what the caller uses the result for: which samples were attacked successfully, and how visible the attack is on the
+    camera side (mean L2 and mean dE2000 of `cam_infer_best` against the scene, projector_based_attack.py:275-283).
+    Envelope: success sets equal up to one sample in eight; distortions within 2 % (measured over the eight runs: sets
+    identical, distortions within 0.5 %: table in profiles/r03_parity.txt)."""
+    A = hip['attack']
+    z = load(golden_dir, name)
+    sd, pc, clf, oclf, scene, setup = _setup_case(hip, z)
+    targets, targeted = [int(t) for t in z['targets']], bool(z['targeted'])
+    tr = []
+    cam, prj = A.spaa(pc, clf, None, targets, targeted, scene, float(z['d_thr']), str(z['stealth']), DEV, setup, trace=tr)
+    cam, prj = cam.cpu(), prj.cpu()
+    st = torch.stack([t[0] for t in tr]).cpu().numpy()         # [50, B, 4]: succ, best_adv, best, top-1
+    ever_hip = st[:, :, 2].any(axis=0)                          # a best image was recorded at least once
+    ever_ref = z['best'].any(axis=0)
+    k = z['cam_infer_best'].shape[0]                            # (spaa_256_near keeps the first two samples)
+    ref_cam = torch.from_numpy(z['cam_infer_best'])
+    sc = scene.expand(len(targets), -1, -1, -1)
+
+    def dist(c):
+        l2 = torch.norm(c - sc[:c.shape[0]], dim=1).mean().item()
+        de = so.ciede2000_diff(so.rgb2lab_diff(c), so.rgb2lab_diff(sc[:c.shape[0]].contiguous())).mean().item()
+        return l2, de
+
+    l2h, deh = dist(cam[:k])
+    l2r, der = dist(ref_cam)
+    print(f'{name}: samples with a recorded best image: HIP {int(ever_hip.sum())} / reference {int(ever_ref.sum())} of {len(targets)}; '
+          f'final-iteration successes HIP {int(st[-1, :, 0].sum())} / reference {int(z["succ"][-1].sum())}; cam_infer_best vs scene: '
+          f'mean L2 {l2h:.5f} / {l2r:.5f} ({(l2h / max(l2r, 1e-12) - 1) * 100:+.1f} %), mean dE {deh:.4f} / {der:.4f} '
+          f'({(deh / max(der, 1e-12) - 1) * 100:+.1f} %)')
+    assert int((ever_hip != ever_ref).sum()) <= (1 if len(targets) >= 8 else 0)
+    # (whether the LAST iteration happens to be a success alternates with the adversarial / colour steps of a sample: logged,
+    # asserted only as a count over a batch)
+    if len(targets) >= 8:
+        assert abs(int(st[-1, :, 0].sum()) - int(z['succ'][-1].sum())) <= 2
+    if l2r > 0:
+        assert abs(l2h / l2r - 1) < 0.02 and abs(deh / der - 1) < 0.02
+    else:   # nobody ever succeeded: the reference returns the scene itself (Q7) and so must we
+        assert l2h == 0.0 and torch.equal(prj, torch.from_numpy(z['prj_adv_best']))
+    assert prj.min() >= 0 and prj.max() <= 1
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def test_full_size_properties_batch64(hip):
     """BASELINE.json config sizes (B=64, 256x256, ResNet-18): size-independent properties of the HIP path."""
@@ -650,7 +701,7 @@ def test_perc_al_adversary_projector(hip, golden_dir, targeted, confidence):
     print(f'PerC-AL targeted={targeted} conf={confidence}: delta rel Linf after it 0/1/2 = '
           f'{[round(rel_inf(tr[k][2], otr[k]["delta"]), 6) for k in range(3)]}')
     assert rel_inf(tr[2][2], otr[2]['delta']) < 1e-4   # (measured 2e-6 ... 3.4e-5: profiles/r02_parity.txt)
-    # (the 50-iteration result itself is chaotic, like spaa(): see test_reference_sensitivity_envelope)
+    # (the 50-iteration result itself is chaotic, like spaa(): tests/test_oracle_golden.py::test_reference_sensitivity_envelope)
     ref = torch.from_numpy(z['x_adv_best'])
     assert ref.shape == out.shape
 
@@ -1129,21 +1180,18 @@ def _first_iteration_gate_aware(hip, body, csd, insz, im_sz, crop, targets, seed
         assert d < 5e-3
     st = A.AttackState(pc, clf, targets, scene, stealth, setup, DEV)
     x0 = torch.full((B, 3, *prj_sz), 0.5)
-    have_gates = True
-    if have_gates:
-        acts, cacts = _oracle_activations(sd, csd, x0, scene.expand(B, -1, -1, -1), im_sz, crop, insz, body)
+    acts, cacts = _oracle_activations(sd, csd, x0, scene.expand(B, -1, -1, -1), im_sz, crop, insz, body)
     errs = {}
-    for mode in ('plain', 'oracle_gates') if have_gates else ('plain',):
+    for mode in ('plain', 'oracle_gates'):
         st.x.copy_(M.to_nhwc4(x0.to(DEV)))
         st.stats[:, 5] = 1e6
         st.forward_decide(targeted, d_thr, 0.9)
-        if have_gates:
-            pairs = gates.pcnet_pairs(st.eng, acts) + dict(vgg16=gates.vgg16_pairs, resnet18=gates.resnet18_pairs,
-                                                           inception_v3=gates.inception_pairs)[body](st.clf.body, cacts)
-            if mode == 'plain':
-                flips, per_layer = gates.count_flips(pairs)
-            else:
-                gates.inject(pairs, (st.eng, st.clf.body))
+        pairs = gates.pcnet_pairs(st.eng, acts) + dict(vgg16=gates.vgg16_pairs, resnet18=gates.resnet18_pairs,
+                                                       inception_v3=gates.inception_pairs)[body](st.clf.body, cacts)
+        if mode == 'plain':
+            flips, per_layer = gates.count_flips(pairs)
+        else:
+            gates.inject(pairs, (st.eng, st.clf.body))
         if mode == 'plain':
             assert rel_inf(M.to_nchw(st.eng.a['Y']), torch.from_numpy(tr[0]['cam_infer'])) < 1e-5
             assert (st.state[:, 3].cpu().numpy() == tr[0]['top1']).all()
@@ -1151,16 +1199,10 @@ def _first_iteration_gate_aware(hip, body, csd, insz, im_sz, crop, targets, seed
         st.backward_step(2, 1)
         xn = M.to_nchw(st.x).cpu()
         errs[mode] = torch.tensor([rel_inf(xn[b], ref[b]) for b in range(B)])
-    if have_gates:
-        print(f'{body} loop, first iteration at cam {im_sz} prj {prj_sz}: gates differing per sample {flips.tolist()} {per_layer}; projector image '
-              f'rel Linf plain {errs["plain"].tolist()}, with the oracle\'s gates {errs["oracle_gates"].tolist()}')
-        assert (errs['plain'][flips == 0] < 1e-4).all() and (errs['oracle_gates'] < 1e-4).all()
-    else:
-        out = outlier_fraction(xn - 0.5, ref - 0.5, 1e-4)
-        print(f'{body} loop, first iteration at {im_sz}: projector image rel Linf {errs["plain"].tolist()}, elements off by '
-              f'more than 1e-4: {out:.2e}')
-        # (no gate bookkeeping for this body's 94 convolutions: 1e-4, or sparse gate-flip differences — see DESIGN.md §4)
-        assert (errs['plain'] < 1e-4).all() or (float(errs['plain'].max()) < 5e-3 and out < 2e-2)
+    print(f'{body} loop, first iteration at cam {im_sz} prj {prj_sz}: gates differing per sample {flips.tolist()} {per_layer}; projector image '
+          f'rel Linf plain {errs["plain"].tolist()}, with the oracle\'s gates {errs["oracle_gates"].tolist()}')
+    assert (errs['plain'][flips == 0] < 1e-4).all() and (errs['oracle_gates'] < 1e-4).all()
+    st.flips = flips
     return st
 
 
@@ -1213,48 +1255,58 @@ def test_full_size_properties_other_classifiers(hip, body):
 
 
 def test_perc_al_with_vgg16_at_full_size(hip):
-    """configs[4] (fp32 part): PerC_AL.adversary_projector with VGG-16 at 256x256 — iteration 0 from identical state vs the
-    oracle, gate-aware (VGG-16 has no skip connections: one ReLU gate or max-pool arg-max within rounding of a tie changes
-    the gradient over the whole image), and output properties over more iterations."""
+    """configs[4] (fp32 part): PerC_AL.adversary_projector with VGG-16 — iteration 0 from identical state vs the oracle,
+    gate-aware (VGG-16 has no skip connections: one ReLU gate or max-pool arg-max within rounding of a tie changes the
+    gradient over the whole image), at 256x256 and at 64x64, and output properties over more iterations.  At 256x256 every
+    sample usually has a few such units (r02: five of 14.7 M per sample), so the plain (no gates exchanged) 1e-4 assertion is
+    carried by the smaller size: the test FAILS if no tested sample anywhere is flip-free."""
     import gates
     from spaa_amd.perc_al import PerC_AL, PerCALState
-    csd = syn.vgg16_state_dict(3, logit_gain=5.0, fc_width=256)
-    clf = hip['clf'].Classifier('vgg16', DEV, state_dict=csd)
-    oclf = so.OracleClassifier('vgg16', csd)
-    scene = syn.scenes(1, 1, (256, 256)).expand(4, -1, -1, -1).contiguous()
-    _, _, idx = oclf(scene[:1], (240, 240))
-    labels = torch.tensor([int(i) for i in idx[0, 1:5]])
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    otr = []
-    so.perc_al_adversary_projector(oclf, scene, labels, 2.0, True, (240, 240), 400, 1., 0.5, 0, stop_after=1, trace=otr)
-    with torch.no_grad():
-        _, cacts = so.vgg16_forward(csd, so.classifier_preprocess(scene, (240, 240), (224, 224)), return_all=True)
-    att = PerC_AL(device=DEV, max_iterations=400, alpha_l_init=1, alpha_c_init=0.5, confidence=0)
-    res = {}
-    for mode in ('plain', 'oracle_gates'):
-        with torch.cuda.device(DEV):
-            st = PerCALState(att, clf, scene, labels, 2.0, True, (240, 240))
-        info = {}
+    n_clean = 0
+    for h, crop, insz, fcw, b in [(64, (60, 60), (48, 48), 256, 8), (256, (240, 240), (224, 224), 256, 4)]:
+        csd = syn.vgg16_state_dict(3, logit_gain=5.0, fc_width=fcw)
+        clf = hip['clf'].Classifier('vgg16', DEV, state_dict=csd, input_sz=insz)
+        oclf = so.OracleClassifier('vgg16', csd, input_sz=insz)
+        # (iteration 0 starts from delta = 0: copies of ONE scene would have identical gates, so the small size uses b scenes)
+        scene = syn.scenes(1, b, (h, h)) if h < 256 else syn.scenes(1, 1, (h, h)).expand(b, -1, -1, -1).contiguous()
+        _, _, idx = oclf(scene[:1], crop)
+        labels = torch.tensor([int(i) for i in idx[0, 1:1 + b]])
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        otr = []
+        so.perc_al_adversary_projector(oclf, scene, labels, 2.0, True, crop, 400, 1., 0.5, 0, stop_after=1, trace=otr)
+        with torch.no_grad():
+            _, cacts = so.vgg16_forward(csd, so.classifier_preprocess(scene, crop, insz), return_all=True)
+        att = PerC_AL(device=DEV, max_iterations=400, alpha_l_init=1, alpha_c_init=0.5, confidence=0)
+        res = {}
+        for mode in ('plain', 'oracle_gates'):
+            with torch.cuda.device(DEV):
+                st = PerCALState(att, clf, scene, labels, 2.0, True, crop)
+            info = {}
 
-        def hook(eng, mode=mode, info=info):
-            pairs = gates.vgg16_pairs(eng.body, cacts)
+            def hook(eng, mode=mode, info=info):
+                pairs = gates.vgg16_pairs(eng.body, cacts)
+                if mode == 'plain':
+                    info['flips'], info['layers'] = gates.count_flips(pairs)
+                else:
+                    gates.inject(pairs)
+
+            st.iteration(0, after_forward=hook)
+            d0 = hip['models'].to_nchw(st.delta).cpu()
+            res[mode] = torch.tensor([rel_inf(d0[k], otr[0]['delta'][k]) for k in range(b)])
             if mode == 'plain':
-                info['flips'], info['layers'] = gates.count_flips(pairs)
-            else:
-                gates.inject(pairs)
-
-        st.iteration(0, after_forward=hook)
-        d0 = hip['models'].to_nchw(st.delta).cpu()
-        res[mode] = torch.tensor([rel_inf(d0[b], otr[0]['delta'][b]) for b in range(4)])
-        if mode == 'plain':
-            flips, layers = info['flips'], info['layers']
-            assert np.allclose(st.stats[:, 3].cpu().numpy(), otr[0]['color_dis'].numpy(), rtol=1e-4)
-            assert (st.state[:, 3].cpu().numpy() == otr[0]['top1']).all()
-    print(f'PerC-AL + VGG-16 at 256x256, iteration 0: gates differing per sample {flips.tolist()} {layers}; delta rel Linf plain '
-          f'{res["plain"].tolist()}, with the oracle\'s gates {res["oracle_gates"].tolist()}')
-    assert (res['plain'][flips == 0] < 1e-4).all() and (res['oracle_gates'] < 1e-4).all()
+                flips, layers = info['flips'], info['layers']
+                # (the colour distance is that of the image AFTER the iteration's adversarial step: 1e-4 where the gates agree)
+                cd, cdo = st.stats[:, 3].cpu().numpy(), otr[0]['color_dis'].numpy()
+                cl = (flips == 0).numpy()
+                assert np.allclose(cd[cl], cdo[cl], rtol=1e-4) and np.allclose(cd, cdo, rtol=2e-3), (cd, cdo, flips)
+                assert (st.state[:, 3].cpu().numpy() == otr[0]['top1']).all()
+        print(f'PerC-AL + VGG-16 at {h}x{h}, iteration 0: gates differing per sample {flips.tolist()} {layers}; delta rel Linf plain '
+              f'{res["plain"].tolist()}, with the oracle\'s gates {res["oracle_gates"].tolist()}')
+        n_clean += int((flips == 0).sum())
+        assert (res['plain'][flips == 0] < 1e-4).all() and (res['oracle_gates'] < 1e-4).all()
+    assert n_clean > 0, 'no flip-free sample at any tested size: the plain 1e-4 assertion never ran'
     out = PerC_AL(device=DEV, max_iterations=6, alpha_l_init=1, alpha_c_init=0.5, confidence=0) \
-        .adversary_projector(clf, scene, labels, None, 2.0, True, (240, 240))
+        .adversary_projector(clf, scene, labels, None, 2.0, True, crop)
     assert out.shape == scene.shape and out.min() >= 0 and out.max() <= 1
     assert (torch.round(out * 255) / 255 - out).abs().max() < 1e-6
 
