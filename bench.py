@@ -302,6 +302,53 @@ def instrumented_pass(st, args, n_prof=3):
     return per_tile, per_layer, other, t_roof_x6, t_roof_f32
 
 
+PCNET_LAYERS = ('conv1', 'conv2', 'conv3', 'conv4', 'conv5', 'conv1_s', 'conv2_s', 'conv3_s', 'conv4_s', 'conv6', 'skipConv2',
+                'skipConv3', 'transConv1', 'transConv2')
+PCNET_ENTRY_POINTS = ('spaa_warp_fwd', 'spaa_warp_bwd_gather', 'spaa_shading_tail_fwd', 'spaa_shading_tail_fwd_f16',
+                      'spaa_shading_head_bwd', 'spaa_shading_head_bwd_f16', 'spaa_stealth_loss_fwd_bwd')
+MB_PCNET_DE_PER_SCENE_256 = 214.0   # PCNet + dE2000 forward / backward, fp32, per scene-iteration
+
+
+def pcnet_de_hbm(per_layer, other, n_prof, batch, size, f16):
+    """north_star's HBM framing: algorithmic bytes of PCNet + dE2000 forward / backward per step (214 MB per scene-
+    iteration in fp32; the network's activations and gradients are half of that in fp16 storage, the 3-channel images stay
+    fp32) over the time of exactly those kernels, as a fraction of 8 TB/s."""
+    ms = 0.0
+    for name, v in per_layer.items():
+        base = name[:-6] if name.endswith('_dgrad') else name
+        if base in PCNET_LAYERS:
+            ms += v[1] / n_prof
+    for name in PCNET_ENTRY_POINTS:
+        if name in other:
+            ms += other[name][0] / n_prof
+    img_mb = 1.57 * 2 + 2.36          # warp forward / backward and the loss: fp32 images in either mode
+    mb = img_mb + (MB_PCNET_DE_PER_SCENE_256 - img_mb) * (0.5 if f16 else 1.0)
+    gb = mb * 1e6 * batch * (size * size) / 65536.0
+    return {'kernels_ms_per_step': round(ms, 3), 'algorithmic_bytes_per_step': round(gb),
+            'achieved_tb_s': round(gb / (ms * 1e-3) / 1e12, 3), 'frac_of_8_tb_s': round(gb / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4)}
+
+
+def time_mode(dev, args, classifier, storage, attack, steps=10, warmup=3):
+    """One extra configuration of BASELINE.json timed like the headline (own state, own warm-up, own region); never `value`."""
+    t_build = time.perf_counter()
+    st, _sd, _csd, _setup, _scenes, _targets = build_attack(0, args.batch, args.size, 8, dev, classifier, storage, attack)
+    torch.cuda.synchronize()
+    dt = timed_steps(st.step, steps, warmup, None, torch.cuda.synchronize)
+    out = {'attack_iterations_per_s': round(steps / dt, 3), 'ms_per_step': round(dt / steps * 1e3, 3), 'steps': steps, 'warmup': warmup,
+           'batch': args.batch, 'size': args.size, 'classifier': classifier,
+           'dtype': 'f32' if storage == 'f32' else 'f16 storage (activations/gradients), f32 accumulation, images and dE2000',
+           'attack': 'spaa loop body' if attack == 'spaa' else 'PerC_AL.adversary_projector loop body'}
+    if attack == 'spaa':
+        per_tile, per_layer, other, _a, _b = instrumented_pass(st, args, 2)
+        out['pcnet_dE_hbm'] = pcnet_de_hbm(per_layer, other, 2, args.batch, args.size, storage == 'f16')
+        tot = sum(v[1] for v in per_tile.values())
+        out['all_tapconv_tflops'] = round(sum(v[0] for v in per_tile.values()) / (tot * 1e-3) / 1e12, 2)
+    out['seconds_incl_build'] = round(time.perf_counter() - t_build, 1)
+    del st
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -317,6 +364,8 @@ def main():
     ap.add_argument('--attack', default='spaa', choices=['spaa', 'perc_al'],
                     help='spaa (the bench line) or perc_al = PerC_AL.adversary_projector loop body (configs[4], with --classifier vgg16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-modes', action='store_true',
+                    help='skip the extra configurations timed after the headline (f16 storage, Inception-v3, VGG-16 + PerC-AL)')
     ap.add_argument('--profile-out', default=None, help='write the per-layer tapconv timing table (JSON) here')
     ap.add_argument('--rehearse-glue', action='store_true',
                     help='CPU/gloo rehearsal of the multi-rank glue with a stand-in step (tests/); not a measurement')
@@ -445,11 +494,16 @@ def main():
                 'avg_launch_us_source': 'HIP events around this kernel\'s launches inside the timed region (launch stream)' if timed_events else 'HIP events, instrumented passes after the timed region',
                 'avg_launch_us_instrumented_pass': round(ms_instr * 1e3 / n_instr, 2),
                 'flop_per_launch': f / n, 'share_of_conv_time': round(ms_instr / tot_ms, 3),
-                **({'executed_tflops': round(ach * 16 / 36, 2)} if dom.startswith('wino') else {}),
+                **({'executed_tflops': round(ach * 16 / 36, 2),
+                    'executed_mfma_frac': round(ach * 16 / 36 * 6 / PEAK_BF16_MFMA_TFLOPS, 4),
+                    'executed_mfma_note': 'bf16 MFMA FLOPs the kernel issues (16 of the 36 products of a 3x3 tap set, six bf16 '
+                                          'MFMAs each) over the dense bf16 peak: the headroom `frac` does not show'}
+                   if dom.startswith('wino') else {}),
                 'all_tapconv_tflops': round(sum(v[0] for v in per_tile.values()) / (tot_ms * 1e-3) / 1e12, 2),
                 'conv_ms_per_step': round(tot_ms / n_prof, 3),
                 'other_kernels_ms_per_step': round(other_ms, 3),
                 'groups': groups,
+                'pcnet_dE_hbm': pcnet_de_hbm(per_layer, other, n_prof, args.batch, args.size, args.dtype == 'f16s') if args.attack == 'spaa' else None,
                 'step': {'T_roof_ms': round(t_roof_x6 * 1e3 + other_roof, 3),
                          'T_roof_ms_f32_mfma_peak': round(t_roof_f32 * 1e3 + other_roof, 3),
                          'ms_per_step': round(ms_step, 3),
@@ -490,6 +544,17 @@ def main():
             out['cpu_baseline'] = cpu_baseline(sd, csd, setup, scenes)
         else:
             out['cpu_baseline'] = None
+        default_run = world == 1 and args.classifier == 'resnet18' and args.dtype == 'f32' and args.attack == 'spaa'
+        if default_run and not args.no_modes:
+            # the other configurations of BASELINE.json, each timed like the headline after it (never part of `value`)
+            log('extra modes: f16 storage, Inception-v3, VGG-16 + PerC-AL in f16 storage')
+            del st
+            torch.cuda.empty_cache()
+            out['modes'] = {
+                'configs[1] in f16 storage (resnet18, SPAA loop)': time_mode(dev, args, 'resnet18', 'f16', 'spaa'),
+                'configs[2] (inception_v3 at 299x299, SPAA loop, f32)': time_mode(dev, args, 'inception_v3', 'f32', 'spaa'),
+                'configs[4] per GPU (vgg16, PerC-AL loop body, f16 storage)': time_mode(dev, args, 'vgg16', 'f16', 'perc_al'),
+            }
         json_out.write(json.dumps(out) + '\n')
         json_out.flush()
     if dist is not None:

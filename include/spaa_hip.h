@@ -201,8 +201,8 @@ int spaa_shading_head_bwd_f16(const float* gp, const float* w6t, const uint16_t*
 int spaa_relu_gate(const float* g, const float* act, float* out, int64_t n, spaa_stream_t stream);
 /* torch.optim.Adam step on one flat parameter tensor (train_network.py:252-254: betas (0.9, 0.999), eps 1e-8, L2 weight
  * decay added to the gradient); `step` counts from 1 */
-int spaa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                   float beta2, float eps, float weight_decay, int step, spaa_stream_t stream);
+int spaa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, double beta1,
+                   double beta2, float eps, float weight_decay, int step, spaa_stream_t stream);
 
 /* ---- stealthiness losses (projector_based_attack.py:275-287; perc_al/differential_color_functions.py) ----- */
 /* rgb [B,H,W,4] -> lab [B,H,W,4]  (rgb2lab_diff :39-64) */

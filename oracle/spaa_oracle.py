@@ -177,13 +177,13 @@ def compennet_pp_forward(sd, x, s, out_size):
     return compennet_forward(sd, warp(sd, x, out_size), warp(sd, s, out_size))
 
 
-def pcnet_forward(sd, x, s, per_batch_grid=False):
-    """PCNet.forward (models.py:335-346), use_mask=True, use_rough=True."""
+def pcnet_forward(sd, x, s, per_batch_grid=False, use_rough=True):
+    """PCNet.forward (models.py:335-346), use_mask=True; `use_rough=False`: the surface branch sees s alone (:344-345)."""
     full = _sd(sd, '')
     mask = full['mask']
     out_size = mask.shape[-2:]
     xw = warp(sd, x, out_size, per_batch_grid) * mask
-    return shading_net(sd, xw, (s, xw * s))
+    return shading_net(sd, xw, (s, xw * s) if use_rough else (s,))
 
 
 # --------------------------------------------------------------------------------------

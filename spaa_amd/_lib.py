@@ -44,7 +44,7 @@ class TapConv(C.Structure):
     ]
 
 
-_i, _f, _p, _l = C.c_int, C.c_float, C.c_void_p, C.c_int64
+_i, _f, _p, _l, _d = C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_double
 
 # name -> argument types (all return int)
 _SIGNATURES = {
@@ -66,7 +66,7 @@ _SIGNATURES = {
     'spaa_shading_tail_fwd_f16': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     'spaa_shading_head_bwd_f16': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     'spaa_relu_gate': [_p, _p, _p, _l, _p],
-    'spaa_adam_step': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p],
+    'spaa_adam_step': [_p, _p, _p, _p, _l, _f, _d, _d, _f, _f, _i, _p],
     'spaa_rgb2lab': [_p, _p, _i, _p],
     'spaa_ciede2000': [_p, _p, _p, _i, _p],
     'spaa_rgb2lab_bwd': [_p, _p, _p, _i, _p],

@@ -362,7 +362,7 @@ def _classify_impl(clf, im, crop_sz):
         eng = clf.engine(b, (h, w), tuple(crop_sz))
         im4 = to_nhwc4(im)
         logits = eng.forward(im4).clone()
-        saved = dict(eng=eng, version=eng.version, im4=im4)
+        saved = dict(eng=eng, version=eng.version, im4=im4, clf=weakref.ref(clf), key=(b, (h, w), tuple(crop_sz)))
         clf._last_saved = saved
         return logits, saved
 
@@ -371,6 +371,9 @@ def _classify_backward_impl(saved, g):
     eng = saved['eng']
     with _lib.on_device(g.device):
         if eng.version != saved['version']:  # workspaces reused by a later forward: recompute this call's activations
+            if eng.owner is not None and eng.owner() is not None and saved['clf']() is not None:
+                # ... and the engine has since been leased to an attack state: leave ITS workspaces alone, take a free engine
+                eng = saved['eng'] = saved['clf']().engine(*saved['key'])
             eng.forward(saved['im4'])
             saved['version'] = eng.version
         return to_nchw(eng.backward(g.detach().float().contiguous()))

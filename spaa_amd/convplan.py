@@ -59,6 +59,32 @@ def _load_tune():
 
 
 TUNE = _load_tune()  # shape key -> tile id, measured on MI355X by tools/autotune.py (absent key = heuristic)
+_NEAREST = {}
+
+
+def tuned_tile(key):
+    """Tile for a layer-shape key `Cin_Cout_taps_sin_sout_M[_fold]`: the measured one, else the measured choice of the SAME layer
+    at the nearest pixel count M (ratio at most 4 either way: batch 10 borrows from batch 8 or 16, not from batch 64's 256-row
+    persistent tiles), else -1 (the heuristic of `_default_tile`)."""
+    t = TUNE.get(key)
+    if t is not None:
+        return t
+    if key in _NEAREST:
+        return _NEAREST[key]
+    parts = key.split('_')
+    fold = parts[-1] == 'fold'
+    m = int(parts[5])
+    stem = '_'.join(parts[:5]) + '_'
+    best, best_r = -1, 4.0001
+    for k, v in TUNE.items():
+        if not k.startswith(stem) or k.endswith('_fold') != fold:
+            continue
+        mk = int(k.split('_')[5])
+        r = max(mk, m) / max(1, min(mk, m))
+        if r < best_r:
+            best, best_r = v, r
+    _NEAREST[key] = best
+    return best
 
 
 _STREAMK_WS = {}
@@ -137,7 +163,7 @@ class ConvPlan:
         self.flops_per_pixel = 2 * sum(c['ntaps'] for c in self.cls) * cin * ngemm
         self.ntaps_total = sum(c['ntaps'] for c in self.cls)
         self._ws = None  # split-K workspace, allocated on first use
-        self._w_chunks, self._npad, self._dev = w_chunks, npad, device
+        self._npad, self._dev = npad, device
         self.w_half = None  # fp16 plane for the fp16-storage kernels, packed on first use (half_plane())
         self.wino = None    # the same layer in Winograd F(2x2,3x3) form (attach_winograd), run as tile 70
         self.fixed_tile = 0
@@ -146,14 +172,15 @@ class ConvPlan:
     def half_plane(self):
         """The weights rounded to fp16, per class [Npad][K rounded up to 64] (zero padded), classes back to back: the
         operand of the fp16-storage kernels (csrc/tapconv_h16.hip)."""
-        if self.w_half is None:
+        if self.w_half is None:   # (from the device copy of the weights: what `refresh` keeps up to date)
             parts = []
-            for c, wp in zip(self.cls, self._w_chunks):
+            for c in self.cls:
                 k64 = _ceil(c['K'], 64)
-                wh = torch.zeros(self._npad, k64, dtype=torch.float16)
-                wh[:, :c['K']] = wp.view(self._npad, c['Kpad'])[:, :c['K']].to(torch.float16)
+                wp = self.weights[c['w_off']:c['w_off'] + self._npad * c['Kpad']].view(self._npad, c['Kpad'])
+                wh = torch.zeros(self._npad, k64, dtype=torch.float16, device=self.weights.device)
+                wh[:, :c['K']] = wp[:, :c['K']].to(torch.float16)
                 parts.append(wh.reshape(-1))
-            self.w_half = (torch.cat(parts) if parts else torch.zeros(8, dtype=torch.float16)).to(self._dev)
+            self.w_half = torch.cat(parts) if parts else torch.zeros(8, dtype=torch.float16, device=self.weights.device)
         return self.w_half
 
     def run(self, inp, out, add=None, gate=None, gate_mode=_lib.GATE_POS, act=_lib.ACT_NONE, aux_out=None,
@@ -226,7 +253,7 @@ class ConvPlan:
             forced = 0
         if (25 <= forced <= 27 or 30 <= forced <= 37 or (39 <= forced <= 46 or 48 <= forced <= 54)) and (self.cin_p % 32 or any(c['Kpad'] != c['K'] for c in self.cls)):
             forced = 0
-        tile = forced if forced else TUNE.get(key, -1)
+        tile = forced if forced else tuned_tile(key)
         if tile < 0:
             tile = self._default_tile(b * d.Hm * d.Wm)
         if tile == 70:   # Winograd form of a 3x3 / stride-1 layer (csrc/tapconv_wino.hip): fp32 storage, same-size output

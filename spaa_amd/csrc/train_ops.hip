@@ -230,12 +230,13 @@ int spaa_relu_gate(const float* g, const float* act, float* out, int64_t n, spaa
     return (int)hipGetLastError();
 }
 
-int spaa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                   float beta2, float eps, float weight_decay, int step, spaa_stream_t stream) {
+int spaa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, double beta1,
+                   double beta2, float eps, float weight_decay, int step, spaa_stream_t stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1) return hipErrorInvalidValue;
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    // bias corrections in double from the double betas, as torch.optim.Adam forms them (1 - 0.999f^t is off by 1.3e-5 at t = 1)
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
+                       exp_avg_sq, n, lr, (float)beta1, (float)beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
     return (int)hipGetLastError();
 }
 

@@ -188,8 +188,6 @@ class PCNet(nn.Module):
             self.name += '_no_mask'
         if not use_rough:
             self.name += '_no_rough'
-        if not use_rough:
-            raise NotImplementedError('spaa_amd implements the SPAA configuration (use_rough=True) only')
 
         def unwrap(m):
             return copy.deepcopy(m.module if hasattr(m, 'module') else m)
@@ -199,7 +197,7 @@ class PCNet(nn.Module):
             self.warping_net = WarpingNet(out_size=out_size)
         else:
             self.warping_net = unwrap(warping_net)
-        self.shading_net = unwrap(shading_net) if shading_net is not None else ShadingNetSPAA()
+        self.shading_net = unwrap(shading_net) if shading_net is not None else ShadingNetSPAA(use_rough)
         if use_mask:
             self.register_buffer('mask', mask.clone().float())
         for p in self.shading_net.parameters():
@@ -234,7 +232,11 @@ class PCNet(nn.Module):
         self._engines = {}
 
     def forward(self, x, s):
-        """models.py:335-346 through the registered custom op `spaa::pcnet_forward` (differentiable w.r.t. x)."""
+        """models.py:335-346 through the registered custom op `spaa::pcnet_forward` (differentiable w.r.t. x; gradients w.r.t.
+        the parameters are PCNetTrainer's: spaa_amd/train_network.py)."""
+        if isinstance(s, torch.Tensor) and s.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError('spaa_amd.PCNet.forward is differentiable w.r.t. the projector image x only: detach the '
+                                      'scene `s` (a gradient w.r.t. it would silently be missing)')
         from . import ops
         return torch.ops.spaa.pcnet_forward(x, s, ops.handle_of(self))
 
@@ -303,6 +305,11 @@ class PCNetEngine:
         if dev.type != 'cuda':
             raise RuntimeError('PCNetEngine needs the model on the GPU (no CPU fallback)')
         self.dev, self.B = dev, batch
+        # models.py:342-345: with use_rough the surface branch sees cat([s, x_w * s]) and depends on the projector image;
+        # without it the branch sees the scene alone: a constant of the attack, computed once in set_scene()
+        self.rough = bool(pcnet.use_rough)
+        if sn.conv1_s.weight.shape[1] != (6 if self.rough else 3):
+            raise ValueError(f'shading_net.conv1_s takes {sn.conv1_s.weight.shape[1]} channels: use_rough={self.rough} needs {6 if self.rough else 3}')
         self.Hp, self.Wp = prj_size
         self.Hc, self.Wc = wn.out_size
         if self.Hc % 4 or self.Wc % 4:
@@ -322,6 +329,8 @@ class PCNetEngine:
                        ('conv2_s', 2), ('conv3_s', 1), ('conv4_s', 1), ('conv6', 1), ('skipConv3', 1)):
             m = getattr(sn, nm)
             f[nm] = cp.conv_fwd_plan(m.weight, m.bias, st, 1, dev, nm)
+            if nm.endswith('_s') and not self.rough:
+                continue   # (no gradient through a branch that does not depend on the projector image)
             d[nm] = cp.conv_dgrad_plan(m.weight, st, 1, dev, nm + '_dgrad', in_ch=(3, 6) if nm == 'conv1_s' else None)
         f['skipConv2'] = cp.conv_fwd_plan(sn.skipConv2.weight, sn.skipConv2.bias, 1, 0, dev, 'skipConv2')
         d['skipConv2'] = cp.conv_dgrad_plan(sn.skipConv2.weight, 1, 0, dev, 'skipConv2_dgrad')
@@ -391,6 +400,16 @@ class PCNetEngine:
         self.f['skip1a'].run(scene4, t0, act=_lib.ACT_RELU)
         self.f['skip1b'].run(t0, t1, act=_lib.ACT_RELU)
         self.f['skip1c'].run(t1, self.a['R1'], act=_lib.ACT_RELU)
+        if not self.rough:
+            self._surface_branch(scene4)
+
+    def _surface_branch(self, inp):
+        a, f, R = self.a, self.f, _lib.ACT_RELU
+        m = self.m if (USE_GATE_MASKS or self.storage == 'f16') else {k: None for k in self.m}
+        f['conv1_s'].run(inp, a['S1'], act=R, mask_out=m['S1'])
+        f['conv2_s'].run(a['S1'], a['S2'], act=R, mask_out=m['S2'])
+        f['conv3_s'].run(a['S2'], a['S3'], act=R, mask_out=m['S3'])
+        f['conv4_s'].run(a['S3'], a['S4'], act=R, mask_out=m['S4'])
 
     def warp(self, x4, clamp01=True):
         a = self.a
@@ -411,10 +430,8 @@ class PCNetEngine:
         self.version += 1
         self.warp(x4, clamp01)
         m = self.m if (USE_GATE_MASKS or self.storage == 'f16') else {k: None for k in self.m}
-        f['conv1_s'].run(a['cat8'], a['S1'], act=R, mask_out=m['S1'])
-        f['conv2_s'].run(a['S1'], a['S2'], act=R, mask_out=m['S2'])
-        f['conv3_s'].run(a['S2'], a['S3'], act=R, mask_out=m['S3'])
-        f['conv4_s'].run(a['S3'], a['S4'], act=R, mask_out=m['S4'])
+        if self.rough:
+            self._surface_branch(a['cat8'])
         f['conv1'].run(a['xw'], a['X1'], add=a['S1'], act=R, mask_out=m['X1'])
         f['skipConv2'].run(a['X1'], a['R2'], act=N)
         f['conv2'].run(a['X1'], a['X2'], add=a['S2'], act=R, mask_out=m['X2'])
@@ -453,12 +470,18 @@ class PCNetEngine:
             d['conv6'].run(gP, g['P7'], gate_bits=m['X7'])
             d['transConv2'].run(g['P7'], g['P6'], gate_bits=m['X6'])
         d['transConv1'].run(g['P6'], g['P5'], gate_bits=m['X5'])
-        d['conv5'].run(g['P5'], g['P4'], gate_bits=m['X4'], aux_out=g['S4'], gate2_bits=m['S4'])
+        if self.rough:
+            d['conv5'].run(g['P5'], g['P4'], gate_bits=m['X4'], aux_out=g['S4'], gate2_bits=m['S4'])
+        else:
+            d['conv5'].run(g['P5'], g['P4'], gate_bits=m['X4'])
         d['conv4'].run(g['P4'], g['P3'], gate_bits=m['X3'])
         d['skipConv3'].run(g['P5'], g['t2'])
         d['conv3'].run(g['P3'], g['P2'], add=g['t2'], gate_bits=m['X2'])
         d['skipConv2'].run(g['P6'], g['t1'])
         d['conv2'].run(g['P2'], g['P1'], add=g['t1'], gate_bits=m['X1'])
+        if not self.rough:   # the surface branch is a constant: the gradient reaches the warped image through conv1 alone
+            d['conv1'].run(g['P1'], g['xw'])
+            return self.warp_backward(g['xw'])
         # surface branch (depends on x through the rough input x*s)
         d['conv4_s'].run(g['S4'], g['S3'], add=g['P3'], gate_bits=m['S3'])
         d['conv3_s'].run(g['S3'], g['S2'], add=g['P2'], gate_bits=m['S2'])
@@ -472,6 +495,8 @@ class PCNetEngine:
     def _backward_float_gates(self, gP):
         """The same backward pass reading the fp32 activations as gates (SPAA_GATE_MASKS=0: A/B measurements)."""
         a, g, d = self.a, self.g, self.d
+        if not self.rough:
+            raise NotImplementedError('SPAA_GATE_MASKS=0 (A/B measurements) covers the use_rough=True network only')
         d['conv6'].run(gP, g['P7'], gate=a['X7'])
         d['transConv2'].run(g['P7'], g['P6'], gate=a['X6'])
         d['transConv1'].run(g['P6'], g['P5'], gate=a['X5'])
@@ -528,7 +553,7 @@ def _pcnet_forward_impl(pcnet, x, s):
         eng.set_scene(s4)
         x4 = to_nhwc4(x)
         y4 = eng.forward(x4, clamp01=False)
-        saved = dict(eng=eng, version=eng.version, x4=x4, s4=s4)
+        saved = dict(eng=eng, version=eng.version, x4=x4, s4=s4, pcnet=weakref.ref(pcnet), key=(b, tuple(x.shape[-2:])))
         pcnet._last_saved = saved
         return to_nchw(y4), saved
 
@@ -538,7 +563,10 @@ def _pcnet_backward_impl(saved, gy):
     with _lib.on_device(gy.device):
         if eng.version != saved['version']:
             # the engine's workspaces were overwritten by a later forward (y1 = pcnet(x1, s); y2 = pcnet(x2, s);
-            # (l1 + l2).backward()): recompute this call's activations from its own saved inputs
+            # (l1 + l2).backward()): recompute this call's activations from its own saved inputs -- on a free engine if this
+            # one has since been leased to an AttackState (whose scene and activations must not be touched)
+            if eng.owner is not None and eng.owner() is not None and saved['pcnet']() is not None:
+                eng = saved['eng'] = saved['pcnet']().engine(*saved['key'])
             eng.set_scene(saved['s4'])
             eng.forward(saved['x4'], clamp01=False)
             saved['version'] = eng.version

@@ -45,12 +45,13 @@ class PerC_AL:
         if targeted and self.confidence != 0:
             print('Only support setting confidence in untargeted case!')
             return None
-        if not isinstance(classifier, Classifier):
-            raise TypeError('spaa_amd.PerC_AL needs a spaa_amd.Classifier (no generic fallback)')
         dev = self.device
         if dev.type != 'cuda':
             raise RuntimeError('spaa_amd.PerC_AL runs on the GPU only (no CPU fallback)')
         with _lib.on_device(dev):
+            if not isinstance(classifier, Classifier):
+                # the reference calls whatever it is given as classifier(inputs + delta, cp_sz) (perc_al/__init__.py:181)
+                return self._adversary_projector_foreign(classifier, inputs, labels, d_thr, targeted, cp_sz, trace)
             return self._adversary_projector(classifier, inputs, labels, d_thr, targeted, cp_sz, trace)
 
     def _adversary_projector(self, classifier, inputs, labels, d_thr, targeted, cp_sz, trace):
@@ -60,6 +61,68 @@ class PerC_AL:
             if trace is not None:
                 trace.append((st.state.clone(), st.stats.clone(), to_nchw(st.delta)))
         return st.result()
+
+
+    def _adversary_projector_foreign(self, classifier, inputs, labels, d_thr, targeted, cp_sz, trace):
+        """Any callable `classifier(im, crop_sz) -> (raw_score, p_sorted, idx)` that is not a spaa_amd.Classifier: the fused
+        loop cannot run its body, so torch.autograd carries the gradient through it; the colour distance (Lab + dE2000 map and
+        its gradient) stays on the HIP ops of spaa_amd.differential_color_functions.  Follows perc_al/__init__.py:157-245 step
+        by step."""
+        from .differential_color_functions import rgb2lab_diff, ciede2000_diff
+        dev = self.device
+        n_it = self.max_iterations
+        a_l_min, a_c_min = self.alpha_l_init / 100, self.alpha_c_init / 10
+        mult = -1.0 if targeted else 1.0
+        inputs = inputs.detach().float().to(dev).contiguous()
+        labels = labels.to(dev).long()
+        B = inputs.shape[0]
+        ar = torch.arange(B, device=dev)
+        best_img = inputs.clone()
+        lab_in = rgb2lab_diff(inputs, dev)                                                          # :166
+        delta = torch.zeros_like(inputs, requires_grad=True)
+        best_adv = torch.zeros(B, dtype=torch.bool, device=dev)
+        bound = torch.full((B,), 100000., device=dev)
+        for i in range(n_it):
+            raw, p, idx = classifier(inputs + delta, cp_sz)                                         # :181
+            alpha_c = a_c_min + 0.5 * (self.alpha_c_init - a_c_min) * (1 + cos(i / n_it * pi))     # :184-185
+            alpha_l = a_l_min + 0.5 * (self.alpha_l_init - a_l_min) * (1 + cos(i / n_it * pi))
+            loss = mult * torch.nn.functional.cross_entropy(raw, labels.to(raw.device), reduction='sum')   # :186
+            g_a, = torch.autograd.grad(loss, delta)
+            with torch.no_grad():
+                step = alpha_l * g_a / g_a.flatten(1).norm(dim=1).view(-1, 1, 1, 1)
+                delta += torch.where((~best_adv).view(-1, 1, 1, 1), step, torch.zeros_like(step))  # :193-195
+            d_map = ciede2000_diff(lab_in, rgb2lab_diff(inputs + delta, dev), dev)                  # :197
+            color_dis = d_map.flatten(1).norm(dim=1)                                                # :198
+            g_c, = torch.autograd.grad(color_dis.sum(), delta)
+            with torch.no_grad():
+                step = alpha_c * g_c / g_c.flatten(1).norm(dim=1).view(-1, 1, 1, 1)
+                delta -= torch.where(best_adv.view(-1, 1, 1, 1), step, torch.zeros_like(step))     # :204-209
+                delta.copy_((inputs + delta).clamp(0, 1) - inputs)                                  # :211
+                x_round = quantization(inputs + delta)                                              # :212
+                caml2 = torch.norm(delta, dim=1).mean(1).mean(1)                                    # :215
+                high_pert = caml2 * 255 > d_thr
+                raw2, p2, idx2 = classifier(x_round, cp_sz)                                         # :220 / :229 / :235
+                top1 = torch.as_tensor(idx2[:, 0]).to(dev)
+                if not targeted and self.confidence != 0:                                           # :218-225
+                    raw2 = raw2.detach().to(dev)
+                    real = raw2[ar, labels]
+                    other = raw2.clone()
+                    other[ar, labels] = float('-inf')
+                    isadv = (real - other.max(1)[0]) <= -40                                         # (the reference hard-codes 40)
+                    best_adv = isadv & high_pert
+                elif targeted:                                                                      # :227-232
+                    isadv = top1 == labels
+                    best_adv = isadv & (torch.as_tensor(p2[:, 0]).to(dev) > 0.9) & high_pert
+                else:                                                                               # :233-238
+                    isadv = top1 != labels
+                    best_adv = isadv & high_pert
+                best = (color_dis.detach() < bound) & best_adv                                      # :240-242
+                bound = torch.where(best, color_dis.detach(), bound)
+                best_img = torch.where((isadv | best).view(-1, 1, 1, 1), x_round, best_img)         # :244-245
+            if trace is not None:
+                trace.append(dict(isadv=isadv.clone(), best_adv=best_adv.clone(), top1=top1.clone(), color_dis=color_dis.detach().clone(),
+                                  caml2=caml2.clone(), delta=delta.detach().clone()))
+        return best_img
 
 
 class PerCALState:
@@ -122,7 +185,8 @@ class PerCALState:
             _lib.call('spaa_masked_step', p(delta), p(self.g_col), p(part1), p(state), 1, 1, -float(alpha_c), B, HW)  # :204-209
             _lib.call('spaa_perc_clamp_quant', p(x_in), p(delta), p(self.x_round), p(part1), B, HW)  # :211-216
             logits2 = clf.forward(self.x_round)                                            # :220/229/235
-            _lib.call('spaa_perc_decide', p(logits2), clf.ncls, p(self.label), self.mode, float(att.confidence), p(part1),
+            # (untargeted with confidence != 0: the reference's margin is the literal 40 whatever `confidence` is, :223)
+            _lib.call('spaa_perc_decide', p(logits2), clf.ncls, p(self.label), self.mode, 40.0 if att.confidence != 0 else 0.0, p(part1),
                       self.nblk, HW, p(self.color_dis), self.d_thr, 0.9, p(state), p(self.stats), B)  # :216-243
             _lib.call('spaa_track_where', p(self.x_round), p(self.x_best), p(state), B, HW)  # :244-245
 

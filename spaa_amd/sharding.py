@@ -16,10 +16,11 @@ def shard_range(n, rank, world):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def gather_results(local_tensors, n_total, dist=None):
+def gather_results(local_tensors, n_total, dist=None, always_collective=False):
     """All-gather per-rank result blocks (possibly unequal sizes) back into global sample order.
-    local_tensors: tuple of [n_local, ...] tensors.  Returns tuple of [n_total, ...] tensors on every rank."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    local_tensors: tuple of [n_local, ...] tensors.  Returns tuple of [n_total, ...] tensors on every rank.
+    `always_collective`: enter the collective even with one rank (tests: the RCCL path on a one-GPU box)."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not always_collective):
         return tuple(local_tensors)
     world, rank = dist.get_world_size(), dist.get_rank()
     out = []
@@ -39,7 +40,7 @@ def gather_results(local_tensors, n_total, dist=None):
 
 
 def spaa_sharded(pcnet, classifier, imagenet_labels, target_idx, targeted, cam_scene, d_thr, stealth_loss, device,
-                 setup_info, dist=None, attack=None, **kw):
+                 setup_info, dist=None, attack=None, always_collective=False, **kw):
     """`spaa()` over this rank's block of the batch, then one gather. `cam_scene`: [1|B,3,H,W].
     A rank whose block is empty (fewer samples than ranks) runs no attack and contributes zero-length blocks, so every
     rank still enters the collective.  `attack` replaces `spaa` (the CPU tests pass a stand-in)."""
@@ -47,7 +48,7 @@ def spaa_sharded(pcnet, classifier, imagenet_labels, target_idx, targeted, cam_s
         from .projector_based_attack import spaa as attack
     n = len(target_idx)
     world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
-    rank = dist.get_rank() if world > 1 else 0
+    rank = dist.get_rank() if world > 1 else 0   # (one rank, or no process group: the whole batch)
     lo, hi = shard_range(n, rank, world)
     while cam_scene.ndim < 4:
         cam_scene = cam_scene[None]
@@ -61,4 +62,4 @@ def spaa_sharded(pcnet, classifier, imagenet_labels, target_idx, targeted, cam_s
         dev = torch.device(device)
         cam = torch.zeros((0, 3) + tuple(cam_scene.shape[-2:]), device=dev)
         prj = torch.zeros((0, 3) + tuple(setup_info['prj_im_sz']), device=dev)
-    return gather_results((cam, prj), n, dist)
+    return gather_results((cam, prj), n, dist, always_collective)

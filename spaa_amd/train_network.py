@@ -51,6 +51,8 @@ class PCNetTrainer:
         wn, sn = pcnet.warping_net, pcnet.shading_net
         if not wn.with_refine:
             raise NotImplementedError('training covers the SPAA configuration (WarpingNet with the grid-refine net)')
+        if not pcnet.use_rough:
+            raise NotImplementedError('training covers the SPAA configuration (use_rough=True)')
         with _lib.on_device(dev):
             s = cam_scene.detach().float().to(dev)
             while s.ndim < 4:

@@ -87,9 +87,17 @@ def gen_color(ref):
          sharma=sharma, oracle_maxdiff=diff)
 
 
-def gen_pcnet(ref, name, prj_sz, cam_sz, mask, seed, bsz=2):
+def gen_pcnet(ref, name, prj_sz, cam_sz, mask, seed, bsz=2, use_rough=True):
     sd = syn.pcnet_state_dict(seed, cam_sz=cam_sz, mask=mask)
-    pc = ref_shims.make_reference_pcnet(ref, sd, prj_sz, cam_sz)
+    if use_rough:
+        pc = ref_shims.make_reference_pcnet(ref, sd, prj_sz, cam_sz)
+    else:   # models.py:344-345: shading_net(x, s); ShadingNetSPAA(use_rough=False) has a 3-channel conv1_s
+        sd['shading_net.conv1_s.weight'] = sd['shading_net.conv1_s.weight'][:, :3].contiguous()
+        holder = types.SimpleNamespace
+        pc = ref.models.PCNet(sd['mask'], holder(module=ref.models.WarpingNet(out_size=tuple(cam_sz))),
+                              holder(module=ref.models.ShadingNetSPAA(use_rough=False)), fix_shading_net=True, use_rough=False)
+        pc.load_state_dict(sd)
+        pc.eval()
     rng = np.random.default_rng(seed + 100)
     x = torch.from_numpy(rng.random((bsz, 3, *prj_sz)).astype(np.float32)).requires_grad_(True)
     s = syn.scenes(seed + 1, bsz, cam_sz)
@@ -98,13 +106,13 @@ def gen_pcnet(ref, name, prj_sz, cam_sz, mask, seed, bsz=2):
     (y * r).sum().backward()
     g = x.grad.clone()
     x2 = x.detach().clone().requires_grad_(True)
-    y2 = so.pcnet_forward(sd, x2, s)
+    y2 = so.pcnet_forward(sd, x2, s, use_rough=use_rough)
     (y2 * r).sum().backward()
     diff = max((y2 - y).abs().max().item(), (x2.grad - g).abs().max().item())
     fine = so.warping_fine_grid(sd, x.shape, cam_sz)
     print(f'  {name}: oracle maxdiff {diff:.3e}')
     save(name, seed=seed, prj_sz=prj_sz, cam_sz=cam_sz, mask=mask, x=x.detach(), s=s, r=r, y=y.detach(), grad_x=g,
-         fine_grid=fine, wsum=weights_checksum(sd), oracle_maxdiff=diff)
+         fine_grid=fine, wsum=weights_checksum(sd), oracle_maxdiff=diff, use_rough=use_rough)
 
 
 def gen_compennet_pp(ref, name, sz, seed):
@@ -424,6 +432,7 @@ CASES = {
     'color_kat': lambda r: gen_color(r),
     'pcnet_64': lambda r: gen_pcnet(r, 'pcnet_64', (64, 64), (64, 64), 'rect', 0),
     'pcnet_nonsq': lambda r: gen_pcnet(r, 'pcnet_nonsq', (64, 64), (48, 80), 'ones', 3),
+    'pcnet_norough_64': lambda r: gen_pcnet(r, 'pcnet_norough_64', (64, 64), (64, 64), 'rect', 6, use_rough=False),
     'pcnet_256': lambda r: gen_pcnet(r, 'pcnet_256', (256, 256), (256, 256), 'ones', 0, bsz=1),
     'spaa_64_untargeted': lambda r: gen_spaa(r, 'spaa_64_untargeted', (64, 64), False, 'true', 5, 'camdE_caml2'),
     'spaa_64_imagenet10': lambda r: gen_spaa(r, 'spaa_64_imagenet10', (64, 64), True, syn.IMAGENET10_TARGETS, 5,

@@ -42,21 +42,24 @@ def test_color_known_answers(golden_dir):
     assert np.allclose(so.rgb2lab_diff(torch.zeros(1, 3, 1, 1)).numpy().ravel(), [-16, 0, 0])
 
 
-@pytest.mark.parametrize('name', ['pcnet_64', 'pcnet_nonsq', 'pcnet_256'])
+@pytest.mark.parametrize('name', ['pcnet_64', 'pcnet_nonsq', 'pcnet_256', 'pcnet_norough_64'])
 def test_pcnet_forward_and_input_gradient(golden_dir, name):
     z = load(golden_dir, name)
     cam_sz = tuple(int(v) for v in z['cam_sz'])
     sd = syn.pcnet_state_dict(int(z['seed']), cam_sz=cam_sz, mask=str(z['mask']))
+    rough = bool(z['use_rough']) if 'use_rough' in z.files else True
+    if not rough:   # PCNet(use_rough=False): ShadingNetSPAA(use_rough=False) has a 3-channel conv1_s (models.py:223,344-345)
+        sd['shading_net.conv1_s.weight'] = sd['shading_net.conv1_s.weight'][:, :3].contiguous()
     assert np.allclose(checksum(sd), z['wsum'], rtol=1e-9), 'synthetic weight generator drifted from the fixtures'
     x = torch.from_numpy(z['x']).requires_grad_(True)
-    y = so.pcnet_forward(sd, x, torch.from_numpy(z['s']))
+    y = so.pcnet_forward(sd, x, torch.from_numpy(z['s']), use_rough=rough)
     (y * torch.from_numpy(z['r'])).sum().backward()
     assert np.abs(y.detach().numpy() - z['y']).max() <= 1e-6
     assert np.abs(x.grad.numpy() - z['grad_x']).max() <= 1e-5 * np.abs(z['grad_x']).max()
     fine = so.warping_fine_grid(sd, x.shape, cam_sz)
     assert np.abs(fine.numpy() - z['fine_grid']).max() <= 1e-6
     # the literal per-iteration, per-sample grid rebuild of the reference gives the same result
-    y2 = so.pcnet_forward(sd, x.detach(), torch.from_numpy(z['s']), per_batch_grid=True)
+    y2 = so.pcnet_forward(sd, x.detach(), torch.from_numpy(z['s']), per_batch_grid=True, use_rough=rough)
     assert np.abs(y2.numpy() - z['y']).max() <= 1e-6
 
 

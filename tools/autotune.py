@@ -12,10 +12,35 @@ import bench  # noqa: E402
 from spaa_amd import convplan  # noqa: E402
 
 
+def build_reference_shape(batch, classifier, cam, prj):
+    """The reference's own call shape (main.py:19-33, projector_based_attack.py:107,120): projector `prj` -> camera `cam`,
+    classifier crop 240 x 240, B = 1 (untargeted) or 10 (targeted)."""
+    from spaa_amd import synthetic as syn
+    from spaa_amd.models import PCNet, WarpingNet
+    from spaa_amd.classifier import Classifier
+    from spaa_amd.projector_based_attack import AttackState
+    dev = 'cuda:0'
+    sd = syn.pcnet_state_dict(0, cam_sz=cam, mask='ones')
+    pc = PCNet(sd['mask'], WarpingNet(out_size=cam))
+    pc.load_state_dict(sd)
+    pc = pc.to(dev)
+    csd = {'resnet18': syn.resnet18_state_dict, 'vgg16': syn.vgg16_state_dict,
+           'inception_v3': syn.inception_v3_state_dict}[classifier](2, logit_gain=20.0)
+    clf = Classifier(classifier, dev, state_dict=csd)
+    setup = dict(classifier_crop_sz=(240, 240), prj_brightness=0.5, prj_im_sz=prj)
+    targets = (syn.IMAGENET10_TARGETS * 8)[:batch]
+    return AttackState(pc, clf, targets, syn.scenes(1, 1, cam), 'camdE_caml2', setup, dev)
+
+
 def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     classifier = sys.argv[2] if len(sys.argv) > 2 else 'resnet18'  # other classifiers: their layer shapes are MERGED
-    st, *_ = bench.build_attack(0, batch, 256, 8, 'cuda:0', classifier)
+    shape = sys.argv[3] if len(sys.argv) > 3 else ''                # e.g. 240x320: camera size of the reference's call shape
+    if shape:
+        cam = tuple(int(v) for v in shape.split('x'))
+        st = build_reference_shape(batch, classifier, cam, (256, 256))
+    else:
+        st, *_ = bench.build_attack(0, batch, 256, 8, 'cuda:0', classifier)
     hp = dict(targeted=True, d_thr=5, adv_lr=2, col_lr=1, p_thresh=0.9)
     st.iteration(**hp)
     torch.cuda.synchronize()
@@ -51,9 +76,9 @@ def main():
     for r in sorted(rows, reverse=True)[:40]:
         print(f'{r[0]*1e3:8.0f} us/iter  {r[1]:32s} best={r[3]} {r[4]} {r[2]}')
     print(f'sum of best per-launch times: {total_best:.2f} ms/iteration')
-    out = os.path.join(ROOT, 'gpurun_out', 'tapconv_tune.json')
+    out = os.path.join(ROOT, 'gpurun_out', os.environ.get('SPAA_TUNE_OUT', 'tapconv_tune.json'))
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    if classifier != 'resnet18':  # keep the measured choices of the other workloads; add this one's new shapes
+    if classifier != 'resnet18' or shape or batch != 64:  # keep the measured choices of the other workloads; add this one's new shapes
         merged = dict(convplan.TUNE)
         merged.update({k: v for k, v in tune.items() if k not in merged})
         tune = merged
