@@ -328,6 +328,45 @@ def pcnet_de_hbm(per_layer, other, n_prof, batch, size, f16):
             'achieved_tb_s': round(gb / (ms * 1e-3) / 1e12, 3), 'frac_of_8_tb_s': round(gb / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4)}
 
 
+def configs0_gpu(sd, csd, setup, scenes, dev):
+    """BASELINE.json configs[0] on the GPU, next to the CPU leg's `configs0`: ONE scene, the reference's two calls
+    (projector_based_attack.py:107 untargeted B = 1, :120 targeted K = 10), 50 iterations each through `spaa()` itself (state
+    build, HIP-graph capture and replay, result conversion included)."""
+    from spaa_amd import synthetic as syn
+    from spaa_amd.models import PCNet, WarpingNet
+    from spaa_amd.classifier import Classifier
+    from spaa_amd.projector_based_attack import spaa, AttackState
+    sz = tuple(setup['prj_im_sz'])
+    pc = PCNet(sd['mask'], WarpingNet(out_size=sz))
+    pc.load_state_dict(sd)
+    pc = pc.to(dev)
+    clf = Classifier('resnet18', dev, state_dict=csd)
+    out = {}
+    for name, tg, targeted in (('untargeted_B1_50it', [1], False), ('targeted_K10_50it', list(syn.IMAGENET10_TARGETS), True)):
+        spaa(pc, clf, None, tg, targeted, scenes[:1], 5, 'camdE_caml2', dev, setup, iters=4)     # warm-up: engines, kernel attributes
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cam, prj = spaa(pc, clf, None, tg, targeted, scenes[:1], 5, 'camdE_caml2', dev, setup, iters=50)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # host time to ENQUEUE one eagerly launched iteration (what the graph replay removes)
+        st = AttackState(pc, clf, tg, scenes[:1], 'camdE_caml2', setup, dev)
+        st.iteration(targeted, 5, 2, 1, 0.9)
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        for _ in range(10):
+            st.iteration(targeted, 5, 2, 1, 0.9)
+        h1 = time.perf_counter()
+        torch.cuda.synchronize()
+        h2 = time.perf_counter()
+        out[name] = {'seconds': round(dt, 4), 'iterations_per_s': round(50 / dt, 2),
+                     'eager_host_enqueue_ms_per_iteration': round((h1 - h0) / 10 * 1e3, 3),
+                     'eager_ms_per_iteration': round((h2 - h0) / 10 * 1e3, 3)}
+        del st
+    out['note'] = 'spaa() end to end (50 iterations: one eager, one captured, 48 graph replays); eager_* = the same loop body launched kernel by kernel'
+    return out
+
+
 def time_mode(dev, args, classifier, storage, attack, steps=10, warmup=3):
     """One extra configuration of BASELINE.json timed like the headline (own state, own warm-up, own region); never `value`."""
     t_build = time.perf_counter()
@@ -550,6 +589,7 @@ def main():
             log('extra modes: f16 storage, Inception-v3, VGG-16 + PerC-AL in f16 storage')
             del st
             torch.cuda.empty_cache()
+            out['configs0_gpu'] = configs0_gpu(sd, csd, setup, scenes, dev)
             out['modes'] = {
                 'configs[1] in f16 storage (resnet18, SPAA loop)': time_mode(dev, args, 'resnet18', 'f16', 'spaa'),
                 'configs[2] (inception_v3 at 299x299, SPAA loop, f32)': time_mode(dev, args, 'inception_v3', 'f32', 'spaa'),
