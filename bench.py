@@ -304,7 +304,7 @@ def instrumented_pass(st, args, n_prof=3):
 
 PCNET_LAYERS = ('conv1', 'conv2', 'conv3', 'conv4', 'conv5', 'conv1_s', 'conv2_s', 'conv3_s', 'conv4_s', 'conv6', 'skipConv2',
                 'skipConv3', 'transConv1', 'transConv2')
-PCNET_ENTRY_POINTS = ('spaa_warp_fwd', 'spaa_warp_bwd_gather', 'spaa_shading_tail_fwd', 'spaa_shading_tail_fwd_f16',
+PCNET_ENTRY_POINTS = ('spaa_warp_fwd', 'spaa_warp_bwd_gather', 'spaa_warp_bwd_tiled', 'spaa_shading_tail_fwd', 'spaa_shading_tail_fwd_f16',
                       'spaa_shading_head_bwd', 'spaa_shading_head_bwd_f16', 'spaa_stealth_loss_fwd_bwd')
 MB_PCNET_DE_PER_SCENE_256 = 214.0   # PCNet + dE2000 forward / backward, fp32, per scene-iteration
 
@@ -511,6 +511,7 @@ def main():
         scale = args.batch * (args.size * args.size) / 65536.0 * 1e6
         groups = {}
         for gname, entry in (('warp_fwd', 'spaa_warp_fwd'), ('warp_bwd_gather', 'spaa_warp_bwd_gather'),
+                             ('warp_bwd_gather', 'spaa_warp_bwd_tiled'),   # (the LDS-staged form of the same adjoint)
                              ('stealth_loss', 'spaa_stealth_loss_fwd_bwd'), ('step_and_track', 'spaa_step_and_track')):
             if entry in other:
                 us = other[entry][0] * 1e3 / other[entry][1]

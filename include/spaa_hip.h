@@ -161,6 +161,14 @@ int spaa_warp_taps(const float* grid, int Hp, int Wp, int Hc, int Wc, int32_t* s
 int spaa_warp_bwd_gather(const float* g_xw, const float* g_xs, const float* x, const float* mask, const float* s,
                          const int32_t* off, const int32_t* order, const float* wgt, float* g_x, int B, int Hp, int Wp,
                          int Hc, int Wc, int clamp01, spaa_stream_t stream);
+/* The same gather (mask folded into the weights, no second gradient) with the camera-side operand staged through LDS: a
+ * workgroup owns a 16 x 16 tile of projector pixels and 4 images and reads the bounding box of the camera pixels its tap
+ * lists touch once per image.  lidx / w_e: per tap-list entry (in the order of `off`) the index inside the tile's box and
+ * the weight; tbox: per tile (cy0, cx0, rows, columns) of its box, at most box_cap pixels (box_cap * 64 B <= 64 KiB).
+ * Built once per attack by spaa_amd/models.py: tiled_taps.  Results are bitwise those of spaa_warp_bwd_gather. */
+int spaa_warp_bwd_tiled(const float* g_xw, const float* x, const int32_t* off, const int32_t* lidx, const float* w_e,
+                        const int32_t* tbox, int box_cap, float* g_x, int B, int Hp, int Wp, int Hc, int Wc, int clamp01,
+                        spaa_stream_t stream);
 
 /* ---- PCNet training step: WarpingNet parameter gradients and the optimiser (train_network.py:235-363) ------- */
 /* d loss / d fine_grid summed over the batch: grid_sampler_2d_backward w.r.t. the GRID (models.py:184 under autograd).

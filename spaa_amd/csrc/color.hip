@@ -80,6 +80,29 @@ __device__ __forceinline__ float hue_deg(float x, float y) {
     return t >= 0.f ? t : 360.f + t;
 }
 
+// Trigonometry of the dE2000 weighting terms on the hardware transcendentals (v_sin_f32 / v_cos_f32 / v_exp_f32: one 8-cycle
+// instruction each instead of libm's ~40-instruction sequences; 14 of them per pixel and pass).  Arguments are bounded
+// (|angle| <= 4 x 360 + 63 degrees), the results enter dE through weights of at most 0.32 (T), 30 (dRO, Gaussian) and the
+// half hue difference: absolute errors of ~1e-6 in sin / cos move dE by < 1e-5 of its value (gated by the known-answer and
+// gradient tests against the reference's fixtures).  SPAA_COLOR_LIBM: the libm forms, for A/B accuracy runs.
+#ifdef SPAA_COLOR_LIBM
+__device__ __forceinline__ float fsin(float x) { return sinf(x); }
+__device__ __forceinline__ float fcos(float x) { return cosf(x); }
+__device__ __forceinline__ float fexp(float x) { return expf(x); }
+#else
+__device__ __forceinline__ float fsin(float x) { return __sinf(x); }
+__device__ __forceinline__ float fcos(float x) { return __cosf(x); }
+__device__ __forceinline__ float fexp(float x) { return __expf(x); }
+#endif
+
+// x / y through v_rcp_f32 (1 ulp) instead of the IEEE-exact ten-instruction sequence: 64 divisions per pixel in the dE2000 map
+// and its reverse mode.  Every divisor is non-zero where it is used (guards below); results move by ~1e-7 relative.
+#ifdef SPAA_COLOR_LIBM
+__device__ __forceinline__ float fdiv(float x, float y) { return x / y; }
+#else
+__device__ __forceinline__ float fdiv(float x, float y) { return x * __builtin_amdgcn_rcpf(y); }
+#endif
+
 struct DE {
     float de;
     float gL, gA, gB;  // d de / d (L1, A1, B1)
@@ -95,9 +118,9 @@ __device__ __forceinline__ DE ciede2000(float L1, float A1, float B1, float L2, 
     if (m02) B2 += 0.0001f;
     const float C1 = sqrtf(A1 * A1 + B1 * B1);
     const float C2 = sqrtf(A2 * A2 + B2 * B2);
-    const float aC = (C1 + C2) / 2.f;
+    const float aC = ((C1 + C2) * 0.5f);
     const float aC7 = pow7(aC);
-    const float fG = aC7 / (aC7 + k25_7);
+    const float fG = fdiv(aC7, (aC7 + k25_7));
     const float sfG = sqrtf(fG);
     const float G = 0.5f * (1.f - sfG);
     const float a1P = (1.f + G) * A1;
@@ -113,12 +136,12 @@ __device__ __forceinline__ DE ciede2000(float L1, float A1, float B1, float L2, 
     float dhP = 0.f;
     if (!mc0) dhP = (fabsf(dh) <= 180.f) ? dh : (dh > 180.f ? dh - 360.f : dh + 360.f);
     const float sq = sqrtf(c1P * c2P);
-    const float half = (dhP * kRad) / 2.f;
-    const float sn = sinf(half), cs = cosf(half);
+    const float half = ((dhP * kRad) * 0.5f);
+    const float sn = fsin(half), cs = fcos(half);
     const float m_no = (m01 || m02) ? 0.f : 1.f;
     const float dHP = 2.f * sq * sn * m_no;
-    const float aL = (L1 + L2) / 2.f;
-    const float aCP = (c1P + c2P) / 2.f;
+    const float aL = ((L1 + L2) * 0.5f);
+    const float aCP = ((c1P + c2P) * 0.5f);
     const float hs = h1P + h2P;
     float aHP = 0.f;
     if (!mc0) {
@@ -127,21 +150,21 @@ __device__ __forceinline__ DE ciede2000(float L1, float A1, float B1, float L2, 
     }
     const float t1 = (aHP - 39.f) * kRad, t2 = (2.f * aHP) * kRad, t3 = (3.f * aHP + 6.f) * kRad,
                 t4 = (4.f * aHP - 63.f) * kRad;
-    const float T = 1.f - 0.17f * cosf(t1) + 0.24f * cosf(t2) + 0.32f * cosf(t3) - 0.2f * cosf(t4);
-    const float e = (aHP - 275.f) / 25.f;
-    const float dRO = 30.f * expf(-1.f * (e * e));
+    const float T = 1.f - 0.17f * fcos(t1) + 0.24f * fcos(t2) + 0.32f * fcos(t3) - 0.2f * fcos(t4);
+    const float e = ((aHP - 275.f) * (1.f / 25.f));
+    const float dRO = 30.f * fexp(-1.f * (e * e));
     const float aCP7 = pow7(aCP);
-    const float fR = aCP7 / (aCP7 + k25_7);
+    const float fR = fdiv(aCP7, (aCP7 + k25_7));
     const float rC = sqrtf(fR);
     const float q = (aL - 50.f) * (aL - 50.f);
     const float sq20 = sqrtf(20.f + q);
-    const float sL = 1.f + (0.015f * q) / sq20;
+    const float sL = 1.f + fdiv((0.015f * q), sq20);
     const float sC = 1.f + 0.045f * aCP;
     const float sH = 1.f + 0.015f * aCP * T;
     const float ang = (2.f * dRO) * kRad;
-    const float sa = sinf(ang);
+    const float sa = fsin(ang);
     const float rT = -2.f * rC * sa;
-    const float u = dLP / sL, v = dCP / sC, w = dHP / sH;
+    const float u = fdiv(dLP, sL), v = fdiv(dCP, sC), w = fdiv(dHP, sH);
     const float rs = u * u + (v * v) * m_no + (w * w) * m_no + rT * v * w * m_no;
     const bool m0 = rs <= 0.f;
     out.de = m0 ? 0.f : sqrtf(rs);
@@ -149,37 +172,37 @@ __device__ __forceinline__ DE ciede2000(float L1, float A1, float B1, float L2, 
     if (!GRAD || m0) return out;
 
     // ---- reverse mode -----------------------------------------------------------------------------------
-    const float rs_b = 0.5f / out.de;
+    const float rs_b = fdiv(0.5f, out.de);
     const float u_b = rs_b * 2.f * u;
     const float v_b = rs_b * m_no * (2.f * v + rT * w);
     const float w_b = rs_b * m_no * (2.f * w + rT * v);
     const float rT_b = rs_b * m_no * v * w;
-    const float dLP_b = u_b / sL;
-    const float sL_b = -u_b * dLP / (sL * sL);
-    const float dCP_b = v_b / sC;
-    const float sC_b = -v_b * dCP / (sC * sC);
-    const float dHP_b = w_b / sH;
-    const float sH_b = -w_b * dHP / (sH * sH);
+    const float dLP_b = fdiv(u_b, sL);
+    const float sL_b = -u_b * fdiv(dLP, (sL * sL));
+    const float dCP_b = fdiv(v_b, sC);
+    const float sC_b = -v_b * fdiv(dCP, (sC * sC));
+    const float dHP_b = fdiv(w_b, sH);
+    const float sH_b = -w_b * fdiv(dHP, (sH * sH));
     const float rC_b = rT_b * (-2.f * sa);
-    const float dRO_b = rT_b * (-2.f * rC * cosf(ang)) * (2.f * kRad);
+    const float dRO_b = rT_b * (-2.f * rC * fcos(ang)) * (2.f * kRad);
     float aCP_b = sH_b * 0.015f * T + sC_b * 0.045f;
     const float T_b = sH_b * 0.015f * aCP;
-    const float q_b = sL_b * 0.015f * (1.f / sq20 - 0.5f * q / (sq20 * sq20 * sq20));
+    const float q_b = sL_b * 0.015f * (fdiv(1.f, sq20) - 0.5f * fdiv(q, (sq20 * sq20 * sq20)));
     const float aL_b = q_b * 2.f * (aL - 50.f);
     {
         const float den = aCP7 + k25_7;
-        const float aCP6 = aCP7 / aCP;
-        aCP_b += rC_b * (0.5f / rC) * (k25_7 / (den * den)) * 7.f * aCP6;
+        const float aCP6 = fdiv(aCP7, aCP);
+        aCP_b += rC_b * (fdiv(0.5f, rC)) * (fdiv(k25_7, (den * den))) * 7.f * aCP6;
     }
-    float aHP_b = dRO_b * dRO * (-2.f * e / 25.f);
-    aHP_b += T_b * kRad * (0.17f * sinf(t1) - 0.48f * sinf(t2) - 0.96f * sinf(t3) + 0.8f * sinf(t4));
+    float aHP_b = dRO_b * dRO * (-2.f * (e * (1.f / 25.f)));
+    aHP_b += T_b * kRad * (0.17f * fsin(t1) - 0.48f * fsin(t2) - 0.96f * fsin(t3) + 0.8f * fsin(t4));
     const float dHPm_b = dHP_b * m_no;
     const float sq_b = dHPm_b * 2.f * sn;
-    const float dhP_b = dHPm_b * 2.f * sq * cs * (kRad / 2.f);
+    const float dhP_b = dHPm_b * 2.f * sq * cs * (kRad * 0.5f);
     float c1P_b = 0.f, c2P_b = 0.f;
     if (sq_b != 0.f) {
-        c1P_b = sq_b * (0.5f / sq) * c2P;
-        c2P_b = sq_b * (0.5f / sq) * c1P;
+        c1P_b = sq_b * (fdiv(0.5f, sq)) * c2P;
+        c2P_b = sq_b * (fdiv(0.5f, sq)) * c1P;
     }
     c1P_b += aCP_b * 0.5f - dCP_b;
     c2P_b += aCP_b * 0.5f + dCP_b;
@@ -192,27 +215,27 @@ __device__ __forceinline__ DE ciede2000(float L1, float A1, float B1, float L2, 
     float a1P_b = 0.f, a2P_b = 0.f, B1_b = 0.f;
     if (!m01 && !(B1 == 0.f && a1P == 0.f)) {
         const float den = B1 * B1 + a1P * a1P;
-        B1_b += h1P_b * kDeg * (a1P / den);
-        a1P_b += h1P_b * kDeg * (-B1 / den);
+        B1_b += h1P_b * kDeg * (fdiv(a1P, den));
+        a1P_b += h1P_b * kDeg * (-fdiv(B1, den));
     }
     if (!m02 && !(B2 == 0.f && a2P == 0.f)) {
         const float den = B2 * B2 + a2P * a2P;
-        a2P_b += h2P_b * kDeg * (-B2 / den);
+        a2P_b += h2P_b * kDeg * (-fdiv(B2, den));
     }
-    a1P_b += c1P_b * (a1P / c1P);
-    B1_b += c1P_b * (B1 / c1P);
-    a2P_b += c2P_b * (a2P / c2P);
+    a1P_b += c1P_b * (fdiv(a1P, c1P));
+    B1_b += c1P_b * (fdiv(B1, c1P));
+    a2P_b += c2P_b * (fdiv(a2P, c2P));
     float A1_b = a1P_b * (1.f + G);
     const float G_b = a1P_b * A1 + a2P_b * A2;
     float aC_b = 0.f;
     if (G_b != 0.f) {
         const float den = aC7 + k25_7;
-        const float aC6 = aC7 / aC;
-        aC_b = G_b * (-0.25f / sfG) * (k25_7 / (den * den)) * 7.f * aC6;
+        const float aC6 = fdiv(aC7, aC);
+        aC_b = G_b * (-fdiv(0.25f, sfG)) * (fdiv(k25_7, (den * den))) * 7.f * aC6;
     }
     const float C1_b = aC_b * 0.5f;
-    A1_b += C1_b * (A1 / C1);
-    B1_b += C1_b * (B1 / C1);
+    A1_b += C1_b * (fdiv(A1, C1));
+    B1_b += C1_b * (fdiv(B1, C1));
     out.gL = L1_b;
     out.gA = A1_b;
     out.gB = B1_b;

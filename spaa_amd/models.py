@@ -261,6 +261,9 @@ def to_nchw(x4, clamp01=False):
     return out
 
 
+TILED_WARP_BWD = os.environ.get('SPAA_TILED_WARP_BWD', '1') != '0'   # LDS-staged grid_sample adjoint (0: the untiled gather)
+
+
 def transposed_taps(grid, prj_size, cam_size, mask=None):
     """Transposed sampling structure for the deterministic backward of grid_sample (index plumbing, once per grid):
     the 4 bilinear taps of every camera pixel (spaa_warp_taps), sorted by the projector pixel they read (CSR).
@@ -276,6 +279,47 @@ def transposed_taps(grid, prj_size, cam_size, mask=None):
     # bilinear weight x mask of the camera pixel the tap belongs to (entry 4*campix + tap)
     tap_wm = (tap_w.view(hwc, 4) * mask.view(hwc, 1)).reshape(-1).contiguous() if mask is not None else tap_w
     return bounds.to(torch.int32).contiguous(), order.to(torch.int32).contiguous(), tap_wm
+
+
+TILED_BOX_CAP = int(os.environ.get('SPAA_TILED_BOX_CAP', '576'))   # camera pixels per (16 x 16 projector tile, image) staged in LDS: 4 images x 9 KiB -> 4 workgroups per CU
+
+
+def tiled_taps(tap_off, tap_order, tap_wm, prj_size, cam_size):
+    """Per-tile structure for spaa_warp_bwd_tiled (index plumbing, once per grid): the bounding box in the camera image of
+    the tap-list entries of every 16 x 16 tile of projector pixels, each entry's index inside its tile's box, and the weights
+    in entry order.  Returns (lidx, w_e, tbox, box_cap) or None when a box would not fit (a wild warp: the untiled gather
+    stays in charge).  Reports nothing else: `tbox[:, 2] < 0` marks the tiles gathered from global memory."""
+    dev = tap_off.device
+    (hp, wp), (hc, wc) = prj_size, cam_size
+    ts = 16
+    ntx, nty = (wp + ts - 1) // ts, (hp + ts - 1) // ts
+    n_ent = int(tap_off[-1])
+    if n_ent == 0:
+        return None
+    order = tap_order[:n_ent].long()
+    counts = (tap_off[1:] - tap_off[:-1]).long()
+    sp = torch.repeat_interleave(torch.arange(hp * wp, device=dev), counts)          # projector pixel of every entry
+    tile = (sp // wp // ts) * ntx + (sp % wp) // ts
+    cpix = order >> 2
+    cy, cx = cpix // wc, cpix % wc
+    big = 1 << 30
+    y0 = torch.full((ntx * nty,), big, device=dev, dtype=torch.long).scatter_reduce(0, tile, cy, 'amin')
+    x0 = torch.full((ntx * nty,), big, device=dev, dtype=torch.long).scatter_reduce(0, tile, cx, 'amin')
+    y1 = torch.full((ntx * nty,), -1, device=dev, dtype=torch.long).scatter_reduce(0, tile, cy, 'amax')
+    x1 = torch.full((ntx * nty,), -1, device=dev, dtype=torch.long).scatter_reduce(0, tile, cx, 'amax')
+    empty = y1 < 0
+    ch, cw = torch.where(empty, 0, y1 - y0 + 1), torch.where(empty, 0, x1 - x0 + 1)
+    y0, x0 = torch.where(empty, 0, y0), torch.where(empty, 0, x0)
+    # a tile whose box does not fit (clamped grids pile the camera pixels of a whole border strip onto the projector's border
+    # pixels) is gathered from global memory: rows = -1, its entries carry the camera pixel itself
+    direct = ch * cw > TILED_BOX_CAP
+    if bool(direct.float().mean() > 0.5):
+        return None
+    cap = int(torch.where(direct, 0, ch * cw).max())
+    lidx = torch.where(direct[tile], cpix, (cy - y0[tile]) * cw[tile] + (cx - x0[tile])).to(torch.int32).contiguous()
+    w_e = tap_wm[order].contiguous()
+    tbox = torch.stack([y0, x0, torch.where(direct, -1, ch), cw], 1).to(torch.int32).contiguous()
+    return lidx, w_e, tbox, max(cap, 1)
 
 
 class _Activations(dict):
@@ -324,6 +368,7 @@ class PCNetEngine:
         if self.mask is not None:
             assert self.mask.numel() == self.Hc * self.Wc
         self.tap_off, self.tap_order, self.tap_wm = transposed_taps(self.grid, prj_size, (self.Hc, self.Wc), self.mask)
+        self.tiled = tiled_taps(self.tap_off, self.tap_order, self.tap_wm, prj_size, (self.Hc, self.Wc)) if TILED_WARP_BWD else None
         f, d = {}, {}
         for nm, st in (('conv1', 2), ('conv2', 2), ('conv3', 1), ('conv4', 1), ('conv5', 1), ('conv1_s', 2),
                        ('conv2_s', 2), ('conv3_s', 1), ('conv4_s', 1), ('conv6', 1), ('skipConv3', 1)):
@@ -529,6 +574,11 @@ class PCNetEngine:
         """Adjoint of the masked grid_sample (models.py:184,340): deterministic gather over the transposed tap lists; the
         mask is folded into the tap weights."""
         g = self.g
+        if self.tiled is not None:
+            lidx, w_e, tbox, cap = self.tiled
+            _lib.call('spaa_warp_bwd_tiled', _lib.ptr(g_xw), _lib.ptr(self._x), C_ptr(self.tap_off), C_ptr(lidx), _lib.ptr(w_e),
+                      C_ptr(tbox), cap, _lib.ptr(g['x']), self.B, self.Hp, self.Wp, self.Hc, self.Wc, self._clamp)
+            return g['x']
         _lib.call('spaa_warp_bwd_gather', _lib.ptr(g_xw), None, _lib.ptr(self._x), None, None, C_ptr(self.tap_off),
                   C_ptr(self.tap_order), _lib.ptr(self.tap_wm), _lib.ptr(g['x']), self.B, self.Hp, self.Wp, self.Hc,
                   self.Wc, self._clamp)

@@ -187,6 +187,7 @@ class PCNetTrainer:
         eng = self.eng
         eng.grid = ws['fine']
         eng.tap_off, eng.tap_order, eng.tap_wm = transposed_taps(eng.grid, prj_size, (H, W), eng.mask)
+        eng.tiled = None   # (the grid changes every step: the per-tile boxes of the LDS-staged gather are not rebuilt)
 
     def _set_scene(self):
         """PCNetEngine.set_scene, keeping the skipConv1 intermediates."""

@@ -1322,6 +1322,35 @@ def test_reference_call_shapes_graph_replay(hip):
     assert prj_g.shape == (10, 3, 256, 256) and cam_g.shape == (10, 3, 240, 320)
 
 
+@pytest.mark.parametrize('cam,prj,b', [((64, 64), (64, 64), 5), ((240, 320), (256, 256), 3), ((48, 80), (64, 64), 9), ((256, 256), (256, 256), 6)])
+def test_warp_backward_tiled_equals_gather(hip, cam, prj, b):
+    """csrc/warp.hip: the LDS-staged adjoint of grid_sample (16 x 16 projector tiles, the camera-side bounding box of their tap
+    lists read once per image) sums every projector pixel's list in the same order as the untiled gather: bitwise equal, also
+    for projector != camera sizes, batch sizes that are not multiples of 4 and a masked camera image."""
+    M = hip['models']
+    sd = syn.pcnet_state_dict(3, cam_sz=cam, mask='rect')
+    pc = make_pcnet(hip, sd, cam)
+    eng = M.PCNetEngine(pc, b, prj)
+    assert eng.tiled is not None
+    torch.manual_seed(b)
+    x = torch.rand(b, prj[0], prj[1], 4, device=DEV) * 1.4 - 0.2       # (values outside [0, 1]: the clamp gate)
+    x[..., 3] = 0
+    eng._x, eng._clamp = x, 1
+    g = torch.randn(b, cam[0], cam[1], 4, device=DEV)
+    g[..., 3] = 0
+    a = eng.warp_backward(g).clone()
+    tiled, eng.tiled = eng.tiled, None
+    ref = eng.warp_backward(g).clone()
+    eng.tiled = tiled
+    assert torch.equal(a, ref)
+    # and against autograd through F.grid_sample on the CPU
+    xc = x[..., :3].permute(0, 3, 1, 2).cpu().clone().requires_grad_(True)
+    grid = eng.grid[..., :2].cpu()[None].expand(b, -1, -1, -1)
+    y = F.grid_sample(xc.clamp(0, 1), grid, mode='bilinear', padding_mode='zeros', align_corners=True) * sd['mask']
+    (y * g[..., :3].permute(0, 3, 1, 2).cpu()).sum().backward()
+    assert rel_inf(a[..., :3].permute(0, 3, 1, 2), xc.grad) < 5e-5   # (border pixels sum hundreds of taps: another order on the CPU)
+
+
 def test_vgg16_attack_loop_first_iteration(hip):
     """configs[4]'s classifier inside the SPAA loop (not just as a bare classifier)."""
     csd = syn.vgg16_state_dict(3, logit_gain=5.0, fc_width=512)

@@ -1,5 +1,5 @@
 """Timing-only ablations of the Winograd kernel (DBG template bits, wrong results): where does a conv4-shaped launch spend its time?"""
-import sys, torch
+import os, sys, torch
 sys.path.insert(0, '.')
 from spaa_amd import convplan as cp, _lib
 _lib.load()
@@ -14,7 +14,7 @@ for ci, co, res in [(128, 256, False), (128, 256, True), (256, 128, False)]:
     add = torch.randn(64, 64, 64, co, device=DEV) if res else None
     mask = torch.zeros(64, 64, 64, co // 4, device=DEV, dtype=torch.uint8) if res else None
     cp.FORCE_TILE = 70
-    order = [0, 32, 1, 33]
+    order = [int(v) for v in os.environ.get('WINO_DBG', '0').split(',')]
     res_t = {k: [] for k in order}
     for rnd in range(3):
         for dbg in order:
