@@ -100,7 +100,8 @@ typedef struct {
                              channel n.  The input is read once instead of once per class. */
     int32_t reserved0;
     int32_t io_dtype;     /* fp16-STORAGE mode (BASELINE.json configs[4]: "fp16 with fp32 dE2000"), bit flags:
-                             SPAA_IO_IN_F16  (tiles 60..65 only): `in` is fp16 NHWC (strides / offsets still in elements) and the
+                             SPAA_IO_IN_F16  (tiles 60..65; tile 29 with an fp32 output of at most 4 channels: the image-side input
+                                             gradients): `in` is fp16 NHWC (strides / offsets still in elements) and the
                                              weights come from `w_half`; fp32 accumulation on v_mfma_f32_16x16x32_f16;
                              SPAA_IO_OUT_F16 (tiles 60..65, and the kernels that read fp32 IMAGES: 15..24, 38):
                                              `out`, `add`, `gate`, `aux_out`, `gate2` are fp16.

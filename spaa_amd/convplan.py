@@ -48,6 +48,10 @@ ENABLE_X6 = True  # build the split-bf16 weight planes (needed by tiles 12-14)
 WINOGRAD = os.environ.get('SPAA_WINOGRAD', '1') != '0'  # 3x3/s1 layers: allow the Winograd F(2x2,3x3) kernel (tile 70)
 
 
+def masked_any(*m):
+    return any(x is not None for x in m)
+
+
 def _load_tune():
     import json
     import os
@@ -265,6 +269,9 @@ class ConvPlan:
             ngemm = self.cout * self.nfold
             if 60 <= forced <= 65:
                 tile = forced
+            elif (not out_f16 and self.cout <= 4 and self.nfold == 1 and self.s_in == 1 and self.cin_p % 32 == 0 and not masked_any(mask_out, gate_bits, gate2_bits)
+                  and forced in (0, 29) and 'thin' not in DEFAULT_DISABLE):
+                tile = 29   # thin fp32 output from an fp16 activation (image-side input gradients): the patch-staged VALU kernel
             else:
                 tile = 60 if ngemm > 64 else 61 if ngemm > 32 else 62 if ngemm > 16 else 63
                 m_all = b * d.Hm * d.Wm

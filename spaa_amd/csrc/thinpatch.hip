@@ -21,6 +21,7 @@
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -41,11 +42,14 @@ __device__ __forceinline__ int swz(int q) {
     return L == 8 ? (q >> 1) & 7 : (q >> 2) & 3;
 }
 
-template <int L, int NOUT, int P>
+// HIN: the input is an fp16 activation (fp16-STORAGE mode: the image-side input gradients of conv1 / conv1_s / the ResNet stem
+// read fp16 gradients and write the fp32 image gradient); a 16-byte chunk then holds 8 channels, the arithmetic stays fp32
+template <int L, int NOUT, int P, bool HIN = false>
 __global__ __launch_bounds__(256) void thinpatch_kernel(const spaa_tapconv_t p, const int tiles_x, const int tiles_y,
                                                         const int dymin, const int dxmin, const int PH, const int PW) {
     constexpr int PIX_PER_PIECE = 64 / L;
-    constexpr int CCH = 4 * L;
+    constexpr int CCH = (HIN ? 8 : 4) * L;
+    constexpr int EB = HIN ? 2 : 4;   // bytes per input element
     constexpr int TH = TH1 * P;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void thinpatch_kernel(const spaa_tapconv_t p, 
     const int b = tile / (tiles_x * tiles_y);
     const int y0 = ty * TH, x0 = tx * TW;
 
-    const uint32_t in_bytes = (uint32_t)p.B * (uint32_t)(p.Hin * p.Win) * (uint32_t)p.in_cstride * 4u;
+    const uint32_t in_bytes = (uint32_t)p.B * (uint32_t)(p.Hin * p.Win) * (uint32_t)p.in_cstride * (uint32_t)EB;
     const uint64_t in_addr = reinterpret_cast<uint64_t>(p.in);
     const uint32_t in_lo = __builtin_amdgcn_readfirstlane((uint32_t)in_addr);
     const uint32_t in_hi = __builtin_amdgcn_readfirstlane((uint32_t)(in_addr >> 32));
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void thinpatch_kernel(const spaa_tapconv_t p, 
                                                             (int)__builtin_amdgcn_readfirstlane(in_bytes), 0x00020000);
     const int npix = PH * PW;
     const int npieces = (npix + PIX_PER_PIECE - 1) / PIX_PER_PIECE;
-    const int row_bytes = p.in_cstride * 4;
+    const int row_bytes = p.in_cstride * EB;
 
     const int lx = tid & (TW - 1), ly = tid / TW;  // the lane's pixels: (lx, ly + TH1 * pi), pi < P
     const int x = x0 + lx;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) void thinpatch_kernel(const spaa_tapconv_t p, 
             const int c = (lane % L) ^ swz<L>(q);
             const int iy = y0 + dymin + py, ix = x0 + dxmin + px;
             const bool v = q < npix && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-            const int off = ((b * p.Hin + iy) * p.Win + ix) * row_bytes + (p.in_coff + c0 + 4 * c) * 4;
+            const int off = ((b * p.Hin + iy) * p.Win + ix) * row_bytes + (p.in_coff + c0) * EB + 16 * c;
             dma16(rsrc_in, smem + i * 1024, v ? off : (int)0x80000000);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -124,15 +128,34 @@ __global__ __launch_bounds__(256) void thinpatch_kernel(const spaa_tapconv_t p, 
 #pragma unroll
                 for (int pi = 0; pi < P; ++pi) {
                     const int q = (ly + TH1 * pi + dy - dymin) * PW + (lx + dx - dxmin);
-                    pp[pi] = smem + q * (CCH * 4);
+                    pp[pi] = smem + q * (16 * L);
                     sw[pi] = swz<L>(q);
                 }
 #pragma unroll
-                for (int g = 0; g < L / 4; ++g) {  // 16 channels at a time: one s_load_dwordx16 per output channel
+                for (int g = 0; g < CCH / 16; ++g) {  // 16 channels at a time: one s_load_dwordx16 per output channel
                     f16v w[NOUT];
 #pragma unroll
                     for (int n = 0; n < NOUT; ++n)
                         w[n] = *(cf16_ptr)(uintptr_t)(wbase + (size_t)n * cl.Kpad + t * p.Cin + 16 * g);
+                    if constexpr (HIN) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                            for (int pi = 0; pi < P; ++pi) {
+                                const h8 ah = *reinterpret_cast<const h8*>(pp[pi] + (((2 * g + u) ^ sw[pi]) * 16));
+#pragma unroll
+                                for (int v2 = 0; v2 < 4; ++v2) {
+                                    const f2 a2 = {(float)ah[2 * v2], (float)ah[2 * v2 + 1]};
+#pragma unroll
+                                    for (int n = 0; n < NOUT; ++n) {
+                                        const f2 w2 = {w[n][8 * u + 2 * v2], w[n][8 * u + 2 * v2 + 1]};
+                                        acc[ci][pi][n] = __builtin_elementwise_fma(a2, w2, acc[ci][pi][n]);
+                                    }
+                                }
+                            }
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -229,7 +252,7 @@ __global__ __launch_bounds__(256) void thinpatch_kernel(const spaa_tapconv_t p, 
     }
 }
 
-template <int L, int NOUT, int P>
+template <int L, int NOUT, int P, bool HIN = false>
 int launch_tp(const spaa_tapconv_t& d, int dymin, int dxmin, int PH, int PW, hipStream_t stream) {
     constexpr int TH = TH1 * P;
     const int tiles_x = (d.Wm + TW - 1) / TW, tiles_y = (d.Hm + TH - 1) / TH;
@@ -237,11 +260,11 @@ int launch_tp(const spaa_tapconv_t& d, int dymin, int dxmin, int PH, int PW, hip
     if (smem > 64 * 1024) return hipErrorInvalidValue;
     static bool attr_set[SPAA_MAX_DEVICES] = {};
     {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&thinpatch_kernel<L, NOUT, P>), 64 * 1024, attr_set);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&thinpatch_kernel<L, NOUT, P, HIN>), 64 * 1024, attr_set);
         if (e != hipSuccess) return (int)e;
     }
     dim3 grid((unsigned)(tiles_x * tiles_y * d.B), 1, 1);
-    hipLaunchKernelGGL((thinpatch_kernel<L, NOUT, P>), grid, dim3(256), smem, stream, d, tiles_x, tiles_y, dymin, dxmin, PH, PW);
+    hipLaunchKernelGGL((thinpatch_kernel<L, NOUT, P, HIN>), grid, dim3(256), smem, stream, d, tiles_x, tiles_y, dymin, dxmin, PH, PW);
     return (int)hipGetLastError();
 }
 
@@ -254,13 +277,16 @@ int spaa_launch_thinpatch(const spaa_tapconv_t& d, hipStream_t stream) {
     // latency are shared by twice the FMAs)
     const int L = d.tile == 28 ? 8 : 4;
     const int P = d.tile == 47 ? 2 : 1;
-    if (d.Cout > 4 || d.s_in != 1 || (d.Cin % (4 * L)) != 0) return hipErrorInvalidValue;
+    const bool hin = (d.io_dtype & SPAA_IO_IN_F16) != 0;   // fp16 activation in, fp32 image gradient out (tile 29 only)
+    if (hin && (d.tile != 29 || (d.io_dtype & SPAA_IO_OUT_F16))) return hipErrorInvalidValue;
+    if (d.Cout > 4 || d.s_in != 1 || (d.Cin % ((hin ? 8 : 4) * L)) != 0) return hipErrorInvalidValue;
     const int dymin = d.tap_range[0], dymax = d.tap_range[1], dxmin = d.tap_range[2], dxmax = d.tap_range[3];
     if (dymax < dymin || dxmax < dxmin || dymax - dymin > 16 || dxmax - dxmin > 16) return hipErrorInvalidValue;
     const int PH = TH1 * P + dymax - dymin, PW = TW + dxmax - dxmin;
     for (int c = 0; c < d.nclass; ++c)
         if (d.cls[c].Kpad % 16) return hipErrorInvalidValue;
     const bool n3 = d.Cout <= 3;
+    if (hin) return n3 ? launch_tp<4, 3, 1, true>(d, dymin, dxmin, PH, PW, stream) : launch_tp<4, 4, 1, true>(d, dymin, dxmin, PH, PW, stream);
     if (L == 8) return n3 ? launch_tp<8, 3, 1>(d, dymin, dxmin, PH, PW, stream) : launch_tp<8, 4, 1>(d, dymin, dxmin, PH, PW, stream);
     if (P == 2) return n3 ? launch_tp<4, 3, 2>(d, dymin, dxmin, PH, PW, stream) : launch_tp<4, 4, 2>(d, dymin, dxmin, PH, PW, stream);
     return n3 ? launch_tp<4, 3, 1>(d, dymin, dxmin, PH, PW, stream) : launch_tp<4, 4, 1>(d, dymin, dxmin, PH, PW, stream);

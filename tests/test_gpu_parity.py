@@ -1657,6 +1657,37 @@ def test_tapconv_fp16_storage(hip, tile):
         cp.FORCE_TILE = 0
 
 
+def test_thin_output_from_fp16_activation(hip):
+    """fp16-storage mode: the image-side input gradients (conv1 / conv1_s: 32 -> 3 over four parity classes; ResNet stem: 64 -> 3,
+    7 x 7) read an fp16 gradient and write the fp32 image gradient: the patch-staged VALU kernel's fp16-input form (tile 29)
+    against fp64 on the same fp16-rounded operands, with the residual / multiplicative-gate epilogues the engine uses."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(5)
+    for ci, co, k, s, h, w, b in [(3, 32, 3, 2, 24, 40, 3), (3, 64, 7, 2, 30, 28, 2), (2, 32, 3, 1, 16, 18, 2)]:
+        wt = torch.randn(co, ci, k, k) / (ci * k * k) ** 0.5
+        ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+        gy = _h(torch.randn(b, co, ho, wo))
+        x = torch.zeros(b, ci, h, w, dtype=torch.float64, requires_grad=True)
+        F.conv2d(x, wt.double(), None, s, k // 2).backward(gy.double())
+        dplan = cp.conv_dgrad_plan(wt, s, k // 2, DEV)
+        add = torch.randn(b, h, w, 4, device=DEV)
+        add[..., ci:] = 0
+        gate = torch.rand(b, h, w, 4, device=DEV)
+        for tile in (0, 63):   # (63: the fp16-MFMA thin tile, whose WEIGHTS are fp16 as well: 2^-11 per product)
+            cp.FORCE_TILE = tile
+            tol = 2e-5 if tile == 0 else 1.5e-3
+            try:
+                gx = torch.zeros(b, h, w, 4, device=DEV)
+                dplan.run(nhwc(gy, dplan.cin_p).half().to(DEV), gx)
+                assert rel_inf(nchw(gx.cpu(), ci), x.grad.float()) < tol, (ci, co, k, tile)
+                gx2 = torch.zeros(b, h, w, 4, device=DEV)
+                dplan.run(nhwc(gy, dplan.cin_p).half().to(DEV), gx2, add=add, gate=gate, gate_mode=lib.GATE_MUL)
+                want = (x.grad.float().permute(0, 2, 3, 1) + add.cpu()[..., :ci]) * gate.cpu()[..., :ci]
+                assert rel_inf(gx2.cpu()[..., :ci], want) < tol, (ci, co, k, tile, 'epilogue')
+            finally:
+                cp.FORCE_TILE = 0
+
+
 def test_fp16_storage_pcnet_and_classifier(hip, golden_dir):
     """fp16-storage engines vs the fp32 oracle on the reference's golden PCNet case: forward values to fp16 rounding
     accumulated over the 14 layers, input gradients to a few percent (fp16-rounded activations flip more ReLU gates than
