@@ -33,9 +33,9 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               42: 'x6d16a3_128x64', 43: 'x6d16a3_128x32', 44: 'x6da3_128x64', 45: 'x6d16coa3_128x64', 46: 'x6d16coa3_128x32', 47: 'thinpatch16x2',
               48: 'x6d16p_128x128', 49: 'x6d16p_128x64', 50: 'x6d16a3p_128x64', 51: 'x6da3p_128x64', 52: 'x6d16p_256x128',
               53: 'x6d16p_128x32', 54: 'x6dp_128x128',
-              60: 'h16_128x128', 61: 'h16_128x64', 62: 'h16_128x32', 63: 'h16_128x16', 64: 'h16_256x128', 65: 'h16_256x256',
+              60: 'h16_128x128', 61: 'h16_128x64', 62: 'h16_128x32', 63: 'h16_128x16', 64: 'h16_256x128', 65: 'h16_256x256', 68: 'h16p_16x32x128',
               70: 'wino_x6_16x32x128', 71: 'wino_x6_16x32x64'}   # (71: reporting only: tile 70 run by its 64-wide instantiation)
-STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 66)) | {70}  # shared epilogue (epilogue.hpp)
+STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 66)) | {68, 70}  # shared epilogue (epilogue.hpp)
 F16OUT_TILES = set(range(15, 25)) | {38} | set(range(60, 66))  # ... of which these may write fp16 (fp32 image in, fp16 activation out)
 DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
 DEBUG_TAPMAJOR = int(os.environ.get('SPAA_X6D_TAPMAJOR', '0'))      # 1: tap-major K order (A/B measurements only)
@@ -267,7 +267,10 @@ class ConvPlan:
             tile = 0 if forced else self._default_tile(b * d.Hm * d.Wm, winograd=False)
         if in_f16:    # fp16 activations: the h16 kernels, N tile by the GEMM's width
             ngemm = self.cout * self.nfold
-            if 60 <= forced <= 65:
+            patch_ok = (len(self.cls) == 1 and self.ntaps_total == 9 and self.s_in == 1 and self.s_out == 1 and self.nfold == 1
+                        and (hin, win) == (hout, wout) and self.tap_range[0] >= -1 and self.tap_range[1] <= 1
+                        and self.tap_range[2] >= -1 and self.tap_range[3] <= 1)
+            if 60 <= forced <= 65 or (forced == 68 and patch_ok):
                 tile = forced
             elif (not out_f16 and self.cout <= 4 and self.nfold == 1 and self.s_in == 1 and self.cin_p % 32 == 0 and not masked_any(mask_out, gate_bits, gate2_bits)
                   and forced in (0, 29) and 'thin' not in DEFAULT_DISABLE):
@@ -275,7 +278,10 @@ class ConvPlan:
             else:
                 tile = 60 if ngemm > 64 else 61 if ngemm > 32 else 62 if ngemm > 16 else 63
                 m_all = b * d.Hm * d.Wm
-                if tile == 60 and m_all >= 256 * 512:   # enough pixels to fill the chip with 256-row tiles: less weight
+                if (patch_ok and self.cout >= 64 and 'h16p' not in DEFAULT_DISABLE and forced == 0
+                        and b * ((hout + 15) // 16) * ((wout + 31) // 32) * ((self.cout + 127) // 128) >= 256):
+                    tile = 68   # 3x3 / stride 1: the input patch staged once for the nine taps (csrc/tapconv_h16p.hip)
+                elif tile == 60 and m_all >= 256 * 512:   # enough pixels to fill the chip with 256-row tiles: less weight
                     tile = 65 if ngemm > 128 else 64    # traffic per pixel (and one N tile for the 256-channel layers)
         elif out_f16:  # fp32 image in, fp16 activation out: any kernel built on the shared epilogue, without split-K
             tile %= 100
@@ -319,7 +325,7 @@ class ConvPlan:
                 raise ValueError(f'{self.name}: gate masks need a layer shape served by the bf16x6 / smallcin kernels')
         if self.fixed_tile:
             tile, d.ksplit, d.splitk_ws = self.fixed_tile, 0, None
-        d.tile = tile
+        d.tile = self.last_tile = tile     # (last_tile: for tests and reports)
         d.reserved0 = DEBUG_TAPMAJOR | (DEBUG_PERSIST_CAP << 8) | (DEBUG_WINO << 16)  # measurement / test switches of the x6d kernels
         d.nclass = len(self.cls)
         d.tap_range[:] = self.tap_range

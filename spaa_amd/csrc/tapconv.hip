@@ -21,6 +21,7 @@
 int spaa_launch_tapconv_x6(const spaa_tapconv_t& d, int tile, hipStream_t stream);   // tapconv_x6.hip
 int spaa_launch_tapconv_x6d(const spaa_tapconv_t& d, int tile, hipStream_t stream);  // tapconv_x6d.hip
 int spaa_launch_tapconv_h16(const spaa_tapconv_t& d, int tile, hipStream_t stream);  // tapconv_h16.hip
+int spaa_launch_tapconv_h16p(const spaa_tapconv_t& d, hipStream_t stream);           // tapconv_h16p.hip
 int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream);          // tapconv_wino.hip
 int spaa_launch_thinpatch(const spaa_tapconv_t& d, hipStream_t stream);               // thinpatch.hip
 int spaa_launch_smallcin(const spaa_tapconv_t& d, hipStream_t stream);                // smallcin.hip
@@ -555,7 +556,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         // byte masks (1 byte per 4 channels): only the epilogues built on epilogue.hpp's store4 know them, and only in its
         // 4-channel-vector form
         const int t = d.tile;
-        if (!((t >= 15 && t <= 27) || (t >= 30 && t <= 46) || (t >= 48 && t <= 54) || (t >= 60 && t <= 65) || t == 70)) return hipErrorInvalidValue;
+        if (!((t >= 15 && t <= 27) || (t >= 30 && t <= 46) || (t >= 48 && t <= 54) || (t >= 60 && t <= 65) || t == 68 || t == 70)) return hipErrorInvalidValue;
         if ((d.Cout | d.out_cstride | d.out_coff) & 3) return hipErrorInvalidValue;
         if (d.add != nullptr && ((d.add_cstride | d.add_coff) & 3)) return hipErrorInvalidValue;
         if (d.gate_bits != nullptr && (d.gate != nullptr || ((d.gate_cstride | d.gate_coff) & 3))) return hipErrorInvalidValue;
@@ -578,9 +579,9 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         if ((int64_t)((d.Cout + 127) & ~127) * d.cls[c].Kpad * 4 >= (int64_t)1 << 31) return hipErrorInvalidValue;
     int tile = d.tile;
     // fp16-storage mode: fp16 inputs only through the h16 kernels; fp16 outputs only through the shared epilogue
-    if ((d.io_dtype & SPAA_IO_IN_F16) && !((tile >= 60 && tile <= 65) || (tile == 29 && !(d.io_dtype & SPAA_IO_OUT_F16)))) return hipErrorInvalidValue;
+    if ((d.io_dtype & SPAA_IO_IN_F16) && !((tile >= 60 && tile <= 65) || tile == 68 || (tile == 29 && !(d.io_dtype & SPAA_IO_OUT_F16)))) return hipErrorInvalidValue;
     if (!(d.io_dtype & SPAA_IO_IN_F16) && tile >= 60 && tile <= 63) return hipErrorInvalidValue;
-    if ((d.io_dtype & SPAA_IO_OUT_F16) && !((tile >= 15 && tile <= 24) || tile == 38 || (tile >= 60 && tile <= 65)))
+    if ((d.io_dtype & SPAA_IO_OUT_F16) && !((tile >= 15 && tile <= 24) || tile == 38 || (tile >= 60 && tile <= 65) || tile == 68))
         return hipErrorInvalidValue;
     if ((d.io_dtype & SPAA_IO_OUT_F16) && (d.ksplit > 1 || d.ksplit < 0)) return hipErrorInvalidValue;  // (fp32 partial sums)
     if (d.gate != nullptr && d.gate_mode == SPAA_GATE_MUL && tile < 25) return hipErrorInvalidValue;
@@ -653,6 +654,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         case 63:
         case 64:
         case 65: return spaa_launch_tapconv_h16(d, tile, stream);
+        case 68: return spaa_launch_tapconv_h16p(d, stream);
         case 70: return spaa_launch_tapconv_wino(d, stream);
         default: return hipErrorInvalidValue;
     }

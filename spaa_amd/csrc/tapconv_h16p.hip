@@ -1,0 +1,221 @@
+// tapconv_h16p.hip — fp16-STORAGE mode, 3x3 / stride-1 / pad-1 convolutions and their input gradients with the input PATCH
+// staged once in LDS.
+//
+// The implicit-GEMM fp16 kernel (tapconv_h16.hip) gathers its activation operand once per TAP: a 32-pixel row block of 64 bytes
+// per 32-deep sub-step and wave, i.e. 128 bytes of L2 -> LDS traffic per MFMA instruction at BN = 128 -- 32 B/clk/CU at the
+// full matrix-core rate, more than twice what a CU's LDS-DMA path delivers.  Measured (profiles/r03_*): the six 64 x 64 x
+// (128 <-> 256) layers sit at 460-590 TF whatever the pipeline depth (a three-stage counted-vmcnt pipeline: +-0) or the pixel
+// block per wave.  A 3x3 convolution reads every input pixel nine times; here a workgroup stages the 18 x 34 pixel patch of
+// its 16 x 32 output pixels ONCE per 32-channel block (LDS-DMA, out-of-image pixels = the out-of-range offset = the zero
+// padding) and the nine taps read their B fragments from it at shifted positions: 39 KB of patch + 72 KB of weights per 9 x
+// 32 MFMAs per wave = 12 B/clk/CU.
+//   * workgroup = 8 waves = 16 x 32 output pixels x BN channels; wave w owns output rows 2w, 2w + 1 = four 16-pixel blocks:
+//     a weight fragment read from LDS feeds four MFMAs;
+//   * K order: 32-channel block, then tap; a step = three taps: 24 KB of weights (three LDS stages, DMA two steps ahead behind
+//     a counted vmcnt and a raw s_barrier), 96 MFMAs per wave between barriers; the patch is double-buffered (the next block's
+//     is requested at the block's first step);
+//   * fp16 operands, fp32 accumulation (v_mfma_f32_16x16x32_f16), the shared fp32 epilogue (epilogue.hpp).
+#include <hip/hip_runtime.h>
+#include "launch_util.hpp"
+#include <stdint.h>
+#include "../../include/spaa_hip.h"
+#include "epilogue.hpp"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rsrc, unsigned char* dst, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)dst, 16, voff, soff, 0, 0);
+}
+// chunk swizzle of a 64-byte row (four 16-byte chunks): rows 8 apart swap chunk pairs (tapconv_h16.hip swz64)
+__device__ __forceinline__ int swz64(int r) { return ((r >> 3) & 1) << 1; }
+
+constexpr int OH = 16, OW = 32;                // output pixels of a workgroup
+constexpr int PH = OH + 2, PW = OW + 2;        // input patch 18 x 34
+constexpr int NPX = PH * PW;                   // 612
+constexpr int P_PIECES = (NPX + 15) / 16;      // 1-KiB pieces of 16 pixels x 32 channels (fp16): 39
+constexpr int PPW = (P_PIECES + 7) / 8;        // per wave: 5
+constexpr int PATCH_BYTES = PPW * 8 * 1024;    // 40960 (pieces 39: pad)
+
+template <int BN>
+__global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, const int wg_y, const int wg_x, const int n_tiles) {
+    constexpr int TJ = BN / 16;
+    constexpr int NW = 8;
+    constexpr int W_TAP = BN * 64;                     // one tap's weight rows (32 fp16 each)
+    constexpr int W_PIECES = 3 * BN / 16;              // per step (three taps)
+    constexpr int WPW = (W_PIECES + NW - 1) / NW;      // 3 (BN = 128) or 2 (BN = 64: 12 pieces, the last four DMA slots are pad)
+    constexpr int WS_BYTES = WPW * NW * 1024;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char* const wsm = smem + 2 * PATCH_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const spaa_tapclass_t cl = p.cls[0];
+    const int Cin = p.Cin, H = p.Hin, W = p.Win;
+
+    int n_blk, img, oy0, ox0;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+        n_blk = (t % n_tiles) * BN;
+        t /= n_tiles;
+        ox0 = (t % wg_x) * OW;
+        t /= wg_x;
+        oy0 = (t % wg_y) * OH;
+        img = t / wg_y;
+    }
+    const int row_bytes = p.in_cstride * 2;
+    const uint32_t in_bytes = (uint32_t)p.B * (uint32_t)(H * W) * (uint32_t)row_bytes;
+    const uint64_t in_addr = reinterpret_cast<uint64_t>(p.in);
+    const uint32_t in_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)in_addr);
+    const uint32_t in_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(in_addr >> 32));
+    const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)in_hi << 32) | in_lo), 0,
+                                                            (int)__builtin_amdgcn_readfirstlane(in_bytes), 0x00020000);
+    const int K64 = (cl.K + 63) & ~63;
+    const int npad = (p.Cout + 127) & ~127;
+    const uint64_t w_addr = reinterpret_cast<uint64_t>(p.w_half);
+    const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)w_addr);
+    const uint32_t w_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(w_addr >> 32));
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)w_hi << 32) | w_lo), 0,
+                                                           (int)__builtin_amdgcn_readfirstlane((uint32_t)npad * (uint32_t)K64 * 2u), 0x00020000);
+    typedef const __attribute__((address_space(4))) int* cint_ptr;
+    cint_ptr ctaps = (cint_ptr)(uintptr_t)(p.taps + 2 * cl.tap_off);
+
+    // ---- patch staging: piece i (16 consecutive patch pixels) -> wave i % 8; lane -> (pixel lane >> 2, physical chunk lane & 3)
+    auto dma_patch = [&](const int buf, const int kb) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));   // (per-lane constants recomputed here, not kept in registers across the K loop)
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int q = (wave + NW * i) * 16 + (ln >> 2);          // patch pixel
+            const int pr = q / PW, pc = q - pr * PW;
+            const int iy = oy0 - 1 + pr, ix = ox0 - 1 + pc;
+            const bool ok = q < NPX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const int c = (ln & 3) ^ swz64(q);
+            const int off = ok ? ((img * H + iy) * W + ix) * row_bytes + (p.in_coff + kb * 32) * 2 + c * 16 : (int)0x80000000;
+            dma16(rsrc_in, smem + buf * PATCH_BYTES + (wave + NW * i) * 1024, off, 0);
+        }
+    };
+    // ---- weights of step (kb, s): taps 3 s .. 3 s + 2; piece q = wave + 8 i -> (tap q / (BN / 16), 16-row block q % (BN / 16))
+    const int w_voff = (lane >> 2) * K64 * 2 + (((lane & 3) ^ swz64(lane >> 2)) << 4);
+    auto dma_w = [&](const int stage, const int kb, const int s) {
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            const int q = wave + NW * i;
+            const int tl = q / (BN / 16), rb = q - tl * (BN / 16);
+            const int soff = (n_blk + 16 * rb) * K64 * 2 + ((3 * s + tl) * Cin + kb * 32) * 2;
+            dma16(rsrc_w, wsm + stage * WS_BYTES + q * 1024, q < W_PIECES ? w_voff : (int)0x80000000, soff);
+        }
+    };
+    const int w_addr_l = (lane & 15) * 64 + (((lane >> 4) ^ swz64(lane & 15)) * 16);
+
+    f32x4 acc[4][TJ];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkb = Cin >> 5;
+    const int nsteps = 3 * nkb;
+    dma_patch(0, 0);
+    dma_w(0, 0, 0);
+    if (nsteps > 1) dma_w(1, 0, 1);
+    int st = 0;
+    for (int kb = 0; kb < nkb; ++kb) {
+        const unsigned char* pb = smem + (kb & 1) * PATCH_BYTES;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int step = 3 * kb + s;
+            // this wave's pieces of the step's weights (and, at s == 0, of the block's patch) have landed
+            if (step + 1 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (s != 0 && kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + PPW) : "memory");   // (the next block's patch, requested at s == 0)
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (step + 2 < nsteps) {
+                const int st2 = st >= 1 ? st - 1 : 2;
+                const int s2 = s + 2 >= 3 ? s - 1 : s + 2, kb2 = s + 2 >= 3 ? kb + 1 : kb;
+                dma_w(st2, kb2, s2);
+            }
+            if (s == 0 && kb + 1 < nkb) dma_patch((kb + 1) & 1, kb + 1);
+#pragma unroll
+            for (int tl = 0; tl < 3; ++tl) {
+                const int dy = ctaps[2 * (3 * s + tl)], dx = ctaps[2 * (3 * s + tl) + 1];
+                h8 bf[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    // pixel block b = (row 2 wave + (b >> 1), columns 16 (b & 1) ..): patch pixel of this lane's column
+                    const int q = (2 * wave + (b >> 1) + dy + 1) * PW + 16 * (b & 1) + dx + 1 + (lane & 15);
+                    bf[b] = *reinterpret_cast<const h8*>(pb + q * 64 + (((lane >> 4) ^ swz64(q)) << 4));
+                }
+                const unsigned char* wc = wsm + st * WS_BYTES + tl * W_TAP + w_addr_l;
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const h8 wf = *reinterpret_cast<const h8*>(wc + j * 1024);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, bf[b], acc[b][j], 0, 0, 0);
+                }
+            }
+            st = st == 2 ? 0 : st + 1;
+        }
+    }
+
+    // ---- epilogue: D layout of a 16x16 block: column (lane & 15) = pixel, rows 4 (lane >> 4) + e = 4 consecutive channels
+    const bool vec = !((p.Cout | p.out_cstride | p.out_coff) & 3) &&
+                     (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
+                     (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
+                     (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
+#define H16P_EPI(T, b)                                                                                             \
+    {                                                                                                              \
+        const int oy = oy0 + 2 * wave + ((b) >> 1), ox = ox0 + 16 * ((b) & 1) + (lane & 15);                       \
+        if (oy < p.Hout && ox < p.Wout) {                                                                          \
+            const size_t o = ((size_t)img * p.Hout + oy) * p.Wout + ox;                                            \
+            _Pragma("unroll") for (int j = 0; j < TJ; ++j) {                                                       \
+                float v[4] = {acc[b][j][0], acc[b][j][1], acc[b][j][2], acc[b][j][3]};                             \
+                store4_t<T>(p, o, n_blk + 16 * j + 4 * (lane >> 4), v, vec);                                       \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
+    if (p.io_dtype & SPAA_IO_OUT_F16) {
+        H16P_EPI(_Float16, 0) H16P_EPI(_Float16, 1) H16P_EPI(_Float16, 2) H16P_EPI(_Float16, 3)
+    } else {
+        H16P_EPI(float, 0) H16P_EPI(float, 1) H16P_EPI(float, 2) H16P_EPI(float, 3)
+    }
+#undef H16P_EPI
+}
+
+}  // namespace
+
+// called by spaa_tapconv_f32 (tapconv.hip) for tile 68 after the common shape checks: ONE class of nine taps inside
+// [-1, 1]^2 (a 3x3 convolution or its input gradient), stride 1, same input and output size, fp16 input, Cin % 32 == 0
+int spaa_launch_tapconv_h16p(const spaa_tapconv_t& d, hipStream_t stream) {
+    if (!(d.io_dtype & SPAA_IO_IN_F16) || d.w_half == nullptr || (d.Cin % 32) != 0 || d.nclass != 1 || d.cls[0].ntaps != 9 ||
+        d.cls[0].K != 9 * d.Cin || d.s_in != 1 || d.s_out != 1 || d.Hin != d.Hout ||
+        d.Win != d.Wout || d.Hm != d.Hout || d.Wm != d.Wout || d.nfold > 1 || d.ksplit > 1 || d.ksplit < 0)
+        return hipErrorInvalidValue;
+    if (d.tap_range[0] < -1 || d.tap_range[1] > 1 || d.tap_range[2] < -1 || d.tap_range[3] > 1) return hipErrorInvalidValue;
+    if ((int64_t)((d.Cout + 127) & ~127) * ((d.cls[0].K + 63) & ~63) * 2 >= (int64_t)1 << 31) return hipErrorInvalidValue;
+    if ((int64_t)d.B * d.Hin * d.Win * d.in_cstride * 2 >= (int64_t)1 << 31) return hipErrorInvalidValue;
+    const int wg_y = (d.Hout + OH - 1) / OH, wg_x = (d.Wout + OW - 1) / OW;
+    const int BN = d.Cout <= 64 ? 64 : 128;
+    const int n_tiles = (d.Cout + BN - 1) / BN;
+    const int64_t nwg = (int64_t)d.B * wg_y * wg_x * n_tiles;
+    if (nwg > 0x7fffffff) return hipErrorInvalidValue;
+    static bool attr_set[2][SPAA_MAX_DEVICES] = {};
+#define H16P_LAUNCH(N, SLOT)                                                                                               \
+    {                                                                                                                      \
+        const size_t smem = 2 * (size_t)PATCH_BYTES + 3 * (size_t)(((3 * N / 16 + 7) / 8) * 8 * 1024);                     \
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&h16p_kernel<N>), (int)smem, attr_set[SLOT]);      \
+        if (e != hipSuccess) return (int)e;                                                                                \
+        hipLaunchKernelGGL((h16p_kernel<N>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles);        \
+    }
+    if (BN == 64) H16P_LAUNCH(64, 0) else H16P_LAUNCH(128, 1)
+#undef H16P_LAUNCH
+    return (int)hipGetLastError();
+}

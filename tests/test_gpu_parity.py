@@ -1588,7 +1588,7 @@ def _h(x):
     return x.half().float()
 
 
-@pytest.mark.parametrize('tile', [0, 60, 61, 62, 63, 64, 65])
+@pytest.mark.parametrize('tile', [0, 60, 61, 62, 63, 64, 65, 68])
 def test_tapconv_fp16_storage(hip, tile):
     cp, lib = hip['cp'], hip['lib']
     torch.manual_seed(31 + tile)
@@ -1653,6 +1653,48 @@ def test_tapconv_fp16_storage(hip, tile):
             plan.run(nhwc(x, plan.cin_p).to(DEV), out, act=lib.ACT_RELU, mask_out=mask)
             assert rel_inf(nchw(out.float().cpu(), co), y) < 1e-3, ('image->f16', ci, co, k, s)
             assert torch.equal(mask, lib.pack_gate_mask(out.float()))
+    finally:
+        cp.FORCE_TILE = 0
+
+
+def test_tapconv_fp16_patch_staged(hip):
+    """fp16-storage 3x3 / stride-1 layers on the patch-staged kernel (csrc/tapconv_h16p.hip, tile 68): several workgroup tiles
+    per image with ragged right / bottom edges, one and two channel tiles, the 64-wide instantiation; forward (residual + ReLU +
+    byte mask, fp16 out; fp32 out) and input gradient (byte-mask gate), against fp64 on the same fp16-rounded operands."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(68)
+    try:
+        for ci, co, h, w, b in [(128, 256, 40, 70, 2), (256, 128, 33, 32, 1), (64, 64, 17, 65, 2), (32, 192, 16, 32, 1), (96, 72, 5, 3, 3)]:
+            x = _h(torch.randn(b, ci, h, w))
+            wt = _h(torch.randn(co, ci, 3, 3) / (ci * 9) ** 0.5)
+            bias = torch.randn(co)
+            y = F.conv2d(x.double(), wt.double(), bias.double(), 1, 1).float()
+            add = _h(torch.randn_like(y))
+            plan = cp.conv_fwd_plan(wt, bias, 1, 1, DEV)
+            cp.FORCE_TILE = 68
+            out = torch.zeros(b, h, w, co, device=DEV, dtype=torch.float16)
+            mask = torch.zeros(b, h, w, co // 4, dtype=torch.uint8, device=DEV)
+            plan.run(nhwc(x).half().to(DEV), out, add=nhwc(add).half().to(DEV), act=lib.ACT_RELU, mask_out=mask)
+            assert plan.last_tile == 68, plan.last_tile
+            assert rel_inf(nchw(out.float().cpu(), co), F.relu(y + add)) < 1.5e-3, (ci, co, h, w)
+            assert torch.equal(mask, lib.pack_gate_mask(out.float()))
+            out32 = torch.zeros(b, h, w, co, device=DEV)
+            plan.run(nhwc(x).half().to(DEV), out32)
+            assert rel_inf(nchw(out32.cpu(), co), y) < 2e-5, (ci, co, h, w, rel_inf(nchw(out32.cpu(), co), y))
+            cp.FORCE_TILE = 60
+            ref60 = torch.zeros(b, h, w, co, device=DEV)
+            plan.run(nhwc(x).half().to(DEV), ref60)
+            cp.FORCE_TILE = 68
+            assert rel_inf(out32, ref60) < 2e-6       # (the same products, another summation order)
+            gy = _h(torch.randn(b, co, h, w))
+            gx_ref = torch.nn.grad.conv2d_input((b, ci, h, w), wt.double(), gy.double(), 1, 1).float()
+            gate_act = torch.randn(b, h, w, ci, device=DEV)
+            dplan = cp.conv_dgrad_plan(wt, 1, 1, DEV)
+            if dplan.cin_p % 32 == 0:
+                gx = torch.zeros(b, h, w, ci, device=DEV, dtype=torch.float16)
+                dplan.run(nhwc(gy, dplan.cin_p).half().to(DEV), gx, gate_bits=lib.pack_gate_mask(gate_act))
+                assert dplan.last_tile == 68
+                assert rel_inf(nchw(gx.float().cpu(), ci), gx_ref * (nchw(gate_act.cpu(), ci) > 0)) < 1.5e-3, ('dgrad', ci, co)
     finally:
         cp.FORCE_TILE = 0
 
