@@ -279,8 +279,11 @@ class ConvPlan:
                 tile = 60 if ngemm > 64 else 61 if ngemm > 32 else 62 if ngemm > 16 else 63
                 m_all = b * d.Hm * d.Wm
                 if (patch_ok and self.cout >= 64 and 'h16p' not in DEFAULT_DISABLE and forced == 0
-                        and b * ((hout + 15) // 16) * ((wout + 31) // 32) * ((self.cout + 127) // 128) >= 256):
+                        and b * ((hout + 15) // 16) * ((wout + 31) // 32) * ((self.cout + 127) // 128) >= 256
+                        and hout * wout >= 0.6 * ((hout + 15) // 16 * 16) * ((wout + 31) // 32 * 32)):   # (16 x 32-pixel tiles)
                     tile = 68   # 3x3 / stride 1: the input patch staged once for the nine taps (csrc/tapconv_h16p.hip)
+                elif tile == 60 and (m_all + 127) // 128 * ((ngemm + 127) // 128) < 256 and 'h16n64' not in DEFAULT_DISABLE:
+                    tile = 61   # too few 128 x 128 tiles for 256 CUs (ResNet layer3 / layer4 at batch 64): twice as many of 128 x 64
                 elif tile == 60 and m_all >= 256 * 512:   # enough pixels to fill the chip with 256-row tiles: less weight
                     tile = 65 if ngemm > 128 else 64    # traffic per pixel (and one N tile for the 256-channel layers)
         elif out_f16:  # fp32 image in, fp16 activation out: any kernel built on the shared epilogue, without split-K
