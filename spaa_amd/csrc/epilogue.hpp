@@ -203,6 +203,121 @@ __device__ __forceinline__ void store4_pre(const spaa_tapconv_t& p, const size_t
     }
 }
 
+// ---- the same epilogue WITHOUT a branch, for the operand combinations of the attack loops (bias, residual, ReLU, byte-mask
+// gate, byte mask out, second output gated by a second byte mask): absent tensors are buffer descriptors with ZERO records
+// (loads give 0, stores are dropped) and out-of-range pixels / channels use the out-of-bounds offset, so that a kernel can keep
+// the operand loads of several pixels per lane in flight -- the conditional loads of epi_load() make the compiler wait for
+// each one (s_waitcnt vmcnt(0) at every join).  32-bit byte offsets: fits_32bit_offsets().
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct fast_epi_t {
+    __amdgpu_buffer_rsrc_t out, add, gbits, g2bits, mask, aux;
+    float bias[4];
+    bool has_gate, relu;
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_or_empty(const void* ptr, const int64_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const int n = ptr != nullptr ? (int)bytes : 0;
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
+}
+// (the launcher checks that every operand of the fast path is below 2 GiB: fits_32bit_offsets)
+__device__ __forceinline__ bool fits_32bit_offsets(const spaa_tapconv_t& p) {
+    const int64_t npix = (int64_t)p.B * p.Hout * p.Wout;
+    const int64_t widest = p.io_dtype & SPAA_IO_OUT_F16 ? 2 : 4;
+    const int cs = p.out_cstride > p.add_cstride ? p.out_cstride : p.add_cstride;
+    const int cg = p.gate_cstride > p.gate2_cstride ? p.gate_cstride : p.gate2_cstride;
+    return npix * (cs > cg ? cs : cg) * widest < ((int64_t)1 << 31);
+}
+__device__ __forceinline__ fast_epi_t make_fast_epi(const spaa_tapconv_t& p, const int n) {
+    fast_epi_t f;
+    const int64_t npix = (int64_t)p.B * p.Hout * p.Wout;
+    const int64_t eb = p.io_dtype & SPAA_IO_OUT_F16 ? 2 : 4;
+    f.out = rsrc_or_empty(p.out, npix * p.out_cstride * eb);
+    f.aux = rsrc_or_empty(p.gate2_bits != nullptr ? p.aux_out : nullptr, npix * p.out_cstride * eb);
+    f.add = rsrc_or_empty(p.add, npix * p.add_cstride * eb);
+    f.gbits = rsrc_or_empty(p.gate_bits, npix * p.gate_cstride / 4);
+    f.g2bits = rsrc_or_empty(p.gate2_bits, npix * p.gate2_cstride / 4);
+    f.mask = rsrc_or_empty(p.mask_out, npix * p.out_cstride / 4);
+    const auto rb = rsrc_or_empty(p.bias, (int64_t)p.Cout * 4);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rb, n * 4, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f.bias[e] = __uint_as_float(b[e]);
+    f.has_gate = p.gate_bits != nullptr;
+    f.relu = p.act == SPAA_ACT_RELU;
+    return f;
+}
+template <typename T> struct fast_io;
+template <> struct fast_io<_Float16> {
+    typedef u32x2 vec_t;
+    static __device__ __forceinline__ vec_t ld(const __amdgpu_buffer_rsrc_t r, const int off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0); }
+    static __device__ __forceinline__ void to_float(const vec_t x, float (&v)[4]) {
+        const h4 h = __builtin_bit_cast(h4, x);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (float)h[e];
+    }
+    static __device__ __forceinline__ void st(const __amdgpu_buffer_rsrc_t r, const int off, const float (&v)[4]) {
+        const h4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), r, off, 0, 0);
+    }
+};
+template <> struct fast_io<float> {
+    typedef u32x4 vec_t;
+    static __device__ __forceinline__ vec_t ld(const __amdgpu_buffer_rsrc_t r, const int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
+    static __device__ __forceinline__ void to_float(const vec_t x, float (&v)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(x[e]);
+    }
+    static __device__ __forceinline__ void st(const __amdgpu_buffer_rsrc_t r, const int off, const float (&v)[4]) {
+        const u32x4 x = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(x, r, off, 0, 0);
+    }
+};
+
+template <typename T>
+struct fast_pre_t {
+    typename fast_io<T>::vec_t add;
+    unsigned int gb, g2;
+};
+// eligibility (uniform): 4-channel vectors, no float gates, plain or ReLU activation, every operand below 2 GiB
+__device__ __forceinline__ bool fast_epi_ok(const spaa_tapconv_t& p, const bool vec) {
+    return vec && p.gate == nullptr && p.gate2 == nullptr && (p.act == SPAA_ACT_NONE || p.act == SPAA_ACT_RELU) && fits_32bit_offsets(p);
+}
+// operands of output pixel o (index over B x Hout x Wout), channels n .. n + 3; ok = the pixel / channels exist
+template <typename T>
+__device__ __forceinline__ fast_pre_t<T> fast_epi_load(const fast_epi_t& fe, const spaa_tapconv_t& p, const int o, const int n, const bool ok) {
+    constexpr int OOB = (int)0x80000000;
+    fast_pre_t<T> r;
+    r.add = fast_io<T>::ld(fe.add, ok ? (o * p.add_cstride + p.add_coff + n) * (int)sizeof(T) : OOB);
+    r.gb = __builtin_amdgcn_raw_buffer_load_b8(fe.gbits, ok ? (o * p.gate_cstride + p.gate_coff + n) >> 2 : OOB, 0, 0);
+    r.g2 = __builtin_amdgcn_raw_buffer_load_b8(fe.g2bits, ok ? (o * p.gate2_cstride + p.gate2_coff + n) >> 2 : OOB, 0, 0);
+    return r;
+}
+// store4_pre()'s arithmetic in its order: bias, residual, ReLU, gate, rounding to the storage type, out, mask of the STORED
+// value, second output gated by the second mask
+template <typename T, typename ACC>
+__device__ __forceinline__ void fast_epi_store(const fast_epi_t& fe, const spaa_tapconv_t& p, const int o, const int n, const bool ok,
+                                               const ACC& a, const fast_pre_t<T>& r) {
+    constexpr int OOB = (int)0x80000000;
+    const int oi = o * p.out_cstride + p.out_coff + n;
+    float ad[4], v[4], u[4];
+    fast_io<T>::to_float(r.add, ad);
+    const unsigned int g = fe.has_gate ? r.gb : 15u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = a[e] + fe.bias[e];
+        v[e] += ad[e];
+        v[e] = fe.relu ? fmaxf(v[e], 0.f) : v[e];
+        v[e] = ((g >> e) & 1u) ? v[e] : 0.f;
+        v[e] = (float)(T)v[e];
+        u[e] = ((r.g2 >> e) & 1u) ? v[e] : 0.f;
+    }
+    fast_io<T>::st(fe.out, ok ? oi * (int)sizeof(T) : OOB, v);
+    const unsigned char mb = (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
+    __builtin_amdgcn_raw_buffer_store_b8(mb, fe.mask, ok ? oi >> 2 : OOB, 0, 0);
+    fast_io<T>::st(fe.aux, ok ? oi * (int)sizeof(T) : OOB, u);
+}
+
 // storage type chosen at run time (kernels that read fp32 IMAGES and may write fp16 activations: smallcin, x6v2/v3; the
 // fp32-only bf16x6 kernels call store4_t<float> directly and keep their register budget)
 __device__ __forceinline__ void store4(const spaa_tapconv_t& p, const size_t o, const int n0, float (&v)[4], const bool vec) {

@@ -41,74 +41,6 @@ constexpr int P_PIECES = (NPX + 15) / 16;      // 1-KiB pieces of 16 pixels x 32
 constexpr int PPW = (P_PIECES + 7) / 8;        // per wave: 5
 constexpr int PATCH_BYTES = PPW * 8 * 1024;    // 40960 (pieces 39: pad)
 
-// ---- branch-free epilogue operands: buffer descriptors with zero records for absent tensors
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-struct fast_epi_t {
-    __amdgpu_buffer_rsrc_t out, add, gbits, g2bits, mask, aux;
-    float bias[4];
-    bool has_gate, relu;
-};
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_or_empty(const void* ptr, const int64_t bytes) {
-    const uint64_t a = reinterpret_cast<uint64_t>(ptr);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-    const int n = ptr != nullptr ? (int)bytes : 0;
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
-}
-// (the launcher checks that every operand of the fast path is below 2 GiB: fits_32bit_offsets)
-__device__ __forceinline__ bool fits_32bit_offsets(const spaa_tapconv_t& p) {
-    const int64_t npix = (int64_t)p.B * p.Hout * p.Wout;
-    const int64_t widest = p.io_dtype & SPAA_IO_OUT_F16 ? 2 : 4;
-    const int cs = p.out_cstride > p.add_cstride ? p.out_cstride : p.add_cstride;
-    const int cg = p.gate_cstride > p.gate2_cstride ? p.gate_cstride : p.gate2_cstride;
-    return npix * (cs > cg ? cs : cg) * widest < ((int64_t)1 << 31);
-}
-__device__ __forceinline__ fast_epi_t make_fast_epi(const spaa_tapconv_t& p, const int n) {
-    fast_epi_t f;
-    const int64_t npix = (int64_t)p.B * p.Hout * p.Wout;
-    const int64_t eb = p.io_dtype & SPAA_IO_OUT_F16 ? 2 : 4;
-    f.out = rsrc_or_empty(p.out, npix * p.out_cstride * eb);
-    f.aux = rsrc_or_empty(p.gate2_bits != nullptr ? p.aux_out : nullptr, npix * p.out_cstride * eb);
-    f.add = rsrc_or_empty(p.add, npix * p.add_cstride * eb);
-    f.gbits = rsrc_or_empty(p.gate_bits, npix * p.gate_cstride / 4);
-    f.g2bits = rsrc_or_empty(p.gate2_bits, npix * p.gate2_cstride / 4);
-    f.mask = rsrc_or_empty(p.mask_out, npix * p.out_cstride / 4);
-    const auto rb = rsrc_or_empty(p.bias, (int64_t)p.Cout * 4);
-    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rb, n * 4, 0, 0);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) f.bias[e] = __uint_as_float(b[e]);
-    f.has_gate = p.gate_bits != nullptr;
-    f.relu = p.act == SPAA_ACT_RELU;
-    return f;
-}
-template <typename T> struct fast_io;
-template <> struct fast_io<_Float16> {
-    typedef u32x2 vec_t;
-    static __device__ __forceinline__ vec_t ld(const __amdgpu_buffer_rsrc_t r, const int off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0); }
-    static __device__ __forceinline__ void to_float(const vec_t x, float (&v)[4]) {
-        const h4 h = __builtin_bit_cast(h4, x);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (float)h[e];
-    }
-    static __device__ __forceinline__ void st(const __amdgpu_buffer_rsrc_t r, const int off, const float (&v)[4]) {
-        const h4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), r, off, 0, 0);
-    }
-};
-template <> struct fast_io<float> {
-    typedef u32x4 vec_t;
-    static __device__ __forceinline__ vec_t ld(const __amdgpu_buffer_rsrc_t r, const int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
-    static __device__ __forceinline__ void to_float(const vec_t x, float (&v)[4]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(x[e]);
-    }
-    static __device__ __forceinline__ void st(const __amdgpu_buffer_rsrc_t r, const int off, const float (&v)[4]) {
-        const u32x4 x = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-        __builtin_amdgcn_raw_buffer_store_b128(x, r, off, 0, 0);
-    }
-};
-
 template <int BN>
 __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, const int wg_y, const int wg_x, const int n_tiles) {
     constexpr int TJ = BN / 16;
@@ -250,7 +182,7 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
     // the operand combinations of the fp16-storage networks (bias, residual, ReLU, byte-mask gates, byte mask out, second gated
     // output) without a branch: absent tensors are zero-record buffer descriptors (loads give 0, stores are dropped), so that
     // the operand loads of four pixels per lane are in flight together; anything else: the shared store4_t
-    const bool fast = vec && p.gate == nullptr && p.gate2 == nullptr && (p.act == SPAA_ACT_NONE || p.act == SPAA_ACT_RELU) && (fits_32bit_offsets(p));
+    const bool fast = fast_epi_ok(p, vec);
 #define H16P_TO_LDS(hb)                                                                                            \
     _Pragma("unroll") for (int bb = 0; bb < 2; ++bb)                                                               \
     _Pragma("unroll") for (int j = 0; j < TJ; ++j)                                                                 \
@@ -278,36 +210,15 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
         if (oy < p.Hout) {                                                                                         \
             const int orow = (img * p.Hout + oy) * p.Wout + ox0;                                                   \
             _Pragma("unroll 1") for (int i0 = 0; i0 < 32 / PPI; i0 += 4) {                                         \
-                typename fast_io<T>::vec_t av[4];                                                                  \
-                unsigned int gb[4], g2[4];                                                                         \
+                fast_pre_t<T> pre[4];                                                                              \
                 _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
                     const int pr = (i0 + i) * PPI + lane / LPP;                                                    \
-                    const bool ok = n_ok && ox0 + pr < p.Wout;                                                     \
-                    const int o = orow + pr;                                                                       \
-                    av[i] = fast_io<T>::ld(fe.add, ok ? (o * p.add_cstride + p.add_coff + n) * (int)sizeof(T) : OOB);   \
-                    gb[i] = __builtin_amdgcn_raw_buffer_load_b8(fe.gbits, ok ? (o * p.gate_cstride + p.gate_coff + n) >> 2 : OOB, 0, 0);   \
-                    g2[i] = __builtin_amdgcn_raw_buffer_load_b8(fe.g2bits, ok ? (o * p.gate2_cstride + p.gate2_coff + n) >> 2 : OOB, 0, 0); \
+                    pre[i] = fast_epi_load<T>(fe, p, orow + pr, n, n_ok && ox0 + pr < p.Wout);                     \
                 }                                                                                                  \
                 _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
                     const int pr = (i0 + i) * PPI + lane / LPP;                                                    \
-                    const bool ok = n_ok && ox0 + pr < p.Wout;                                                     \
-                    const int oi = (orow + pr) * p.out_cstride + p.out_coff + n;                                   \
                     const f32x4 a = *reinterpret_cast<const f32x4*>(eb + pr * ROWB + ch * 4);                      \
-                    float v[4];                                                                                    \
-                    fast_io<T>::to_float(av[i], v);                                                                \
-                    const unsigned int g = fe.has_gate ? gb[i] : 15u;                                              \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                \
-                        v[e] += a[e] + fe.bias[e];                                                                 \
-                        v[e] = fe.relu ? fmaxf(v[e], 0.f) : v[e];                                                  \
-                        v[e] = ((g >> e) & 1u) ? v[e] : 0.f;                                                       \
-                        v[e] = (float)(T)v[e];                                                                     \
-                    }                                                                                              \
-                    fast_io<T>::st(fe.out, ok ? oi * (int)sizeof(T) : OOB, v);                                     \
-                    const unsigned char mb = (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u)); \
-                    __builtin_amdgcn_raw_buffer_store_b8(mb, fe.mask, ok ? oi >> 2 : OOB, 0, 0);                   \
-                    float u[4];                                                                                    \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e) u[e] = ((g2[i] >> e) & 1u) ? v[e] : 0.f;         \
-                    fast_io<T>::st(fe.aux, ok ? oi * (int)sizeof(T) : OOB, u);                                     \
+                    fast_epi_store<T>(fe, p, orow + pr, n, n_ok && ox0 + pr < p.Wout, a, pre[i]);                  \
                 }                                                                                                  \
             }                                                                                                      \
         }                                                                                                          \
@@ -316,7 +227,6 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
     if (fast) {
         const int n = n_blk + ch;
         const bool n_ok = n < p.Cout;
-        constexpr int OOB = (int)0x80000000;
         const fast_epi_t fe = make_fast_epi(p, n_ok ? n : 0);
         if (p.io_dtype & SPAA_IO_OUT_F16) {
             H16P_EPI_FAST(_Float16, 0) H16P_EPI_FAST(_Float16, 1)

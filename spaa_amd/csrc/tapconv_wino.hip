@@ -373,6 +373,47 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
     constexpr int ROWB = BN * 4;          // bytes of a pixel's BN channels in the LDS image
     constexpr int LPP = BN / 4;           // lanes (16-byte chunks) per pixel: 32 or 16
     constexpr int PPI = 64 / LPP;         // pixels per wave store instruction
+    if (fast_epi_ok(p, vec)) {
+        // The operand combinations of the attack loops, branch-free (epilogue.hpp: fast_epi_*): a wave's 32 x 2 pixels go
+        // through a PRIVATE LDS region (row = 16 (pixel column & 1) + tile column, padded by 16 bytes: conflict-free writes
+        // from the MFMA layout, a lane keeps ONE channel quad), so that one barrier after the main loop is all the
+        // synchronisation there is, and the residual / gate operands of eight pixels per lane are in flight together.
+        constexpr int ROWP = BN * 4 + 16;
+        const int n = n_blk + 4 * (lane & (LPP - 1));
+        const bool n_ok = n < p.Cout;
+        const fast_epi_t fe = make_fast_epi(p, n_ok ? n : 0);
+        wg_barrier<false>();
+        unsigned char* const eb = smem + wave * (32 * ROWP);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    *reinterpret_cast<f32x4*>(eb + (16 * c + tx) * ROWP + ((4 * j + q8) << 4)) = Y[2 * half + c][j];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int oy = oy0 + 2 * wave + half;
+            const int orow = (img * p.Hout + oy) * p.Wout + ox0;
+            constexpr int EB = 8;
+#pragma unroll 1
+            for (int it0 = 0; it0 < 32 / PPI; it0 += EB) {
+                fast_pre_t<float> pre[EB];
+#pragma unroll
+                for (int u = 0; u < EB; ++u) {
+                    const int r = (it0 + u) * PPI + lane / LPP, px = 2 * (r & 15) + (r >> 4);
+                    pre[u] = fast_epi_load<float>(fe, p, orow + px, n, n_ok && oy < p.Hout && ox0 + px < p.Wout);
+                }
+#pragma unroll
+                for (int u = 0; u < EB; ++u) {
+                    const int r = (it0 + u) * PPI + lane / LPP, px = 2 * (r & 15) + (r >> 4);
+                    const f32x4 y = *reinterpret_cast<const f32x4*>(eb + r * ROWP + ((lane & (LPP - 1)) << 4));
+                    fast_epi_store<float>(fe, p, orow + px, n, n_ok && oy < p.Hout && ox0 + px < p.Wout, y, pre[u]);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        return;
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         wg_barrier<(DBG & 64) != 0>();   // the main loop's (resp. the previous half's) LDS reads are done (raw: the stores stay in flight)
