@@ -211,7 +211,7 @@ __device__ __forceinline__ void store4_pre(const spaa_tapconv_t& p, const size_t
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct fast_epi_t {
-    __amdgpu_buffer_rsrc_t out, add, gbits, g2bits, mask, aux;
+    __amdgpu_buffer_rsrc_t out, add, gbits, g2bits, mask, aux, rbias;
     float bias[4];
     bool has_gate, relu;
 };
@@ -239,8 +239,8 @@ __device__ __forceinline__ fast_epi_t make_fast_epi(const spaa_tapconv_t& p, con
     f.gbits = rsrc_or_empty(p.gate_bits, npix * p.gate_cstride / 4);
     f.g2bits = rsrc_or_empty(p.gate2_bits, npix * p.gate2_cstride / 4);
     f.mask = rsrc_or_empty(p.mask_out, npix * p.out_cstride / 4);
-    const auto rb = rsrc_or_empty(p.bias, (int64_t)p.Cout * 4);
-    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rb, n * 4, 0, 0);
+    f.rbias = rsrc_or_empty(p.bias, (int64_t)p.Cout * 4);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(f.rbias, n * 4, 0, 0);
 #pragma unroll
     for (int e = 0; e < 4; ++e) f.bias[e] = __uint_as_float(b[e]);
     f.has_gate = p.gate_bits != nullptr;
@@ -277,25 +277,29 @@ template <> struct fast_io<float> {
 template <typename T>
 struct fast_pre_t {
     typename fast_io<T>::vec_t add;
+    u32x4 bias;            // (LOADB only)
     unsigned int gb, g2;
 };
 // eligibility (uniform): 4-channel vectors, no float gates, plain or ReLU activation, every operand below 2 GiB
 __device__ __forceinline__ bool fast_epi_ok(const spaa_tapconv_t& p, const bool vec) {
     return vec && p.gate == nullptr && p.gate2 == nullptr && (p.act == SPAA_ACT_NONE || p.act == SPAA_ACT_RELU) && fits_32bit_offsets(p);
 }
-// operands of output pixel o (index over B x Hout x Wout), channels n .. n + 3; ok = the pixel / channels exist
-template <typename T>
+// operands of output pixel o (index over B x Hout x Wout), channels n .. n + 3; ok = the pixel / channels exist.
+// LOADB: the lane's channels change from call to call (MFMA-layout epilogues): the bias is fetched per call instead of once
+// per lane (make_fast_epi)
+template <typename T, bool LOADB = false>
 __device__ __forceinline__ fast_pre_t<T> fast_epi_load(const fast_epi_t& fe, const spaa_tapconv_t& p, const int o, const int n, const bool ok) {
     constexpr int OOB = (int)0x80000000;
     fast_pre_t<T> r;
     r.add = fast_io<T>::ld(fe.add, ok ? (o * p.add_cstride + p.add_coff + n) * (int)sizeof(T) : OOB);
     r.gb = __builtin_amdgcn_raw_buffer_load_b8(fe.gbits, ok ? (o * p.gate_cstride + p.gate_coff + n) >> 2 : OOB, 0, 0);
     r.g2 = __builtin_amdgcn_raw_buffer_load_b8(fe.g2bits, ok ? (o * p.gate2_cstride + p.gate2_coff + n) >> 2 : OOB, 0, 0);
+    if constexpr (LOADB) r.bias = __builtin_amdgcn_raw_buffer_load_b128(fe.rbias, ok ? n * 4 : OOB, 0, 0);
     return r;
 }
 // store4_pre()'s arithmetic in its order: bias, residual, ReLU, gate, rounding to the storage type, out, mask of the STORED
 // value, second output gated by the second mask
-template <typename T, typename ACC>
+template <typename T, typename ACC, bool LOADB = false>
 __device__ __forceinline__ void fast_epi_store(const fast_epi_t& fe, const spaa_tapconv_t& p, const int o, const int n, const bool ok,
                                                const ACC& a, const fast_pre_t<T>& r) {
     constexpr int OOB = (int)0x80000000;
@@ -305,7 +309,7 @@ __device__ __forceinline__ void fast_epi_store(const fast_epi_t& fe, const spaa_
     const unsigned int g = fe.has_gate ? r.gb : 15u;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        v[e] = a[e] + fe.bias[e];
+        v[e] = a[e] + (LOADB ? __uint_as_float(r.bias[e]) : fe.bias[e]);
         v[e] += ad[e];
         v[e] = fe.relu ? fmaxf(v[e], 0.f) : v[e];
         v[e] = ((g >> e) & 1u) ? v[e] : 0.f;
@@ -339,6 +343,19 @@ __device__ __forceinline__ void store4_fold_t(const spaa_tapconv_t& p, const int
     const int oy = 2 * y + (c >> 1), ox = 2 * x + (c & 1);
     if (oy >= p.Hout || ox >= p.Wout) return;
     store4_t<T>(p, ((size_t)b * p.Hout + oy) * p.Wout + ox, n0 - c * p.Cout, v, vec);
+}
+
+// the same mapping for the branch-free epilogue: output pixel o and channel n of GEMM (row m, column quad n0); false when absent
+__device__ __forceinline__ bool fold_pixel(const spaa_tapconv_t& p, const int m, const int M, const int HWm, const int n0, int& o, int& n) {
+    const int c = n0 / p.Cout;
+    const int b = m / HWm;
+    const int rr = m - b * HWm;
+    const int y = rr / p.Wm;
+    const int x = rr - y * p.Wm;
+    const int oy = 2 * y + (c >> 1), ox = 2 * x + (c & 1);
+    o = (b * p.Hout + oy) * p.Wout + ox;
+    n = n0 - c * p.Cout;
+    return m < M && c < p.nfold && oy < p.Hout && ox < p.Wout;
 }
 
 // output pixel index of tile row m (class grid -> output grid); false when the pixel does not exist

@@ -124,6 +124,8 @@ __global__ __launch_bounds__(256) void smallcin_kernel(const spaa_tapconv_t p, c
 
     const int lx = lane & 31;
     const int slab_off = ((PH * PW * PIXB + 1023) / 1024) * 1024;
+    const bool fast = SLAB && fast_epi_ok(p, vec);
+    const fast_epi_t fe = make_fast_epi(p, 4 * (lane & 7) < p.Cout ? 4 * (lane & 7) : 0);
 #pragma unroll
     for (int r = 0; r < TH / 4; ++r) {
         const int ly = wave * (TH / 4) + r;
@@ -160,6 +162,26 @@ __global__ __launch_bounds__(256) void smallcin_kernel(const spaa_tapconv_t p, c
             *reinterpret_cast<f4*>(slab + lx * 36 + 8 * g + 4 * (lane >> 5)) = f4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
         // ... read back 8 lanes per pixel, 4 channels per lane
         const int y = y0 + ly;
+        if (fast) {   // branch-free operand accesses, the row's four pixel groups in flight (epilogue.hpp: fast_epi_*)
+#define SC_FAST(T)                                                                                                     \
+    {                                                                                                                  \
+        fast_pre_t<T> pre[4];                                                                                          \
+        size_t oo[4] = {0, 0, 0, 0};                                                                                   \
+        bool ok[4];                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+            const int x = x0 + 8 * i + (lane >> 3);                                                                    \
+            ok[i] = y < p.Hm && x < p.Wm && out_pixel(p, cl, (b * p.Hm + y) * p.Wm + x, M, HWm, oo[i]) && 4 * (lane & 7) < p.Cout; \
+            pre[i] = fast_epi_load<T>(fe, p, (int)oo[i], 4 * (lane & 7), ok[i]);                                       \
+        }                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+            const f4 t = *reinterpret_cast<const f4*>(slab + (8 * i + (lane >> 3)) * 36 + 4 * (lane & 7));             \
+            fast_epi_store<T>(fe, p, (int)oo[i], 4 * (lane & 7), ok[i], t, pre[i]);                                    \
+        }                                                                                                              \
+    }
+            if (p.io_dtype & SPAA_IO_OUT_F16) SC_FAST(_Float16) else SC_FAST(float)
+#undef SC_FAST
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int px = 8 * i + (lane >> 3), x = x0 + px;

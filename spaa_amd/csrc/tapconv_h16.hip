@@ -221,6 +221,41 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 1 : 2) void tapconv_h16_kernel(co
             }                                                                                                      \
         }                                                                                                          \
     }
+    if (fast_epi_ok(p, vec)) {   // branch-free operand accesses, a pixel's TJ channel quads in flight (epilogue.hpp: fast_epi_*)
+        const fast_epi_t fe = make_fast_epi(p, 0);
+#define H16_FAST_IB(T, ib)                                                                                         \
+    {                                                                                                              \
+        const int m = m_blk + 32 * wave + 16 * (ib) + (lane & 15);                                                 \
+        size_t o1 = 0;                                                                                             \
+        const bool ok1 = p.nfold > 1 ? false : out_pixel(p, cl, m, M, HWm, o1);                                    \
+        constexpr int CH = TJ < 8 ? TJ : 8;                                                                        \
+        _Pragma("unroll") for (int j0 = 0; j0 < TJ; j0 += CH) {                                                    \
+            fast_pre_t<T> pre[CH];                                                                                 \
+            int oo[CH], nn[CH];                                                                                    \
+            bool ok[CH];                                                                                           \
+            _Pragma("unroll") for (int j = 0; j < CH; ++j) {                                                       \
+                const int n0 = n_blk + 16 * (j0 + j) + 4 * (lane >> 4);                                            \
+                if (p.nfold > 1) {                                                                                 \
+                    ok[j] = fold_pixel(p, m, M, HWm, n0, oo[j], nn[j]);                                            \
+                } else {                                                                                           \
+                    oo[j] = (int)o1, nn[j] = n0, ok[j] = ok1 && n0 < p.Cout;                                       \
+                }                                                                                                  \
+                pre[j] = fast_epi_load<T, true>(fe, p, oo[j], nn[j], ok[j]);                                       \
+            }                                                                                                      \
+            _Pragma("unroll") for (int j = 0; j < CH; ++j)                                                         \
+                fast_epi_store<T, f32x4, true>(fe, p, oo[j], nn[j], ok[j], acc[ib][j0 + j], pre[j]);               \
+        }                                                                                                          \
+    }
+        if (p.io_dtype & SPAA_IO_OUT_F16) {
+            H16_FAST_IB(_Float16, 0)
+            H16_FAST_IB(_Float16, 1)
+        } else {
+            H16_FAST_IB(float, 0)
+            H16_FAST_IB(float, 1)
+        }
+#undef H16_FAST_IB
+        return;
+    }
     if (p.io_dtype & SPAA_IO_OUT_F16) {  // fp16 activation / gradient out
         H16_EPI_IB(_Float16, 0)
         H16_EPI_IB(_Float16, 1)

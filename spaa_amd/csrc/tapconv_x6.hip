@@ -480,6 +480,36 @@ __global__ __launch_bounds__(256, 2) void tapconv_x6v2_kernel(const spaa_tapconv
                      (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
                      (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
                      (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
+    if (fast_epi_ok(p, vec)) {   // branch-free operand accesses, a pixel's four channel quads in flight (epilogue.hpp: fast_epi_*)
+        const fast_epi_t fe = make_fast_epi(p, 0);
+#define V2_FAST(T)                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                                       \
+        size_t o = 0;                                                                                                      \
+        const bool okp = out_pixel(p, cl, m_blk + wm0 + 32 * i + (lane & 31), M, HWm, o);                                  \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                                   \
+            fast_pre_t<T> pre[4];                                                                                          \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                \
+                const int n0 = n_blk + wn0 + 32 * j + 8 * g + 4 * (lane >> 5);                                             \
+                pre[g] = fast_epi_load<T, true>(fe, p, (int)o, n0, okp && n0 < p.Cout);                                    \
+            }                                                                                                              \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                \
+                const int n0 = n_blk + wn0 + 32 * j + 8 * g + 4 * (lane >> 5);                                             \
+                float v[4];                                                                                                \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                            \
+                    const int r = 4 * g + e;                                                                               \
+                    float t = acc[0][i][j][r];                                                                             \
+                    if (NG == 2) t += acc[NG > 1 ? 1 : 0][i][j][r];                                                        \
+                    if (NG == 3) t += acc[NG > 1 ? 1 : 0][i][j][r] + acc[NG > 2 ? 2 : 0][i][j][r];                         \
+                    v[e] = t;                                                                                              \
+                }                                                                                                          \
+                fast_epi_store<T, float[4], true>(fe, p, (int)o, n0, okp && n0 < p.Cout, v, pre[g]);                       \
+            }                                                                                                              \
+        }                                                                                                                  \
+    }
+        if (p.io_dtype & SPAA_IO_OUT_F16) V2_FAST(_Float16) else V2_FAST(float)
+#undef V2_FAST
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m_blk + wm0 + 32 * i + (lane & 31);
@@ -740,6 +770,36 @@ __global__ __launch_bounds__(256, 2) void tapconv_x6v3_kernel(const spaa_tapconv
                      (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
                      (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
                      (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
+    if (fast_epi_ok(p, vec)) {   // branch-free operand accesses, a pixel's four channel quads in flight (epilogue.hpp: fast_epi_*)
+        const fast_epi_t fe = make_fast_epi(p, 0);
+#define V2_FAST(T)                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                                       \
+        size_t o = 0;                                                                                                      \
+        const bool okp = out_pixel(p, cl, m_blk + wm0 + 32 * i + (lane & 31), M, HWm, o);                                  \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                                   \
+            fast_pre_t<T> pre[4];                                                                                          \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                \
+                const int n0 = n_blk + wn0 + 32 * j + 8 * g + 4 * (lane >> 5);                                             \
+                pre[g] = fast_epi_load<T, true>(fe, p, (int)o, n0, okp && n0 < p.Cout);                                    \
+            }                                                                                                              \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                \
+                const int n0 = n_blk + wn0 + 32 * j + 8 * g + 4 * (lane >> 5);                                             \
+                float v[4];                                                                                                \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                            \
+                    const int r = 4 * g + e;                                                                               \
+                    float t = acc[0][i][j][r];                                                                             \
+                    if (NG == 2) t += acc[NG > 1 ? 1 : 0][i][j][r];                                                        \
+                    if (NG == 3) t += acc[NG > 1 ? 1 : 0][i][j][r] + acc[NG > 2 ? 2 : 0][i][j][r];                         \
+                    v[e] = t;                                                                                              \
+                }                                                                                                          \
+                fast_epi_store<T, float[4], true>(fe, p, (int)o, n0, okp && n0 < p.Cout, v, pre[g]);                       \
+            }                                                                                                              \
+        }                                                                                                                  \
+    }
+        if (p.io_dtype & SPAA_IO_OUT_F16) V2_FAST(_Float16) else V2_FAST(float)
+#undef V2_FAST
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m_blk + wm0 + 32 * i + (lane & 31);

@@ -547,6 +547,47 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
                                 (p.Wm == p.Wout);
             int m = m_blk_e + 32 * wave + lane / LPR;
             int pb = m / HWm, py = (m - pb * HWm) / p.Wm, px = m - pb * HWm - py * p.Wm;
+            if (fast_epi_ok(p, vec)) {   // branch-free operand accesses, several rows in flight per lane (epilogue.hpp: fast_epi_*)
+                const int n_e = n0 - cfold * p.Cout;
+                const bool n_ok = cfold < (p.nfold > 1 ? p.nfold : 1) && n_e < p.Cout;
+                const fast_epi_t fe = make_fast_epi(p, n_ok ? n_e : 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                constexpr int NP = 32 / RPI, EB = NP < 8 ? NP : 8;
+#pragma unroll 1
+                for (int i0 = 0; i0 < NP; i0 += EB) {
+                    fast_pre_t<float> pre[EB];
+                    int oo[EB];
+                    bool ok[EB];
+#pragma unroll
+                    for (int u = 0; u < EB; ++u) {
+                        int oy, ox;
+                        if (p.nfold > 1) {
+                            oy = 2 * py + (cfold >> 1), ox = 2 * px + (cfold & 1);
+                        } else {
+                            oy = cl.oy0 + py * p.s_out, ox = cl.ox0 + px * p.s_out;
+                        }
+                        ok[u] = m < M && n_ok && oy < p.Hout && ox < p.Wout;
+                        oo[u] = (pb * p.Hout + oy) * p.Wout + ox;
+                        pre[u] = fast_epi_load<float>(fe, p, oo[u], n_e, ok[u]);
+                        m += RPI;
+                        px += RPI;
+                        while (px >= p.Wm) {
+                            px -= p.Wm;
+                            py += 1;
+                        }
+                        while (py >= p.Hm) {
+                            py -= p.Hm;
+                            pb += 1;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < EB; ++u) {
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(slab + ((i0 + u) * RPI + lane / LPR) * PITCH + 4 * (lane % LPR));
+                        fast_epi_store<float>(fe, p, oo[u], n_e, ok[u], t, pre[u]);
+                    }
+                }
+                break;
+            }
 #pragma unroll
             for (int i = 0; i < 32 / RPI; ++i) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(slab + (i * RPI + lane / LPR) * PITCH + 4 * (lane % LPR));
@@ -615,6 +656,38 @@ __global__ __launch_bounds__(64 * NW, 2) void tapconv_x6d_kernel(const spaa_tapc
             }
     } else {
         // D layout of a 16x16 tile: column (lane & 15) = pixel, rows 4*(lane>>4) + i = 4 consecutive output channels
+        if (fast_epi_ok(p, vec)) {   // branch-free operand accesses, a pixel's TJ channel quads in flight (epilogue.hpp: fast_epi_*)
+            const fast_epi_t fe = make_fast_epi(p, 0);
+            size_t o[2] = {0, 0};
+            bool okp[2];
+            fast_pre_t<float> pre[2][TJ];
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) okp[ib] = out_pixel(p, cl, m_blk_e + 32 * wave + 16 * ib + (lane & 15), M, HWm, o[ib]);
+            // narrow tiles: both pixel blocks' operands in flight; wide ones: one block at a time (registers)
+#pragma unroll
+            for (int ib = 0; ib < (TJ <= 4 ? 2 : 1); ++ib)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const int n = n_blk_e + 16 * j + 4 * (lane >> 4);
+                    pre[ib][j] = fast_epi_load<float, true>(fe, p, (int)o[ib], n, okp[ib] && n < p.Cout);
+                }
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                if (TJ > 4 && ib == 1) {
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) {
+                        const int n = n_blk_e + 16 * j + 4 * (lane >> 4);
+                        pre[1][j] = fast_epi_load<float, true>(fe, p, (int)o[1], n, okp[1] && n < p.Cout);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const int n = n_blk_e + 16 * j + 4 * (lane >> 4);
+                    fast_epi_store<float, f32x4, true>(fe, p, (int)o[ib], n, okp[ib] && n < p.Cout, acc16[ib][j], pre[ib][j]);
+                }
+            }
+            break;
+        }
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
             size_t o;
