@@ -1924,10 +1924,10 @@ def test_training_loss_and_gradient(hip):
                      1.0 if 'ssim' in opt else 0.0, lib.ptr(ws[0]), lib.ptr(ws[1]), lib.ptr(ws[2]), lib.ptr(part), lib.ptr(ws[3]), b, h, w)
             s = part.sum(dim=0).cpu() / (3.0 * b * h * w)
             val = float(s[1]) + ((1 - float(s[0])) if 'ssim' in opt else 0.0)
-            assert abs(val - float(loss)) < 1e-5 * max(1.0, abs(float(loss))) and abs(float(s[2]) - float(l2)) < 1e-6
+            assert abs(val - float(loss.detach())) < 1e-5 * max(1.0, abs(float(loss.detach()))) and abs(float(s[2]) - float(l2)) < 1e-6
             assert rel_inf(M.to_nchw(ws[3]), yc.grad) < 1e-4, (b, h, w, opt)
             got, _ = tn.compute_loss(y.to(DEV), t, opt)
-            assert abs(float(got) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+            assert abs(float(got) - float(loss.detach())) < 1e-5 * max(1.0, abs(float(loss.detach())))
 
 
 def test_pcnet_training_step(hip):
