@@ -140,13 +140,13 @@ def cpu_baseline(sd, csd, setup, scenes, budget_b=16, iters=8):
 def pmc_traffic(tile):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py), or None."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
-    path = next((os.path.join(prof, f) for f in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+    path = next((os.path.join(prof, f) for f in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
                  if os.path.exists(os.path.join(prof, f))), None)
     if path is None:
         return None, None
     m = re.match(r'(x6d(?:16)?(?:co)?(?:a3)?|x6v\d|x6)_(\d+)x(\d+)(?:g(\d))?', tile)
     if tile.startswith('wino'):
-        want = 'wino_x6_kernel<64, 2>' if tile.endswith('x64') else 'wino_x6_kernel<128, 3>'   # (template arguments: N tile, kernel variant)
+        want = 'wino_x6_kernel<64, 2' if tile.endswith('x64') else 'wino_x6_kernel<128, 3'   # (template arguments: N tile, kernel variant)
     elif not m:
         return None, None
     else:
