@@ -35,6 +35,9 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               53: 'x6d16p_128x32', 54: 'x6dp_128x128',
               60: 'h16_128x128', 61: 'h16_128x64', 62: 'h16_128x32', 63: 'h16_128x16', 64: 'h16_256x128', 65: 'h16_256x256', 68: 'h16p_16x32x128',
               70: 'wino_x6_16x32x128', 71: 'wino_x6_16x32x64'}   # (71: reporting only: tile 70 run by its 64-wide instantiation)
+X6D_TILES = set(range(25, 28)) | set(range(30, 38)) | set(range(39, 47)) | set(range(48, 55))   # DMA-staged bf16x6 kernels (csrc/tapconv_x6d.hip)
+X6D_PERSISTENT = set(range(48, 55))      # ... of which the persistent ones (stream-K capable)
+H16_TILES = set(range(60, 66))           # fp16 implicit-GEMM kernels (csrc/tapconv_h16.hip); 68 = patch-staged 3x3 (tapconv_h16p.hip)
 STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 66)) | {68, 70}  # shared epilogue (epilogue.hpp)
 F16OUT_TILES = set(range(15, 25)) | {38} | set(range(60, 66))  # ... of which these may write fp16 (fp32 image in, fp16 activation out)
 DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
@@ -255,7 +258,7 @@ class ConvPlan:
             forced = 0
         if forced in (28, 29, 47) and (self.cout > 4 or self.s_in != 1 or self.cin_p % (32 if forced == 28 else 16)):
             forced = 0
-        if (25 <= forced <= 27 or 30 <= forced <= 37 or (39 <= forced <= 46 or 48 <= forced <= 54)) and (self.cin_p % 32 or any(c['Kpad'] != c['K'] for c in self.cls)):
+        if forced in X6D_TILES and (self.cin_p % 32 or any(c['Kpad'] != c['K'] for c in self.cls)):
             forced = 0
         tile = forced if forced else tuned_tile(key)
         if tile < 0:
@@ -270,7 +273,7 @@ class ConvPlan:
             patch_ok = (len(self.cls) == 1 and self.ntaps_total == 9 and self.s_in == 1 and self.s_out == 1 and self.nfold == 1
                         and (hin, win) == (hout, wout) and self.tap_range[0] >= -1 and self.tap_range[1] <= 1
                         and self.tap_range[2] >= -1 and self.tap_range[3] <= 1)
-            if 60 <= forced <= 65 or (forced == 68 and patch_ok):
+            if forced in H16_TILES or (forced == 68 and patch_ok):
                 tile = forced
             elif (not out_f16 and self.cout <= 4 and self.nfold == 1 and self.s_in == 1 and self.cin_p % 32 == 0 and not masked_any(mask_out, gate_bits, gate2_bits)
                   and forced in (0, 29) and 'thin' not in DEFAULT_DISABLE):
@@ -295,11 +298,11 @@ class ConvPlan:
         ksplit, tile = (tile // 100, tile % 100) if tile >= 100 else (1, tile)
         if self.nfold > 1:  # only the DMA-staged kernels know the folded epilogue
             ksplit = 1
-            if not (25 <= tile <= 27 or 30 <= tile <= 37 or (39 <= tile <= 46 or 48 <= tile <= 54) or 60 <= tile <= 65):
+            if not (tile in X6D_TILES or tile in H16_TILES):
                 tile = 34
             d.nfold = self.nfold
         if ksplit == 9:  # stream-K (persistent x6d tiles, one class): workspace shared by all plans (one stream)
-            if len(self.cls) != 1 or self.nfold > 1 or not (48 <= tile <= 54) or self.cin_p % 32:
+            if len(self.cls) != 1 or self.nfold > 1 or tile not in X6D_PERSISTENT or self.cin_p % 32:
                 ksplit, tile = 1, (0 if forced else tile)
             else:
                 d.splitk_ws, d.ksplit = _streamk_workspace(inp.device).data_ptr(), -1
@@ -308,7 +311,7 @@ class ConvPlan:
             ksplit = 1
         if ksplit > 1:
             nk = self.cls[0]['Kpad'] // BK
-            if len(self.cls) != 1 or nk < 2 * ksplit or not (25 <= tile <= 27 or 30 <= tile <= 37 or (39 <= tile <= 46 or 48 <= tile <= 54)) or self.cin_p % 32:
+            if len(self.cls) != 1 or nk < 2 * ksplit or tile not in X6D_TILES or self.cin_p % 32:
                 ksplit, tile = 1, (0 if forced else tile)
         if ksplit > 1:
             need = ksplit * b * d.Hm * d.Wm * ((self.cout + 127) // 128 * 128)

@@ -148,13 +148,15 @@ NEAR_ZERO = 1.3e-6   # 3 x the largest seen (4.2e-7 of the layer's largest activ
 VALUE_TOL = 1.3e-5   # 3 x 4.1e-6
 
 
-def count_flips(pairs, near_zero=NEAR_ZERO, value_tol=VALUE_TOL):
+def count_flips(pairs, near_zero=NEAR_ZERO, value_tol=VALUE_TOL, measured=None):
     """Per-sample number of gates on which HIP and oracle disagree.  Asserts (a) the activations themselves agree to
     `value_tol` relative L-inf per layer, (b) every disagreeing ReLU/clamp unit is within `near_zero` x layer scale of the
     gate's threshold on both sides, (c) every disagreeing max-pool arg-max is a tie: the two candidate inputs are within
     `near_zero` x layer scale of each other on both sides (and a disagreeing "maximum > 0" bit is a maximum within
-    `near_zero` of zero).  Returns (flips [B] int tensor, {layer: count})."""
+    `near_zero` of zero).  Returns (flips [B] int tensor, {layer: count}).  `measured`: where the largest quantities seen are
+    recorded (default: the module's MEASURED, the fp32 record the tolerances above are derived from)."""
     flips, per_layer = None, {}
+    MEASURED = measured if measured is not None else globals()['MEASURED']   # (fp16-storage runs keep their own record)
     for name, kind, hip, orc in pairs:
         h = hip.detach().cpu()
         assert h.shape == orc.shape, (name, h.shape, orc.shape)
