@@ -37,8 +37,11 @@ __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rsrc, unsigne
 // chunk swizzle of a 64-byte row (4 chunks): see tapconv_x6d.hip swz_w<16>
 __device__ __forceinline__ int swz64(int r) { return ((r >> 3) & 1) << 1; }
 
-template <int NW, int BN>
-__global__ __launch_bounds__(64 * NW, NW > 4 ? 1 : 2) void tapconv_h16_kernel(const spaa_tapconv_t p, const int m_tiles, const int n_tiles) {
+// NS = LDS stages.  2: the DMA of step t + 1 lands during step t's MFMAs -- enough when two workgroups per CU (or a long
+// MFMA phase) cover the load latency.  4: the small-M layers (ResNet layer3 / layer4 at batch 64: fewer workgroups than CUs,
+// one wave per SIMD, 16 MFMAs per step against ~1 us of load latency) keep three steps in flight behind a counted vmcnt.
+template <int NW, int BN, int NS = 2>
+__global__ __launch_bounds__(64 * NW, (NW > 4 || NS > 2) ? 1 : 2) void tapconv_h16_kernel(const spaa_tapconv_t p, const int m_tiles, const int n_tiles) {
     constexpr int BM = 32 * NW;
     constexpr int TJ = BN / 16;
     constexpr int A_SUB = BM * 64;               // one sub-step's pixel rows
@@ -173,14 +176,29 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 1 : 2) void tapconv_h16_kernel(co
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[ib][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (nk > 0) H16_STAGE(0, 0)
+    constexpr int DPS = 4 + WPW;   // DMAs a wave issues per K-step (NS > 2: W_PIECES % NW == 0, every wave issues all of them)
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i)
+        if (i < nk) H16_STAGE(i, i)
+    int cur = 0;
     for (int ks = 0; ks < nk; ++ks) {
         // own DMAs of step ks have landed (vmcnt) and everybody's have (barrier); every wave is also past its reads of
-        // the other stage, which is refilled during this step
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int cur = ks & 1;
-        if (ks + 1 < nk) H16_STAGE(ks + 1, cur ^ 1)
+        // the stage that is refilled during this step (read at step ks - 1)
+        if constexpr (NS == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
+            if (ks + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS * (NS - 2)) : "memory");
+            else if (NS > 3 && ks + NS - 3 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS * (NS > 3 ? NS - 3 : 0)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        if (ks + NS - 1 < nk) {
+            const int nxt = cur == 0 ? NS - 1 : cur - 1;
+            H16_STAGE(ks + NS - 1, nxt)
+        }
         const unsigned char* sb = smem + cur * STAGE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -195,6 +213,7 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 1 : 2) void tapconv_h16_kernel(co
                 acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, pf1, acc[1][j], 0, 0, 0);
             }
         }
+        cur = cur == NS - 1 ? 0 : cur + 1;
     }
 #undef H16_STAGE
 
@@ -266,7 +285,7 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 1 : 2) void tapconv_h16_kernel(co
 #undef H16_EPI_IB
 }
 
-template <int NW, int BN>
+template <int NW, int BN, int NS = 2>
 int launch_h16(const spaa_tapconv_t& d, hipStream_t stream) {
     constexpr int BM = 32 * NW;
     const int64_t M = (int64_t)d.B * d.Hm * d.Wm;
@@ -274,14 +293,21 @@ int launch_h16(const spaa_tapconv_t& d, hipStream_t stream) {
     const int nfold = d.nfold > 1 ? d.nfold : 1;
     if (nfold > 1 && (nfold != 4 || d.nclass != 1 || d.s_out != 2 || (d.Cout & 3))) return hipErrorInvalidValue;
     const int n_tiles = (d.Cout * nfold + BN - 1) / BN;
-    const size_t smem = 2 * (size_t)(2 * BM * 64 + 2 * BN * 64);
+    // at most one workgroup per compute unit and a long K loop (ResNet layer4 at batch 64: 64 -> 61 us): the four-stage
+    // instantiation; with more workgroups than CUs two resident two-stage workgroups do better (layer3: 42 against 66 us)
+    if constexpr (NS == 2 && NW == 4 && BN >= 32 && BN <= 128) {
+        int64_t kmin = 1 << 30;
+        for (int c = 0; c < d.nclass; ++c) kmin = d.cls[c].K < kmin ? d.cls[c].K : kmin;
+        if ((int64_t)m_tiles * n_tiles * d.nclass <= 256 && kmin >= 16 * 64 && !((d.reserved0 >> 25) & 1)) return launch_h16<NW, BN, 4>(d, stream);
+    }
+    const size_t smem = NS * (size_t)(2 * BM * 64 + 2 * BN * 64);
     static bool attr_set[SPAA_MAX_DEVICES] = {};
     {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&tapconv_h16_kernel<NW, BN>), (int)smem, attr_set);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&tapconv_h16_kernel<NW, BN, NS>), (int)smem, attr_set);
         if (e != hipSuccess) return (int)e;
     }
     dim3 grid(m_tiles * n_tiles, d.nclass, 1);
-    hipLaunchKernelGGL((tapconv_h16_kernel<NW, BN>), grid, dim3(64 * NW), smem, stream, d, m_tiles, n_tiles);
+    hipLaunchKernelGGL((tapconv_h16_kernel<NW, BN, NS>), grid, dim3(64 * NW), smem, stream, d, m_tiles, n_tiles);
     return (int)hipGetLastError();
 }
 
