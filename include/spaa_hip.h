@@ -98,12 +98,13 @@ typedef struct {
                              a kernel-2 stride-2 ConvTranspose2d share their single tap, so they are folded into the GEMM N
                              dimension: weight rows [nfold*Cout], row c*Cout + n -> output pixel (2y + c/2, 2x + c%2),
                              channel n.  The input is read once instead of once per class. */
-    int32_t reserved0;
+    int32_t reserved0;    /* measurement switches (A/B runs of kernel variants: spaa_amd/convplan.py DEBUG_*); 0 in production */
     int32_t io_dtype;     /* fp16-STORAGE mode (BASELINE.json configs[4]: "fp16 with fp32 dE2000"), bit flags:
-                             SPAA_IO_IN_F16  (tiles 60..65; tile 29 with an fp32 output of at most 4 channels: the image-side input
+                             SPAA_IO_IN_F16  (tiles 60..65; tile 68: 3x3 / stride-1 layers with the input patch staged once in LDS;
+                                             tile 29 with an fp32 output of at most 4 channels: the image-side input
                                              gradients): `in` is fp16 NHWC (strides / offsets still in elements) and the
                                              weights come from `w_half`; fp32 accumulation on v_mfma_f32_16x16x32_f16;
-                             SPAA_IO_OUT_F16 (tiles 60..65, and the kernels that read fp32 IMAGES: 15..24, 38):
+                             SPAA_IO_OUT_F16 (tiles 60..65, 68, and the kernels that read fp32 IMAGES: 15..24, 38):
                                              `out`, `add`, `gate`, `aux_out`, `gate2` are fp16.
                              0 = everything fp32 (the default path; dtype "f32" in bench.py). */
     int32_t reserved1;
