@@ -587,13 +587,14 @@ def main():
         default_run = world == 1 and args.classifier == 'resnet18' and args.dtype == 'f32' and args.attack == 'spaa'
         if default_run and not args.no_modes:
             # the other configurations of BASELINE.json, each timed like the headline after it (never part of `value`)
-            log('extra modes: f16 storage, Inception-v3, VGG-16 + PerC-AL in f16 storage')
+            log('extra modes: f16 storage, Inception-v3 (f32, f16 storage), VGG-16 + PerC-AL in f16 storage')
             del st
             torch.cuda.empty_cache()
             out['configs0_gpu'] = configs0_gpu(sd, csd, setup, scenes, dev)
             out['modes'] = {
                 'configs[1] in f16 storage (resnet18, SPAA loop)': time_mode(dev, args, 'resnet18', 'f16', 'spaa'),
                 'configs[2] (inception_v3 at 299x299, SPAA loop, f32)': time_mode(dev, args, 'inception_v3', 'f32', 'spaa'),
+                'configs[2] in f16 storage (inception_v3 at 299x299, SPAA loop)': time_mode(dev, args, 'inception_v3', 'f16', 'spaa'),
                 'configs[4] per GPU (vgg16, PerC-AL loop body, f16 storage)': time_mode(dev, args, 'vgg16', 'f16', 'perc_al'),
             }
         json_out.write(json.dumps(out) + '\n')

@@ -294,6 +294,11 @@ int spaa_avgpool2d_fwd(const float* in, float* out, int B, int Hin, int Win, int
                        int p, int out_cstride, int out_coff, spaa_stream_t stream);
 int spaa_avgpool2d_bwd(const float* g_out, float* g_in, int B, int Hin, int Win, int C, int Hout, int Wout, int k,
                        int s, int p, int gout_cstride, int gout_coff, spaa_stream_t stream);
+/* fp16-storage variants (fp32 accumulation, one rounding on the way out): Inception-v3's 3x3 / stride-1 branch pools */
+int spaa_avgpool2d_fwd_f16(const void* in, void* out, int B, int Hin, int Win, int C, int Hout, int Wout, int k, int s,
+                           int p, int out_cstride, int out_coff, spaa_stream_t stream);
+int spaa_avgpool2d_bwd_f16(const void* g_out, void* g_in, int B, int Hin, int Win, int C, int Hout, int Wout, int k,
+                           int s, int p, int gout_cstride, int gout_coff, spaa_stream_t stream);
 /* adaptive_avg_pool2d((Hout, Wout)) */
 int spaa_adaptive_avgpool_fwd(const float* in, float* out, int B, int Hin, int Win, int C, int Hout, int Wout,
                               spaa_stream_t stream);

@@ -95,6 +95,8 @@ _SIGNATURES = {
     'spaa_avgpool_bwd_f16': [_p, _p, _p, _i, _i, _i, _p],
     'spaa_avgpool2d_fwd': [_p, _p] + [_i] * 11 + [_p],
     'spaa_avgpool2d_bwd': [_p, _p] + [_i] * 11 + [_p],
+    'spaa_avgpool2d_fwd_f16': [_p, _p] + [_i] * 11 + [_p],
+    'spaa_avgpool2d_bwd_f16': [_p, _p] + [_i] * 11 + [_p],
     'spaa_adaptive_avgpool_fwd': [_p, _p] + [_i] * 6 + [_p],
     'spaa_adaptive_avgpool_bwd': [_p, _p, _p] + [_i] * 6 + [_p],
     'spaa_avgpool_fwd': [_p, _p, _i, _i, _i, _p],

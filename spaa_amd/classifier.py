@@ -309,10 +309,8 @@ class VGG16Body:
 
 
 def _inception_body(sd, batch, in_hw, dev, storage='f32'):
-    if storage != 'f32':
-        raise NotImplementedError('fp16-storage mode covers ResNet-18 and VGG-16 (BASELINE.json configs[4]); Inception-v3 runs in fp32')
     from .inception import InceptionV3Body
-    return InceptionV3Body(sd, batch, in_hw, dev)
+    return InceptionV3Body(sd, batch, in_hw, dev, storage)
 
 
 BODIES = {'resnet18': ResNet18Body, 'vgg16': VGG16Body, 'inception_v3': _inception_body}

@@ -91,8 +91,8 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ g_out, const uchar4* __
 }
 
 // avg_pool2d(k, s, p), count_include_pad=True (divisor k*k), optional output channel window of a concat buffer
-__global__ void avgpool_fwd_kernel(const float4* __restrict__ in, float4* __restrict__ out, Geo g, int out_c4stride,
-                                   int out_c4off) {
+template <typename T>
+__global__ void avgpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out, Geo g, int out_c4stride, int out_c4off) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= g.B * g.Hout * g.Wout * g.C4) return;
     const int c = idx % g.C4;
@@ -108,17 +108,17 @@ __global__ void avgpool_fwd_kernel(const float4* __restrict__ in, float4* __rest
         for (int kx = 0; kx < g.k; ++kx) {
             const int ix = ox * g.s - g.p + kx;
             if ((unsigned)ix >= (unsigned)g.Win) continue;
-            const float4 v = in[(((size_t)b * g.Hin + iy) * g.Win + ix) * g.C4 + c];
+            const f4 v = io4<T>::ld(in, 4 * ((((size_t)b * g.Hin + iy) * g.Win + ix) * g.C4 + c));
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
     }
     const float d = (float)(g.k * g.k);
-    out[(((size_t)b * g.Hout + oy) * g.Wout + ox) * out_c4stride + out_c4off + c] =
-        make_float4(a.x / d, a.y / d, a.z / d, a.w / d);
+    io4<T>::st(out, 4 * ((((size_t)b * g.Hout + oy) * g.Wout + ox) * out_c4stride + out_c4off + c),
+               f4{a.x / d, a.y / d, a.z / d, a.w / d});
 }
 
-__global__ void avgpool_bwd_kernel(const float4* __restrict__ g_out, float4* __restrict__ g_in, Geo g,
-                                   int gout_c4stride, int gout_c4off) {
+template <typename T>
+__global__ void avgpool_bwd_kernel(const T* __restrict__ g_out, T* __restrict__ g_in, Geo g, int gout_c4stride, int gout_c4off) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= g.B * g.Hin * g.Win * g.C4) return;
     const int c = idx % g.C4;
@@ -138,12 +138,12 @@ __global__ void avgpool_bwd_kernel(const float4* __restrict__ g_out, float4* __r
             if (u < 0 || (u % g.s)) continue;
             const int ox = u / g.s;
             if (ox >= g.Wout) continue;
-            const float4 go = g_out[(((size_t)b * g.Hout + oy) * g.Wout + ox) * gout_c4stride + gout_c4off + c];
+            const f4 go = io4<T>::ld(g_out, 4 * ((((size_t)b * g.Hout + oy) * g.Wout + ox) * gout_c4stride + gout_c4off + c));
             acc.x += go.x; acc.y += go.y; acc.z += go.z; acc.w += go.w;
         }
     }
     const float d = (float)(g.k * g.k);
-    g_in[idx] = make_float4(acc.x / d, acc.y / d, acc.z / d, acc.w / d);
+    io4<T>::st(g_in, 4 * (size_t)idx, f4{acc.x / d, acc.y / d, acc.z / d, acc.w / d});
 }
 
 // adaptive_avg_pool2d to (Hout, Wout) with ATen's window rule
@@ -268,8 +268,19 @@ int spaa_avgpool2d_fwd(const float* in, float* out, int B, int Hin, int Win, int
         out_coff + C > out_cstride)
         return hipErrorInvalidValue;
     Geo g{B, Hin, Win, C / 4, Hout, Wout, k, s, p};
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(nb((int64_t)B * Hout * Wout * g.C4)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)in, (float4*)out, g, out_cstride / 4, out_coff / 4);
+    hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(nb((int64_t)B * Hout * Wout * g.C4)), dim3(256), 0, (hipStream_t)stream,
+                       in, out, g, out_cstride / 4, out_coff / 4);
+    return (int)hipGetLastError();
+}
+
+int spaa_avgpool2d_fwd_f16(const void* in, void* out, int B, int Hin, int Win, int C, int Hout, int Wout, int k, int s,
+                           int p, int out_cstride, int out_coff, spaa_stream_t stream) {
+    if (!in || !out || !geo_ok(B, Hin, Win, C, Hout, Wout, k, s, p) || (out_cstride & 3) || (out_coff & 3) ||
+        out_coff + C > out_cstride)
+        return hipErrorInvalidValue;
+    Geo g{B, Hin, Win, C / 4, Hout, Wout, k, s, p};
+    hipLaunchKernelGGL(avgpool_fwd_kernel<_Float16>, dim3(nb((int64_t)B * Hout * Wout * g.C4)), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)in, (_Float16*)out, g, out_cstride / 4, out_coff / 4);
     return (int)hipGetLastError();
 }
 
@@ -279,8 +290,19 @@ int spaa_avgpool2d_bwd(const float* g_out, float* g_in, int B, int Hin, int Win,
         gout_coff + C > gout_cstride)
         return hipErrorInvalidValue;
     Geo g{B, Hin, Win, C / 4, Hout, Wout, k, s, p};
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(nb((int64_t)B * Hin * Win * g.C4)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)g_out, (float4*)g_in, g, gout_cstride / 4, gout_coff / 4);
+    hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(nb((int64_t)B * Hin * Win * g.C4)), dim3(256), 0, (hipStream_t)stream,
+                       g_out, g_in, g, gout_cstride / 4, gout_coff / 4);
+    return (int)hipGetLastError();
+}
+
+int spaa_avgpool2d_bwd_f16(const void* g_out, void* g_in, int B, int Hin, int Win, int C, int Hout, int Wout, int k,
+                           int s, int p, int gout_cstride, int gout_coff, spaa_stream_t stream) {
+    if (!g_out || !g_in || !geo_ok(B, Hin, Win, C, Hout, Wout, k, s, p) || (gout_cstride & 3) || (gout_coff & 3) ||
+        gout_coff + C > gout_cstride)
+        return hipErrorInvalidValue;
+    Geo g{B, Hin, Win, C / 4, Hout, Wout, k, s, p};
+    hipLaunchKernelGGL(avgpool_bwd_kernel<_Float16>, dim3(nb((int64_t)B * Hin * Win * g.C4)), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)g_out, (_Float16*)g_in, g, gout_cstride / 4, gout_coff / 4);
     return (int)hipGetLastError();
 }
 

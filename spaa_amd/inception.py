@@ -5,6 +5,11 @@ The reference builds it with `models.inception_v3(init_weights=False, transform_
 (/root/reference/src/python/classifier.py:29-33).  The architecture is third-party (torchvision==0.15.1); it is
 restated here from its published definition.  BasicConv2d = conv(bias=False) + BatchNorm(eps=1e-3) + ReLU, with the
 BatchNorm folded into the convolution; concatenations are channel windows of one NHWC buffer (no copy).
+
+fp16-STORAGE mode (`storage='f16'`: activations and their gradients fp16 in HBM, fp32 accumulation; image, pooled features
+and logits fp32): the fp16 matrix-core kernels take 32-channel slices, so the two layers whose width is not a multiple of 32
+(`Conv2d_3b_1x1`: 80, `Mixed_5x.branch5x5_1`: 48) are built 96 / 64 wide with ZERO weights and biases in the extra channels
+(their activations and gradients are exactly 0; the consumer's weights for them are zero too).
 """
 import torch
 
@@ -79,22 +84,27 @@ def _osz(n, k, s, p):
 
 
 class InceptionV3Body:
-    def __init__(self, sd, batch, in_hw, dev):
+    def __init__(self, sd, batch, in_hw, dev, storage='f32'):
         from .classifier import _strip
         sd = _strip(sd)
-        self.B, self.dev, self.sd = batch, dev, sd
+        self.B, self.dev, self.sd, self.storage = batch, dev, sd, storage
+        self.h16 = storage == 'f16'
+        hd = torch.float16 if self.h16 else torch.float32
         self.ops = []
         h, w = in_hw
         self.in_hw = (h, w)
 
-        def z(*shape):
+        def zf(*shape):
             return torch.zeros(*shape, device=dev)
+
+        def z(*shape):
+            return torch.zeros(*shape, device=dev, dtype=hd)
 
         self.z = z
         # transform_input=True (torchvision): per-channel affine on the already-normalised image, folded into the
         # first convolution:  x' = a_c * x + b_c  =>  W' = W * a_c, bias' += sum_taps W * b_c  -- valid only where no
         # zero padding is involved: Conv2d_1a has padding 0, so the folding is exact.
-        self.x_in = Ten(z(batch, h, w, 4), 0, 3, z(batch, h, w, 4), kind='input')
+        self.x_in = Ten(zf(batch, h, w, 4), 0, 3, zf(batch, h, w, 4), kind='input')
         t = self.x_in
         first = True
         for item in STEM:
@@ -109,12 +119,12 @@ class InceptionV3Body:
         self.feat = t
         fh, fw = t.hw
         self.feat_hw = fh * fw
-        self.pooled = z(batch, 1, 1, 2048)
-        self.g_pooled = z(batch, 1, 1, 2048)
+        self.pooled = zf(batch, 1, 1, 2048)
+        self.g_pooled = zf(batch, 1, 1, 2048)
         self.ncls = sd['fc.weight'].shape[0]
         self.fc_f = cp.linear_fwd_plan(sd['fc.weight'], sd['fc.bias'], dev, 'fc')
         self.fc_d = cp.linear_dgrad_plan(sd['fc.weight'], dev, 'fc_dgrad')
-        self.logits = z(batch, 1, 1, self.ncls)
+        self.logits = zf(batch, 1, 1, self.ncls)
 
     # ---- graph construction ------------------------------------------------------------------------------------
     def folded(self, name, fold_input_affine=False):
@@ -132,10 +142,19 @@ class InceptionV3Body:
     def add_conv(self, name, inp, cout, k, stride, pad, out=None, fold_input_affine=False):
         hin, win = inp.hw
         ho, wo = _osz(hin, k[0], stride, pad[0]), _osz(win, k[1], stride, pad[1])
+        wgt, b = self.folded(name, fold_input_affine)
+        if self.h16:   # 32-channel slices: zero-padded widths (see the module docstring)
+            cout_p = cout if out is not None else -(-cout // 32) * 32
+            cin_p = inp.c if inp.kind != 'input' else wgt.shape[1]
+            if cout_p != cout or cin_p != wgt.shape[1]:
+                wp = torch.zeros(cout_p, cin_p, *wgt.shape[2:], dtype=wgt.dtype)
+                wp[:cout, :wgt.shape[1]] = wgt
+                bp = torch.zeros(cout_p, dtype=b.dtype)
+                bp[:cout] = b
+                wgt, b, cout = wp, bp, cout_p
         if out is None:
             out = Ten(self.z(self.B, ho, wo, cout), 0, cout, self.z(self.B, ho, wo, cout))
         assert out.hw == (ho, wo) and out.c == cout
-        wgt, b = self.folded(name, fold_input_affine)
         op = dict(kind='conv', name=name, inp=inp, out=out,
                   f=cp.conv_fwd_plan(wgt, b, stride, pad, self.dev, name),
                   d=cp.conv_dgrad_plan(wgt, stride, pad, self.dev, name + '_dgrad'))
@@ -221,14 +240,15 @@ class InceptionV3Body:
             elif op['kind'] == 'max':
                 hin, win = i.hw
                 ho, wo = o.hw
-                _lib.call('spaa_maxpool_fwd', _lib.ptr(i.buf), _lib.ptr(o.buf), _lib.ptr(op['arg']), B, hin, win, i.c, ho,
-                          wo, op['k'], op['s'], op['p'], o.buf.shape[3], o.coff)
+                _lib.call('spaa_maxpool_fwd_f16' if self.h16 else 'spaa_maxpool_fwd', _lib.hptr(i.buf), _lib.hptr(o.buf),
+                          _lib.ptr(op['arg']), B, hin, win, i.c, ho, wo, op['k'], op['s'], op['p'], o.buf.shape[3], o.coff)
             else:
                 hin, win = i.hw
                 ho, wo = o.hw
-                _lib.call('spaa_avgpool2d_fwd', _lib.ptr(i.buf), _lib.ptr(o.buf), B, hin, win, i.c, ho, wo, op['k'],
-                          op['s'], op['p'], o.buf.shape[3], o.coff)
-        _lib.call('spaa_avgpool_fwd', _lib.ptr(self.feat.buf), _lib.ptr(self.pooled), B, self.feat_hw, 2048)
+                _lib.call('spaa_avgpool2d_fwd_f16' if self.h16 else 'spaa_avgpool2d_fwd', _lib.hptr(i.buf), _lib.hptr(o.buf), B,
+                          hin, win, i.c, ho, wo, op['k'], op['s'], op['p'], o.buf.shape[3], o.coff)
+        _lib.call('spaa_avgpool_fwd_f16' if self.h16 else 'spaa_avgpool_fwd', _lib.hptr(self.feat.buf), _lib.ptr(self.pooled), B,
+                  self.feat_hw, 2048)
         self.fc_f.run(self.pooled, self.logits)
         return self.logits.view(B, self.ncls)
 
@@ -236,8 +256,8 @@ class InceptionV3Body:
         B = self.B
         self.fc_d.run(g_logits.view(B, 1, 1, self.ncls), self.g_pooled)
         # gradient w.r.t. the pre-activations of the last concat (all four slices are ReLU outputs)
-        _lib.call('spaa_avgpool_bwd', _lib.ptr(self.g_pooled), _lib.ptr(self.feat.buf), _lib.ptr(self.feat.gbuf), B,
-                  self.feat_hw, 2048)
+        _lib.call('spaa_avgpool_bwd_f16' if self.h16 else 'spaa_avgpool_bwd', _lib.ptr(self.g_pooled), _lib.hptr(self.feat.buf),
+                  _lib.hptr(self.feat.gbuf), B, self.feat_hw, 2048)
         written = set()
         for op in reversed(self.ops):
             i, o = op['inp'], op['out']
@@ -253,13 +273,13 @@ class InceptionV3Body:
                 hin, win = i.hw
                 ho, wo = o.hw
                 if op['kind'] == 'max':
-                    _lib.call('spaa_maxpool_bwd', _lib.ptr(o.gbuf), _lib.ptr(op['arg']),
-                              int(gate is not None), _lib.ptr(i.gbuf), B, hin, win, i.c, ho, wo,
+                    _lib.call('spaa_maxpool_bwd_f16' if self.h16 else 'spaa_maxpool_bwd', _lib.hptr(o.gbuf), _lib.ptr(op['arg']),
+                              int(gate is not None), _lib.hptr(i.gbuf), B, hin, win, i.c, ho, wo,
                               op['k'], op['s'], op['p'], o.gbuf.shape[3], o.coff)
                 else:
                     assert gate is None, 'avg-pool is never the only consumer in Inception-v3'
-                    _lib.call('spaa_avgpool2d_bwd', _lib.ptr(o.gbuf), _lib.ptr(i.gbuf), B, hin, win, i.c, ho, wo, op['k'],
-                              op['s'], op['p'], o.gbuf.shape[3], o.coff)
+                    _lib.call('spaa_avgpool2d_bwd_f16' if self.h16 else 'spaa_avgpool2d_bwd', _lib.hptr(o.gbuf), _lib.hptr(i.gbuf), B,
+                              hin, win, i.c, ho, wo, op['k'], op['s'], op['p'], o.gbuf.shape[3], o.coff)
             written.add(key)
         return self.x_in.gbuf
 

@@ -99,23 +99,34 @@ def vgg16_pairs(body, cacts):
     return out
 
 
+class _Recorded(list):
+    """ReLU outputs in call order; `.pools` = the (input, kernel, stride, padding) of every F.max_pool2d call."""
+    pools = None
+
+
 class record_relu:
-    """Context manager: every F.relu output produced inside (the oracle's forward) is collected in call order."""
+    """Context manager: every F.relu output produced inside (the oracle's forward) is collected in call order, and the
+    input and geometry of every F.max_pool2d call (for the arg-max gates)."""
 
     def __enter__(self):
         import torch.nn.functional as F
-        self.F, self.orig, self.outs = F, F.relu, []
+        self.F, self.orig, self.orig_mp, self.outs = F, F.relu, F.max_pool2d, _Recorded()
+        self.outs.pools = []
 
         def relu(t, *a, **k):
             o = self.orig(t, *a, **k)
             self.outs.append(o.detach())
             return o
 
-        F.relu = relu
+        def max_pool2d(t, kernel_size, stride=None, padding=0, *a, **k):
+            self.outs.pools.append((t.detach(), kernel_size, stride if stride is not None else kernel_size, padding))
+            return self.orig_mp(t, kernel_size, stride, padding, *a, **k)
+
+        F.relu, F.max_pool2d = relu, max_pool2d
         return self.outs
 
     def __exit__(self, *exc):
-        self.F.relu = self.orig
+        self.F.relu, self.F.max_pool2d = self.orig, self.orig_mp
         return False
 
 
@@ -123,20 +134,38 @@ def inception_pairs(body, relu_outs):
     """Inception-v3: the HIP body's 94 convolutions (every one followed by a ReLU) are matched with the oracle's recorded
     ReLU outputs by shape and value (call orders differ inside the mixed blocks)."""
     out, used = [], set()
+    h16 = getattr(body, 'h16', False)     # fp16 storage: matching to fp16 accuracy; two layers carry zero pad channels
     for n, op in enumerate(o for o in body.ops if o['kind'] == 'conv'):
         t = op['out']
         hip = t.buf[..., t.coff:t.coff + t.c]
         h = hip.detach().float().cpu()
         best = None
         for i, r in enumerate(relu_outs):
-            if i in used or r.ndim != 4 or (r.shape[0], r.shape[2], r.shape[3], r.shape[1]) != tuple(h.shape):
+            if i in used or r.ndim != 4 or (r.shape[0], r.shape[2], r.shape[3]) != tuple(h.shape[:3]):
                 continue
-            e = float((r.permute(0, 2, 3, 1) - h).abs().max()) / (float(r.abs().max()) + 1e-30)
+            if r.shape[1] != h.shape[3] and not (h16 and r.shape[1] < h.shape[3] and -(-r.shape[1] // 32) * 32 == h.shape[3]):
+                continue
+            e = float((r.permute(0, 2, 3, 1) - h[..., :r.shape[1]]).abs().max()) / (float(r.abs().max()) + 1e-30)
             if best is None or e < best[1]:
                 best = (i, e)
-        assert best is not None and best[1] < 1e-3, (n, op.get('name'), best)
+        assert best is not None and best[1] < (2e-2 if h16 else 1e-3), (n, op.get('name'), best)
         used.add(best[0])
-        out.append((f'inception.{op.get("name", n)}', 'relu', hip, _nhwc(relu_outs[best[0]])))
+        c = relu_outs[best[0]].shape[1]
+        assert c == h.shape[3] or float(h[..., c:].abs().max()) == 0.0      # (pad channels are exactly zero)
+        out.append((f'inception.{op.get("name", n)}', 'relu', hip[..., :c], _nhwc(relu_outs[best[0]])))
+    # the max-pools (stem x 2, Mixed_6a, Mixed_7a), in call order on both sides
+    import torch.nn.functional as F
+    pools = getattr(relu_outs, 'pools', None) or []
+    mops = [o for o in body.ops if o['kind'] == 'max']
+    assert len(pools) in (0, len(mops)), (len(pools), len(mops))
+    for n, (op, (inp, k, st, pd)) in enumerate(zip(mops, pools)):
+        pooled, idx = F.max_pool2d(inp, k, st, pd, return_indices=True)
+        i, o = op['inp'], op['out']
+        c = inp.shape[1]
+        # the pooled tensor itself gates the layers that consume it (its sign: maximum > 0)
+        out.append((f'inception.maxpool{n}.out', 'relu', o.buf[..., o.coff:o.coff + c], _nhwc(pooled)))
+        out.append((f'inception.maxpool{n}', 'argmax', op['arg'][..., :c] if op['arg'].shape[3] != c else op['arg'],
+                    ArgmaxRef(_argmax_codes(idx, inp, inp.shape[2:], k, st, pd), i.buf[..., :c], _nhwc(inp), k, st, pd)))
     return out
 
 
