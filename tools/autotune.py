@@ -74,13 +74,16 @@ def main():
         total_best += avg[best] * n
         rows.append((avg[best] * n, key, sorted(names[key])[:3], best, {t: round(a * 1e3) for t, a in avg.items()}))
     for r in sorted(rows, reverse=True)[:40]:
-        print(f'{r[0]*1e3:8.0f} us/iter  {r[1]:32s} best={r[3]} {r[4]} {r[2]}')
+        top = dict(sorted(r[4].items(), key=lambda kv: kv[1])[:6])
+        print(f'{r[0]*1e3:8.0f} us/iter  {r[1]:32s} best={r[3]} was={convplan.TUNE.get(r[1])} {top} {r[2]}')
     print(f'sum of best per-launch times: {total_best:.2f} ms/iteration')
     out = os.path.join(ROOT, 'gpurun_out', os.environ.get('SPAA_TUNE_OUT', 'tapconv_tune.json'))
     os.makedirs(os.path.dirname(out), exist_ok=True)
     if classifier != 'resnet18' or shape or batch != 64:  # keep the measured choices of the other workloads; add this one's new shapes
         merged = dict(convplan.TUNE)
-        merged.update({k: v for k, v in tune.items() if k not in merged})
+        # SPAA_TUNE_UPDATE=1: re-measured shapes replace their entries (after a kernel change); default: only new shapes are added
+        upd = os.environ.get('SPAA_TUNE_UPDATE', '0') == '1'
+        merged.update({k: v for k, v in tune.items() if upd or k not in merged})
         tune = merged
     with open(out, 'w') as fh:
         json.dump(tune, fh, indent=0, sort_keys=True)
