@@ -71,7 +71,7 @@ typedef struct {
     const float* gate;    /* indexed like `out`, or NULL */
     int32_t gate_cstride, gate_coff, gate_mode;
     int32_t act;
-    int32_t tile;         /* 0 = auto; 1..54 = explicit kernel / workgroup tile (the dispatcher in tapconv.hip lists them;
+    int32_t tile;         /* 0 = auto; 1..54, 60..65, 68, 70, 72 = explicit kernel / workgroup tile (the dispatcher in tapconv.hip lists them;
                              spaa_amd/convplan.py: TILE_NAMES; chosen per layer shape by tools/autotune.py) */
     float* aux_out;       /* optional second output (indexed like `out`):
                              act == SPAA_ACT_RELU_CLAMP1: the value BEFORE the clamp;
@@ -101,6 +101,7 @@ typedef struct {
     int32_t reserved0;    /* measurement switches (A/B runs of kernel variants: spaa_amd/convplan.py DEBUG_*); 0 in production */
     int32_t io_dtype;     /* fp16-STORAGE mode (BASELINE.json configs[4]: "fp16 with fp32 dE2000"), bit flags:
                              SPAA_IO_IN_F16  (tiles 60..65; tile 68: 3x3 / stride-1 layers with the input patch staged once in LDS;
+                                             tile 72: thin outputs with the parity classes folded into N, fp32 out;
                                              tile 29 with an fp32 output of at most 4 channels: the image-side input
                                              gradients): `in` is fp16 NHWC (strides / offsets still in elements) and the
                                              weights come from `w_half`; fp32 accumulation on v_mfma_f32_16x16x32_f16;

@@ -33,7 +33,7 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               42: 'x6d16a3_128x64', 43: 'x6d16a3_128x32', 44: 'x6da3_128x64', 45: 'x6d16coa3_128x64', 46: 'x6d16coa3_128x32', 47: 'thinpatch16x2',
               48: 'x6d16p_128x128', 49: 'x6d16p_128x64', 50: 'x6d16a3p_128x64', 51: 'x6da3p_128x64', 52: 'x6d16p_256x128',
               53: 'x6d16p_128x32', 54: 'x6dp_128x128',
-              60: 'h16_128x128', 61: 'h16_128x64', 62: 'h16_128x32', 63: 'h16_128x16', 64: 'h16_256x128', 65: 'h16_256x256', 68: 'h16p_16x32x128',
+              60: 'h16_128x128', 61: 'h16_128x64', 62: 'h16_128x32', 63: 'h16_128x16', 64: 'h16_256x128', 65: 'h16_256x256', 68: 'h16p_16x32x128', 72: 'thinmf_12x32',
               70: 'wino_x6_16x32x128', 71: 'wino_x6_16x32x64'}   # (71: reporting only: tile 70 run by its 64-wide instantiation)
 X6D_TILES = set(range(25, 28)) | set(range(30, 38)) | set(range(39, 47)) | set(range(48, 55))   # DMA-staged bf16x6 kernels (csrc/tapconv_x6d.hip)
 X6D_PERSISTENT = set(range(48, 55))      # ... of which the persistent ones (stream-K capable)
@@ -176,6 +176,49 @@ class ConvPlan:
         self.wino = None    # the same layer in Winograd F(2x2,3x3) form (attach_winograd), run as tile 70
         self.fixed_tile = 0
         self.alg_taps = self.ntaps_total
+        self._thin = {}     # folded weight layouts of the thin-output matrix-core kernel (thin_fold), packed on first use
+
+    def thin_ok(self):
+        """Thin output on the matrix cores (csrc/tapconv_thinmf.hip, tile 72): at most 4 output channels, stride-1 input sampling,
+        the S x S output-parity classes in row-major order, a tap box of at most 4 x 4."""
+        s = self.s_out
+        if not (self.cout <= 4 and self.cin_p % 32 == 0 and self.s_in == 1 and self.nfold == 1 and s in (1, 2) and len(self.cls) == s * s):
+            return False
+        if any((c['oy0'], c['ox0']) != (i // s, i % s) for i, c in enumerate(self.cls)):
+            return False
+        dy0, dy1, dx0, dx1 = self.tap_range
+        return dy1 - dy0 + 1 <= 4 and dx1 - dx0 + 1 <= 4
+
+    def thin_fold(self, half):
+        """The weights in the folded layout of the thin-output matrix-core kernel: GEMM rows = class * 4 + channel (16 rows; rows of
+        taps a class does not have, of absent channels and classes: zero), [channel block][tap column][plane][tap row][16][32
+        channels], 16-byte chunks of a 64-byte row swapped in pairs for rows 8-15 (conflict-free fragment reads: swz64).  Planes:
+        fp16 (`half`) or three bf16 with w == h + m + l exactly."""
+        key = 'h' if half else 's'
+        if key not in self._thin:
+            s, dev = self.s_out, self.weights.device
+            dy0, dy1, dx0, dx1 = self.tap_range
+            tbh, tbw, nkb = max(dy1 - dy0 + 1, 2), dx1 - dx0 + 1, self.cin_p // 32
+            wf = torch.zeros(16, tbh, tbw, self.cin_p, device=dev)
+            for i, (c, spec) in enumerate(zip(self.cls, self.classes_host)):
+                wp = self.weights[c['w_off']:c['w_off'] + self._npad * c['Kpad']].view(self._npad, c['Kpad'])
+                for t, (dy, dx, _w) in enumerate(spec.taps):
+                    wf[4 * i:4 * i + self.cout, dy - dy0, dx - dx0] = wp[:self.cout, t * self.cin_p:(t + 1) * self.cin_p]
+            w = wf.view(16, tbh, tbw, nkb, 4, 8).permute(3, 2, 1, 0, 4, 5).contiguous()   # [kb][dxi][dyi][row][chunk][8]
+            sw = w.clone()
+            sw[..., 8:, 0, :], sw[..., 8:, 2, :] = w[..., 8:, 2, :], w[..., 8:, 0, :]
+            sw[..., 8:, 1, :], sw[..., 8:, 3, :] = w[..., 8:, 3, :], w[..., 8:, 1, :]
+            sw = sw.reshape(nkb, tbw, tbh, 16, 32)
+            if half:
+                planes = sw.half().unsqueeze(2).view(torch.int16)
+            else:
+                h = sw.to(torch.bfloat16)
+                r1 = sw - h.float()
+                m = r1.to(torch.bfloat16)
+                lo = (r1 - m.float()).to(torch.bfloat16)
+                planes = torch.stack([h, m, lo], dim=2).view(torch.int16)               # [kb][dxi][plane][dyi][16][32]
+            self._thin[key] = planes.contiguous().reshape(-1)
+        return self._thin[key]
 
     def half_plane(self):
         """The weights rounded to fp16, per class [Npad][K rounded up to 64] (zero padded), classes back to back: the
@@ -264,6 +307,14 @@ class ConvPlan:
         tile = forced if forced else tuned_tile(key)
         if tile < 0:
             tile = self._default_tile(b * d.Hm * d.Wm)
+        thin_mf = (forced in (0, 72) and 'thinmf' not in DEFAULT_DISABLE and not out_f16 and not masked and self.thin_ok())
+        if thin_mf and not in_f16:
+            # fp32 input (bf16x6: the 3-way operand split costs as much as the products): only where the VALU kernel is far from its
+            # bound -- four classes and a long K (ResNet stem 7 x 7: 253 against 325 us; conv1 3 x 3: 70 against 61; VGG-16's
+            # stride-1 first layer fills 4 of 16 rows: 498 against 270; tools/lab/thin_time.py).  fp16 input: always (57 against 307 us).
+            box = (self.tap_range[1] - self.tap_range[0] + 1) * (self.tap_range[3] - self.tap_range[2] + 1)
+            if forced == 72 or (self.s_out == 2 and box * self.cin_p >= 512):
+                tile = 72   # thin output: the parity classes folded into the N dimension of a matrix-core tile (csrc/tapconv_thinmf.hip)
         if tile == 70:   # Winograd form of a 3x3 / stride-1 layer (csrc/tapconv_wino.hip): fp32 storage, same-size output
             if self.wino is not None and WINOGRAD and not (in_f16 or out_f16) and (hin, win) == (hout, wout):
                 return self.wino.run(inp, out, add, gate, gate_mode, act, aux_out, gate2, in_coff, out_coff, add_coff, gate_coff,
@@ -276,6 +327,8 @@ class ConvPlan:
                         and self.tap_range[2] >= -1 and self.tap_range[3] <= 1)
             if forced in H16_TILES or (forced == 68 and patch_ok):
                 tile = forced
+            elif thin_mf:
+                tile = 72
             elif (not out_f16 and self.cout <= 4 and self.nfold == 1 and self.s_in == 1 and self.cin_p % 32 == 0 and not masked_any(mask_out, gate_bits, gate2_bits)
                   and forced in (0, 29) and 'thin' not in DEFAULT_DISABLE):
                 tile = 29   # thin fp32 output from an fp16 activation (image-side input gradients): the patch-staged VALU kernel
@@ -332,6 +385,11 @@ class ConvPlan:
                 raise ValueError(f'{self.name}: gate masks need a layer shape served by the bf16x6 / smallcin kernels')
         if self.fixed_tile:
             tile, d.ksplit, d.splitk_ws = self.fixed_tile, 0, None
+        if tile == 72:
+            if in_f16:
+                d.w_half = self.thin_fold(True).data_ptr()
+            else:
+                d.w_split = self.thin_fold(False).data_ptr()
         d.tile = self.last_tile = tile     # (last_tile: for tests and reports)
         d.reserved0 = DEBUG_TAPMAJOR | (DEBUG_PERSIST_CAP << 8) | (DEBUG_WINO << 16) | (DEBUG_H16_2STAGE << 25)  # measurement / test switches of the x6d kernels
         d.nclass = len(self.cls)
@@ -415,6 +473,7 @@ class ConvPlan:
                 parts.append(torch.stack([h, m, lo]).view(torch.int16).reshape(-1))
             self.w_split.copy_(torch.cat(parts))
         self.w_half = None
+        self._thin = {}
         if self.wino is not None:
             _winograd_weights(self, self.wino)
         if bias is not None:

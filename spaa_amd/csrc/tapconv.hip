@@ -22,6 +22,7 @@ int spaa_launch_tapconv_x6(const spaa_tapconv_t& d, int tile, hipStream_t stream
 int spaa_launch_tapconv_x6d(const spaa_tapconv_t& d, int tile, hipStream_t stream);  // tapconv_x6d.hip
 int spaa_launch_tapconv_h16(const spaa_tapconv_t& d, int tile, hipStream_t stream);  // tapconv_h16.hip
 int spaa_launch_tapconv_h16p(const spaa_tapconv_t& d, hipStream_t stream);           // tapconv_h16p.hip
+int spaa_launch_tapconv_thinmf(const spaa_tapconv_t& d, hipStream_t stream);         // tapconv_thinmf.hip
 int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream);          // tapconv_wino.hip
 int spaa_launch_thinpatch(const spaa_tapconv_t& d, hipStream_t stream);               // thinpatch.hip
 int spaa_launch_smallcin(const spaa_tapconv_t& d, hipStream_t stream);                // smallcin.hip
@@ -579,7 +580,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         if ((int64_t)((d.Cout + 127) & ~127) * d.cls[c].Kpad * 4 >= (int64_t)1 << 31) return hipErrorInvalidValue;
     int tile = d.tile;
     // fp16-storage mode: fp16 inputs only through the h16 kernels; fp16 outputs only through the shared epilogue
-    if ((d.io_dtype & SPAA_IO_IN_F16) && !((tile >= 60 && tile <= 65) || tile == 68 || (tile == 29 && !(d.io_dtype & SPAA_IO_OUT_F16)))) return hipErrorInvalidValue;
+    if ((d.io_dtype & SPAA_IO_IN_F16) && !((tile >= 60 && tile <= 65) || tile == 68 || ((tile == 29 || tile == 72) && !(d.io_dtype & SPAA_IO_OUT_F16)))) return hipErrorInvalidValue;
     if (!(d.io_dtype & SPAA_IO_IN_F16) && tile >= 60 && tile <= 63) return hipErrorInvalidValue;
     if ((d.io_dtype & SPAA_IO_OUT_F16) && !((tile >= 15 && tile <= 24) || tile == 38 || (tile >= 60 && tile <= 65) || tile == 68))
         return hipErrorInvalidValue;
@@ -656,6 +657,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         case 65: return spaa_launch_tapconv_h16(d, tile, stream);
         case 68: return spaa_launch_tapconv_h16p(d, stream);
         case 70: return spaa_launch_tapconv_wino(d, stream);
+        case 72: return spaa_launch_tapconv_thinmf(d, stream);
         default: return hipErrorInvalidValue;
     }
 }

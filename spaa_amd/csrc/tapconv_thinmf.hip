@@ -1,0 +1,300 @@
+// tapconv_thinmf.hip — THIN outputs (Cout <= 4: the image-side input gradients of conv1 / conv1_s and of the classifiers' first
+// layers) on the matrix cores, with the output-parity classes folded into the GEMM's N dimension.
+//
+// The VALU kernel (thinpatch.hip) spends one 16-byte LDS read per six packed FMAs and is LDS-bandwidth bound: the ResNet stem's
+// input gradient (64 -> 3, 7 x 7 / stride 2: 15.1 GFLOP) takes 354 us at 43 TFLOP/s.  A matrix-core tile is 16 wide and a thin
+// layer has 3 outputs -- but a stride-2 layer's input gradient has FOUR output-parity classes that read the same input
+// neighbourhood: with N = 4 classes x 4 channels = 16 rows (weight rows of taps a class does not have are zero) one MFMA tile
+// produces the 2 x 2 output pixels of a class-grid position.  Stem: K = 16 taps x 64 channels, 77 % of the products are real.
+//   * workgroup = 8 waves = 12 rows x 32 columns of the class grid; wave = 3 rows x 16 columns;
+//   * the input patch ((12 + TBH - 1) x (32 + TBW - 1) pixels of a 32-channel block; TBH x TBW <= 4 x 4 = the tap box) is staged
+//     once by LDS-DMA (out-of-image = out-of-range offset = zeros), double-buffered over the channel blocks;
+//   * K order: channel block, then tap COLUMN dx: a wave reads the 3 + TBH - 1 pixel-row fragments of that column once (fp32: two
+//     16-byte reads and one exact 3-way bf16 split each) and uses each for up to TBH taps x 3 rows; the column's weights (TBH taps x
+//     16 rows x 32 channels, 1 KiB per plane and tap, chunk swizzle baked in by the host) are LDS-DMA'd one step ahead;
+//   * fp32 input: bf16x6 arithmetic (exact operands, six MFMAs per product: tapconv_x6d.hip); fp16 input (fp16-STORAGE mode): fp16
+//     weights, one MFMA per product; fp32 accumulation and fp32 output either way;
+//   * epilogue: a lane holds the 4 channels of ONE output pixel (class = lane >> 4): a 16-byte store, 512 contiguous bytes per
+//     output row and wave; residual and multiplicative gate (the two forms the PCNet engine uses) branch-free, anything else through
+//     the shared store4_t.
+#include <hip/hip_runtime.h>
+#include "launch_util.hpp"
+#include <stdint.h>
+#include "../../include/spaa_hip.h"
+#include "epilogue.hpp"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rsrc, unsigned char* dst, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)dst, 16, voff, soff, 0, 0);
+}
+
+__device__ __forceinline__ unsigned int cvt2(float a, float b) {
+    f2 v = {a, b};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float lo_f(unsigned int p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float hi_f(unsigned int p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+// 8 fp32 -> three bf16x8 with x == h + m + l exactly (tapconv_x6d.hip: split8)
+__device__ __forceinline__ void split8(const f32x4 x0, const f32x4 x1, bf16x8& h, bf16x8& m, bf16x8& l) {
+    const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    u4 hh, mm, ll;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned int ph = cvt2(x[2 * i], x[2 * i + 1]);
+        const float r0 = x[2 * i] - lo_f(ph), r1 = x[2 * i + 1] - hi_f(ph);
+        const unsigned int pm = cvt2(r0, r1);
+        const float s0 = r0 - lo_f(pm), s1 = r1 - hi_f(pm);
+        hh[i] = ph;
+        mm[i] = pm;
+        ll[i] = cvt2(s0, s1);
+    }
+    h = __builtin_bit_cast(bf16x8, hh);
+    m = __builtin_bit_cast(bf16x8, mm);
+    l = __builtin_bit_cast(bf16x8, ll);
+}
+
+constexpr int TR = 12, TW = 32, RW = 3;   // class-grid rows x columns of a workgroup; rows of a wave
+constexpr int NW = 8;
+
+// HIN: fp16 input (one weight plane, one MFMA per product); TBH: rows of the tap box (2..4)
+template <bool HIN, int TBH>
+__global__ __launch_bounds__(512, 1) void thinmf_kernel(const spaa_tapconv_t p, const int tiles_y, const int tiles_x, const int TBW,
+                                                        const int npieces) {
+    constexpr int PB = HIN ? 64 : 128;     // bytes of a staged pixel (32 channels)
+    constexpr int CPP = PB / 16;           // 16-byte chunks per pixel
+    constexpr int PPP = 1024 / PB;         // pixels per 1-KiB piece
+    constexpr int NPL = HIN ? 1 : 3;       // weight planes
+    constexpr int WST = NPL * TBH;         // 1-KiB weight pieces per step (one tap column of one channel block)
+    constexpr int NB = RW + TBH - 1;       // pixel-row fragments a wave reads per step
+    constexpr int PPWMAX = HIN ? 5 : 9;    // patch pieces per wave at most (15 x 35 pixels)
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wrow = wave >> 1, pb = wave & 1;
+    const int S = p.s_out;
+    const int dy0 = p.tap_range[0], dx0 = p.tap_range[2];
+    const int PW = TW + TBW - 1;
+    const int NPX = (TR + TBH - 1) * PW;
+    const int pbuf = npieces * 1024;                       // bytes of a patch buffer
+    unsigned char* const wsm = smem + 2 * pbuf;            // two weight stages of WST KiB
+
+    int img, y0, x0;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+        x0 = (t % tiles_x) * TW;
+        t /= tiles_x;
+        y0 = (t % tiles_y) * TR;
+        img = t / tiles_y;
+    }
+    const int EB = HIN ? 2 : 4;
+    const int row_bytes = p.in_cstride * EB;
+    const uint64_t in_addr = reinterpret_cast<uint64_t>(p.in);
+    const uint32_t in_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)in_addr);
+    const uint32_t in_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(in_addr >> 32));
+    const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((uint64_t)in_hi << 32) | in_lo), 0,
+        (int)__builtin_amdgcn_readfirstlane((uint32_t)p.B * (uint32_t)(p.Hin * p.Win) * (uint32_t)row_bytes), 0x00020000);
+    const int nkb = p.Cin >> 5;
+    const int nsteps = nkb * TBW;
+    const void* wptr = HIN ? p.w_half : (const void*)p.w_split;
+    const uint64_t w_addr = reinterpret_cast<uint64_t>(wptr);
+    const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)w_addr);
+    const uint32_t w_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(w_addr >> 32));
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)w_hi << 32) | w_lo), 0,
+                                                           (int)__builtin_amdgcn_readfirstlane((uint32_t)(nsteps * WST * 1024)), 0x00020000);
+
+    // ---- patch staging: piece i of this wave = piece wave + 8 i = PPP consecutive patch pixels; lane -> (pixel, physical chunk)
+    int pvoff[PPWMAX];
+#pragma unroll
+    for (int i = 0; i < PPWMAX; ++i) {
+        const int q = (wave + NW * i) * PPP + lane / CPP;   // patch pixel
+        const int pr = q / PW, pc = q - pr * PW;
+        const int iy = y0 + dy0 + pr, ix = x0 + dx0 + pc;
+        const bool ok = q < NPX && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+        const int c = (lane % CPP) ^ (HIN ? (q >> 2) & 3 : (q >> 1) & 7);   // logical chunk held at this lane's slot
+        pvoff[i] = ok ? ((img * p.Hin + iy) * p.Win + ix) * row_bytes + p.in_coff * EB + c * 16 : (int)0x80000000;
+    }
+    auto dma_patch = [&](const int buf, const int kb, const int share, const int nshare) {
+#pragma unroll
+        for (int i = 0; i < PPWMAX; ++i)
+            if (wave + NW * i < npieces && (nshare == 1 || i % nshare == share))
+                dma16(rsrc_in, smem + buf * pbuf + (wave + NW * i) * 1024, pvoff[i], kb * 32 * EB);
+    };
+    auto dma_w = [&](const int stage, const int s) {
+#pragma unroll
+        for (int i = 0; i < (WST + NW - 1) / NW; ++i)
+            if (wave + NW * i < WST) dma16(rsrc_w, wsm + stage * (WST * 1024) + (wave + NW * i) * 1024, lane * 16, (s * WST + wave + NW * i) * 1024);
+    };
+    // weight fragment address inside a 1-KiB (tap, plane) block: row lane & 15, k-chunk lane >> 4 (host-side swizzle: swz64)
+    const int w_addr_l = (lane & 15) * 64 + ((((lane >> 4) ^ (((lane >> 3) & 1) << 1))) << 4);
+
+    f32x4 acc[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    dma_patch(0, 0, 0, 1);
+    dma_w(0, 0);
+    for (int s = 0; s < nsteps; ++s) {
+        const int kb = s / TBW, dxi = s - kb * TBW;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this step's weights, and the patch pieces requested so far, have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 1 < nsteps) dma_w((s + 1) & 1, s + 1);
+        if (kb + 1 < nkb) dma_patch((kb + 1) & 1, kb + 1, dxi, TBW);   // (a share per step: every wait above stays short)
+        const unsigned char* pbase = smem + (kb & 1) * pbuf;
+        const unsigned char* wbase = wsm + (s & 1) * (WST * 1024) + w_addr_l;
+        if constexpr (HIN) {
+            h8 bf[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int q = (RW * wrow + j) * PW + 16 * pb + dxi + (lane & 15);
+                bf[j] = *reinterpret_cast<const h8*>(pbase + q * 64 + (((lane >> 4) ^ ((q >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int dyi = 0; dyi < TBH; ++dyi) {
+                const h8 wf = *reinterpret_cast<const h8*>(wbase + dyi * 1024);
+#pragma unroll
+                for (int r = 0; r < RW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, bf[r + dyi], acc[r], 0, 0, 0);
+            }
+        } else {
+            bf16x8 bfr[NB][3];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int q = (RW * wrow + j) * PW + 16 * pb + dxi + (lane & 15);
+                const int sw = (q >> 1) & 7, c0 = 2 * (lane >> 4);
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(pbase + q * 128 + ((c0 ^ sw) << 4));
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(pbase + q * 128 + (((c0 + 1) ^ sw) << 4));
+                split8(v0, v1, bfr[j][0], bfr[j][1], bfr[j][2]);
+            }
+#pragma unroll
+            for (int dyi = 0; dyi < TBH; ++dyi) {
+                bf16x8 wf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wf[pl] = *reinterpret_cast<const bf16x8*>(wbase + (pl * TBH + dyi) * 1024);
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {   // small terms first (tapconv_x6d.hip: X6D_MFMA6)
+                    f32x4 a = acc[r];
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2], bfr[r + dyi][0], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], bfr[r + dyi][2], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], bfr[r + dyi][1], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], bfr[r + dyi][0], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], bfr[r + dyi][1], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], bfr[r + dyi][0], a, 0, 0, 0);
+                    acc[r] = a;
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane = (class-grid column lane & 15, class lane >> 4): the 4 channels of output pixel (S y + cls / S, S x + cls % S)
+    const int cls = lane >> 4;
+    const int cy = cls / S, cx = cls - cy * S;
+    const bool cls_ok = cls < S * S;
+    const int xg = x0 + 16 * pb + (lane & 15);
+    const int ox = S * xg + cx;
+    const bool simple = p.out_cstride == 4 && p.out_coff == 0 && p.Cout >= 3 && p.act == SPAA_ACT_NONE && p.gate2 == nullptr &&
+                        p.gate_bits == nullptr && p.gate2_bits == nullptr && p.mask_out == nullptr && p.aux_out == nullptr &&
+                        (p.add == nullptr || (p.add_cstride == 4 && p.add_coff == 0)) &&
+                        (p.gate == nullptr || (p.gate_cstride == 4 && p.gate_coff == 0 && p.gate_mode == SPAA_GATE_MUL)) &&
+                        (int64_t)p.B * p.Hout * p.Wout * 16 < ((int64_t)1 << 31);
+    if (simple) {
+        // out = (acc + bias + add) * gate, four channels per 16-byte access, absent operands = zero-record descriptors
+        const int64_t nb = (int64_t)p.B * p.Hout * p.Wout * 16;
+        const auto r_out = rsrc_or_empty(p.out, nb), r_add = rsrc_or_empty(p.add, nb), r_gate = rsrc_or_empty(p.gate, nb);
+        const auto r_bias = rsrc_or_empty(p.bias, (int64_t)p.Cout * 4);
+        float bias[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_bias, e < p.Cout ? e * 4 : (int)0x80000000, 0, 0));
+        const bool has_gate = p.gate != nullptr;
+        int off[RW];
+        u32x4 av[RW], gv[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int oy = S * (y0 + RW * wrow + r) + cy;
+            const bool ok = cls_ok && oy < p.Hout && ox < p.Wout && xg < p.Wm && y0 + RW * wrow + r < p.Hm;
+            off[r] = ok ? ((img * p.Hout + oy) * p.Wout + ox) * 16 : (int)0x80000000;
+            av[r] = __builtin_amdgcn_raw_buffer_load_b128(r_add, off[r], 0, 0);
+            gv[r] = __builtin_amdgcn_raw_buffer_load_b128(r_gate, off[r], 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[r][e] + bias[e];
+                v += __uint_as_float(av[r][e]);
+                v = has_gate ? v * __uint_as_float(gv[r][e]) : v;
+                o[e] = __float_as_uint(e < p.Cout ? v : 0.f);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(o, r_out, off[r], 0, 0);
+        }
+        return;
+    }
+    const bool vec = !((p.Cout | p.out_cstride | p.out_coff) & 3) &&
+                     (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
+                     (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
+                     (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int yg = y0 + RW * wrow + r, oy = S * yg + cy;
+        if (cls_ok && yg < p.Hm && xg < p.Wm && oy < p.Hout && ox < p.Wout) {
+            float v[4] = {acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+            store4_t<float>(p, ((size_t)img * p.Hout + oy) * p.Wout + ox, 0, v, vec);
+        }
+    }
+}
+
+}  // namespace
+
+// called by spaa_tapconv_f32 (tapconv.hip) for tile 72.  The descriptor describes the layer as usual (its classes are used only
+// to check the geometry); the weights come from `w_split` (fp32 input: three bf16 planes) or `w_half` (fp16 input) in the FOLDED
+// layout [channel block][tap column][plane][tap row][16 rows = class * 4 + channel][32 channels] that
+// spaa_amd/convplan.py: ConvPlan.thin_fold() packs (rows of taps a class does not have are zero; chunk swizzle swz64 baked in).
+int spaa_launch_tapconv_thinmf(const spaa_tapconv_t& d, hipStream_t stream) {
+    const bool hin = (d.io_dtype & SPAA_IO_IN_F16) != 0;
+    if ((d.io_dtype & SPAA_IO_OUT_F16) || d.Cout > 4 || (d.Cin % 32) != 0 || d.s_in != 1 || (d.s_out != 1 && d.s_out != 2) ||
+        d.nclass != d.s_out * d.s_out || d.nfold > 1 || d.ksplit > 1 || d.ksplit < 0 || (hin ? d.w_half == nullptr : d.w_split == nullptr))
+        return hipErrorInvalidValue;
+    for (int c = 0; c < d.nclass; ++c)   // class c writes output pixels (S y + c / S, S x + c % S)
+        if (d.cls[c].oy0 != c / d.s_out || d.cls[c].ox0 != c % d.s_out) return hipErrorInvalidValue;
+    const int tbh = d.tap_range[1] - d.tap_range[0] + 1, tbw = d.tap_range[3] - d.tap_range[2] + 1;
+    if (tbh < 1 || tbh > 4 || tbw < 1 || tbw > 4) return hipErrorInvalidValue;
+    if (d.Hm != (d.Hout + d.s_out - 1) / d.s_out || d.Wm != (d.Wout + d.s_out - 1) / d.s_out) return hipErrorInvalidValue;
+    if ((int64_t)d.B * d.Hin * d.Win * d.in_cstride * (hin ? 2 : 4) >= (int64_t)1 << 31) return hipErrorInvalidValue;
+    const int th = tbh < 2 ? 2 : tbh;   // (a one-row box runs as two rows with zero weights: convplan packs it that way)
+    const int pw = TW + tbw - 1, npx = (TR + th - 1) * pw;
+    const int ppp = hin ? 16 : 8;
+    const int npieces = (npx + ppp - 1) / ppp;
+    if (npieces > NW * (hin ? 5 : 9)) return hipErrorInvalidValue;
+    const int tiles_y = (d.Hm + TR - 1) / TR, tiles_x = (d.Wm + TW - 1) / TW;
+    const int64_t nwg = (int64_t)d.B * tiles_y * tiles_x;
+    if (nwg > 0x7fffffff) return hipErrorInvalidValue;
+    const size_t smem = 2 * (size_t)npieces * 1024 + 2 * (size_t)(hin ? 1 : 3) * th * 1024;
+    static bool attr_set[6][SPAA_MAX_DEVICES] = {};
+#define THINMF_LAUNCH(H, T, SLOT)                                                                                          \
+    {                                                                                                                      \
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&thinmf_kernel<H, T>), 160 * 1024, attr_set[SLOT]); \
+        if (e != hipSuccess) return (int)e;                                                                                \
+        hipLaunchKernelGGL((thinmf_kernel<H, T>), dim3((unsigned)nwg), dim3(512), smem, stream, d, tiles_y, tiles_x, tbw, npieces); \
+    }
+    if (hin) {
+        if (th == 2) THINMF_LAUNCH(true, 2, 0) else if (th == 3) THINMF_LAUNCH(true, 3, 1) else THINMF_LAUNCH(true, 4, 2)
+    } else {
+        if (th == 2) THINMF_LAUNCH(false, 2, 3) else if (th == 3) THINMF_LAUNCH(false, 3, 4) else THINMF_LAUNCH(false, 4, 5)
+    }
+#undef THINMF_LAUNCH
+    return (int)hipGetLastError();
+}

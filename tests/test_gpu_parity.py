@@ -1707,6 +1707,52 @@ def test_tapconv_fp16_patch_staged(hip):
         cp.FORCE_TILE = 0
 
 
+def test_thin_output_on_matrix_cores(hip):
+    """Thin outputs with the output-parity classes folded into the N dimension of a matrix-core tile (csrc/tapconv_thinmf.hip,
+    tile 72; fp32 input: bf16x6 arithmetic): the input gradients of the stride-2 first layers (ResNet stem 7 x 7, conv1 / Inception
+    3 x 3), of a stride-1 first layer (VGG-16: one class, 3 x 3 box) and a 1 x 3 box, several workgroup tiles with ragged edges,
+    against fp64; equal to the VALU kernel (tile 29) to fp32 rounding; residual / multiplicative-gate epilogue and the generic one."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(72)
+    for ci, co, k, s, pad, h, w, b in [(3, 64, 7, 2, 3, 62, 90, 2), (3, 32, 3, 2, 1, 52, 70, 3), (3, 64, 3, 1, 1, 27, 40, 2),
+                                       (3, 32, 3, 2, 0, 31, 33, 2), (2, 96, (1, 3), 1, (0, 1), 13, 35, 1)]:
+        kh, kw = (k, k) if isinstance(k, int) else k
+        wt = torch.randn(co, ci, kh, kw) / (ci * kh * kw) ** 0.5
+        x = torch.zeros(b, ci, h, w, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x, wt.double(), None, s, pad)
+        gy = torch.randn(y.shape[0], co, y.shape[2], y.shape[3])
+        y.backward(gy.double())
+        dplan = cp.conv_dgrad_plan(wt, s, pad, DEV)
+        assert dplan.thin_ok()
+        add = torch.randn(b, h, w, 4, device=DEV)
+        add[..., ci:] = 0
+        gate = torch.rand(b, h, w, 4, device=DEV)
+        res = {}
+        try:
+            for tile in (72, 29):
+                cp.FORCE_TILE = tile
+                gx = torch.zeros(b, h, w, 4, device=DEV)
+                dplan.run(nhwc(gy, dplan.cin_p).to(DEV), gx)
+                assert dplan.last_tile == tile, dplan.last_tile
+                assert rel_inf(nchw(gx.cpu(), ci), x.grad.float()) < 2e-6, (ci, co, k, s, tile, rel_inf(nchw(gx.cpu(), ci), x.grad.float()))
+                if ci < 4:
+                    assert (gx[..., ci:] == 0).all()
+                gx2 = torch.zeros(b, h, w, 4, device=DEV)
+                dplan.run(nhwc(gy, dplan.cin_p).to(DEV), gx2, add=add, gate=gate, gate_mode=lib.GATE_MUL)
+                want = (x.grad.float().permute(0, 2, 3, 1) + add.cpu()[..., :ci]) * gate.cpu()[..., :ci]
+                assert rel_inf(gx2.cpu()[..., :ci], want) < 2e-6, (ci, co, k, s, tile, 'epilogue')
+                res[tile] = gx
+            assert rel_inf(res[72], res[29]) < 1e-6
+            # the generic epilogue (shared store4_t): a channel window of a wider buffer
+            cp.FORCE_TILE = 72
+            wide = torch.zeros(b, h, w, 8, device=DEV)
+            dplan.run(nhwc(gy, dplan.cin_p).to(DEV), wide, out_coff=4)
+            assert dplan.last_tile == 72 and (wide[..., :4] == 0).all()
+            assert rel_inf(wide.cpu()[..., 4:4 + ci], x.grad.float().permute(0, 2, 3, 1)) < 2e-6
+        finally:
+            cp.FORCE_TILE = 0
+
+
 def test_thin_output_from_fp16_activation(hip):
     """fp16-storage mode: the image-side input gradients (conv1 / conv1_s: 32 -> 3 over four parity classes; ResNet stem: 64 -> 3,
     7 x 7) read an fp16 gradient and write the fp32 image gradient: the patch-staged VALU kernel's fp16-input form (tile 29)
@@ -1723,12 +1769,13 @@ def test_thin_output_from_fp16_activation(hip):
         add = torch.randn(b, h, w, 4, device=DEV)
         add[..., ci:] = 0
         gate = torch.rand(b, h, w, 4, device=DEV)
-        for tile in (0, 63):   # (63: the fp16-MFMA thin tile, whose WEIGHTS are fp16 as well: 2^-11 per product)
+        for tile in (0, 29, 63):   # (0 -> 72, the folded matrix-core kernel, and 63: fp16 WEIGHTS as well: 2^-11 per product)
             cp.FORCE_TILE = tile
-            tol = 2e-5 if tile == 0 else 1.5e-3
+            tol = 2e-5 if tile == 29 else 1.5e-3
             try:
                 gx = torch.zeros(b, h, w, 4, device=DEV)
                 dplan.run(nhwc(gy, dplan.cin_p).half().to(DEV), gx)
+                assert dplan.last_tile == (72 if tile == 0 else tile), dplan.last_tile
                 assert rel_inf(nchw(gx.cpu(), ci), x.grad.float()) < tol, (ci, co, k, tile)
                 gx2 = torch.zeros(b, h, w, 4, device=DEV)
                 dplan.run(nhwc(gy, dplan.cin_p).half().to(DEV), gx2, add=add, gate=gate, gate_mode=lib.GATE_MUL)
