@@ -53,7 +53,9 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out
     argmax[idx] = am;
 }
 
-template <typename T>
+// CK/CS/CP > 0: kernel / stride / padding known at compile time (3 / 2 / 1: the ResNet stem pool in fp16 storage -- the runtime
+// divisions of the generic form cost more than the loads)
+template <typename T, int CK = 0, int CS = 0, int CP = 0>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ g_out, const uchar4* __restrict__ argmax,
                                    const int relu_gate, T* __restrict__ g_in, Geo g,
                                    int gout_c4stride, int gout_c4off) {
@@ -65,22 +67,23 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ g_out, const uchar4* __
     r /= g.Win;
     const int iy = r % g.Hin;
     const int b = r / g.Hin;
+    const int K = CK ? CK : g.k, S = CS ? CS : g.s, P = CK ? CP : g.p;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const unsigned char need = relu_gate ? 0x80 : 0x00;  // relu_gate: only windows whose maximum is positive pass
-    for (int ky = 0; ky < g.k; ++ky) {
-        const int t = iy + g.p - ky;
-        if (t < 0 || (t % g.s)) continue;
-        const int oy = t / g.s;
+    for (int ky = 0; ky < K; ++ky) {
+        const int t = iy + P - ky;
+        if (t < 0 || (t % S)) continue;
+        const int oy = t / S;
         if (oy >= g.Hout) continue;
-        for (int kx = 0; kx < g.k; ++kx) {
-            const int u = ix + g.p - kx;
-            if (u < 0 || (u % g.s)) continue;
-            const int ox = u / g.s;
+        for (int kx = 0; kx < K; ++kx) {
+            const int u = ix + P - kx;
+            if (u < 0 || (u % S)) continue;
+            const int ox = u / S;
             if (ox >= g.Wout) continue;
             const size_t opix = ((size_t)b * g.Hout + oy) * g.Wout + ox;
             const uchar4 am = argmax[opix * g.C4 + c];
             const f4 go = io4<T>::ld(g_out, 4 * (opix * gout_c4stride + gout_c4off + c));
-            const unsigned char kk = (unsigned char)(ky * g.k + kx);
+            const unsigned char kk = (unsigned char)(ky * K + kx);
             if ((am.x & 0x7f) == kk && (am.x & need) == need) acc.x += go.x;
             if ((am.y & 0x7f) == kk && (am.y & need) == need) acc.y += go.y;
             if ((am.z & 0x7f) == kk && (am.z & need) == need) acc.z += go.z;
@@ -256,9 +259,14 @@ int spaa_maxpool_bwd_f16(const void* g_out, const uint8_t* argmax, int relu_gate
         (gout_coff & 3) || gout_coff + C > gout_cstride)
         return hipErrorInvalidValue;
     Geo g{B, Hin, Win, C / 4, Hout, Wout, k, s, p};
-    hipLaunchKernelGGL(maxpool_bwd_kernel<_Float16>, dim3(nb((int64_t)B * Hin * Win * g.C4)), dim3(256), 0,
-                       (hipStream_t)stream, (const _Float16*)g_out, (const uchar4*)argmax, relu_gate, (_Float16*)g_in, g,
-                       gout_cstride / 4, gout_coff / 4);
+    if (k == 3 && s == 2 && p == 1)
+        hipLaunchKernelGGL((maxpool_bwd_kernel<_Float16, 3, 2, 1>), dim3(nb((int64_t)B * Hin * Win * g.C4)), dim3(256), 0,
+                           (hipStream_t)stream, (const _Float16*)g_out, (const uchar4*)argmax, relu_gate, (_Float16*)g_in, g,
+                           gout_cstride / 4, gout_coff / 4);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel<_Float16>, dim3(nb((int64_t)B * Hin * Win * g.C4)), dim3(256), 0,
+                           (hipStream_t)stream, (const _Float16*)g_out, (const uchar4*)argmax, relu_gate, (_Float16*)g_in, g,
+                           gout_cstride / 4, gout_coff / 4);
     return (int)hipGetLastError();
 }
 
