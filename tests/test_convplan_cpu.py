@@ -93,3 +93,44 @@ def test_linear_and_bn_fold():
     ref = F.batch_norm(F.conv2d(xi, cw, None, 1, 1), m, v, g, bb, False, 0.0, 1e-5)
     fw, fb = cp.fold_bn(cw, g, bb, m, v)
     assert torch.allclose(F.conv2d(xi, fw, fb, 1, 1), ref, atol=1e-5)
+
+
+@pytest.mark.parametrize('ci,co,k,s,p,h,w', [(3, 64, 7, 2, 3, 14, 18), (3, 32, 3, 2, 1, 10, 12), (3, 64, 3, 1, 1, 7, 9), (3, 32, 3, 2, 0, 11, 9)])
+def test_thin_fold_layout(ci, co, k, s, p, h, w):
+    """The folded weight layout of the thin-output matrix-core kernel (ConvPlan.thin_fold, csrc/tapconv_thinmf.hip): emulated on the
+    CPU exactly as the kernel reads it -- GEMM row = class * 4 + channel, [channel block][tap column][plane][tap row][16][32], the
+    chunk swap of rows 8-15, output pixel (S y + class / S, S x + class % S) -- it gives the layer's input gradient; the three bf16
+    planes sum to the fp32 weights exactly."""
+    x = torch.randn(2, ci, h, w, requires_grad=True)
+    wt = torch.randn(co, ci, k, k)
+    y = F.conv2d(x, wt, None, s, p)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    dplan = cp.conv_dgrad_plan(wt, s, p, device='cpu')
+    assert dplan.thin_ok()
+    S = dplan.s_out
+    dy0, dy1, dx0, dx1 = dplan.tap_range
+    tbh, tbw, nkb = max(dy1 - dy0 + 1, 2), dx1 - dx0 + 1, dplan.cin_p // 32
+    planes = dplan.thin_fold(False).view(torch.bfloat16).view(nkb, tbw, 3, tbh, 16, 32).float()
+    wsum = planes.sum(dim=2)                                           # h + m + l
+    half = dplan.thin_fold(True).view(torch.float16).view(nkb, tbw, 1, tbh, 16, 32).float()[:, :, 0]
+    assert (half - wsum).abs().max() <= 1e-3 * wsum.abs().max()
+    un = wsum.view(nkb, tbw, tbh, 16, 4, 8).clone()                    # undo the chunk swap of rows 8-15
+    un[..., 8:, 0, :], un[..., 8:, 2, :] = wsum.view(nkb, tbw, tbh, 16, 4, 8)[..., 8:, 2, :], wsum.view(nkb, tbw, tbh, 16, 4, 8)[..., 8:, 0, :]
+    un[..., 8:, 1, :], un[..., 8:, 3, :] = wsum.view(nkb, tbw, tbh, 16, 4, 8)[..., 8:, 3, :], wsum.view(nkb, tbw, tbh, 16, 4, 8)[..., 8:, 1, :]
+    wf = un.view(nkb, tbw, tbh, 16, 32).permute(3, 2, 1, 0, 4).reshape(16, tbh, tbw, dplan.cin_p)   # [row][dyi][dxi][c]
+    g = nhwc(gy, dplan.cin_p)                                          # [B, Hm, Wm, cin_p] (class grid = its input grid)
+    hm, wm = (h + S - 1) // S, (w + S - 1) // S                        # class grid; beyond gy: zeros
+    gp = F.pad(g, (0, 0, max(-dx0, 0) + 4, dx1 + 4 + wm - g.shape[2], max(-dy0, 0) + 4, dy1 + 4 + hm - g.shape[1]))
+    oy_, ox_ = max(-dy0, 0) + 4, max(-dx0, 0) + 4
+    out = torch.zeros(2, h, w, 4)
+    for cls in range(S * S):
+        acc = torch.zeros(2, hm, wm, 4)
+        for dyi in range(tbh):
+            for dxi in range(tbw):
+                patch = gp[:, oy_ + dy0 + dyi:oy_ + dy0 + dyi + hm, ox_ + dx0 + dxi:ox_ + dx0 + dxi + wm]
+                acc += torch.einsum('bhwc,nc->bhwn', patch, wf[4 * cls:4 * cls + 4, dyi, dxi])
+        cy, cx = cls // S, cls % S
+        out[:, cy::S, cx::S] = acc[:, :(h - cy + S - 1) // S, :(w - cx + S - 1) // S]
+    assert torch.allclose(nchw(out)[:, :ci], x.grad, atol=1e-3), float((nchw(out)[:, :ci] - x.grad).abs().max())
+    assert (out[..., ci:] == 0).all()
