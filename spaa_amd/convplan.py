@@ -44,6 +44,7 @@ DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
 DEBUG_TAPMAJOR = int(os.environ.get('SPAA_X6D_TAPMAJOR', '0'))      # 1: tap-major K order (A/B measurements only)
 DEBUG_PERSIST_CAP = int(os.environ.get('SPAA_X6D_PERSIST_CAP', '0'))  # > 0: persistent launches use this many workgroups
 DEBUG_WINO = int(os.environ.get('SPAA_WINO_DBG', '0'))              # timing experiments of the Winograd kernel
+DEBUG_THINMF = int(os.environ.get('SPAA_THINMF_DBG', '0'))           # timing experiments of csrc/tapconv_thinmf.hip (builds with -DSPAA_THINMF_ABLATE)
 DEBUG_SMALLCIN_NOSLAB = int(os.environ.get('SPAA_SMALLCIN_NOSLAB', '0'))  # 1: stride-2 smallcin layers store from the MFMA layout (A/B)
 DEBUG_H16_2STAGE = int(os.environ.get('SPAA_H16_2STAGE', '0'))      # 1: the fp16 implicit-GEMM kernel never takes its four-stage form (A/B measurements)
 FOLD_K3S2 = os.environ.get('SPAA_FOLD_K3S2', '1') != '0'   # 3x3 / s2 input gradients with few output channels: classes folded
@@ -392,7 +393,7 @@ class ConvPlan:
             else:
                 d.w_split = self.thin_fold(False).data_ptr()
         d.tile = self.last_tile = tile     # (last_tile: for tests and reports)
-        d.reserved0 = DEBUG_TAPMAJOR | (DEBUG_PERSIST_CAP << 8) | (DEBUG_WINO << 16) | (DEBUG_H16_2STAGE << 25) | (DEBUG_SMALLCIN_NOSLAB << 26)  # measurement / test switches of the x6d kernels
+        d.reserved0 = DEBUG_TAPMAJOR | (DEBUG_PERSIST_CAP << 8) | (DEBUG_WINO << 16) | (DEBUG_H16_2STAGE << 25) | (DEBUG_SMALLCIN_NOSLAB << 26) | (DEBUG_THINMF << 27)  # measurement / test switches of the x6d kernels
         d.nclass = len(self.cls)
         d.tap_range[:] = self.tap_range
         for i, c in enumerate(self.cls):

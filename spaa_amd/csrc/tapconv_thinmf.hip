@@ -177,6 +177,13 @@ __global__ __launch_bounds__(512, 1) void thinmf_kernel(const spaa_tapconv_t p, 
                 const int sw = (q >> 1) & 7, c0 = 2 * (lane >> 4);
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(pbase + q * 128 + ((c0 ^ sw) << 4));
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(pbase + q * 128 + (((c0 + 1) ^ sw) << 4));
+#ifdef SPAA_THINMF_ABLATE
+                if ((p.reserved0 >> 27) & 1) {   // timing only: no operand split
+                    bfr[j][0] = __builtin_bit_cast(bf16x8, v0);
+                    bfr[j][1] = __builtin_bit_cast(bf16x8, v1);
+                    bfr[j][2] = bfr[j][0];
+                } else
+#endif
                 split8(v0, v1, bfr[j][0], bfr[j][1], bfr[j][2]);
             }
 #pragma unroll
