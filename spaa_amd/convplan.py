@@ -306,6 +306,8 @@ class ConvPlan:
             forced = 0
         if forced in X6D_TILES and (self.cin_p % 32 or any(c['Kpad'] != c['K'] for c in self.cls)):
             forced = 0
+        if (forced in H16_TILES or forced == 68) and not in_f16:   # fp16 kernels forced (A/B runs) on a layer with fp32 input
+            forced = 0
         tile = forced if forced else tuned_tile(key)
         if tile < 0:
             tile = self._default_tile(b * d.Hm * d.Wm)
@@ -343,11 +345,11 @@ class ConvPlan:
                     tile = 68   # 3x3 / stride 1: the input patch staged once for the nine taps (csrc/tapconv_h16p.hip)
                 elif tile == 60 and (m_all + 127) // 128 * ((ngemm + 127) // 128) < 256 and 'h16n64' not in DEFAULT_DISABLE:
                     tile = 61   # too few 128 x 128 tiles for 256 CUs (ResNet layer3 / layer4 at batch 64): twice as many of 128 x 64
-                elif tile == 60 and m_all >= 256 * 512:   # enough pixels to fill the chip with 256-row tiles: less weight
-                    tile = 65 if ngemm > 128 else 64    # traffic per pixel (and one N tile for the 256-channel layers)
+                # (the 256-row tiles 64 / 65 paid on the 64 x 64 3x3 layers, which the patch-staged kernel serves now; for what is
+                # left -- strided and folded layers -- 128 x 128 is as good or better: tools/lab/f16_tiles.py)
         elif out_f16:  # fp32 image in, fp16 activation out: any kernel built on the shared epilogue, without split-K
             tile %= 100
-            if tile not in F16OUT_TILES:
+            if tile not in F16OUT_TILES or tile in H16_TILES:   # (the fp16 implicit-GEMM tiles need an fp16 input as well)
                 tile = 38 if (len(self.cls) == 1 and self.cin_p in (4, 8) and self.cout <= 32 and self.ntaps_total <= 9
                               and self.s_in <= 2) else (18 if self.cout > 32 else 16)
         # tune values >= 100 encode split-K: tile + 100 * ksplit (x6d tiles, one class, enough K-steps per split)
