@@ -326,9 +326,9 @@ class ConvPlan:
             tile = 0 if forced else self._default_tile(b * d.Hm * d.Wm, winograd=False)
         if in_f16:    # fp16 activations: the h16 kernels, N tile by the GEMM's width
             ngemm = self.cout * self.nfold
-            patch_ok = (len(self.cls) == 1 and self.ntaps_total == 9 and self.s_in == 1 and self.s_out == 1 and self.nfold == 1
-                        and (hin, win) == (hout, wout) and self.tap_range[0] >= -1 and self.tap_range[1] <= 1
-                        and self.tap_range[2] >= -1 and self.tap_range[3] <= 1)
+            patch_ok = (len(self.cls) == 1 and 4 <= self.ntaps_total <= 9 and self.s_in == 1 and (hin, win) == (d.Hm, d.Wm)
+                        and self.tap_range[0] >= -1 and self.tap_range[1] <= 1 and self.tap_range[2] >= -1 and self.tap_range[3] <= 1
+                        and ((self.nfold == 1 and self.s_out == 1) or (self.nfold == 4 and self.s_out == 2)))
             if forced in H16_TILES or (forced == 68 and patch_ok):
                 tile = forced
             elif thin_mf:
@@ -339,10 +339,10 @@ class ConvPlan:
             else:
                 tile = 60 if ngemm > 64 else 61 if ngemm > 32 else 62 if ngemm > 16 else 63
                 m_all = b * d.Hm * d.Wm
-                if (patch_ok and self.cout >= 64 and 'h16p' not in DEFAULT_DISABLE and forced == 0
-                        and b * ((hout + 15) // 16) * ((wout + 31) // 32) * ((self.cout + 127) // 128) >= 256
-                        and hout * wout >= 0.6 * ((hout + 15) // 16 * 16) * ((wout + 31) // 32 * 32)):   # (16 x 32-pixel tiles)
-                    tile = 68   # 3x3 / stride 1: the input patch staged once for the nine taps (csrc/tapconv_h16p.hip)
+                if (patch_ok and ngemm >= 64 and 'h16p' not in DEFAULT_DISABLE and forced == 0
+                        and b * ((d.Hm + 15) // 16) * ((d.Wm + 31) // 32) * ((ngemm + 127) // 128) >= 256
+                        and d.Hm * d.Wm >= 0.6 * ((d.Hm + 15) // 16 * 16) * ((d.Wm + 31) // 32 * 32)):   # (16 x 32-pixel tiles)
+                    tile = 68   # 3x3 / stride 1 (or a folded stride-2 transposed layer): the input patch staged once for all taps (csrc/tapconv_h16p.hip)
                 elif tile == 60 and (m_all + 127) // 128 * ((ngemm + 127) // 128) < 256 and 'h16n64' not in DEFAULT_DISABLE:
                     tile = 61   # too few 128 x 128 tiles for 256 CUs (ResNet layer3 / layer4 at batch 64): twice as many of 128 x 64
                 # (the 256-row tiles 64 / 65 paid on the 64 x 64 3x3 layers, which the patch-staged kernel serves now; for what is
@@ -356,7 +356,7 @@ class ConvPlan:
         ksplit, tile = (tile // 100, tile % 100) if tile >= 100 else (1, tile)
         if self.nfold > 1:  # only the DMA-staged kernels know the folded epilogue
             ksplit = 1
-            if not (tile in X6D_TILES or tile in H16_TILES):
+            if not (tile in X6D_TILES or tile in H16_TILES or tile == 68):
                 tile = 34
             d.nfold = self.nfold
         if ksplit == 9:  # stream-K (persistent x6d tiles, one class): workspace shared by all plans (one stream)

@@ -586,7 +586,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         return hipErrorInvalidValue;
     if ((d.io_dtype & SPAA_IO_OUT_F16) && (d.ksplit > 1 || d.ksplit < 0)) return hipErrorInvalidValue;  // (fp32 partial sums)
     if (d.gate != nullptr && d.gate_mode == SPAA_GATE_MUL && tile < 25) return hipErrorInvalidValue;
-    if (d.nfold > 1 && !((tile >= 25 && tile <= 27) || (tile >= 30 && tile <= 37) || (tile >= 39 && tile <= 46) || (tile >= 48 && tile <= 54) || (tile >= 60 && tile <= 65)))
+    if (d.nfold > 1 && !((tile >= 25 && tile <= 27) || (tile >= 30 && tile <= 37) || (tile >= 39 && tile <= 46) || (tile >= 48 && tile <= 54) || (tile >= 60 && tile <= 65) || tile == 68))
         return hipErrorInvalidValue;
     if (tile == 0) {  // heuristic: widest N tile that fits Cout; shrink M when the grid would not fill 256 CUs twice
         const int64_t M = (int64_t)d.B * d.Hm * d.Wm * d.nclass;

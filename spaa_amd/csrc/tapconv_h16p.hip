@@ -77,7 +77,10 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
     const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)in_hi << 32) | in_lo), 0,
                                                             (int)__builtin_amdgcn_readfirstlane(in_bytes), 0x00020000);
     const int K64 = (cl.K + 63) & ~63;
-    const int npad = (p.Cout + 127) & ~127;
+    const int nfold = p.nfold > 1 ? p.nfold : 1;
+    const int ntaps = cl.ntaps;
+    const int spk = (ntaps + 2) / 3;            // steps of three taps per channel block (2 or 3)
+    const int npad = (p.Cout * nfold + 127) & ~127;
     const uint64_t w_addr = reinterpret_cast<uint64_t>(p.w_half);
     const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)w_addr);
     const uint32_t w_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(w_addr >> 32));
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
             const int q = wave + NW * i;
             const int tl = q / (BN / 16), rb = q - tl * (BN / 16);
             const int soff = (n_blk + 16 * rb) * K64 * 2 + ((3 * s + tl) * Cin + kb * 32) * 2;
-            dma16(rsrc_w, wsm + stage * WS_BYTES + q * 1024, q < W_PIECES ? w_voff : (int)0x80000000, soff);
+            dma16(rsrc_w, wsm + stage * WS_BYTES + q * 1024, (q < W_PIECES && 3 * s + tl < ntaps) ? w_voff : (int)0x80000000, soff);
         }
     };
     const int w_addr_l = (lane & 15) * 64 + (((lane >> 4) ^ swz64(lane & 15)) * 16);
@@ -121,16 +124,15 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
         for (int j = 0; j < TJ; ++j) acc[b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nkb = Cin >> 5;
-    const int nsteps = 3 * nkb;
+    const int nsteps = spk * nkb;
     dma_patch(0, 0);
     dma_w(0, 0, 0);
     if (nsteps > 1) dma_w(1, 0, 1);
     int st = 0;
     for (int kb = 0; kb < nkb; ++kb) {
         const unsigned char* pb = smem + (kb & 1) * PATCH_BYTES;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int step = 3 * kb + s;
+        for (int s = 0; s < spk; ++s) {
+            const int step = spk * kb + s;
             // this wave's pieces of the step's weights (and, at s == 0, of the block's patch) have landed
             if (step + 1 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (s != 0 && kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + PPW) : "memory");   // (the next block's patch, requested at s == 0)
@@ -140,12 +142,13 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
             asm volatile("" ::: "memory");
             if (step + 2 < nsteps) {
                 const int st2 = st >= 1 ? st - 1 : 2;
-                const int s2 = s + 2 >= 3 ? s - 1 : s + 2, kb2 = s + 2 >= 3 ? kb + 1 : kb;
+                const int kb2 = (step + 2) / spk, s2 = step + 2 - kb2 * spk;
                 dma_w(st2, kb2, s2);
             }
             if (s == 0 && kb + 1 < nkb) dma_patch((kb + 1) & 1, kb + 1);
 #pragma unroll
             for (int tl = 0; tl < 3; ++tl) {
+                if (3 * s + tl >= ntaps) break;   // (uniform: a tap list that is not a multiple of three ends inside a step)
                 const int dy = ctaps[2 * (3 * s + tl)], dx = ctaps[2 * (3 * s + tl) + 1];
                 h8 bf[4];
 #pragma unroll
@@ -192,13 +195,16 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
     {                                                                                                              \
         H16P_TO_LDS(hb)                                                                                            \
         const int oy = oy0 + 2 * wave + (hb);                                                                      \
-        if (oy < p.Hout) {                                                                                         \
-            const size_t orow = ((size_t)img * p.Hout + oy) * p.Wout + ox0;                                        \
+        if (oy < p.Hm) {                                                                                           \
+            const size_t orow = ((size_t)img * p.Hm + oy) * p.Wm + ox0;                                            \
             for (int i = 0; i < 32 / PPI; ++i) {                                                                   \
                 const int pr = i * PPI + lane / LPP;                                                               \
                 const f32x4 a = *reinterpret_cast<const f32x4*>(eb + pr * ROWB + ch * 4);                          \
                 float v[4] = {a[0], a[1], a[2], a[3]};                                                             \
-                if (ox0 + pr < p.Wout) store4_t<T>(p, orow + pr, n_blk + ch, v, vec);                              \
+                if (ox0 + pr < p.Wm) {                                                                             \
+                    if (p.nfold > 1) store4_fold_t<T>(p, (int)(orow + pr), p.B * p.Hm * p.Wm, p.Hm * p.Wm, n_blk + ch, v, vec); \
+                    else store4_t<T>(p, orow + pr, n_blk + ch, v, vec);                                            \
+                }                                                                                                  \
             }                                                                                                      \
         }                                                                                                          \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
@@ -207,26 +213,32 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
     {                                                                                                              \
         H16P_TO_LDS(hb)                                                                                            \
         const int oy = oy0 + 2 * wave + (hb);                                                                      \
-        if (oy < p.Hout) {                                                                                         \
-            const int orow = (img * p.Hout + oy) * p.Wout + ox0;                                                   \
+        if (oy < p.Hm) {                                                                                           \
+            /* output pixel of class-grid pixel (oy, ox0 + pr): itself, or (2 oy + cy, 2 x + cx) of a folded transposed layer */ \
+            const int orow = (img * p.Hout + fs * oy + cy) * p.Wout + fs * ox0 + cx;                               \
+            const bool row_ok = n_ok && fs * oy + cy < p.Hout;                                                     \
             _Pragma("unroll 1") for (int i0 = 0; i0 < 32 / PPI; i0 += 4) {                                         \
                 fast_pre_t<T> pre[4];                                                                              \
                 _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
                     const int pr = (i0 + i) * PPI + lane / LPP;                                                    \
-                    pre[i] = fast_epi_load<T>(fe, p, orow + pr, n, n_ok && ox0 + pr < p.Wout);                     \
+                    pre[i] = fast_epi_load<T>(fe, p, orow + fs * pr, n, row_ok && ox0 + pr < p.Wm && fs * (ox0 + pr) + cx < p.Wout); \
                 }                                                                                                  \
                 _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
                     const int pr = (i0 + i) * PPI + lane / LPP;                                                    \
                     const f32x4 a = *reinterpret_cast<const f32x4*>(eb + pr * ROWB + ch * 4);                      \
-                    fast_epi_store<T>(fe, p, orow + pr, n, n_ok && ox0 + pr < p.Wout, a, pre[i]);                  \
+                    fast_epi_store<T>(fe, p, orow + fs * pr, n, row_ok && ox0 + pr < p.Wm && fs * (ox0 + pr) + cx < p.Wout, a, pre[i]); \
                 }                                                                                                  \
             }                                                                                                      \
         }                                                                                                          \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
     }
     if (fast) {
-        const int n = n_blk + ch;
-        const bool n_ok = n < p.Cout;
+        // (folded layer: GEMM column n_blk + ch = class * Cout + channel; the lane's class is fixed, so is its output parity)
+        const int ng = n_blk + ch;
+        const int fc = nfold > 1 ? ng / p.Cout : 0;
+        const int n = ng - fc * p.Cout;
+        const bool n_ok = fc < nfold && n < p.Cout;
+        const int fs = nfold > 1 ? 2 : 1, cy = fc >> 1, cx = fc & 1;
         const fast_epi_t fe = make_fast_epi(p, n_ok ? n : 0);
         if (p.io_dtype & SPAA_IO_OUT_F16) {
             H16P_EPI_FAST(_Float16, 0) H16P_EPI_FAST(_Float16, 1)
@@ -245,19 +257,25 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
 
 }  // namespace
 
-// called by spaa_tapconv_f32 (tapconv.hip) for tile 68 after the common shape checks: ONE class of nine taps inside
-// [-1, 1]^2 (a 3x3 convolution or its input gradient), stride 1, same input and output size, fp16 input, Cin % 32 == 0
+// called by spaa_tapconv_f32 (tapconv.hip) for tile 68 after the common shape checks: ONE class of four to nine taps inside
+// [-1, 1]^2 sampled at stride 1 -- a 3x3 convolution or its input gradient (same input and output size), or the FOLDED form of a
+// stride-2 transposed layer (nfold = 4: a 3x3 / s2 transposed convolution, the input gradient of a 3x3 / s2 convolution: four
+// taps, GEMM columns = parity class * Cout + channel, output twice the input size); fp16 input, Cin % 32 == 0
 int spaa_launch_tapconv_h16p(const spaa_tapconv_t& d, hipStream_t stream) {
-    if (!(d.io_dtype & SPAA_IO_IN_F16) || d.w_half == nullptr || (d.Cin % 32) != 0 || d.nclass != 1 || d.cls[0].ntaps != 9 ||
-        d.cls[0].K != 9 * d.Cin || d.s_in != 1 || d.s_out != 1 || d.Hin != d.Hout ||
-        d.Win != d.Wout || d.Hm != d.Hout || d.Wm != d.Wout || d.nfold > 1 || d.ksplit > 1 || d.ksplit < 0)
+    const int nfold = d.nfold > 1 ? d.nfold : 1;
+    if (!(d.io_dtype & SPAA_IO_IN_F16) || d.w_half == nullptr || (d.Cin % 32) != 0 || d.nclass != 1 || d.cls[0].ntaps < 4 ||
+        d.cls[0].ntaps > 9 || d.cls[0].K != d.cls[0].ntaps * d.Cin || d.s_in != 1 || d.Hm != d.Hin || d.Wm != d.Win ||
+        d.ksplit > 1 || d.ksplit < 0)
+        return hipErrorInvalidValue;
+    if (nfold == 1 ? (d.s_out != 1 || d.Hm != d.Hout || d.Wm != d.Wout)
+                   : (nfold != 4 || d.s_out != 2 || (d.Cout & 3) || d.Hm != (d.Hout + 1) / 2 || d.Wm != (d.Wout + 1) / 2))
         return hipErrorInvalidValue;
     if (d.tap_range[0] < -1 || d.tap_range[1] > 1 || d.tap_range[2] < -1 || d.tap_range[3] > 1) return hipErrorInvalidValue;
-    if ((int64_t)((d.Cout + 127) & ~127) * ((d.cls[0].K + 63) & ~63) * 2 >= (int64_t)1 << 31) return hipErrorInvalidValue;
+    if ((int64_t)((d.Cout * nfold + 127) & ~127) * ((d.cls[0].K + 63) & ~63) * 2 >= (int64_t)1 << 31) return hipErrorInvalidValue;
     if ((int64_t)d.B * d.Hin * d.Win * d.in_cstride * 2 >= (int64_t)1 << 31) return hipErrorInvalidValue;
-    const int wg_y = (d.Hout + OH - 1) / OH, wg_x = (d.Wout + OW - 1) / OW;
-    const int BN = d.Cout <= 64 ? 64 : 128;
-    const int n_tiles = (d.Cout + BN - 1) / BN;
+    const int wg_y = (d.Hm + OH - 1) / OH, wg_x = (d.Wm + OW - 1) / OW;
+    const int BN = d.Cout * nfold <= 64 ? 64 : 128;
+    const int n_tiles = (d.Cout * nfold + BN - 1) / BN;
     const int64_t nwg = (int64_t)d.B * wg_y * wg_x * n_tiles;
     if (nwg > 0x7fffffff) return hipErrorInvalidValue;
     static bool attr_set[2][SPAA_MAX_DEVICES] = {};

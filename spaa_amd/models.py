@@ -379,7 +379,10 @@ class PCNetEngine:
             d[nm] = cp.conv_dgrad_plan(m.weight, st, 1, dev, nm + '_dgrad', in_ch=(3, 6) if nm == 'conv1_s' else None)
         f['skipConv2'] = cp.conv_fwd_plan(sn.skipConv2.weight, sn.skipConv2.bias, 1, 0, dev, 'skipConv2')
         d['skipConv2'] = cp.conv_dgrad_plan(sn.skipConv2.weight, 1, 0, dev, 'skipConv2_dgrad')
-        f['transConv1'] = cp.deconv_fwd_plan(sn.transConv1.weight, sn.transConv1.bias, 2, 1, dev, 'transConv1')
+        # (fp16 storage: the four parity classes folded into the GEMM columns -- the patch-staged fp16 kernel reads the input once;
+        # in fp32 the folded form is slower than the four classes: 16 instead of 9 (class, tap) products)
+        f['transConv1'] = cp.deconv_fwd_plan(sn.transConv1.weight, sn.transConv1.bias, 2, 1, dev, 'transConv1',
+                                             fold=True if storage == 'f16' else None)
         d['transConv1'] = cp.deconv_dgrad_plan(sn.transConv1.weight, 2, 1, dev, 'transConv1_dgrad')
         f['transConv2'] = cp.deconv_fwd_plan(sn.transConv2.weight, sn.transConv2.bias, 2, 0, dev, 'transConv2')
         d['transConv2'] = cp.deconv_dgrad_plan(sn.transConv2.weight, 2, 0, dev, 'transConv2_dgrad')

@@ -1703,6 +1703,35 @@ def test_tapconv_fp16_patch_staged(hip):
                 dplan.run(nhwc(gy, dplan.cin_p).half().to(DEV), gx, gate_bits=lib.pack_gate_mask(gate_act))
                 assert dplan.last_tile == 68
                 assert rel_inf(nchw(gx.float().cpu(), ci), gx_ref * (nchw(gate_act.cpu(), ci) > 0)) < 1.5e-3, ('dgrad', ci, co)
+        # folded stride-2 transposed layers (four taps, GEMM columns = parity class * Cout + channel): a 3x3 / s2 transposed
+        # convolution (ReLU + byte mask) and the input gradient of a 3x3 / s2 convolution (byte-mask gate, residual)
+        for ci, co, h, w, b in [(128, 64, 40, 70, 2), (64, 32, 33, 32, 3), (32, 96, 17, 65, 1)]:
+            xt = _h(torch.randn(b, ci, h, w))
+            wtt = _h(torch.randn(ci, co, 3, 3) / (ci * 9) ** 0.5)
+            bt = torch.randn(co)
+            ref = F.relu(F.conv_transpose2d(xt.double(), wtt.double(), bt.double(), 2, 1, 1).float())
+            tplan = cp.deconv_fwd_plan(wtt, bt, 2, 1, DEV)
+            outt = torch.zeros(b, 2 * h, 2 * w, co, device=DEV, dtype=torch.float16)
+            maskt = torch.zeros(b, 2 * h, 2 * w, co // 4, dtype=torch.uint8, device=DEV)
+            cp.FORCE_TILE = 68
+            tplan.run(nhwc(xt).half().to(DEV), outt, act=lib.ACT_RELU, mask_out=maskt)
+            if tplan.nfold == 4:
+                assert tplan.last_tile == 68, tplan.last_tile
+            assert rel_inf(nchw(outt.float().cpu(), co), ref) < 1.5e-3, ('deconv', ci, co)
+            assert torch.equal(maskt, lib.pack_gate_mask(outt.float()))
+            # input gradient of a 3x3 / s2 convolution co <- ci ... (weights [ci_out = co2, ci_in]): gradient wrt a (2h x 2w) input
+            wt2 = _h(torch.randn(ci, co, 3, 3) / (co * 9) ** 0.5)           # conv co -> ci, stride 2
+            gy = _h(torch.randn(b, ci, h, w))
+            gx_ref = torch.nn.grad.conv2d_input((b, co, 2 * h, 2 * w), wt2.double(), gy.double(), 2, 1).float()
+            dplan = cp.conv_dgrad_plan(wt2, 2, 1, DEV)
+            gate_act = torch.randn(b, 2 * h, 2 * w, co, device=DEV)
+            addt = _h(torch.randn(b, 2 * h, 2 * w, co))
+            gx = torch.zeros(b, 2 * h, 2 * w, co, device=DEV, dtype=torch.float16)
+            dplan.run(nhwc(gy).half().to(DEV), gx, add=addt.half().to(DEV), gate_bits=lib.pack_gate_mask(gate_act))
+            if dplan.nfold == 4:
+                assert dplan.last_tile == 68, dplan.last_tile
+            want = (gx_ref.permute(0, 2, 3, 1) + addt) * (gate_act.cpu() > 0)
+            assert rel_inf(gx.float().cpu(), want) < 1.5e-3, ('s2 dgrad', ci, co)
     finally:
         cp.FORCE_TILE = 0
 
