@@ -43,6 +43,7 @@ F16OUT_TILES = set(range(15, 25)) | {38} | set(range(60, 66))  # ... of which th
 DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
 DEBUG_TAPMAJOR = int(os.environ.get('SPAA_X6D_TAPMAJOR', '0'))      # 1: tap-major K order (A/B measurements only)
 DEBUG_PERSIST_CAP = int(os.environ.get('SPAA_X6D_PERSIST_CAP', '0'))  # > 0: persistent launches use this many workgroups
+FORCE_KSPLIT = int(os.environ.get('SPAA_FORCE_KSPLIT', '0'))        # split-K factor of the fp16 implicit-GEMM kernel (A/B runs, tests)
 DEBUG_WINO = int(os.environ.get('SPAA_WINO_DBG', '0'))              # timing experiments of the Winograd kernel
 DEBUG_THINMF = int(os.environ.get('SPAA_THINMF_DBG', '0'))           # timing experiments of csrc/tapconv_thinmf.hip (builds with -DSPAA_THINMF_ABLATE)
 DEBUG_SMALLCIN_NOSLAB = int(os.environ.get('SPAA_SMALLCIN_NOSLAB', '0'))  # 1: stride-2 smallcin layers store from the MFMA layout (A/B)
@@ -367,9 +368,17 @@ class ConvPlan:
                 ksplit = 1
         if in_f16 or out_f16:
             ksplit = 1
+            if (in_f16 and tile in (60, 61, 62, 63) and len(self.cls) == 1 and self.nfold == 1 and 'h16splitk' not in DEFAULT_DISABLE
+                    and (forced == 0 or FORCE_KSPLIT)):
+                # skinny GEMMs of the fp16 path (VGG-16's fully connected layers at batch 64: ONE row tile, K = 25088; ResNet layer4):
+                # split K until the grid covers the chip about twice, at least eight 64-deep steps per split
+                bn = {60: 128, 61: 64, 62: 32, 63: 16}[tile]
+                wgs = (b * d.Hm * d.Wm + 127) // 128 * ((self.cout + bn - 1) // bn)
+                nk = (self.cls[0]['K'] + 63) // 64
+                ksplit = FORCE_KSPLIT if FORCE_KSPLIT else max(1, min(16, 512 // max(wgs, 1), nk // 8))
         if ksplit > 1:
             nk = self.cls[0]['Kpad'] // BK
-            if len(self.cls) != 1 or nk < 2 * ksplit or tile not in X6D_TILES or self.cin_p % 32:
+            if len(self.cls) != 1 or nk < 2 * ksplit or (tile not in X6D_TILES and not (in_f16 and tile in (60, 61, 62, 63))) or self.cin_p % 32:
                 ksplit, tile = 1, (0 if forced else tile)
         if ksplit > 1:
             need = ksplit * b * d.Hm * d.Wm * ((self.cout + 127) // 128 * 128)

@@ -128,7 +128,13 @@ __global__ __launch_bounds__(64 * NW, (NW > 4 || NS > 2) ? 1 : 2) void tapconv_h
     }
 
     const int nsub = cl.K / 32;          // real sub-steps
-    const int nk = (nsub + 1) >> 1;      // K-steps (the last one may hold a single real sub-step)
+    const int nk_all = (nsub + 1) >> 1;  // K-steps (the last one may hold a single real sub-step)
+    // split-K (p.ksplit > 1: skinny GEMMs -- few pixels, long K: the fully connected layers of VGG-16 at batch 64, ResNet layer4):
+    // grid.z workgroups take equal ranges of the K-steps and write raw fp32 partial sums; h16_splitk_reduce_kernel adds them in
+    // fixed order and applies the epilogue
+    const int ksp = p.ksplit > 1 ? p.ksplit : 1;
+    const int ks0 = (int)((int64_t)nk_all * blockIdx.z / ksp), ks1 = (int)((int64_t)nk_all * (blockIdx.z + 1) / ksp);
+    const int nk = ks1 - ks0;            // this workgroup's K-steps: ks0 + 0 .. ks0 + nk - 1
     const bool chunk_major = (cl.ntaps > 1) && (Cin > 32);
     const int cpt = Cin >> 5;            // 32-channel chunks per tap
 
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(64 * NW, (NW > 4 || NS > 2) ? 1 : 2) void tapconv_h
     constexpr int DPS = 4 + WPW;   // DMAs a wave issues per K-step (NS > 2: W_PIECES % NW == 0, every wave issues all of them)
 #pragma unroll
     for (int i = 0; i < NS - 1; ++i)
-        if (i < nk) H16_STAGE(i, i)
+        if (i < nk) H16_STAGE(ks0 + i, i)
     int cur = 0;
     for (int ks = 0; ks < nk; ++ks) {
         // own DMAs of step ks have landed (vmcnt) and everybody's have (barrier); every wave is also past its reads of
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(64 * NW, (NW > 4 || NS > 2) ? 1 : 2) void tapconv_h
         }
         if (ks + NS - 1 < nk) {
             const int nxt = cur == 0 ? NS - 1 : cur - 1;
-            H16_STAGE(ks + NS - 1, nxt)
+            H16_STAGE(ks0 + ks + NS - 1, nxt)
         }
         const unsigned char* sb = smem + cur * STAGE;
 #pragma unroll
@@ -216,6 +222,20 @@ __global__ __launch_bounds__(64 * NW, (NW > 4 || NS > 2) ? 1 : 2) void tapconv_h
         cur = cur == NS - 1 ? 0 : cur + 1;
     }
 #undef H16_STAGE
+
+    if (ksp > 1) {   // raw partial sums [split][M][npad] (npad = Cout rounded up to 128)
+        float* ws = p.splitk_ws + (size_t)blockIdx.z * M * npad;
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            const int m = m_blk + 32 * wave + 16 * ib + (lane & 15);
+            if (m < M) {
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    if (n_blk + 16 * j < npad) *reinterpret_cast<f32x4*>(ws + (size_t)m * npad + n_blk + 16 * j + 4 * (lane >> 4)) = acc[ib][j];
+            }
+        }
+        return;
+    }
 
     // ---- epilogue.  D layout of a 16x16 tile: column (lane & 15) = pixel, rows 4*(lane>>4) + i = 4 consecutive channels
     const bool vec = !((p.Cout | p.out_cstride | p.out_coff) & 3) &&
@@ -285,6 +305,25 @@ __global__ __launch_bounds__(64 * NW, (NW > 4 || NS > 2) ? 1 : 2) void tapconv_h
 #undef H16_EPI_IB
 }
 
+// second pass of split-K: out = epilogue( sum over the splits, in fixed order ), 4 channels per thread
+template <typename T>
+__global__ __launch_bounds__(256) void h16_splitk_reduce_kernel(const spaa_tapconv_t p, const int M, const int npad) {
+    const int nq = (p.Cout + 3) >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * nq) return;
+    const int m = (int)(idx / nq), n0 = (int)(idx - (int64_t)m * nq) * 4;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.ksplit; ++s) sum += *reinterpret_cast<const f32x4*>(p.splitk_ws + ((size_t)s * M + m) * npad + n0);
+    size_t o;
+    if (!out_pixel(p, p.cls[0], m, M, p.Hm * p.Wm, o)) return;
+    const bool vec = !((p.Cout | p.out_cstride | p.out_coff) & 3) &&
+                     (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
+                     (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
+                     (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
+    float v[4] = {sum[0], sum[1], sum[2], sum[3]};
+    store4_t<T>(p, o, n0, v, vec);
+}
+
 template <int NW, int BN, int NS = 2>
 int launch_h16(const spaa_tapconv_t& d, hipStream_t stream) {
     constexpr int BM = 32 * NW;
@@ -298,7 +337,7 @@ int launch_h16(const spaa_tapconv_t& d, hipStream_t stream) {
     if constexpr (NS == 2 && NW == 4 && BN >= 32 && BN <= 128) {
         int64_t kmin = 1 << 30;
         for (int c = 0; c < d.nclass; ++c) kmin = d.cls[c].K < kmin ? d.cls[c].K : kmin;
-        if ((int64_t)m_tiles * n_tiles * d.nclass <= 256 && kmin >= 16 * 64 && !((d.reserved0 >> 25) & 1)) return launch_h16<NW, BN, 4>(d, stream);
+        if ((int64_t)m_tiles * n_tiles * d.nclass * (d.ksplit > 1 ? d.ksplit : 1) <= 256 && kmin >= 16 * 64 * (d.ksplit > 1 ? d.ksplit : 1) && !((d.reserved0 >> 25) & 1)) return launch_h16<NW, BN, 4>(d, stream);
     }
     const size_t smem = NS * (size_t)(2 * BM * 64 + 2 * BN * 64);
     static bool attr_set[SPAA_MAX_DEVICES] = {};
@@ -306,8 +345,18 @@ int launch_h16(const spaa_tapconv_t& d, hipStream_t stream) {
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&tapconv_h16_kernel<NW, BN, NS>), (int)smem, attr_set);
         if (e != hipSuccess) return (int)e;
     }
-    dim3 grid(m_tiles * n_tiles, d.nclass, 1);
+    const int ksp = d.ksplit > 1 ? d.ksplit : 1;
+    if (ksp > 1 && (d.nclass != 1 || nfold > 1 || d.splitk_ws == nullptr)) return hipErrorInvalidValue;
+    dim3 grid(m_tiles * n_tiles, d.nclass, ksp);
     hipLaunchKernelGGL((tapconv_h16_kernel<NW, BN, NS>), grid, dim3(64 * NW), smem, stream, d, m_tiles, n_tiles);
+    if (ksp > 1) {
+        const int npad = (d.Cout + 127) & ~127;
+        const int64_t nthr = M * ((d.Cout + 3) >> 2);
+        if (d.io_dtype & SPAA_IO_OUT_F16)
+            hipLaunchKernelGGL(h16_splitk_reduce_kernel<_Float16>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, d, (int)M, npad);
+        else
+            hipLaunchKernelGGL(h16_splitk_reduce_kernel<float>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, d, (int)M, npad);
+    }
     return (int)hipGetLastError();
 }
 
@@ -315,7 +364,7 @@ int launch_h16(const spaa_tapconv_t& d, hipStream_t stream) {
 
 // called by spaa_tapconv_f32 (tapconv.hip) for tiles 60..65 after the common shape checks
 int spaa_launch_tapconv_h16(const spaa_tapconv_t& d, int tile, hipStream_t stream) {
-    if (!(d.io_dtype & SPAA_IO_IN_F16) || d.w_half == nullptr || (d.Cin % 32) != 0 || d.ksplit > 1 || d.ksplit < 0)
+    if (!(d.io_dtype & SPAA_IO_IN_F16) || d.w_half == nullptr || (d.Cin % 32) != 0 || d.ksplit < 0 || (d.ksplit > 1 && tile > 63))
         return hipErrorInvalidValue;
     const int nfold = d.nfold > 1 ? d.nfold : 1;
     for (int c = 0; c < d.nclass; ++c) {

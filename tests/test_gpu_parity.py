@@ -1665,6 +1665,52 @@ def test_tapconv_fp16_storage(hip, tile):
         cp.FORCE_TILE = 0
 
 
+def test_tapconv_fp16_split_k(hip):
+    """Split-K of the fp16 implicit-GEMM kernel (skinny GEMMs: a fully connected layer at batch 64, a 7 x 7 x 512 layer): raw fp32
+    partial sums + a fixed-order second pass with the epilogue; against fp64 on the same fp16-rounded operands and against the
+    unsplit kernel (same products, another summation order), fp16 and fp32 output, bias + ReLU + float gate."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(9)
+    try:
+        # linear layer: 64 samples, K = 6272 -> 520
+        k, n = 6272, 520
+        w = _h(torch.randn(n, k) / k ** 0.5)
+        bias = torch.randn(n)
+        x = _h(torch.randn(64, k))
+        ref = F.relu(x.double() @ w.double().t() + bias.double()).float()
+        plan = cp.linear_fwd_plan(w, bias, DEV, 'fc')
+        outs = {}
+        for ks in (1, 4, 7):
+            cp.FORCE_KSPLIT = ks
+            cp.FORCE_TILE = 61
+            y = torch.zeros(64, 1, 1, n, device=DEV, dtype=torch.float16)
+            plan.run(x.view(64, 1, 1, k).half().to(DEV), y, act=lib.ACT_RELU)
+            assert rel_inf(y.float().cpu().view(64, n), ref) < 1.5e-3, ks
+            y32 = torch.zeros(64, 1, 1, n, device=DEV)
+            plan.run(x.view(64, 1, 1, k).half().to(DEV), y32, act=lib.ACT_RELU)
+            assert rel_inf(y32.cpu().view(64, n), ref) < 2e-5, ks
+            outs[ks] = y32
+        assert rel_inf(outs[4], outs[1]) < 2e-6 and rel_inf(outs[7], outs[1]) < 2e-6
+        # 3x3 convolution on 7 x 7 maps, 512 -> 256, and its input gradient with a float gate
+        xc = _h(torch.randn(5, 512, 7, 7))
+        wc = _h(torch.randn(256, 512, 3, 3) / (512 * 9) ** 0.5)
+        yc = F.conv2d(xc.double(), wc.double(), None, 1, 1).float()
+        cplan = cp.conv_fwd_plan(wc, None, 1, 1, DEV)
+        cp.FORCE_KSPLIT, cp.FORCE_TILE = 6, 60
+        oc = torch.zeros(5, 7, 7, 256, device=DEV, dtype=torch.float16)
+        cplan.run(nhwc(xc).half().to(DEV), oc)
+        assert rel_inf(nchw(oc.float().cpu(), 256), yc) < 1.5e-3
+        gy = _h(torch.randn(5, 256, 7, 7))
+        gx_ref = torch.nn.grad.conv2d_input((5, 512, 7, 7), wc.double(), gy.double(), 1, 1).float()
+        gate = torch.randn(5, 7, 7, 512, device=DEV).half()
+        dplan = cp.conv_dgrad_plan(wc, 1, 1, DEV)
+        gx = torch.zeros(5, 7, 7, 512, device=DEV, dtype=torch.float16)
+        dplan.run(nhwc(gy).half().to(DEV), gx, gate=gate)
+        assert rel_inf(nchw(gx.float().cpu(), 512), gx_ref * (nchw(gate.float().cpu(), 512) > 0)) < 1.5e-3
+    finally:
+        cp.FORCE_KSPLIT, cp.FORCE_TILE = 0, 0
+
+
 def test_tapconv_fp16_patch_staged(hip):
     """fp16-storage 3x3 / stride-1 layers on the patch-staged kernel (csrc/tapconv_h16p.hip, tile 68): several workgroup tiles
     per image with ragged right / bottom edges, one and two channel tiles, the 64-wide instantiation; forward (residual + ReLU +
