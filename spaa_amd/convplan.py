@@ -344,8 +344,13 @@ class ConvPlan:
                         and b * ((d.Hm + 15) // 16) * ((d.Wm + 31) // 32) * ((ngemm + 127) // 128) >= 256
                         and d.Hm * d.Wm >= 0.6 * ((d.Hm + 15) // 16 * 16) * ((d.Wm + 31) // 32 * 32)):   # (16 x 32-pixel tiles)
                     tile = 68   # 3x3 / stride 1 (or a folded stride-2 transposed layer): the input patch staged once for all taps (csrc/tapconv_h16p.hip)
-                elif tile == 60 and (m_all + 127) // 128 * ((ngemm + 127) // 128) < 256 and 'h16n64' not in DEFAULT_DISABLE:
-                    tile = 61   # too few 128 x 128 tiles for 256 CUs (ResNet layer3 / layer4 at batch 64): twice as many of 128 x 64
+                elif tile == 60 and 'h16n64' not in DEFAULT_DISABLE and (
+                        (m_all + 127) // 128 * ((ngemm + 127) // 128) < 256 or
+                        (0 < ngemm % 128 <= 64 and (m_all + 127) // 128 * ((ngemm + 127) // 128) < 1024 and 'h16waste' not in DEFAULT_DISABLE)):
+                    # too few 128 x 128 tiles for 256 CUs (ResNet layer3 / layer4 at batch 64): twice as many of 128 x 64; or a last
+                    # 128-wide tile at most half full on a small grid (Inception-v3's 192-channel layers on 17 x 17 maps: 31 -> 26 us;
+                    # Inception f16 73.2 -> 75.0 it/s.  Preferring 128 x 64 for every small grid costs VGG-16 3 %: tools/lab/f16_tiles.py)
+                    tile = 61
                 # (the 256-row tiles 64 / 65 paid on the 64 x 64 3x3 layers, which the patch-staged kernel serves now; for what is
                 # left -- strided and folded layers -- 128 x 128 is as good or better: tools/lab/f16_tiles.py)
         elif out_f16:  # fp32 image in, fp16 activation out: any kernel built on the shared epilogue, without split-K

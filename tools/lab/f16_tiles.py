@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 import bench
 from spaa_amd import convplan
-st, *_ = bench.build_attack(0, 64, 256, 8, 'cuda:0', 'resnet18', 'f16')
+st, *_ = bench.build_attack(0, 64, 256, 8, 'cuda:0', sys.argv[1] if len(sys.argv) > 1 else 'resnet18', 'f16')
 hp = dict(targeted=True, d_thr=5, adv_lr=2, col_lr=1, p_thresh=0.9)
 st.iteration(**hp)
 torch.cuda.synchronize()
