@@ -91,20 +91,29 @@ __global__ void maxpool_fwd_kernel(const float4* __restrict__ in, float4* __rest
     const int b = r / Hout;
     float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     uchar4 am = make_uchar4(0, 0, 0, 0);
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy * 2 - 1 + ky;
-        if ((unsigned)iy >= (unsigned)Hin) continue;
+    // all nine window loads issued up front at clamped indices (a load under `continue` is waited for before the next is issued);
+    // positions outside the image are skipped in the comparison, in the same row-major order as before
+    float4 v[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox * 2 - 1 + kx;
-            if ((unsigned)ix >= (unsigned)Win) continue;
-            const float4 v = in[(((size_t)b * Hin + iy) * Win + ix) * C4 + c];
-            const unsigned char k = (unsigned char)(ky * 3 + kx);
-            if (v.x > best.x || v.x != v.x) { best.x = v.x; am.x = k; }
-            if (v.y > best.y || v.y != v.y) { best.y = v.y; am.y = k; }
-            if (v.z > best.z || v.z != v.z) { best.z = v.z; am.z = k; }
-            if (v.w > best.w || v.w != v.w) { best.w = v.w; am.w = k; }
+            const int iy = min(max(oy * 2 - 1 + ky, 0), Hin - 1), ix = min(max(ox * 2 - 1 + kx, 0), Win - 1);
+            v[3 * ky + kx] = in[(((size_t)b * Hin + iy) * Win + ix) * C4 + c];
         }
-    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+            const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+            const float4 t = v[3 * ky + kx];
+            const unsigned char k = (unsigned char)(ky * 3 + kx);
+            if (ok && (t.x > best.x || t.x != t.x)) { best.x = t.x; am.x = k; }
+            if (ok && (t.y > best.y || t.y != t.y)) { best.y = t.y; am.y = k; }
+            if (ok && (t.z > best.z || t.z != t.z)) { best.z = t.z; am.z = k; }
+            if (ok && (t.w > best.w || t.w != t.w)) { best.w = t.w; am.w = k; }
+        }
     // bit 7: the maximum is positive — the ReLU gate of the pooled tensor's producer, for the backward pass
     am.x |= best.x > 0.f ? 0x80 : 0;
     am.y |= best.y > 0.f ? 0x80 : 0;
@@ -114,7 +123,9 @@ __global__ void maxpool_fwd_kernel(const float4* __restrict__ in, float4* __rest
     argmax[idx] = am;
 }
 
-// backward as a gather over the (at most 4) windows covering each input pixel; optional ReLU gate of the input
+// backward as a gather over the (at most 4) windows covering each input pixel; optional ReLU gate of the input.  Branch-free:
+// the two candidate output rows / columns of a pixel are computed up front and all four (argmax byte, gradient) pairs are loaded
+// unconditionally at clamped indices (a load inside a branch makes the compiler wait for it before the next one is issued).
 __global__ void maxpool_bwd_kernel(const float4* __restrict__ g_out, const uchar4* __restrict__ argmax,
                                    const int relu_gate, float4* __restrict__ g_in, int B, int Hin,
                                    int Win, int C4, int Hout, int Wout) {
@@ -126,28 +137,40 @@ __global__ void maxpool_bwd_kernel(const float4* __restrict__ g_out, const uchar
     r /= Win;
     const int iy = r % Hin;
     const int b = r / Hin;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const unsigned char need = relu_gate ? 0x80 : 0x00;  // relu_gate: only windows whose maximum is positive pass
-    for (int ky = 0; ky < 3; ++ky) {
-        const int t = iy + 1 - ky;
-        if (t < 0 || (t & 1)) continue;
-        const int oy = t >> 1;
-        if (oy >= Hout) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-            const int s = ix + 1 - kx;
-            if (s < 0 || (s & 1)) continue;
-            const int ox = s >> 1;
-            if (ox >= Wout) continue;
+    // window (oy, ky) covers row iy when iy = 2 oy - 1 + ky: even iy -> (iy / 2, 1); odd iy -> ((iy + 1) / 2, 0) and ((iy - 1) / 2, 2)
+    int oyc[2], kyc[2], oxc[2], kxc[2];
+    bool yok[2], xok[2];
+    if (iy & 1) { oyc[0] = (iy + 1) >> 1; kyc[0] = 0; oyc[1] = (iy - 1) >> 1; kyc[1] = 2; yok[0] = oyc[0] < Hout; yok[1] = true; }
+    else        { oyc[0] = iy >> 1; kyc[0] = 1; oyc[1] = 0; kyc[1] = 0; yok[0] = oyc[0] < Hout; yok[1] = false; }
+    if (ix & 1) { oxc[0] = (ix + 1) >> 1; kxc[0] = 0; oxc[1] = (ix - 1) >> 1; kxc[1] = 2; xok[0] = oxc[0] < Wout; xok[1] = true; }
+    else        { oxc[0] = ix >> 1; kxc[0] = 1; oxc[1] = 0; kxc[1] = 0; xok[0] = oxc[0] < Wout; xok[1] = false; }
+    uchar4 am[4];
+    float4 g[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int oy = yok[i] ? oyc[i] : 0, ox = xok[j] ? oxc[j] : 0;
             const size_t o = (((size_t)b * Hout + oy) * Wout + ox) * C4 + c;
-            const uchar4 am = argmax[o];
-            const float4 g = g_out[o];
-            const unsigned char k = (unsigned char)(ky * 3 + kx);
-            if ((am.x & 0x7f) == k && (am.x & need) == need) acc.x += g.x;
-            if ((am.y & 0x7f) == k && (am.y & need) == need) acc.y += g.y;
-            if ((am.z & 0x7f) == k && (am.z & need) == need) acc.z += g.z;
-            if ((am.w & 0x7f) == k && (am.w & need) == need) acc.w += g.w;
+            am[2 * i + j] = argmax[o];
+            g[2 * i + j] = g_out[o];
         }
-    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (summation order of the old loop: ky ascending, kx ascending -- candidate 1 of an odd coordinate has the LARGER k: add it last)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = yok[i] && xok[j];
+            const unsigned char k = (unsigned char)(kyc[i] * 3 + kxc[j]);
+            const uchar4 a = am[2 * i + j];
+            const float4 v = g[2 * i + j];
+            if (ok && (a.x & 0x7f) == k && (a.x & need) == need) acc.x += v.x;
+            if (ok && (a.y & 0x7f) == k && (a.y & need) == need) acc.y += v.y;
+            if (ok && (a.z & 0x7f) == k && (a.z & need) == need) acc.z += v.z;
+            if (ok && (a.w & 0x7f) == k && (a.w & need) == need) acc.w += v.w;
+        }
     g_in[idx] = acc;
 }
 

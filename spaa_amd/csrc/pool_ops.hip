@@ -70,6 +70,40 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ g_out, const uchar4* __
     const int K = CK ? CK : g.k, S = CS ? CS : g.s, P = CK ? CP : g.p;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const unsigned char need = relu_gate ? 0x80 : 0x00;  // relu_gate: only windows whose maximum is positive pass
+    if constexpr (CK == 3 && CS == 2 && CP == 1) {
+        // branch-free (classifier_ops.hip: maxpool_bwd_kernel): the two candidate output rows / columns, four unconditional loads
+        int oyc[2], kyc[2], oxc[2], kxc[2];
+        bool yok[2], xok[2];
+        if (iy & 1) { oyc[0] = (iy + 1) >> 1; kyc[0] = 0; oyc[1] = (iy - 1) >> 1; kyc[1] = 2; yok[0] = oyc[0] < g.Hout; yok[1] = true; }
+        else        { oyc[0] = iy >> 1; kyc[0] = 1; oyc[1] = 0; kyc[1] = 0; yok[0] = oyc[0] < g.Hout; yok[1] = false; }
+        if (ix & 1) { oxc[0] = (ix + 1) >> 1; kxc[0] = 0; oxc[1] = (ix - 1) >> 1; kxc[1] = 2; xok[0] = oxc[0] < g.Wout; xok[1] = true; }
+        else        { oxc[0] = ix >> 1; kxc[0] = 1; oxc[1] = 0; kxc[1] = 0; xok[0] = oxc[0] < g.Wout; xok[1] = false; }
+        uchar4 am[4];
+        f4 gv[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const size_t opix = ((size_t)b * g.Hout + (yok[i] ? oyc[i] : 0)) * g.Wout + (xok[j] ? oxc[j] : 0);
+                am[2 * i + j] = argmax[opix * g.C4 + c];
+                gv[2 * i + j] = io4<T>::ld(g_out, 4 * (opix * gout_c4stride + gout_c4off + c));
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool ok = yok[i] && xok[j];
+                const unsigned char kk = (unsigned char)(kyc[i] * 3 + kxc[j]);
+                const uchar4 a = am[2 * i + j];
+                const f4 go = gv[2 * i + j];
+                if (ok && (a.x & 0x7f) == kk && (a.x & need) == need) acc.x += go.x;
+                if (ok && (a.y & 0x7f) == kk && (a.y & need) == need) acc.y += go.y;
+                if (ok && (a.z & 0x7f) == kk && (a.z & need) == need) acc.z += go.z;
+                if (ok && (a.w & 0x7f) == kk && (a.w & need) == need) acc.w += go.w;
+            }
+        io4<T>::st(g_in, 4 * (size_t)idx, f4{acc.x, acc.y, acc.z, acc.w});
+        return;
+    }
     for (int ky = 0; ky < K; ++ky) {
         const int t = iy + P - ky;
         if (t < 0 || (t % S)) continue;
