@@ -51,7 +51,43 @@ __global__ void preproc_bwd_kernel(const float4* __restrict__ g_out, float4* __r
     const int r = idx - b * H * W;
     const int py = r / W - cy0, px = r % W - cx0;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    if ((unsigned)py < (unsigned)ch && (unsigned)px < (unsigned)cw) {
+    if (ch >= oh && cw >= ow) {
+        // down-sampling (the attack's 240 -> 224): a pixel lies in at most TWO windows per axis.  Branch-free: the first two covering
+        // outputs among four fixed candidates per axis (selects, no indexed arrays), then the four gradients loaded unconditionally
+        // at clamped indices and added in row-major order (the order of the general path below: the same bits)
+        const bool in = (unsigned)py < (unsigned)ch && (unsigned)px < (unsigned)cw;
+        int oy2[2] = {-1, -1}, yl2[2] = {1, 1}, ox2[2] = {-1, -1}, xl2[2] = {1, 1};
+        const int oy_lo = max((py * oh) / ch - 1, 0), oy_hi = min(((py + 1) * oh + ch - 1) / ch, oh - 1);
+        const int ox_lo = max((px * ow) / cw - 1, 0), ox_hi = min(((px + 1) * ow + cw - 1) / cw, ow - 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int oy = oy_lo + k, ox = ox_lo + k;
+            const int ys = win_start(min(oy, oh - 1), oh, ch), ye = win_end(min(oy, oh - 1), oh, ch);
+            const int xs = win_start(min(ox, ow - 1), ow, cw), xe = win_end(min(ox, ow - 1), ow, cw);
+            const bool cy = in && oy <= oy_hi && py >= ys && py < ye, cx = in && ox <= ox_hi && px >= xs && px < xe;
+            const bool y0 = cy && oy2[0] < 0, y1 = cy && !y0 && oy2[1] < 0;
+            oy2[0] = y0 ? oy : oy2[0]; yl2[0] = y0 ? ye - ys : yl2[0];
+            oy2[1] = y1 ? oy : oy2[1]; yl2[1] = y1 ? ye - ys : yl2[1];
+            const bool x0 = cx && ox2[0] < 0, x1 = cx && !x0 && ox2[1] < 0;
+            ox2[0] = x0 ? ox : ox2[0]; xl2[0] = x0 ? xe - xs : xl2[0];
+            ox2[1] = x1 ? ox : ox2[1]; xl2[1] = x1 ? xe - xs : xl2[1];
+        }
+        float4 gv[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) gv[2 * i + j] = g_out[((size_t)b * oh + max(oy2[i], 0)) * ow + max(ox2[j], 0)];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool ok = oy2[i] >= 0 && ox2[j] >= 0;
+                const float inv = 1.f / (float)(yl2[i] * xl2[j]);
+                a0 += ok ? gv[2 * i + j].x * inv : 0.f;
+                a1 += ok ? gv[2 * i + j].y * inv : 0.f;
+                a2 += ok ? gv[2 * i + j].z * inv : 0.f;
+            }
+    } else if ((unsigned)py < (unsigned)ch && (unsigned)px < (unsigned)cw) {
         // outputs whose window covers p: o in [floor(p*out/in), ceil((p+1)*out/in) - 1] (+-1 for the float window
         // bounds); the covering ones are collected per axis first, then combined (row-major order, as before)
         int oys[5], ylen[5], oxs[5], xlen[5], ny = 0, nx = 0;
