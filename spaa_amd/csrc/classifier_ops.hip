@@ -83,9 +83,9 @@ __global__ void preproc_bwd_kernel(const float4* __restrict__ g_out, float4* __r
             for (int j = 0; j < 2; ++j) {
                 const bool ok = oy2[i] >= 0 && ox2[j] >= 0;
                 const float inv = 1.f / (float)(yl2[i] * xl2[j]);
-                a0 += ok ? gv[2 * i + j].x * inv : 0.f;
-                a1 += ok ? gv[2 * i + j].y * inv : 0.f;
-                a2 += ok ? gv[2 * i + j].z * inv : 0.f;
+                a0 = ok ? fmaf(gv[2 * i + j].x, inv, a0) : a0;   // (fused, as the compiler contracts the general path's a += g * inv)
+                a1 = ok ? fmaf(gv[2 * i + j].y, inv, a1) : a1;
+                a2 = ok ? fmaf(gv[2 * i + j].z, inv, a2) : a2;
             }
     } else if ((unsigned)py < (unsigned)ch && (unsigned)px < (unsigned)cw) {
         // outputs whose window covers p: o in [floor(p*out/in), ceil((p+1)*out/in) - 1] (+-1 for the float window

@@ -83,6 +83,9 @@ __global__ void finish_grid_kernel(const float4* __restrict__ coarse, const floa
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
 
+// (Kept in this form: restructuring the tap loads changes how the compiler contracts bilinear_setup's coordinate arithmetic at
+// this call site -- coordinates move by ~W * 2^-24 pixels, outputs by up to 1e-5 -- and with it the validated trajectories of
+// tests/test_gpu_parity.py::test_free_running_drift_vs_fp64_oracle; the 10 us it would save are not worth re-validating.)
 __global__ void warp_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ grid,
                                 const float* __restrict__ mask, const float4* __restrict__ s,
                                 float4* __restrict__ xw, float4* __restrict__ cat8, int B, int Hp, int Wp, int HWc,
@@ -93,36 +96,31 @@ __global__ void warp_fwd_kernel(const float4* __restrict__ x, const float4* __re
     const float4 g = grid[pix];
     const Bilinear bl = bilinear_setup(g.x, g.y, Wp, Hp);
     const float4* xb = x + (size_t)b * Hp * Wp;
-    // the four taps, the mask and the surface pixel are loaded up front at clamped addresses (a load inside a branch is waited for
-    // before the next one is issued: four dependent round trips); a tap outside the image gets weight 0 -- the same sums
-    const int ty[4] = {bl.y0, bl.y0, bl.y0 + 1, bl.y0 + 1}, tx[4] = {bl.x0, bl.x0 + 1, bl.x0, bl.x0 + 1};
-    const float tw[4] = {bl.nw, bl.ne, bl.sw, bl.se};
-    float4 tv[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) tv[t] = xb[min(max(ty[t], 0), Hp - 1) * Wp + min(max(tx[t], 0), Wp - 1)];
-    const float m = (mask != nullptr) ? mask[pix] : 1.f;
-    float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cat8 != nullptr) sv = s[idx];
     float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        if ((unsigned)ty[t] < (unsigned)Hp && (unsigned)tx[t] < (unsigned)Wp) {
-            float4 v = tv[t];
+    auto tap = [&](int yy, int xx, float wgt) {
+        if ((unsigned)yy < (unsigned)Hp && (unsigned)xx < (unsigned)Wp) {
+            float4 v = xb[yy * Wp + xx];
             if (clamp) {
                 v.x = clamp01(v.x);
                 v.y = clamp01(v.y);
                 v.z = clamp01(v.z);
             }
-            r0 += v.x * tw[t];
-            r1 += v.y * tw[t];
-            r2 += v.z * tw[t];
+            r0 += v.x * wgt;
+            r1 += v.y * wgt;
+            r2 += v.z * wgt;
         }
-    }
+    };
+    tap(bl.y0, bl.x0, bl.nw);
+    tap(bl.y0, bl.x0 + 1, bl.ne);
+    tap(bl.y0 + 1, bl.x0, bl.sw);
+    tap(bl.y0 + 1, bl.x0 + 1, bl.se);
+    const float m = (mask != nullptr) ? mask[pix] : 1.f;
     r0 *= m;
     r1 *= m;
     r2 *= m;
     xw[idx] = make_float4(r0, r1, r2, 0.f);
     if (cat8 != nullptr) {
+        const float4 sv = s[idx];
         cat8[2 * (size_t)idx] = make_float4(sv.x, sv.y, sv.z, r0 * sv.x);
         cat8[2 * (size_t)idx + 1] = make_float4(r1 * sv.y, r2 * sv.z, 0.f, 0.f);
     }
