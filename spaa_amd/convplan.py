@@ -314,11 +314,11 @@ class ConvPlan:
             tile = self._default_tile(b * d.Hm * d.Wm)
         thin_mf = (forced in (0, 72) and 'thinmf' not in DEFAULT_DISABLE and not out_f16 and not masked and self.thin_ok())
         if thin_mf and not in_f16:
-            # fp32 input (bf16x6: the 3-way operand split costs as much as the products): only where the VALU kernel is far from its
-            # bound -- four classes and a long K (ResNet stem 7 x 7: 253 against 325 us; conv1 3 x 3: 70 against 61; VGG-16's
-            # stride-1 first layer fills 4 of 16 rows: 498 against 270; tools/lab/thin_time.py).  fp16 input: always (57 against 307 us).
-            box = (self.tap_range[1] - self.tap_range[0] + 1) * (self.tap_range[3] - self.tap_range[2] + 1)
-            if forced == 72 or (self.s_out == 2 and box * self.cin_p >= 512):
+            # fp32 input (bf16x6: the 3-way operand split costs as much as the products): the stride-2 layers, whose four classes fill
+            # the tile's 16 rows (ResNet stem 7 x 7: 230 against 325 us on the VALU kernel; conv1 3 x 3: 52 against 61; Inception 1a
+            # 74 against 82); VGG-16's stride-1 first layer fills 4 of 16 rows: 465 against 265 (tools/lab/thin_time.py).  fp16 input:
+            # always (55 against 306 us).
+            if forced == 72 or self.s_out == 2:
                 tile = 72   # thin output: the parity classes folded into the N dimension of a matrix-core tile (csrc/tapconv_thinmf.hip)
         if tile == 70:   # Winograd form of a 3x3 / stride-1 layer (csrc/tapconv_wino.hip): fp32 storage, same-size output
             if self.wino is not None and WINOGRAD and not (in_f16 or out_f16) and (hin, win) == (hout, wout):

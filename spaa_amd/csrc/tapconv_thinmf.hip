@@ -6,7 +6,7 @@
 // layer has 3 outputs -- but a stride-2 layer's input gradient has FOUR output-parity classes that read the same input
 // neighbourhood: with N = 4 classes x 4 channels = 16 rows (weight rows of taps a class does not have are zero) one MFMA tile
 // produces the 2 x 2 output pixels of a class-grid position.  Stem: K = 16 taps x 64 channels, 77 % of the products are real.
-//   * workgroup = 8 waves = 12 rows x 32 columns of the class grid; wave = 3 rows x 16 columns;
+//   * workgroup = 8 waves = 12 (fp32 input: 8) rows x 32 columns of the class grid; wave = 3 (2) rows x 16 columns;
 //   * the input patch ((12 + TBH - 1) x (32 + TBW - 1) pixels of a 32-channel block; TBH x TBW <= 4 x 4 = the tap box) is staged
 //     once by LDS-DMA (out-of-image = out-of-range offset = zeros), double-buffered over the channel blocks;
 //   * K order: channel block, then tap COLUMN dx: a wave reads the 3 + TBH - 1 pixel-row fragments of that column once (fp32: two
@@ -62,12 +62,14 @@ __device__ __forceinline__ void split8(const f32x4 x0, const f32x4 x1, bf16x8& h
     l = __builtin_bit_cast(bf16x8, ll);
 }
 
-constexpr int TR = 12, TW = 32, RW = 3;   // class-grid rows x columns of a workgroup; rows of a wave
+constexpr int TW = 32;   // class-grid columns of a workgroup (rows: 4 RW, RW = rows of a wave: template parameter)
 constexpr int NW = 8;
 
-// HIN: fp16 input (one weight plane, one MFMA per product); TBH: rows of the tap box (2..4)
-template <bool HIN, int TBH>
-__global__ __launch_bounds__(512, 1) void thinmf_kernel(const spaa_tapconv_t p, const int tiles_y, const int tiles_x, const int TBW,
+// HIN: fp16 input (one weight plane, one MFMA per product); TBH: rows of the tap box (2..4); RW: class-grid rows per wave (the
+// workgroup covers 4 RW rows); PDB: the patch double-buffered over the channel blocks.  fp32 input runs RW = 2 with a SINGLE patch
+// buffer (49 + 24 KiB: two workgroups per CU cover each other's load phases; 3 / double-buffered needs 156 KiB = one per CU)
+template <bool HIN, int TBH, int RW, bool PDB>
+__global__ __launch_bounds__(512, PDB ? 1 : 2) void thinmf_kernel(const spaa_tapconv_t p, const int tiles_y, const int tiles_x, const int TBW,
                                                         const int npieces) {
     constexpr int PB = HIN ? 64 : 128;     // bytes of a staged pixel (32 channels)
     constexpr int CPP = PB / 16;           // 16-byte chunks per pixel
@@ -75,7 +77,8 @@ __global__ __launch_bounds__(512, 1) void thinmf_kernel(const spaa_tapconv_t p, 
     constexpr int NPL = HIN ? 1 : 3;       // weight planes
     constexpr int WST = NPL * TBH;         // 1-KiB weight pieces per step (one tap column of one channel block)
     constexpr int NB = RW + TBH - 1;       // pixel-row fragments a wave reads per step
-    constexpr int PPWMAX = HIN ? 5 : 9;    // patch pieces per wave at most (15 x 35 pixels)
+    constexpr int TR = 4 * RW;
+    constexpr int PPWMAX = ((TR + 3) * (TW + 3) + PPP - 1) / PPP / NW + 1;   // patch pieces per wave at most
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(512, 1) void thinmf_kernel(const spaa_tapconv_t p, 
     const int PW = TW + TBW - 1;
     const int NPX = (TR + TBH - 1) * PW;
     const int pbuf = npieces * 1024;                       // bytes of a patch buffer
-    unsigned char* const wsm = smem + 2 * pbuf;            // two weight stages of WST KiB
+    unsigned char* const wsm = smem + (PDB ? 2 : 1) * pbuf;   // two weight stages of WST KiB
 
     int img, y0, x0;
     {
@@ -148,13 +151,19 @@ __global__ __launch_bounds__(512, 1) void thinmf_kernel(const spaa_tapconv_t p, 
     dma_w(0, 0);
     for (int s = 0; s < nsteps; ++s) {
         const int kb = s / TBW, dxi = s - kb * TBW;
+        if (!PDB && dxi == 0 && kb > 0) {   // single patch buffer: everybody is done with the previous block's patch
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            dma_patch(0, kb, 0, 1);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this step's weights, and the patch pieces requested so far, have landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (s + 1 < nsteps) dma_w((s + 1) & 1, s + 1);
-        if (kb + 1 < nkb) dma_patch((kb + 1) & 1, kb + 1, dxi, TBW);   // (a share per step: every wait above stays short)
-        const unsigned char* pbase = smem + (kb & 1) * pbuf;
+        if (PDB && kb + 1 < nkb) dma_patch((kb + 1) & 1, kb + 1, dxi, TBW);   // (a share per step: every wait above stays short)
+        const unsigned char* pbase = smem + (PDB ? (kb & 1) : 0) * pbuf;
         const unsigned char* wbase = wsm + (s & 1) * (WST * 1024) + w_addr_l;
         if constexpr (HIN) {
             h8 bf[NB];
@@ -282,25 +291,25 @@ int spaa_launch_tapconv_thinmf(const spaa_tapconv_t& d, hipStream_t stream) {
     if (d.Hm != (d.Hout + d.s_out - 1) / d.s_out || d.Wm != (d.Wout + d.s_out - 1) / d.s_out) return hipErrorInvalidValue;
     if ((int64_t)d.B * d.Hin * d.Win * d.in_cstride * (hin ? 2 : 4) >= (int64_t)1 << 31) return hipErrorInvalidValue;
     const int th = tbh < 2 ? 2 : tbh;   // (a one-row box runs as two rows with zero weights: convplan packs it that way)
-    const int pw = TW + tbw - 1, npx = (TR + th - 1) * pw;
+    const int rw = hin ? 3 : 2, tr = 4 * rw;
+    const int pw = TW + tbw - 1, npx = (tr + th - 1) * pw;
     const int ppp = hin ? 16 : 8;
     const int npieces = (npx + ppp - 1) / ppp;
-    if (npieces > NW * (hin ? 5 : 9)) return hipErrorInvalidValue;
-    const int tiles_y = (d.Hm + TR - 1) / TR, tiles_x = (d.Wm + TW - 1) / TW;
+    const int tiles_y = (d.Hm + tr - 1) / tr, tiles_x = (d.Wm + TW - 1) / TW;
     const int64_t nwg = (int64_t)d.B * tiles_y * tiles_x;
     if (nwg > 0x7fffffff) return hipErrorInvalidValue;
-    const size_t smem = 2 * (size_t)npieces * 1024 + 2 * (size_t)(hin ? 1 : 3) * th * 1024;
+    const size_t smem = (hin ? 2 : 1) * (size_t)npieces * 1024 + 2 * (size_t)(hin ? 1 : 3) * th * 1024;
     static bool attr_set[6][SPAA_MAX_DEVICES] = {};
-#define THINMF_LAUNCH(H, T, SLOT)                                                                                          \
+#define THINMF_LAUNCH(H, T, R, D, SLOT)                                                                                    \
     {                                                                                                                      \
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&thinmf_kernel<H, T>), 160 * 1024, attr_set[SLOT]); \
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&thinmf_kernel<H, T, R, D>), 160 * 1024, attr_set[SLOT]); \
         if (e != hipSuccess) return (int)e;                                                                                \
-        hipLaunchKernelGGL((thinmf_kernel<H, T>), dim3((unsigned)nwg), dim3(512), smem, stream, d, tiles_y, tiles_x, tbw, npieces); \
+        hipLaunchKernelGGL((thinmf_kernel<H, T, R, D>), dim3((unsigned)nwg), dim3(512), smem, stream, d, tiles_y, tiles_x, tbw, npieces); \
     }
     if (hin) {
-        if (th == 2) THINMF_LAUNCH(true, 2, 0) else if (th == 3) THINMF_LAUNCH(true, 3, 1) else THINMF_LAUNCH(true, 4, 2)
+        if (th == 2) THINMF_LAUNCH(true, 2, 3, true, 0) else if (th == 3) THINMF_LAUNCH(true, 3, 3, true, 1) else THINMF_LAUNCH(true, 4, 3, true, 2)
     } else {
-        if (th == 2) THINMF_LAUNCH(false, 2, 3) else if (th == 3) THINMF_LAUNCH(false, 3, 4) else THINMF_LAUNCH(false, 4, 5)
+        if (th == 2) THINMF_LAUNCH(false, 2, 2, false, 3) else if (th == 3) THINMF_LAUNCH(false, 3, 2, false, 4) else THINMF_LAUNCH(false, 4, 2, false, 5)
     }
 #undef THINMF_LAUNCH
     return (int)hipGetLastError();
