@@ -101,7 +101,9 @@ typedef struct {
     int32_t reserved0;    /* measurement switches (A/B runs of kernel variants: spaa_amd/convplan.py DEBUG_*); 0 in production */
     int32_t io_dtype;     /* fp16-STORAGE mode (BASELINE.json configs[4]: "fp16 with fp32 dE2000"), bit flags:
                              SPAA_IO_IN_F16  (tiles 60..65; tile 68: 3x3 / stride-1 layers with the input patch staged once in LDS;
-                                             tile 72: thin outputs with the parity classes folded into N, fp32 out;
+                                             tile 72: thin outputs with the parity classes folded into N, fp32 out (with a
+                                             4-channel pixel stride, offset 0 and Cout < 4 its 16-byte stores write ZERO into
+                                             the pad channels Cout..3; every other tile leaves channels >= Cout untouched);
                                              tile 29 with an fp32 output of at most 4 channels: the image-side input
                                              gradients): `in` is fp16 NHWC (strides / offsets still in elements) and the
                                              weights come from `w_half`; fp32 accumulation on v_mfma_f32_16x16x32_f16;

@@ -24,6 +24,7 @@ import os
 # B * Hc * Wc up to which spaa() replays the iteration as a captured HIP graph (0 disables); above it the GPU is busy for
 # longer than the host needs to enqueue an iteration and eager launches lose nothing (measured: < 1 % at B = 64, 256 x 256)
 GRAPH_MAX_PIXELS = int(os.environ.get('SPAA_GRAPH_MAX_PIXELS', str(16 * 256 * 256)))
+LAST_RUN = {}   # of the last spaa() call: executed iterations (1 eager + iters - 1 replays = iters: a capture executes nothing), graph or not
 
 
 def _unwrap(m):
@@ -175,12 +176,23 @@ def spaa(pcnet, classifier, imagenet_labels, target_idx, targeted, cam_scene, d_
         # captured ONCE as a HIP graph (after one eager iteration: kernel attributes and workspaces exist) and replayed.
         with torch.cuda.device(st.dev):
             st.iteration(targeted, d_thr, adv_lr, col_lr, p_thresh)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                st.iteration(targeted, d_thr, adv_lr, col_lr, p_thresh)
-            for _ in range(iters - 1):
-                graph.replay()
+            done = 1
+            try:
+                # (thread-local: GPU calls of OTHER threads -- a loader's pin-memory thread, another attack -- do not abort it)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    st.iteration(targeted, d_thr, adv_lr, col_lr, p_thresh)   # (recorded, not executed)
+            except RuntimeError:
+                graph = None     # the capture was refused: the remaining iterations run kernel by kernel, same results
+            while done < iters:
+                if graph is not None:
+                    graph.replay()
+                else:
+                    st.iteration(targeted, d_thr, adv_lr, col_lr, p_thresh)
+                done += 1
+        LAST_RUN.update(iterations=done, graph=graph is not None)
         return st.results()
+    LAST_RUN.update(iterations=iters, graph=False)
     for i in range(iters):
         st.iteration(targeted, d_thr, adv_lr, col_lr, p_thresh)
         if trace is not None:

@@ -1323,10 +1323,19 @@ def test_reference_call_shapes_graph_replay(hip):
     targets = list(syn.IMAGENET10_TARGETS)
     assert len(targets) * cam[0] * cam[1] <= A.GRAPH_MAX_PIXELS
     cam_g, prj_g = A.spaa(pc, clf, None, targets, True, scene, 5, 'camdE_caml2', DEV, setup, iters=8)
+    assert A.LAST_RUN == dict(iterations=8, graph=True)   # 1 eager + 7 replays (the capture executes nothing)
     tr = []   # (a trace switches the graph off: eager launches)
     cam_e, prj_e = A.spaa(pc, clf, None, targets, True, scene, 5, 'camdE_caml2', DEV, setup, iters=8, trace=tr)
     assert len(tr) == 8 and torch.equal(cam_g, cam_e) and torch.equal(prj_g, prj_e)
     assert prj_g.shape == (10, 3, 256, 256) and cam_g.shape == (10, 3, 240, 320)
+    # the same with the graph switched off by its size limit (the path a refused capture falls back to)
+    old = A.GRAPH_MAX_PIXELS
+    try:
+        A.GRAPH_MAX_PIXELS = 0
+        cam_0, prj_0 = A.spaa(pc, clf, None, targets, True, scene, 5, 'camdE_caml2', DEV, setup, iters=8)
+    finally:
+        A.GRAPH_MAX_PIXELS = old
+    assert A.LAST_RUN == dict(iterations=8, graph=False) and torch.equal(cam_0, cam_g) and torch.equal(prj_0, prj_g)
 
 
 @pytest.mark.parametrize('cam,prj,b', [((64, 64), (64, 64), 5), ((240, 320), (256, 256), 3), ((48, 80), (64, 64), 9), ((256, 256), (256, 256), 6)])
@@ -2172,7 +2181,7 @@ def test_rccl_path_single_rank():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'nccl_child.py')], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and 'RCCL_SINGLE_RANK_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '2', '--warmup', '1', '--no-cpu-baseline'],
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-modes'],
                        capture_output=True, text=True, timeout=600, env=dict(env, SPAA_BENCH_FORCE_DIST='1'))
     assert r.returncode == 0, r.stderr[-4000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
