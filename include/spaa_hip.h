@@ -71,7 +71,7 @@ typedef struct {
     const float* gate;    /* indexed like `out`, or NULL */
     int32_t gate_cstride, gate_coff, gate_mode;
     int32_t act;
-    int32_t tile;         /* 0 = auto; 1..54, 60..65, 68, 70, 72 = explicit kernel / workgroup tile (the dispatcher in tapconv.hip lists them;
+    int32_t tile;         /* 0 = auto; 1..54, 60..65, 68, 70, 71, 72 = explicit kernel / workgroup tile (the dispatcher in tapconv.hip lists them;
                              spaa_amd/convplan.py: TILE_NAMES; chosen per layer shape by tools/autotune.py) */
     float* aux_out;       /* optional second output (indexed like `out`):
                              act == SPAA_ACT_RELU_CLAMP1: the value BEFORE the clamp;
@@ -126,6 +126,14 @@ int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream);
  *   (train_network.py:316). */
 int spaa_tapconv_wgrad(const spaa_tapconv_t* desc, const float* gout, float* dw_packed, float* dbias, float* workspace,
                        int nchunk, spaa_stream_t stream);
+/* Launch plan of the Winograd F(2x2,3x3) form (tiles 70 / 71; `desc` as for spaa_tapconv_f32 with a 16-position weight matrix):
+ * host-side query, nothing is launched.  plan[0..7] = { N tile (64 / 128), K ranges, canvas layout (0 / 1), images per canvas
+ * (rows), (columns), workgroups, 32-channel blocks per K range, canvases }.  Small images (ResNet-18 layer3 / layer4 behind
+ * classifier.py:26-28, 14 x 14 and 7 x 7) are laid out on virtual canvases so that the 16 x 32-pixel workgroup regions are full,
+ * and few regions with long K are cut into K ranges summed in fixed order by a second kernel: a caller sizes `splitk_ws`
+ * (plan[1] * B * H * W * Npad floats) from the plan and passes plan[1] back as `ksplit` (ksplit = 1: never split; 0 with a
+ * workspace: the launcher's own choice, which this function reports). */
+int spaa_tapconv_wino_plan(const spaa_tapconv_t* desc, int32_t* plan);
 /* layout probes for language bindings: sizeof(spaa_tapconv_t) and the byte offset of field # `field`
  * (0 out, 1 weights, 2 taps, 3 gate2, 4 mask_out, 5 tap_range, 6 splitk_ws, 7 io_dtype, 8 nclass, 9 cls; else -1) */
 int spaa_tapconv_sizeof(void);

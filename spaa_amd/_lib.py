@@ -109,7 +109,7 @@ _SIGNATURES = {
     'spaa_zero': [_p, _l, _p],
 }
 
-EXPORTS = sorted(list(_SIGNATURES) + ['spaa_version', 'spaa_tapconv_sizeof', 'spaa_tapconv_offsetof'])
+EXPORTS = sorted(list(_SIGNATURES) + ['spaa_version', 'spaa_tapconv_sizeof', 'spaa_tapconv_offsetof', 'spaa_tapconv_wino_plan'])
 
 _lib = None
 
@@ -131,6 +131,8 @@ def load():
     lib.spaa_tapconv_sizeof.restype = C.c_int
     lib.spaa_tapconv_offsetof.argtypes = [C.c_int]
     lib.spaa_tapconv_offsetof.restype = C.c_int
+    lib.spaa_tapconv_wino_plan.argtypes = [C.POINTER(TapConv), C.POINTER(C.c_int32)]   # (host-side query: no stream)
+    lib.spaa_tapconv_wino_plan.restype = C.c_int
     _lib = lib
     return lib
 

@@ -34,17 +34,19 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               48: 'x6d16p_128x128', 49: 'x6d16p_128x64', 50: 'x6d16a3p_128x64', 51: 'x6da3p_128x64', 52: 'x6d16p_256x128',
               53: 'x6d16p_128x32', 54: 'x6dp_128x128',
               60: 'h16_128x128', 61: 'h16_128x64', 62: 'h16_128x32', 63: 'h16_128x16', 64: 'h16_256x128', 65: 'h16_256x256', 68: 'h16p_16x32x128', 72: 'thinmf_12x32',
-              70: 'wino_x6_16x32x128', 71: 'wino_x6_16x32x64'}   # (71: reporting only: tile 70 run by its 64-wide instantiation)
+              70: 'wino_x6_16x32x128', 71: 'wino_x6_16x32x64'}   # (70: the launcher chooses the N tile -- reported as 71 when it took 64; 71: 64-wide forced)
 X6D_TILES = set(range(25, 28)) | set(range(30, 38)) | set(range(39, 47)) | set(range(48, 55))   # DMA-staged bf16x6 kernels (csrc/tapconv_x6d.hip)
 X6D_PERSISTENT = set(range(48, 55))      # ... of which the persistent ones (stream-K capable)
 H16_TILES = set(range(60, 66))           # fp16 implicit-GEMM kernels (csrc/tapconv_h16.hip); 68 = patch-staged 3x3 (tapconv_h16p.hip)
-STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 66)) | {68, 70}  # shared epilogue (epilogue.hpp)
+STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 66)) | {68, 70, 71}  # shared epilogue (epilogue.hpp)
 F16OUT_TILES = set(range(15, 25)) | {38} | set(range(60, 66))  # ... of which these may write fp16 (fp32 image in, fp16 activation out)
 DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
 DEBUG_TAPMAJOR = int(os.environ.get('SPAA_X6D_TAPMAJOR', '0'))      # 1: tap-major K order (A/B measurements only)
 DEBUG_PERSIST_CAP = int(os.environ.get('SPAA_X6D_PERSIST_CAP', '0'))  # > 0: persistent launches use this many workgroups
 FORCE_KSPLIT = int(os.environ.get('SPAA_FORCE_KSPLIT', '0'))        # split-K factor of the fp16 implicit-GEMM kernel (A/B runs, tests)
 DEBUG_WINO = int(os.environ.get('SPAA_WINO_DBG', '0'))              # timing experiments of the Winograd kernel
+DEBUG_WINO_NOCANVAS = int(os.environ.get('SPAA_WINO_NOCANVAS', '0'))  # 1: small images keep the image-aligned workgroup regions (A/B); 2: canvas wherever it has fewer regions (tests)
+WINO_SPLITK = os.environ.get('SPAA_WINO_SPLITK', '1') != '0'        # Winograd layers with few workgroups and long K: K ranges + ordered second pass
 DEBUG_THINMF = int(os.environ.get('SPAA_THINMF_DBG', '0'))           # timing experiments of csrc/tapconv_thinmf.hip (builds with -DSPAA_THINMF_ABLATE)
 DEBUG_SMALLCIN_NOSLAB = int(os.environ.get('SPAA_SMALLCIN_NOSLAB', '0'))  # 1: stride-2 smallcin layers store from the MFMA layout (A/B)
 DEBUG_H16_2STAGE = int(os.environ.get('SPAA_H16_2STAGE', '0'))      # 1: the fp16 implicit-GEMM kernel never takes its four-stage form (A/B measurements)
@@ -320,8 +322,10 @@ class ConvPlan:
             # always (55 against 306 us).
             if forced == 72 or self.s_out == 2:
                 tile = 72   # thin output: the parity classes folded into the N dimension of a matrix-core tile (csrc/tapconv_thinmf.hip)
-        if tile == 70:   # Winograd form of a 3x3 / stride-1 layer (csrc/tapconv_wino.hip): fp32 storage, same-size output
+        if tile % 100 in (70, 71):   # Winograd form of a 3x3 / stride-1 layer (csrc/tapconv_wino.hip): fp32 storage, same-size output
+            # (tune values: 70 = the launcher's choice of N tile and K ranges, 71 = 64-wide N tile; + 100 k = k K ranges, k = 1: none)
             if self.wino is not None and WINOGRAD and not (in_f16 or out_f16) and (hin, win) == (hout, wout):
+                self.wino.fixed_tile, self.wino.wino_ksplit = tile % 100, tile // 100
                 return self.wino.run(inp, out, add, gate, gate_mode, act, aux_out, gate2, in_coff, out_coff, add_coff, gate_coff,
                                      mask_out, gate_bits, gate2_bits)
             tile = 0 if forced else self._default_tile(b * d.Hm * d.Wm, winograd=False)
@@ -409,19 +413,35 @@ class ConvPlan:
             else:
                 d.w_split = self.thin_fold(False).data_ptr()
         d.tile = self.last_tile = tile     # (last_tile: for tests and reports)
-        d.reserved0 = DEBUG_TAPMAJOR | (DEBUG_PERSIST_CAP << 8) | (DEBUG_WINO << 16) | (DEBUG_H16_2STAGE << 25) | (DEBUG_SMALLCIN_NOSLAB << 26) | (DEBUG_THINMF << 27)  # measurement / test switches of the x6d kernels
+        d.reserved0 = (DEBUG_TAPMAJOR | (DEBUG_PERSIST_CAP << 8) | (DEBUG_WINO << 16) | (DEBUG_H16_2STAGE << 25) | (DEBUG_SMALLCIN_NOSLAB << 26)
+                       | ((DEBUG_THINMF & 7) << 27) | (((DEBUG_WINO_NOCANVAS & 1) << 30 | (DEBUG_WINO_NOCANVAS >> 1 & 1) << 29) if tile in (70, 71) else 0))  # measurement / test switches
         d.nclass = len(self.cls)
         d.tap_range[:] = self.tap_range
         for i, c in enumerate(self.cls):
             for k, v in c.items():
                 setattr(d.cls[i], k, v)
+        wino_bn = 0
+        if tile in (70, 71):
+            # the launcher's plan (csrc/tapconv_wino.hip: N tile, canvas layout for small images, K ranges for few workgroups with
+            # long K) -- asked for here because the K ranges need a workspace; its K-range count is then passed back explicitly
+            want = getattr(self, 'wino_ksplit', 0)
+            d.ksplit = want if WINO_SPLITK else 1
+            wp = (C.c_int32 * 8)()
+            rc = _lib.load().spaa_tapconv_wino_plan(C.byref(d), wp)
+            if rc != 0:
+                raise RuntimeError(f'{self.name}: spaa_tapconv_wino_plan failed with HIP error {rc}')
+            wino_bn, d.ksplit = wp[0], wp[1]
+            self.last_wino_plan = tuple(wp)
+            if d.ksplit > 1:
+                need = d.ksplit * b * hout * wout * ((self.cout + 127) // 128 * 128)
+                if self._ws is None or self._ws.numel() < need:
+                    self._ws = torch.empty(need, device=inp.device, dtype=torch.float32)
+                d.splitk_ws = self._ws.data_ptr()
         tid = 0
         if PROFILE is not None:
             tid = d.tile + 100 * (d.ksplit if d.ksplit > 1 else (9 if d.ksplit == -1 else 0))
-            if d.tile == 70:   # the launcher's choice of the N tile (csrc/tapconv_wino.hip): a kernel of its own for rocprofv3
-                ncu = torch.cuda.get_device_properties(inp.device).multi_processor_count
-                if self.cout <= 64 or b * ((hout + 15) // 16) * ((wout + 31) // 32) * ((self.cout + 127) // 128) < ncu:
-                    tid = 71
+            if d.tile == 70 and wino_bn == 64:   # the launcher's choice of the N tile: a kernel of its own for rocprofv3
+                tid += 1
         if PROFILE is None or (PROFILE_ONLY is not None and tid not in PROFILE_ONLY):
             _lib.call('spaa_tapconv_f32', C.byref(d))
         else:  # bench.py's instrumented pass: HIP events on the launch stream around this one kernel

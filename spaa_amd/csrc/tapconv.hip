@@ -557,7 +557,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         // byte masks (1 byte per 4 channels): only the epilogues built on epilogue.hpp's store4 know them, and only in its
         // 4-channel-vector form
         const int t = d.tile;
-        if (!((t >= 15 && t <= 27) || (t >= 30 && t <= 46) || (t >= 48 && t <= 54) || (t >= 60 && t <= 65) || t == 68 || t == 70)) return hipErrorInvalidValue;
+        if (!((t >= 15 && t <= 27) || (t >= 30 && t <= 46) || (t >= 48 && t <= 54) || (t >= 60 && t <= 65) || t == 68 || t == 70 || t == 71)) return hipErrorInvalidValue;
         if ((d.Cout | d.out_cstride | d.out_coff) & 3) return hipErrorInvalidValue;
         if (d.add != nullptr && ((d.add_cstride | d.add_coff) & 3)) return hipErrorInvalidValue;
         if (d.gate_bits != nullptr && (d.gate != nullptr || ((d.gate_cstride | d.gate_coff) & 3))) return hipErrorInvalidValue;
@@ -656,7 +656,8 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         case 64:
         case 65: return spaa_launch_tapconv_h16(d, tile, stream);
         case 68: return spaa_launch_tapconv_h16p(d, stream);
-        case 70: return spaa_launch_tapconv_wino(d, stream);
+        case 70:
+        case 71: return spaa_launch_tapconv_wino(d, stream);
         case 72: return spaa_launch_tapconv_thinmf(d, stream);
         default: return hipErrorInvalidValue;
     }

@@ -90,8 +90,22 @@ __device__ __forceinline__ void wg_barrier() {
     }
 }
 
-template <int BN, int VAR, int DBG = 0>   // DBG: timing-only ablations (wrong results): 1 no epilogue, 2 no fold, 4 no V, 8 no barrier, 16 no DMA; 32: raw barrier
-__global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p, const int wg_y, const int wg_x, const int n_tiles) {
+// Small images (ResNet layer3 / layer4: 14 x 14 and 7 x 7; Inception-v3 35 x 35; VGG-16 14 x 14) would leave most of a 16 x 32-pixel
+// workgroup region empty.  CANVAS mode lays the images of the batch out on virtual canvases -- gy x gx images with periods
+// (py, px) >= (H + 1, W + 1): the gap row / column between two images is the zero padding of both -- and the workgroup regions tile
+// the CANVAS: Winograd tiles that straddle a gap compute a discarded output next to a real one, nothing else changes (the patch
+// DMA maps a canvas pixel to (image, y, x) or to the out-of-range offset, the epilogue maps it back).  Few workgroups with long K
+// (layer4: 8 regions x 4 N tiles, 16 channel blocks) are cut along K: split ks computes channel blocks [ks * kb_per, ...) into
+// the fp32 workspace [split][pixel][Npad], wino_splitk_reduce_kernel adds the splits in fixed order and applies the epilogue.
+struct wino_geo_t {
+    int ksplit, kb_per;        // K ranges (1 = off) and 32-channel blocks per range
+    int gy, gx, py, px;        // canvas: images per canvas (rows x columns) and their periods in pixels
+    unsigned int my, mx;       // v / py == (v * my) >> 20 for every canvas coordinate v (launcher: canvas sides <= 4095, periods <= 255)
+    int nsp;                   // workgroup regions of all canvases together
+};
+
+template <int BN, int VAR, int DBG = 0, bool CV = false>   // DBG: timing-only ablations (wrong results): 1 no epilogue, 2 no fold, 4 no V, 8 no barrier, 16 no DMA; 32: raw barrier.  CV: canvas / split-K form
+__global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p, const int wg_y, const int wg_x, const int n_tiles, const wino_geo_t geo) {
     constexpr int TJ = BN / 16;
     constexpr int W_PLANE = BN * 64;
     constexpr int NW = 8;
@@ -108,12 +122,21 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
     const int Cin = p.Cin, H = p.Hin, W = p.Win;
 
     // XCD-aware order over (image, patch row, patch column, n tile): an XCD takes a contiguous range
-    int n_blk, img, oy0, ox0;
+    int n_blk, img, oy0, ox0, ks = 0;   // (CV: img = the canvas, (oy0, ox0) = the region's origin on it)
     {
         const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
         int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-        n_blk = (t % n_tiles) * BN;
-        t /= n_tiles;
+        if constexpr (CV) {
+            // regions fastest: the workgroups of an XCD share ONE (N tile, K range) slice of the weights (layer4: 25 MB of planes
+            // against 4 MB of L2 per XCD)
+            const int combo = t / geo.nsp;
+            t -= combo * geo.nsp;
+            n_blk = (combo % n_tiles) * BN;
+            ks = combo / n_tiles;
+        } else {
+            n_blk = (t % n_tiles) * BN;
+            t /= n_tiles;
+        }
         ox0 = (t % wg_x) * (2 * TX);
         t /= wg_x;
         oy0 = (t % wg_y) * (2 * TY);
@@ -163,11 +186,23 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
 #pragma unroll
         for (int j = 0; j < TJ; ++j) Y[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nkb = Cin >> 5;           // 32-channel blocks
+    // 32-channel blocks of this workgroup: all of them, or (CV) the K range [kb0, kb0 + nkb)
+    const int kb0 = CV ? ks * geo.kb_per : 0;
+    const int nkb = CV ? ((Cin >> 5) - kb0 < geo.kb_per ? (Cin >> 5) - kb0 : geo.kb_per) : (Cin >> 5);
     const int nsteps = nkb * 16;        // (block, position) steps
+    const int ipc = CV ? geo.gy * geo.gx : 1;   // images per canvas
+    // canvas pixel (vy, vx) of canvas `img` -> image pixel index; false: a gap, past the last image, off the canvas
+    auto canvas_pixel = [&](const int vy, const int vx, int& o) -> bool {
+        // (24-bit multiplications, full rate: coordinates <= 4095, multipliers < 2^19, B * H * W < 2^24 -- the launcher checks)
+        const int sy = (int)(__umul24((unsigned int)vy, geo.my) >> 20), sx = (int)(__umul24((unsigned int)vx, geo.mx) >> 20);
+        const int iy = vy - (int)__umul24(sy, geo.py), ix = vx - (int)__umul24(sx, geo.px);
+        const int im = img * ipc + (int)__umul24(sy, geo.gx) + sx;
+        o = (int)__umul24(__umul24(im, H) + iy, W) + ix;
+        return vy >= 0 && vx >= 0 && iy < H && ix < W && sy < geo.gy && sx < geo.gx && im < p.B;
+    };
 #define WINO_DMA_W(st, step)                                                                                      \
     {                                                                                                              \
-        const int kb_ = (step) >> 4, pos_ = (step) & 15;                                                           \
+        const int kb_ = kb0 + ((step) >> 4), pos_ = (step) & 15;                                                   \
         const int soff_ = (pos_ * Cin + kb_ * 32) * 2;                                                             \
         _Pragma("unroll") for (int i = 0; i < WPW; ++i)                                                             \
             dma16(rsrc_w, wsm + (st) * WS_BYTES + (wave + NW * i) * 1024, w_goff[i], soff_);                       \
@@ -182,10 +217,12 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
         const int pix_ = slot_ ^ ((slot_ >> 1) & 1);                                                                 \
         const int pr_ = pix_ / PW, pc_ = pix_ - pr_ * PW;                                                            \
         const int iy_ = oy0 - 1 + pr_, ix_ = ox0 - 1 + pc_;                                                          \
-        const bool ok_ = pix_ < NPX && (unsigned)iy_ < (unsigned)H && (unsigned)ix_ < (unsigned)W;                   \
+        int pxi_ = (img * H + iy_) * W + ix_;                                                                        \
+        bool ok_ = pix_ < NPX && (unsigned)iy_ < (unsigned)H && (unsigned)ix_ < (unsigned)W;                         \
+        if constexpr (CV) ok_ = canvas_pixel(iy_, ix_, pxi_) && pix_ < NPX;                                          \
         const int u_ = pc_ >> 1;                                                                                     \
         const int lc_ = ((((lane & 7) >> 1) - 2 * (u_ >> 2)) & 3) * 2 + ((lane & 1) ^ ((u_ >> 1) & 1));               \
-        const int off_ = ok_ ? ((img * H + iy_) * W + ix_) * row_bytes + p.in_coff * 4 + lc_ * 16 + (kb_) * 128      \
+        const int off_ = ok_ ? pxi_ * row_bytes + p.in_coff * 4 + lc_ * 16 + (kb0 + (kb_)) * 128                     \
                              : (int)0x80000000;                                                                      \
         dma16(rsrc_in, smem + (wave + NW * i) * 1024, off_, 0);                                                      \
     }
@@ -359,10 +396,31 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
     // stored straight from the accumulators a wave-instruction would write 16 pixels x 64 B, 2 KiB apart.  Through LDS
     // (free now) it writes 2 pixels x 512 B: tile row 0 of every tile, then tile row 1 (256 pixels x 128 channels each).
     //   LDS image: pixel pl = 32 wave + 2 tx + (i & 1), 16-byte chunk c of its 128 channels at chunk c ^ (tx & 15)
-    const bool vec = !((p.Cout | p.out_cstride | p.out_coff) & 3) &&
-                     (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
-                     (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
-                     (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
+    // (CV, K range of a split layer: raw partial sums into the workspace slice [ks][pixel][Npad] through the same code -- a
+    // descriptor without bias / residual / gates / masks; the second pass applies the layer's epilogue)
+    spaa_tapconv_t pq = p;
+    if constexpr (CV) {
+        if (geo.ksplit > 1) {
+            pq.out = p.splitk_ws + (size_t)ks * ((size_t)p.B * H * W) * npad;
+            pq.out_cstride = npad;
+            pq.out_coff = 0;
+            pq.bias = nullptr;
+            pq.add = nullptr;
+            pq.gate = nullptr;
+            pq.gate2 = nullptr;
+            pq.gate_bits = nullptr;
+            pq.gate2_bits = nullptr;
+            pq.mask_out = nullptr;
+            pq.aux_out = nullptr;
+            pq.act = SPAA_ACT_NONE;
+            pq.io_dtype = 0;
+        }
+    }
+    const spaa_tapconv_t& e = CV ? pq : p;
+    const bool vec = !((e.Cout | e.out_cstride | e.out_coff) & 3) &&
+                     (e.add == nullptr || !((e.add_cstride | e.add_coff) & 3)) &&
+                     (e.gate == nullptr || !((e.gate_cstride | e.gate_coff) & 3)) &&
+                     (e.gate2 == nullptr || !((e.gate2_cstride | e.gate2_coff) & 3));
     if constexpr (DBG & 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -373,15 +431,15 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
     constexpr int ROWB = BN * 4;          // bytes of a pixel's BN channels in the LDS image
     constexpr int LPP = BN / 4;           // lanes (16-byte chunks) per pixel: 32 or 16
     constexpr int PPI = 64 / LPP;         // pixels per wave store instruction
-    if (fast_epi_ok(p, vec)) {
+    if (fast_epi_ok(e, vec)) {
         // The operand combinations of the attack loops, branch-free (epilogue.hpp: fast_epi_*): a wave's 32 x 2 pixels go
         // through a PRIVATE LDS region (row = 16 (pixel column & 1) + tile column, padded by 16 bytes: conflict-free writes
         // from the MFMA layout, a lane keeps ONE channel quad), so that one barrier after the main loop is all the
         // synchronisation there is, and the residual / gate operands of eight pixels per lane are in flight together.
         constexpr int ROWP = BN * 4 + 16;
         const int n = n_blk + 4 * (lane & (LPP - 1));
-        const bool n_ok = n < p.Cout;
-        const fast_epi_t fe = make_fast_epi(p, n_ok ? n : 0);
+        const bool n_ok = n < e.Cout;
+        const fast_epi_t fe = make_fast_epi(e, n_ok ? n : 0);
         wg_barrier<false>();
         unsigned char* const eb = smem + wave * (32 * ROWP);
 #pragma unroll
@@ -393,21 +451,26 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                     *reinterpret_cast<f32x4*>(eb + (16 * c + tx) * ROWP + ((4 * j + q8) << 4)) = Y[2 * half + c][j];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int oy = oy0 + 2 * wave + half;
-            const int orow = (img * p.Hout + oy) * p.Wout + ox0;
+            const int orow = (img * e.Hout + oy) * e.Wout + ox0;
             constexpr int EB = 8;
 #pragma unroll 1
             for (int it0 = 0; it0 < 32 / PPI; it0 += EB) {
                 fast_pre_t<float> pre[EB];
+                int oo[EB];
+                bool ok[EB];
 #pragma unroll
                 for (int u = 0; u < EB; ++u) {
                     const int r = (it0 + u) * PPI + lane / LPP, px = 2 * (r & 15) + (r >> 4);
-                    pre[u] = fast_epi_load<float>(fe, p, orow + px, n, n_ok && oy < p.Hout && ox0 + px < p.Wout);
+                    oo[u] = orow + px;
+                    ok[u] = n_ok && oy < e.Hout && ox0 + px < e.Wout;
+                    if constexpr (CV) ok[u] = canvas_pixel(oy, ox0 + px, oo[u]) && n_ok;
+                    pre[u] = fast_epi_load<float>(fe, e, oo[u], n, ok[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < EB; ++u) {
-                    const int r = (it0 + u) * PPI + lane / LPP, px = 2 * (r & 15) + (r >> 4);
+                    const int r = (it0 + u) * PPI + lane / LPP;
                     const f32x4 y = *reinterpret_cast<const f32x4*>(eb + r * ROWP + ((lane & (LPP - 1)) << 4));
-                    fast_epi_store<float>(fe, p, orow + px, n, n_ok && oy < p.Hout && ox0 + px < p.Wout, y, pre[u]);
+                    fast_epi_store<float>(fe, e, oo[u], n, ok[u], y, pre[u]);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -437,9 +500,14 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                 const int pl = PPI * ((32 / PPI) * wave + it0 + u) + lane / LPP;
                 const int lc = (lane & (LPP - 1)) ^ ((pl & 31) >> 1);
                 const int oy = oy0 + 2 * (pl >> 5) + half, ox = ox0 + (pl & 31);
-                ok[u] = oy < p.Hout && ox < p.Wout;
-                oo[u] = ((size_t)img * p.Hout + (ok[u] ? oy : 0)) * p.Wout + (ok[u] ? ox : 0);
-                if (vec && ok[u]) pre[u] = epi_load<float>(p, oo[u], n_blk + 4 * lc);
+                ok[u] = oy < e.Hout && ox < e.Wout;
+                oo[u] = ((size_t)img * e.Hout + (ok[u] ? oy : 0)) * e.Wout + (ok[u] ? ox : 0);
+                if constexpr (CV) {
+                    int o_;
+                    ok[u] = canvas_pixel(oy, ox, o_);
+                    oo[u] = ok[u] ? (size_t)o_ : 0;
+                }
+                if (vec && ok[u]) pre[u] = epi_load<float>(e, oo[u], n_blk + 4 * lc);
             }
 #pragma unroll
             for (int u = 0; u < EB; ++u) {
@@ -449,47 +517,182 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
                 const f32x4 y = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + (pc << 4));
                 if (ok[u]) {
                     float v[4] = {y[0], y[1], y[2], y[3]};
-                    if (vec) store4_pre<float>(p, oo[u], n_blk + 4 * lc, v, pre[u]);
-                    else store4_t<float>(p, oo[u], n_blk + 4 * lc, v, vec);
+                    if (vec) store4_pre<float>(e, oo[u], n_blk + 4 * lc, v, pre[u]);
+                    else store4_t<float>(e, oo[u], n_blk + 4 * lc, v, vec);
                 }
             }
         }
     }
 }
 
+// second pass of a K-split layer: out = epilogue( sum over the splits, in fixed order ), 4 channels per thread
+__global__ __launch_bounds__(256) void wino_splitk_reduce_kernel(const spaa_tapconv_t p, const int M, const int npad) {
+    const int nq = (p.Cout + 3) >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * nq) return;
+    const int m = (int)(idx / nq), n0 = (int)(idx - (int64_t)m * nq) * 4;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.ksplit; ++s) sum += *reinterpret_cast<const f32x4*>(p.splitk_ws + ((size_t)s * M + m) * npad + n0);
+    const bool vec = !((p.Cout | p.out_cstride | p.out_coff) & 3) &&
+                     (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
+                     (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
+                     (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
+    float v[4] = {sum[0], sum[1], sum[2], sum[3]};
+    store4_t<float>(p, (size_t)m, n0, v, vec);
+}
+
+// ---- launch plan: N tile, canvas layout, K split (one decision for the launcher and for spaa_tapconv_wino_plan)
+struct wino_plan_t {
+    int bn, ksplit, kb_per, canvas, gy, gx, py, px, ncanvas, wg_y, wg_x, n_tiles;
+    int64_t nwg;
+};
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// `force_bn`: 0 = choose, 64 / 128.  `force_ks`: 0 = choose (only when `allow_split`), else that many K ranges (clamped so that
+// every range holds at least one 32-channel block).  The choice minimises a cost model fitted to the round-3 per-layer tables
+// (profiles/r03_v6_tapconv_layers.json): a workgroup needs 12.8 us (64-wide) / 22.4 us (128-wide) per 32-channel block and 12 / 20
+// us for its prologue + epilogue (64-wide canvas / K-range form: + 6), the launch takes about ceil(workgroups / CUs) such rounds, a K
+// split adds its second pass (5 us + the partial sums at 12 TB/s: L2 / MALL).  Predicted / measured: conv4 438 / 420-457, conv3_s 130 /
+// 128, ResNet layer2 63 / 65, layer1 75 / 75, layer3 (canvas, 4 ranges) 74 / 77, layer4 (8 ranges) 74 / 76, VGG-16 14 x 14 x 512
+// (2 ranges) 210 / 205 (tools/lab/wino_small.py).
+inline wino_plan_t wino_make_plan(const spaa_tapconv_t& d, const int ncu, const int force_bn, const int force_ks, const bool allow_split) {
+    wino_plan_t pl = {};
+    const int H = d.Hout, W = d.Wout, B = d.B;
+    // plain regions: per image
+    const int pwy = cdiv(H, 2 * TY), pwx = cdiv(W, 2 * TX);
+    const int64_t plain = (int64_t)B * pwy * pwx;
+    // best canvas: gy x gx images with periods (H + 1, W + 1); sides <= 4095, periods <= 255 (the kernel's division by multiplication)
+    int64_t best = plain;
+    int cgy = 1, cgx = 1, cnc = B, cwy = pwy, cwx = pwx;
+    const int py = H + 1, px = W + 1;
+    const bool small = (int64_t)B * H * W < ((int64_t)1 << 24) && H <= 4095 && W <= 4095;   // (the canvas / K-range kernel's 24-bit index arithmetic)
+    if (py <= 255 && px <= 255 && small && !((d.reserved0 >> 30) & 1)) {
+        for (int gx = 1; gx <= B && gx * px - 1 <= 4095; ++gx) {
+            const int wx = cdiv(gx * px - 1, 2 * TX);
+            for (int gy = 1; gy * gx <= B + gx - 1 && gy * py - 1 <= 4095; ++gy) {   // (gy up to ceil(B / gx))
+                const int wy = cdiv(gy * py - 1, 2 * TY);
+                const int nc = cdiv(B, gy * gx);
+                const int64_t n = (int64_t)nc * wy * wx;
+                if (n < best) best = n, cgy = gy, cgx = gx, cnc = nc, cwy = wy, cwx = wx;
+            }
+        }
+    }
+    const int nkb = d.Cin / 32;
+    const int64_t M = (int64_t)B * H * W;
+    const int npad = (d.Cout + 127) & ~127;
+    double best_cost = 1e30;
+    for (int cv = 0; cv < 2; ++cv) {
+        if (cv && best >= plain) break;
+        const int64_t regions = cv ? best : plain;
+        for (int bn = 64; bn <= 128; bn += 64) {
+            if (force_bn ? bn != force_bn : (bn == 128 && d.Cout <= 64)) continue;
+            const int nt = cdiv(d.Cout, bn);
+            for (int ks = 1; ks <= nkb; ++ks) {
+                if (force_ks > 0 ? ks != (force_ks < nkb ? force_ks : nkb) : (ks > 1 && (!allow_split || nkb < 2 * ks))) continue;
+                if (ks > 1 && ((d.Cout & 3) || !small)) continue;
+                const int kb_per = cdiv(nkb, ks), ksr = cdiv(nkb, kb_per);
+                if (ksr != ks && force_ks <= 0) continue;   // (the same plan as a smaller ks)
+                const int64_t nwg = regions * nt * ksr;
+                // (a partly filled last round costs less than a full one -- idle compute units leave the others a higher clock:
+                // VGG-16's 28 x 28 x 512 layers, 432 against 512 workgroups, 720 against 780 us)
+                const double rounds = 0.5 * (double)((nwg + ncu - 1) / ncu) + 0.5 * (double)nwg / ncu;
+                double cost = rounds * (kb_per * (bn == 128 ? 22.4 : 12.8) + (bn == 128 ? 20.0 : 12.0) + ((cv || ksr > 1) && bn == 64 ? 6.0 : 0.0));
+                if (ksr > 1) cost += 5.0 + (double)ksr * (double)M * npad * 4.0 / 12e6;   // (second pass: the partial sums come from L2 / MALL)
+                if (cv && !((d.reserved0 >> 29) & 1)) cost *= 1.05;   // (the canvas form must win by 5 %: else the image-aligned regions, unchanged since round 2)
+                if (!cv && best < plain && ((d.reserved0 >> 29) & 1)) cost *= 1e6;   // (tests: canvas wherever it has fewer regions)
+                if (ksr > 1) cost *= 1.02;  // (ties: no split)
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    pl.bn = bn, pl.ksplit = ksr, pl.kb_per = kb_per, pl.canvas = cv, pl.n_tiles = nt, pl.nwg = nwg;
+                }
+            }
+        }
+    }
+    if (!pl.canvas && pl.ksplit == 1 && force_bn == 0) {
+        // image-aligned regions without a split: the N tile by the rule the round-2 / round-3 tune tables were measured with (64
+        // wide for at most 64 output channels and where the 128-wide grid would leave compute units without a workgroup)
+        pl.bn = (d.Cout <= 64 || plain * cdiv(d.Cout, 128) < ncu) ? 64 : 128;
+        pl.n_tiles = cdiv(d.Cout, pl.bn);
+        pl.nwg = plain * pl.n_tiles;
+    }
+    if (pl.canvas) pl.gy = cgy, pl.gx = cgx, pl.ncanvas = cnc, pl.wg_y = cwy, pl.wg_x = cwx;
+    else pl.gy = pl.gx = 1, pl.ncanvas = B, pl.wg_y = pwy, pl.wg_x = pwx;
+    pl.py = py, pl.px = px;
+    return pl;
+}
+
+inline int wino_ncu() {
+    static int ncu[SPAA_MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SPAA_MAX_DEVICES) return 256;
+    if (ncu[dev] == 0 && hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu[dev] = 256;
+    return ncu[dev] > 0 ? ncu[dev] : 256;
+}
+
+inline bool wino_shape_ok(const spaa_tapconv_t& d) {
+    if (d.w_split == nullptr || (d.Cin % 32) != 0 || d.Cin < 32 || d.nclass != 1 || d.cls[0].ntaps != 16 || d.cls[0].K != 16 * d.Cin || d.cls[0].Kpad < d.cls[0].K || (d.cls[0].Kpad & 7) ||
+        d.s_in != 1 || d.s_out != 1 || d.Hin != d.Hout || d.Win != d.Wout || d.Hm != d.Hout || d.Wm != d.Wout || d.nfold > 1 ||
+        d.ksplit < 0 || d.io_dtype != 0 || d.B < 1 || d.Hout < 1 || d.Wout < 1 || d.Cout < 1)
+        return false;
+    if ((int64_t)((d.Cout + 127) & ~127) * d.cls[0].Kpad * 6 >= (int64_t)1 << 31) return false;
+    if ((int64_t)d.B * d.Hin * d.Win * d.in_cstride * 4 >= (int64_t)1 << 31) return false;   // (32-bit DMA offsets)
+    return true;
+}
+
 }  // namespace
 
-// called by spaa_tapconv_f32 (tapconv.hip) for tile 70 after the common shape checks.  The descriptor describes the layer in
+// The launcher's plan for the Winograd form of `desc` (tile 70: N tile chosen, 71: 64-wide N tile; desc->ksplit > 1: that many K
+// ranges, 1: none, 0: chosen): plan[0..7] = {N tile, K ranges, canvas (0 / 1), images per canvas (rows), (columns), workgroups,
+// channel blocks per K range, canvases}.  A caller sizes `splitk_ws` (K ranges x B x H x W x Npad floats) from plan[1] and passes
+// plan[1] back as `ksplit`.
+extern "C" int spaa_tapconv_wino_plan(const spaa_tapconv_t* desc, int32_t* plan) {
+    if (desc == nullptr || plan == nullptr) return hipErrorInvalidValue;
+    spaa_tapconv_t d = *desc;
+    if (d.w_split == nullptr) d.w_split = reinterpret_cast<const uint16_t*>(desc);   // (the plan does not depend on the pointers)
+    if (!wino_shape_ok(d) || (d.tile != 70 && d.tile != 71)) return hipErrorInvalidValue;
+    const wino_plan_t pl = wino_make_plan(d, wino_ncu(), d.tile == 71 ? 64 : 0, d.ksplit, true);
+    plan[0] = pl.bn, plan[1] = pl.ksplit, plan[2] = pl.canvas, plan[3] = pl.gy, plan[4] = pl.gx;
+    plan[5] = (int32_t)(pl.nwg > 0x7fffffff ? 0x7fffffff : pl.nwg), plan[6] = pl.kb_per, plan[7] = pl.ncanvas;
+    return 0;
+}
+
+// called by spaa_tapconv_f32 (tapconv.hip) for tiles 70 / 71 after the common shape checks.  The descriptor describes the layer in
 // Winograd form: ONE class with 16 "taps" = the positions of U = G g G^T (tap entries unused), s_in = s_out = 1, same input and
 // output size, Cin % 32 == 0.
 int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
-    if (d.w_split == nullptr || (d.Cin % 32) != 0 || d.nclass != 1 || d.cls[0].ntaps != 16 || d.cls[0].K != 16 * d.Cin || d.cls[0].Kpad < d.cls[0].K || (d.cls[0].Kpad & 7) ||
-        d.s_in != 1 || d.s_out != 1 || d.Hin != d.Hout || d.Win != d.Wout || d.Hm != d.Hout || d.Wm != d.Wout || d.nfold > 1 ||
-        d.ksplit > 1 || d.ksplit < 0 || d.io_dtype != 0)
-        return hipErrorInvalidValue;
-    if ((int64_t)((d.Cout + 127) & ~127) * d.cls[0].Kpad * 6 >= (int64_t)1 << 31) return hipErrorInvalidValue;
-    const int wg_y = (d.Hout + 2 * TY - 1) / (2 * TY), wg_x = (d.Wout + 2 * TX - 1) / (2 * TX);
-    // N tile: the 64-wide instantiation for layers with at most 64 output channels, and where the 128-wide grid would leave
-    // compute units without a workgroup (one workgroup per CU: ResNet layer2, 28 x 28 images)
-    static int ncu[SPAA_MAX_DEVICES] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SPAA_MAX_DEVICES) return hipErrorInvalidValue;
-    if (ncu[dev] == 0 && hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu[dev] = 256;
-    const int BN = (d.Cout <= 64 || (int64_t)d.B * wg_y * wg_x * ((d.Cout + 127) / 128) < ncu[dev]) ? 64 : 128;
-    const int n_tiles = (d.Cout + BN - 1) / BN;
-    const int64_t nwg = (int64_t)d.B * wg_y * wg_x * n_tiles;
-    if (nwg > 0x7fffffff) return hipErrorInvalidValue;
-    static bool attr_set[8][SPAA_MAX_DEVICES] = {};
+    if (!wino_shape_ok(d)) return hipErrorInvalidValue;
+    // K ranges: the caller's (with its workspace), or chosen here when a workspace is there to take them
+    const bool has_ws = d.splitk_ws != nullptr;
+    if (d.ksplit > 1 && !has_ws) return hipErrorInvalidValue;
+    const wino_plan_t pl = wino_make_plan(d, wino_ncu(), d.tile == 71 ? 64 : 0, has_ws ? d.ksplit : 1, has_ws);
+    if (pl.nwg > 0x7fffffff) return hipErrorInvalidValue;
+    const int BN = pl.bn, n_tiles = pl.n_tiles, wg_y = pl.wg_y, wg_x = pl.wg_x;
+    const int64_t nwg = pl.nwg;
+    const bool cv = pl.canvas || pl.ksplit > 1;
+    wino_geo_t geo = {};
+    geo.ksplit = pl.ksplit, geo.kb_per = pl.kb_per;
+    geo.gy = pl.gy, geo.gx = pl.gx, geo.py = pl.canvas ? pl.py : (1 << 14), geo.px = pl.canvas ? pl.px : (1 << 14);
+    // v / p == (v * m) >> 20 with m = ceil(2^20 / p) for v * p < 2^20 (v <= 4095, p <= 255); image-aligned regions
+    // (period 2^14 > every coordinate): m = 64 gives 0
+    geo.my = ((1u << 20) + geo.py - 1) / geo.py, geo.mx = ((1u << 20) + geo.px - 1) / geo.px;
+    geo.nsp = (int)(nwg / ((int64_t)n_tiles * pl.ksplit));
+    if (cv && !pl.canvas && (d.Hout > 4095 || d.Wout > 4095)) return hipErrorInvalidValue;
+    if (cv && (int64_t)d.B * d.Hout * d.Wout >= ((int64_t)1 << 24)) return hipErrorInvalidValue;   // (the plan never asks for it: wino_make_plan)
+    spaa_tapconv_t dd = d;
+    dd.ksplit = pl.ksplit;
+    static bool attr_set[10][SPAA_MAX_DEVICES] = {};
     // kernel variant: bit 0 = late V (waves 4-7 transform one step ahead), bit 1 = xi groups expanded.  Default 3 / 2 (measured:
     // conv4 500 -> 462 us, conv5 461 -> 415 us against variant 0); `reserved0` bits 16-17 flip bits for A/B measurements
     const int var = (BN == 64 ? 2 : 3) ^ ((d.reserved0 >> 16) & 3);   // (64-wide tile: late V does not pay: 168 / 167 / 159 us for 0 / 3 / 2)
-#define WINO_LAUNCH(N, V, SLOT)                                                                                           \
+#define WINO_LAUNCH_T(N, V, C, SLOT)                                                                                      \
     {                                                                                                                     \
         const size_t smem = (size_t)PATCH_BYTES + 3 * (size_t)(((3 * N / 16 + 7) / 8) * 8 * 1024);                        \
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<N, V>), (int)smem, attr_set[SLOT]); \
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<N, V, 0, C>), (int)smem, attr_set[SLOT]); \
         if (e != hipSuccess) return (int)e;                                                                               \
-        hipLaunchKernelGGL((wino_x6_kernel<N, V>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles); \
+        hipLaunchKernelGGL((wino_x6_kernel<N, V, 0, C>), dim3((unsigned)nwg), dim3(512), smem, stream, dd, wg_y, wg_x, n_tiles, geo); \
     }
+#define WINO_LAUNCH(N, V, SLOT) WINO_LAUNCH_T(N, V, false, SLOT)
 #ifdef SPAA_WINO_ABLATE
     const int dbg = (d.reserved0 >> 18) & 127;
 #define WINO_LAUNCH_DBG(D)                                                                                                \
@@ -498,17 +701,25 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
         const size_t smem = (size_t)PATCH_BYTES + 3 * (size_t)(((3 * 128 / 16 + 7) / 8) * 8 * 1024);                      \
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<128, 3, D>), (int)smem, as_);     \
         if (e != hipSuccess) return (int)e;                                                                               \
-        hipLaunchKernelGGL((wino_x6_kernel<128, 3, D>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles); \
+        hipLaunchKernelGGL((wino_x6_kernel<128, 3, D>), dim3((unsigned)nwg), dim3(512), smem, stream, dd, wg_y, wg_x, n_tiles, geo); \
         return (int)hipGetLastError();                                                                                    \
     }
-    if (BN == 128) {
+    if (BN == 128 && !cv) {
         WINO_LAUNCH_DBG(1) WINO_LAUNCH_DBG(3) WINO_LAUNCH_DBG(5) WINO_LAUNCH_DBG(7) WINO_LAUNCH_DBG(15) WINO_LAUNCH_DBG(31) WINO_LAUNCH_DBG(2) WINO_LAUNCH_DBG(4) WINO_LAUNCH_DBG(8) WINO_LAUNCH_DBG(32) WINO_LAUNCH_DBG(33) WINO_LAUNCH_DBG(64) WINO_LAUNCH_DBG(96)
     }
 #undef WINO_LAUNCH_DBG
 #endif
-    if (BN == 64) {
+    if (cv) {   // canvas / K-split form: the default variants only
+        if (BN == 64) WINO_LAUNCH_T(64, 2, true, 8) else WINO_LAUNCH_T(128, 3, true, 9)
+        if (pl.ksplit > 1) {
+            const int npad = (d.Cout + 127) & ~127;
+            const int64_t M = (int64_t)d.B * d.Hout * d.Wout, nthr = M * ((d.Cout + 3) >> 2);
+            hipLaunchKernelGGL(wino_splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, dd, (int)M, npad);
+        }
+    } else if (BN == 64) {
         if (var == 3) WINO_LAUNCH(64, 3, 4) else if (var == 2) WINO_LAUNCH(64, 2, 5) else if (var == 1) WINO_LAUNCH(64, 1, 6) else WINO_LAUNCH(64, 0, 7)
     } else if (var == 3) WINO_LAUNCH(128, 3, 3) else if (var == 2) WINO_LAUNCH(128, 2, 2) else if (var == 1) WINO_LAUNCH(128, 1, 1) else WINO_LAUNCH(128, 0, 0)
 #undef WINO_LAUNCH
+#undef WINO_LAUNCH_T
     return (int)hipGetLastError();
 }

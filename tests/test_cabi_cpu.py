@@ -103,3 +103,73 @@ def test_torch_library_ops_are_registered():
         assert x4.shape == (2, 8, 10, 4)
         assert torch.ops.spaa.ciede2000(x4, x4).shape == (2, 8, 10) and torch.ops.spaa.rgb2lab(x4).shape == x4.shape
         assert torch.ops.spaa.nhwc4_to_nchw(x4).shape == (2, 3, 8, 10)
+
+
+def _wino_plan(b, h, w, cin, cout, tile=70, ksplit=0, force_canvas=False):
+    d = _lib.TapConv()
+    d.reserved0 = (1 << 29) if force_canvas else 0
+    d.Hin = d.Hout = d.Hm = h
+    d.Win = d.Wout = d.Wm = w
+    d.Cin, d.Cout, d.B, d.s_in, d.s_out, d.nclass = cin, cout, b, 1, 1, 1
+    d.in_cstride, d.out_cstride = cin, cout
+    d.cls[0].ntaps, d.cls[0].K, d.cls[0].Kpad = 16, 16 * cin, 16 * cin + 128
+    d.tile, d.ksplit = tile, ksplit
+    wp = (ctypes.c_int32 * 8)()
+    assert _lib.load().spaa_tapconv_wino_plan(ctypes.byref(d), wp) == 0
+    return dict(zip(('bn', 'ksplit', 'canvas', 'gy', 'gx', 'nwg', 'kb_per', 'ncanvas'), wp))
+
+
+@pytest.mark.parametrize('b,h,w,cin,cout', [(64, 14, 14, 256, 256), (64, 7, 7, 512, 512), (64, 35, 35, 96, 96), (5, 14, 14, 64, 64),
+                                             (64, 17, 17, 128, 128), (3, 7, 9, 512, 512), (64, 14, 14, 512, 512)])
+def test_winograd_canvas_plan_covers_every_pixel_once(b, h, w, cin, cout):
+    """csrc/tapconv_wino.hip, canvas form (small images laid out on virtual canvases, host-side plan through
+    spaa_tapconv_wino_plan): the kernel's index arithmetic restated here -- division by the period as a multiplication by
+    ceil(2^20 / period) -- maps the workgroup regions onto every output pixel exactly once, and the 3 x 3 neighbourhood of every
+    output pixel onto the same image's pixels or onto the zero padding (never onto a neighbouring image)."""
+    import numpy as np
+    pl = _wino_plan(b, h, w, cin, cout, force_canvas=True)
+    assert pl['canvas'] == 1 and pl['ksplit'] * pl['kb_per'] >= cin // 32 > (pl['ksplit'] - 1) * pl['kb_per']
+    gy, gx, nc = pl['gy'], pl['gx'], pl['ncanvas']
+    py, px = h + 1, w + 1
+    assert gy * gx * nc >= b and gy * py - 1 <= 4095 and gx * px - 1 <= 4095 and py <= 255 and px <= 255
+    my, mx = ((1 << 20) + py - 1) // py, ((1 << 20) + px - 1) // px
+    wg_y, wg_x = (gy * py - 1 + 15) // 16, (gx * px - 1 + 31) // 32
+    n_tiles = (cout + pl['bn'] - 1) // pl['bn']
+    assert pl['nwg'] == nc * wg_y * wg_x * n_tiles * pl['ksplit']
+
+    def canvas_pixel(cv, vy, vx):
+        """-> (valid, image, iy, ix): the device lambda `canvas_pixel`, on int arrays (uint32 wrap-around for negative v)"""
+        sy = ((vy.astype(np.int64) & 0xffffffff) * my & 0xffffffff) >> 20
+        sx = ((vx.astype(np.int64) & 0xffffffff) * mx & 0xffffffff) >> 20
+        iy, ix = vy - sy * py, vx - sx * px
+        im = cv * gy * gx + sy * gx + sx
+        ok = (vy >= 0) & (vx >= 0) & (iy < h) & (ix < w) & (sy < gy) & (sx < gx) & (im < b)
+        return ok, im, iy, ix
+
+    count = np.zeros((b, h, w), dtype=np.int64)
+    for cv in range(nc):
+        vy, vx = np.meshgrid(np.arange(16 * wg_y), np.arange(32 * wg_x), indexing='ij')
+        ok, im, iy, ix = canvas_pixel(cv, vy, vx)
+        assert (iy[ok] >= 0).all() and (ix[ok] >= 0).all()
+        np.add.at(count, (im[ok], iy[ok], ix[ok]), 1)
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                ok2, im2, iy2, ix2 = canvas_pixel(cv, vy + dy, vx + dx)
+                inside = ok & (iy + dy >= 0) & (iy + dy < h) & (ix + dx >= 0) & (ix + dx < w)
+                assert (ok2[ok] == inside[ok]).all()                      # a tap is read iff it lies inside the SAME image
+                sel = ok & inside
+                assert (im2[sel] == im[sel]).all() and (iy2[sel] == iy[sel] + dy).all() and (ix2[sel] == ix[sel] + dx).all()
+    assert (count == 1).all()
+
+
+def test_winograd_plan_keeps_the_measured_choices():
+    """Layer shapes whose Winograd launches were tuned in rounds 2 / 3 keep their image-aligned regions and N tiles; explicit K
+    ranges are honoured and clamped."""
+    assert _wino_plan(64, 64, 64, 128, 256) == dict(bn=128, ksplit=1, canvas=0, gy=1, gx=1, nwg=1024, kb_per=4, ncanvas=64)
+    assert _wino_plan(64, 64, 64, 128, 64)['bn'] == 64 and _wino_plan(64, 56, 56, 64, 64)['nwg'] == 512
+    assert _wino_plan(64, 28, 28, 128, 128) == dict(bn=64, ksplit=1, canvas=0, gy=1, gx=1, nwg=256, kb_per=4, ncanvas=64)
+    assert _wino_plan(8, 64, 64, 128, 256) == dict(bn=64, ksplit=1, canvas=0, gy=1, gx=1, nwg=256, kb_per=4, ncanvas=8)
+    p = _wino_plan(64, 14, 14, 256, 256, tile=71, ksplit=3)
+    assert p['bn'] == 64 and p['ksplit'] == 3 and p['kb_per'] == 3
+    assert _wino_plan(64, 14, 14, 256, 256, ksplit=1)['ksplit'] == 1
+    assert _wino_plan(64, 14, 14, 64, 64, ksplit=16)['ksplit'] == 2      # (two 32-channel blocks: at most two ranges)

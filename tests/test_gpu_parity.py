@@ -175,7 +175,8 @@ def test_tapconv_x6_is_fp32_accurate(hip, tile):
         cp.FORCE_TILE = 0
 
 
-@pytest.mark.parametrize('ci,co,h,w,b', [(128, 256, 64, 64, 2), (256, 128, 30, 44, 3), (64, 128, 17, 35, 2), (64, 192, 16, 32, 1)])
+@pytest.mark.parametrize('ci,co,h,w,b', [(128, 256, 64, 64, 2), (256, 128, 30, 44, 3), (64, 128, 17, 35, 2), (64, 192, 16, 32, 1),
+                                         (256, 256, 14, 14, 64), (512, 512, 7, 7, 64)])   # (the last two: ResNet-18 layer3 / layer4 at the benchmark's batch -- canvas layout + K ranges)
 def test_winograd_is_fp32_accurate(hip, ci, co, h, w, b):
     """3x3 / s1 / p1 layers through Winograd F(2x2,3x3) on the bf16x6 arithmetic (csrc/tapconv_wino.hip): forward and input
     gradient against fp64.  The transforms add roundings: the bound is 3x the exact-fp32 MFMA kernel's error (measured ~2x)."""
@@ -205,6 +206,62 @@ def test_winograd_is_fp32_accurate(hip, ci, co, h, w, b):
     print(f'ci={ci} co={co} {h}x{w}: rel err vs fp64 fp32-MFMA {errs[6][0]:.1e}/{errs[6][1]:.1e}  bf16x6 {errs[34][0]:.1e}/{errs[34][1]:.1e}  '
           f'winograd {errs[70][0]:.1e}/{errs[70][1]:.1e}')
     assert errs[70][0] < max(3 * errs[6][0], 6e-7) and errs[70][1] < max(3 * errs[6][1], 6e-7)
+
+
+@pytest.mark.parametrize('ci,co,h,w,b,tile,ks', [(256, 256, 14, 14, 64, 70, 0), (512, 512, 7, 7, 64, 70, 0), (64, 96, 35, 35, 9, 70, 0),
+                                                 (128, 128, 14, 14, 5, 71, 2), (96, 64, 17, 17, 7, 70, 3), (64, 128, 7, 9, 3, 70, 1),
+                                                 (128, 256, 20, 38, 2, 70, 4), (64, 64, 15, 20, 10, 71, 2)])
+def test_winograd_canvas_and_k_ranges(hip, ci, co, h, w, b, tile, ks):
+    """csrc/tapconv_wino.hip, small images: the batch laid out on virtual canvases (workgroup regions tile the canvas, gap rows /
+    columns are the zero padding) and K cut into ranges summed in fixed order by a second kernel.  Against the direct bf16x6
+    kernel and torch on the CPU: every epilogue form (plain; bias + residual + ReLU + byte mask out; byte-mask gate; float gate =
+    the generic path), channel windows of wider buffers, nothing written outside the window, bitwise run to run."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(ci + co + h)
+    x, wt, bias = torch.randn(b, ci, h, w), torch.randn(co, ci, 3, 3) / (3 * ci ** 0.5), torch.randn(co)
+    add, gate = torch.randn(b, co, h, w), torch.randn(b, co, h, w)
+    plan = cp.conv_fwd_plan(wt, bias, 1, 1, DEV)
+    ref = F.conv2d(x, wt, bias, 1, 1)
+    old_nc = cp.DEBUG_WINO_NOCANVAS
+    try:
+        cp.DEBUG_WINO_NOCANVAS = 2     # canvas wherever it has fewer workgroup regions (the cost model may prefer image-aligned ones)
+        cp.FORCE_TILE = tile + 100 * ks
+        xin = nhwc(x).to(DEV)
+        out = torch.zeros(b, h, w, co, device=DEV)
+        plan.run(xin, out)
+        wp = plan.wino.last_wino_plan
+        print(f'{ci}->{co} {h}x{w} B={b}: N tile {wp[0]}, K ranges {wp[1]} x {wp[6]} blocks, canvas {wp[2]} ({wp[3]} x {wp[4]} images, {wp[7]} canvases), {wp[5]} workgroups')
+        assert wp[2] == 1 and (ks == 0 or wp[1] == min(ks, ci // 32)) and plan.wino.last_tile == tile
+        assert rel_inf(nchw(out.cpu()), ref) < 1e-5
+        out2 = torch.zeros_like(out)
+        plan.run(xin, out2)
+        assert torch.equal(out, out2)
+        # the image-aligned form of the same layer, no split: equal up to the summation order over K ranges
+        cp.DEBUG_WINO_NOCANVAS = 1
+        cp.FORCE_TILE = tile + 100
+        out3 = torch.zeros_like(out)
+        plan.run(xin, out3)
+        assert plan.wino.last_wino_plan[2] == 0 and plan.wino.last_wino_plan[1] == 1
+        assert rel_inf(out, out3) < 2e-6 and (wp[1] > 1 or torch.equal(out, out3))
+        cp.DEBUG_WINO_NOCANVAS = 2
+        cp.FORCE_TILE = tile + 100 * ks
+        # bias + residual + ReLU + byte mask out (the branch-free epilogue; behind a K split: the second pass)
+        mask = torch.zeros(b, h, w, co // 4, dtype=torch.uint8, device=DEV)
+        plan.run(xin, out, add=nhwc(add).to(DEV), act=lib.ACT_RELU, mask_out=mask)
+        assert rel_inf(nchw(out.cpu()), F.relu(ref + add)) < 1e-5 and torch.equal(mask, lib.pack_gate_mask(out))
+        gbits = lib.pack_gate_mask(nhwc(gate).to(DEV))
+        plan.run(xin, out, gate_bits=gbits)
+        assert rel_inf(nchw(out.cpu()), ref * (gate > 0)) < 1e-5
+        plan.run(xin, out, gate=nhwc(gate).to(DEV))          # float gate: the generic epilogue
+        assert rel_inf(nchw(out.cpu()), ref * (gate > 0)) < 1e-5
+        wide_in = torch.randn(b, h, w, ci + 32, device=DEV)
+        wide_out = torch.full((b, h, w, co + 64), 7.0, device=DEV)
+        plan.run(wide_in, wide_out, in_coff=32, out_coff=64)
+        ref2 = F.conv2d(nchw(wide_in.cpu())[:, 32:], wt, bias, 1, 1)
+        assert rel_inf(nchw(wide_out.cpu())[:, 64:], ref2) < 1e-5 and (wide_out[..., :64] == 7.0).all()
+    finally:
+        cp.FORCE_TILE = 0
+        cp.DEBUG_WINO_NOCANVAS = old_nc
 
 
 def test_winograd_epilogues_and_masks(hip):
@@ -554,46 +611,59 @@ def _oracle_fp64(sd, csd, insz, targets, targeted, scene, d_thr, stealth, setup,
     return tr
 
 
+DRIFT_CASES = [('spaa_64_near', 12), ('spaa_64_prjl2', 12), ('spaa_64_caml2_dthr', 12), ('spaa_256_near', 8)]
+
+
 def test_free_running_drift_vs_fp64_oracle(hip, golden_dir):
     """Free-running trajectories (no teacher forcing).  The loop amplifies rounding differences ~3x per iteration (the fp32
     oracle == reference drifts from the SAME code run in float64 by 3e-6, 1e-4, 8e-4, 3e-3, ... 2e-1 relative L-inf), so
     'identical results' for 50 iterations is not defined for any two fp32 implementations.  What is defined: the HIP path
-    must not drift from the fp64 trajectory faster than the fp32 reference itself does."""
+    must not drift from the fp64 trajectory faster than the fp32 reference itself does.  WHICH of two fp32 trajectories takes
+    its next gate flip first is itself rounding noise (one scenario reads 0.19 for one build and 1.61 for the next, which
+    differ in the summation order of one input-gradient kernel), so the statement is a STATISTIC over four goldens: the
+    median of the per-scenario geometric-mean ratios (HIP drift / fp32-oracle drift) is at most 1.5, none above 5."""
     A, M = hip['attack'], hip['models']
-    z = load(golden_dir, 'spaa_64_near')
-    sd, pc, clf, oclf, scene, setup = _setup_case(hip, z)
-    csd = syn.resnet18_state_dict(2, logit_gain=float(z['gain']))
-    insz = tuple(int(v) for v in z['input_sz'])
-    targets, d_thr, stealth = [int(t) for t in z['targets']], float(z['d_thr']), str(z['stealth'])
-    iters = 12
-    tr64 = _oracle_fp64(sd, csd, insz, targets, True, scene, d_thr, stealth, setup, iters)
-    tr32 = []
-    so.spaa(sd, oclf, targets, True, scene, d_thr, stealth, setup, iters=iters, trace=tr32)
-    st = A.AttackState(pc, clf, targets, scene, stealth, setup, DEV)
-    d_hip, d_f32 = [], []
-    for k in range(iters):
-        st.iteration(True, d_thr, 2, 1, 0.9)
-        ref = torch.from_numpy(tr64[k]['prj_adv'])
-        d_hip.append(rel_inf(M.to_nchw(st.x).double(), ref))
-        d_f32.append(rel_inf(torch.from_numpy(tr32[k]['prj_adv']).double(), ref))
+    rows, ratios = [], []
+    for name, iters in DRIFT_CASES:
+        z = load(golden_dir, name)
+        sd, pc, clf, oclf, scene, setup = _setup_case(hip, z)
+        csd = syn.resnet18_state_dict(2, logit_gain=float(z['gain']))
+        insz = tuple(int(v) for v in z['input_sz'])
+        targets, d_thr, stealth = [int(t) for t in z['targets']], float(z['d_thr']), str(z['stealth'])
+        tr64 = _oracle_fp64(sd, csd, insz, targets, True, scene, d_thr, stealth, setup, iters)
+        tr32 = []
+        so.spaa(sd, oclf, targets, True, scene, d_thr, stealth, setup, iters=iters, trace=tr32)
+        st = A.AttackState(pc, clf, targets, scene, stealth, setup, DEV)
+        d_hip, d_f32 = [], []
+        for k in range(iters):
+            st.iteration(True, d_thr, 2, 1, 0.9)
+            ref = torch.from_numpy(tr64[k]['prj_adv'])
+            d_hip.append(rel_inf(M.to_nchw(st.x).double(), ref))
+            d_f32.append(rel_inf(torch.from_numpy(tr32[k]['prj_adv']).double(), ref))
+        assert d_hip[0] < 1e-4 and d_f32[0] < 1e-4                      # first iteration: BASELINE.json's bar, both
+        # drift is multiplicative (chaotic amplification): compare in the log domain, geometric mean over the iterations
+        ratio = float(np.exp(np.mean(np.log(np.array(d_hip) / np.array(d_f32)))))
+        ratios.append(ratio)
+        rows.append((name, d_hip, d_f32, ratio))
+        # the drift grows in jumps (a ReLU gate flips: one jump); each iteration is compared with the fp32 oracle's drift up to two
+        # iterations later (measured: the same jump sizes, 1-2 iterations apart)
+        assert all(h < 10 * max(max(d_f32[:i + 3]), 1e-6) for i, h in enumerate(d_hip)), name
+        if name == 'spaa_64_near':
+            # 50-iteration statistics are preserved: camera-side distortion of the best images within 5 % of the reference golden
+            cam, prj = A.spaa(pc, clf, None, targets, True, scene, d_thr, stealth, DEV, setup)
+            ref_cam = torch.from_numpy(z['cam_infer_best'])
+            d_ours = torch.norm(cam.cpu() - scene, dim=1).mean().item()
+            d_ref = torch.norm(ref_cam - scene, dim=1).mean().item()
+            assert abs(d_ours - d_ref) / d_ref < 0.05
+        del st
     print('free-running drift from the fp64 oracle, relative Linf of the projector image per iteration:')
-    print('   HIP          ', ' '.join(f'{v:.1e}' for v in d_hip))
-    print('   fp32 oracle  ', ' '.join(f'{v:.1e}' for v in d_f32))
-    assert d_hip[0] < 1e-4 and d_f32[0] < 1e-4                      # first iteration: BASELINE.json's bar, both
-    # drift is multiplicative (chaotic amplification): compare in the log domain, geometric mean over the iterations
-    ratio = float(np.exp(np.mean(np.log(np.array(d_hip) / np.array(d_f32)))))
-    print(f'   geometric-mean ratio HIP / fp32 oracle = {ratio:.2f}')
-    assert ratio < 3.0
-    # the drift grows in jumps (a ReLU gate flips: one jump); WHEN a trajectory takes its next jump is itself rounding noise, so
-    # each iteration is compared with the fp32 oracle's drift up to two iterations later (measured: the same jump sizes, 1-2
-    # iterations apart)
-    assert all(h < 10 * max(max(d_f32[:i + 3]), 1e-6) for i, h in enumerate(d_hip))
-    # 50-iteration statistics are preserved: camera-side distortion of the best images within 5 % of the reference golden
-    cam, prj = A.spaa(pc, clf, None, targets, True, scene, d_thr, stealth, DEV, setup)
-    ref_cam = torch.from_numpy(z['cam_infer_best'])
-    d_ours = torch.norm(cam.cpu() - scene, dim=1).mean().item()
-    d_ref = torch.norm(ref_cam - scene, dim=1).mean().item()
-    assert abs(d_ours - d_ref) / d_ref < 0.05
+    for name, d_hip, d_f32, ratio in rows:
+        print(f'  {name}: geometric-mean ratio HIP / fp32 oracle = {ratio:.2f}')
+        print('     HIP          ', ' '.join(f'{v:.1e}' for v in d_hip))
+        print('     fp32 oracle  ', ' '.join(f'{v:.1e}' for v in d_f32))
+    med = float(np.median(ratios))
+    print(f'  median of the {len(ratios)} ratios = {med:.2f} (bound 1.5), max = {max(ratios):.2f} (bound 5)')
+    assert med <= 1.5 and max(ratios) < 5.0
 
 
 FIFTY = ['spaa_64_untargeted', 'spaa_64_imagenet10', 'spaa_64_near', 'spaa_64_caml2_dthr', 'spaa_64_prjl2', 'spaa_64_camdE',
