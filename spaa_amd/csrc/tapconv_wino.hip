@@ -102,6 +102,7 @@ struct wino_geo_t {
     int gy, gx, py, px;        // canvas: images per canvas (rows x columns) and their periods in pixels
     unsigned int my, mx;       // v / py == (v * my) >> 20 for every canvas coordinate v (launcher: canvas sides <= 4095, periods <= 255)
     int nsp;                   // workgroup regions of all canvases together
+    int order;                 // 1: regions fastest in the workgroup order, 0: N tiles fastest (as in the image-aligned form)
 };
 
 template <int BN, int VAR, int DBG = 0, bool CV = false>   // DBG: timing-only ablations (wrong results): 1 no epilogue, 2 no fold, 4 no V, 8 no barrier, 16 no DMA; 32: raw barrier.  CV: canvas / split-K form
@@ -127,12 +128,20 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
         const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
         int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
         if constexpr (CV) {
-            // regions fastest: the workgroups of an XCD share ONE (N tile, K range) slice of the weights (layer4: 25 MB of planes
-            // against 4 MB of L2 per XCD)
-            const int combo = t / geo.nsp;
-            t -= combo * geo.nsp;
-            n_blk = (combo % n_tiles) * BN;
-            ks = combo / n_tiles;
+            if (geo.order) {
+                // regions fastest: the workgroups of an XCD share ONE (N tile, K range) slice of the weights (layer4: 25 MB of planes
+                // against 4 MB of L2 per XCD, 6 MB of activations)
+                const int combo = t / geo.nsp;
+                t -= combo * geo.nsp;
+                n_blk = (combo % n_tiles) * BN;
+                ks = combo / n_tiles;
+            } else {
+                // (N tile, K range) fastest: the workgroups of a region, which read the same patch, sit next to each other
+                const int nc = n_tiles * geo.ksplit, combo = t % nc;
+                t /= nc;
+                n_blk = (combo % n_tiles) * BN;
+                ks = combo / n_tiles;
+            }
         } else {
             n_blk = (t % n_tiles) * BN;
             t /= n_tiles;
@@ -212,6 +221,11 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
     // Waves w and w+4 share a SIMD: waves 0-3 form V(t) at the START of step t, waves 4-7 form V(t+1) at the END of step t, so
     // that one wave's transform (VALU) runs under its partner's MFMAs.
 #define WINO_DMA_PATCH(kb_)                                                                                        \
+    if constexpr (CV) {                                                                                              \
+        /* (canvas form: the pixel -> address map of a lane's PPW pieces does not depend on the channel block) */       \
+        _Pragma("unroll") for (int i = 0; i < PPW; ++i)                                                               \
+            dma16(rsrc_in, smem + (wave + NW * i) * 1024, poff[i], (kb0 + (kb_)) * 128);                             \
+    } else                                                                                                           \
     _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                                \
         const int slot_ = (wave + NW * i) * 8 + (lane >> 3);                                                         \
         const int pix_ = slot_ ^ ((slot_ >> 1) & 1);                                                                 \
@@ -225,6 +239,20 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
         const int off_ = ok_ ? pxi_ * row_bytes + p.in_coff * 4 + lc_ * 16 + (kb0 + (kb_)) * 128                     \
                              : (int)0x80000000;                                                                      \
         dma16(rsrc_in, smem + (wave + NW * i) * 1024, off_, 0);                                                      \
+    }
+    int poff[CV ? PPW : 1];
+    if constexpr (CV) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int slot_ = (wave + NW * i) * 8 + (lane >> 3);
+            const int pix_ = slot_ ^ ((slot_ >> 1) & 1);
+            const int pr_ = pix_ / PW, pc_ = pix_ - pr_ * PW;
+            int pxi_;
+            const bool ok_ = canvas_pixel(oy0 - 1 + pr_, ox0 - 1 + pc_, pxi_) && pix_ < NPX;
+            const int u_ = pc_ >> 1;
+            const int lc_ = ((((lane & 7) >> 1) - 2 * (u_ >> 2)) & 3) * 2 + ((lane & 1) ^ ((u_ >> 1) & 1));
+            poff[i] = ok_ ? pxi_ * row_bytes + p.in_coff * 4 + lc_ * 16 : (int)0x80000000;
+        }
     }
     constexpr bool LATE = VAR & 1, XIU = (VAR >> 1) & 1;   // measurement variants (default 0)
     const bool late = LATE && wave >= 4;
@@ -677,6 +705,8 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     // (period 2^14 > every coordinate): m = 64 gives 0
     geo.my = ((1u << 20) + geo.py - 1) / geo.py, geo.mx = ((1u << 20) + geo.px - 1) / geo.px;
     geo.nsp = (int)(nwg / ((int64_t)n_tiles * pl.ksplit));
+    // workgroup order by what an XCD's L2 should keep: the weight planes (16 positions x three bf16) or the activations
+    geo.order = (int64_t)((d.Cout + 127) & ~127) * d.cls[0].Kpad * 6 > (int64_t)d.B * d.Hin * d.Win * d.Cin * 4;
     if (cv && !pl.canvas && (d.Hout > 4095 || d.Wout > 4095)) return hipErrorInvalidValue;
     if (cv && (int64_t)d.B * d.Hout * d.Wout >= ((int64_t)1 << 24)) return hipErrorInvalidValue;   // (the plan never asks for it: wino_make_plan)
     spaa_tapconv_t dd = d;
