@@ -83,3 +83,25 @@ def test_gpus_flag_launches_that_many_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rehearse-glue'],
                         capture_output=True, text=True, timeout=120, env=env2)
     assert r2.returncode != 0 and 'WORLD_SIZE=1' in r2.stderr
+
+
+def test_eight_rank_rehearsal_as_the_driver_launches_it():
+    """The driver's own N = 8 launch line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 8 ...`), rehearsed on gloo with the stand-in step: rendezvous from RANK / WORLD_SIZE / MASTER_*,
+    barrier-bracketed timed region, MAX over the 8 ranks, the preallocated gather of 8 blocks, ONE line from rank 0."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env['OMP_NUM_THREADS'] = '1'
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3',
+                        '--warmup', '1', '--rehearse-glue'], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith('{')]
+    assert len(lines) == 1, r.stdout
+    b = json.loads(lines[0])
+    assert b['n_gpus'] == 8 and len(b['per_rank_ms_per_step']) == 8 and b['gather_ok'] is True and b['value'] is None

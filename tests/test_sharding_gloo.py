@@ -78,3 +78,36 @@ def test_spaa_sharded_slices_targets_and_scenes():
             ret = m.dict()
             mp.spawn(_sharded_worker, args=(2, port, n_total, per_sample, ret), nprocs=2, join=True)
             assert dict(ret) == {0: True, 1: True}, (n_total, per_sample, dict(ret))
+
+
+def _b512_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    n_total = 512
+    targets = [1000 + i for i in range(n_total)]
+    scenes = (torch.arange(n_total, dtype=torch.float32).view(-1, 1, 1, 1) * 1e-3).expand(-1, 3, 4, 6).contiguous()
+    seen = {}
+
+    def attack(pcnet, classifier, labels, target_idx, targeted, cam_scene, *a):
+        seen['n'], seen['first'] = len(target_idx), target_idx[0]
+        return _stub_attack(pcnet, classifier, labels, target_idx, targeted, cam_scene, *a)
+
+    cam, prj = spaa_sharded(None, None, None, targets, True, scenes, 5, 'caml2', 'cpu', dict(prj_im_sz=(2, 3)), dist=dist, attack=attack)
+    want_cam = scenes + torch.tensor(targets, dtype=torch.float32).view(-1, 1, 1, 1)
+    ok = (seen['n'] == 64 and seen['first'] == 1000 + 64 * rank and cam.shape == (512, 3, 4, 6) and torch.equal(cam, want_cam)
+          and torch.equal(prj[:, 0, 0, 0], torch.tensor(targets, dtype=torch.float32)))
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batch_512_over_eight_ranks_keeps_global_order():
+    """BASELINE.json configs[3] / configs[4] by shape: B = 512 over 8 ranks = 64 samples per rank (rank r takes samples
+    64 r .. 64 r + 63 and its scenes), one gather, results in global sample order on every rank (gloo, stand-in attack)."""
+    port = _free_port()
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_b512_worker, args=(8, port, ret), nprocs=8, join=True)
+        assert dict(ret) == {r: True for r in range(8)}
