@@ -315,7 +315,8 @@ def pcnet_de_hbm(per_layer, other, n_prof, batch, size, f16):
     fp32) over the time of exactly those kernels, as a fraction of 8 TB/s."""
     ms = 0.0
     for name, v in per_layer.items():
-        base = name[:-6] if name.endswith('_dgrad') else name
+        base = name.split('+')[0]      # (fused launches: 'transConv1+skipConv2', 'conv2_dgrad+skipConv2_dgrad')
+        base = base[:-6] if base.endswith('_dgrad') else base
         if base in PCNET_LAYERS:
             ms += v[1] / n_prof
     for name in PCNET_ENTRY_POINTS:

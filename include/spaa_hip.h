@@ -71,7 +71,7 @@ typedef struct {
     const float* gate;    /* indexed like `out`, or NULL */
     int32_t gate_cstride, gate_coff, gate_mode;
     int32_t act;
-    int32_t tile;         /* 0 = auto; 1..54, 60..65, 68, 70, 71, 72 = explicit kernel / workgroup tile (the dispatcher in tapconv.hip lists them;
+    int32_t tile;         /* 0 = auto; 1..54, 60..65, 68, 70, 71, 72, 74 = explicit kernel / workgroup tile (the dispatcher in tapconv.hip lists them;
                              spaa_amd/convplan.py: TILE_NAMES; chosen per layer shape by tools/autotune.py) */
     float* aux_out;       /* optional second output (indexed like `out`):
                              act == SPAA_ACT_RELU_CLAMP1: the value BEFORE the clamp;
@@ -113,6 +113,13 @@ typedef struct {
     int32_t reserved1;
     int32_t nclass;
     spaa_tapclass_t cls[SPAA_MAX_CLASSES];
+    /* optional SECOND SOURCE (tile 74 only; NULL = none): a 1 x 1 convolution of a tensor at OUTPUT resolution, added to the
+     * accumulators before bias / residual / activation -- `transConv1(x) + skipConv2(x1)` (models.py:293,299) and its mirror
+     * image in the backward pass as ONE launch: out[b, oy, ox, n] += sum_c in2[b, oy, ox, in2_coff + c] * W2[n][c] */
+    const float* in2;         /* [B, Hout, Wout, in2_cstride] */
+    int32_t in2_cstride, in2_coff, Cin2;   /* Cin2 = 32 or 64 */
+    int32_t reserved2;
+    const uint16_t* w2_split; /* W2 as three bf16 planes [3][Npad][Cin2] with w == h + m + l exactly */
 } spaa_tapconv_t;
 
 int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream);
@@ -135,7 +142,7 @@ int spaa_tapconv_wgrad(const spaa_tapconv_t* desc, const float* gout, float* dw_
  * workspace: the launcher's own choice, which this function reports). */
 int spaa_tapconv_wino_plan(const spaa_tapconv_t* desc, int32_t* plan);
 /* layout probes for language bindings: sizeof(spaa_tapconv_t) and the byte offset of field # `field`
- * (0 out, 1 weights, 2 taps, 3 gate2, 4 mask_out, 5 tap_range, 6 splitk_ws, 7 io_dtype, 8 nclass, 9 cls; else -1) */
+ * (0 out, 1 weights, 2 taps, 3 gate2, 4 mask_out, 5 tap_range, 6 splitk_ws, 7 io_dtype, 8 nclass, 9 cls, 10 in2, 11 w2_split; else -1) */
 int spaa_tapconv_sizeof(void);
 int spaa_tapconv_offsetof(int field);
 

@@ -41,6 +41,8 @@ class TapConv(C.Structure):
         ('splitk_ws', C.c_void_p), ('ksplit', C.c_int32), ('nfold', C.c_int32), ('reserved0', C.c_int32),
         ('io_dtype', C.c_int32), ('reserved1', C.c_int32), ('nclass', C.c_int32),
         ('cls', TapClass * MAX_CLASSES),
+        ('in2', C.c_void_p), ('in2_cstride', C.c_int32), ('in2_coff', C.c_int32), ('Cin2', C.c_int32), ('reserved2', C.c_int32),
+        ('w2_split', C.c_void_p),
     ]
 
 

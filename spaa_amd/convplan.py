@@ -34,11 +34,12 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               48: 'x6d16p_128x128', 49: 'x6d16p_128x64', 50: 'x6d16a3p_128x64', 51: 'x6da3p_128x64', 52: 'x6d16p_256x128',
               53: 'x6d16p_128x32', 54: 'x6dp_128x128',
               60: 'h16_128x128', 61: 'h16_128x64', 62: 'h16_128x32', 63: 'h16_128x16', 64: 'h16_256x128', 65: 'h16_256x256', 68: 'h16p_16x32x128', 72: 'thinmf_12x32',
+              74: 'x6p_8x32',
               70: 'wino_x6_16x32x128', 71: 'wino_x6_16x32x64'}   # (70: the launcher chooses the N tile -- reported as 71 when it took 64; 71: 64-wide forced)
 X6D_TILES = set(range(25, 28)) | set(range(30, 38)) | set(range(39, 47)) | set(range(48, 55))   # DMA-staged bf16x6 kernels (csrc/tapconv_x6d.hip)
 X6D_PERSISTENT = set(range(48, 55))      # ... of which the persistent ones (stream-K capable)
 H16_TILES = set(range(60, 66))           # fp16 implicit-GEMM kernels (csrc/tapconv_h16.hip); 68 = patch-staged 3x3 (tapconv_h16p.hip)
-STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 66)) | {68, 70, 71}  # shared epilogue (epilogue.hpp)
+STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 66)) | {68, 70, 71, 74}  # shared epilogue (epilogue.hpp)
 F16OUT_TILES = set(range(15, 25)) | {38} | set(range(60, 66))  # ... of which these may write fp16 (fp32 image in, fp16 activation out)
 DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
 DEBUG_TAPMAJOR = int(os.environ.get('SPAA_X6D_TAPMAJOR', '0'))      # 1: tap-major K order (A/B measurements only)
@@ -194,6 +195,36 @@ class ConvPlan:
         dy0, dy1, dx0, dx1 = self.tap_range
         return dy1 - dy0 + 1 <= 4 and dx1 - dx0 + 1 <= 4
 
+    def x6p_ok(self):
+        """Stride-2 fractional layer for the patch-staged bf16x6 kernel (csrc/tapconv_x6p.hip, tile 74): four output-parity classes in
+        row-major order, every tap inside one 2 x 2 window, stride-1 input sampling, Cin % 32 == 0, unfolded."""
+        if not (len(self.cls) == 4 and self.s_in == 1 and self.s_out == 2 and self.nfold == 1 and self.cin_p % 32 == 0
+                and self.cin == self.cin_p and self.w_split is not None):
+            return False
+        if any((c['oy0'], c['ox0']) != (i // 2, i % 2) or not 1 <= c['ntaps'] <= 4 or c['Kpad'] != c['K'] for i, c in enumerate(self.cls)):
+            return False
+        dy0, dy1, dx0, dx1 = self.tap_range
+        if not (dy1 - dy0 == 1 and dx1 - dx0 == 1):
+            return False
+        # (the kernel fetches the next window position's pixels under the products of class (1, 1): it must have a tap at each)
+        return sorted((dy, dx) for dy, dx, _ in self.classes_host[3].taps) == [(dy0, dx0), (dy0, dx1), (dy1, dx0), (dy1, dx1)]
+
+    def attach_second_source(self, weight2, bias2=None):
+        """Fuse a 1 x 1 convolution of a tensor at OUTPUT resolution into this stride-2 layer (tile 74): `weight2` [Cout, Cin2] (Cin2 =
+        32 or 64).  `run(..., inp2=...)` then adds it before bias / residual / activation; the bias becomes the sum of both."""
+        assert self.x6p_ok()
+        w2 = weight2.detach().float().reshape(weight2.shape[0], -1).cpu()
+        assert w2.shape[0] == self.cout and w2.shape[1] in (32, 64)
+        wp = torch.zeros(self._npad, w2.shape[1])
+        wp[:self.cout] = w2
+        self.w2_split = split_planes(wp).reshape(-1).to(self._dev)
+        self.cin2 = w2.shape[1]
+        b = self.bias.clone() if self.bias is not None else torch.zeros(self.cout, device=self._dev)
+        if bias2 is not None:
+            b = b + bias2.detach().float().to(b.device)
+        self.bias2 = b          # bias of the fused launch
+        return self
+
     def thin_fold(self, half):
         """The weights in the folded layout of the thin-output matrix-core kernel: GEMM rows = class * 4 + channel (16 rows; rows of
         taps a class does not have, of absent channels and classes: zero), [channel block][tap column][plane][tap row][16][32
@@ -240,11 +271,12 @@ class ConvPlan:
         return self.w_half
 
     def run(self, inp, out, add=None, gate=None, gate_mode=_lib.GATE_POS, act=_lib.ACT_NONE, aux_out=None,
-            gate2=None, in_coff=0, out_coff=0, add_coff=0, gate_coff=0, mask_out=None, gate_bits=None, gate2_bits=None):
+            gate2=None, in_coff=0, out_coff=0, add_coff=0, gate_coff=0, mask_out=None, gate_bits=None, gate2_bits=None,
+            inp2=None, in2_coff=0):
         """inp: [B,Hin,Win,Cs_in], out: [B,Hout,Wout,Cs_out] NHWC float32 CUDA tensors.
         `mask_out` / `gate_bits` / `gate2_bits`: uint8 [B,Hout,Wout,Cs/4] ReLU-gate masks (one byte per 4 channels,
         include/spaa_hip.h): written for this launch's output resp. read instead of a float `gate` / `gate2`."""
-        _lib.check_dev(inp, out, add, gate, aux_out, gate2, half_ok=True)
+        _lib.check_dev(inp, out, add, gate, aux_out, gate2, inp2, half_ok=True)
         _lib.check_mask(mask_out, gate_bits, gate2_bits)
         in_f16, out_f16 = inp.dtype == torch.float16, out.dtype == torch.float16
         for t in (add, gate, aux_out, gate2):
@@ -412,6 +444,17 @@ class ConvPlan:
                 d.w_half = self.thin_fold(True).data_ptr()
             else:
                 d.w_split = self.thin_fold(False).data_ptr()
+        if inp2 is not None:
+            # second source (attach_second_source): the patch-staged stride-2 kernel only, fp32 storage
+            if getattr(self, 'w2_split', None) is None or in_f16 or out_f16 or not self.x6p_ok():
+                raise ValueError(f'{self.name}: a second source needs attach_second_source() on an fp32 stride-2 layer')
+            assert inp2.dtype == torch.float32 and inp2.shape[:3] == out.shape[:3] and in2_coff + self.cin2 <= inp2.shape[3]
+            tile, d.ksplit, d.splitk_ws = 74, 0, None
+            d.in2, d.in2_cstride, d.in2_coff, d.Cin2 = inp2.data_ptr(), inp2.shape[3], in2_coff, self.cin2
+            d.w2_split = self.w2_split.data_ptr()
+            d.bias = self.bias2.data_ptr()
+        if tile == 74 and not (self.x6p_ok() and not (in_f16 or out_f16)):
+            tile = 0 if forced else self._default_tile(b * d.Hm * d.Wm, winograd=False) % 100
         d.tile = self.last_tile = tile     # (last_tile: for tests and reports)
         d.reserved0 = (DEBUG_TAPMAJOR | (DEBUG_PERSIST_CAP << 8) | (DEBUG_WINO << 16) | (DEBUG_H16_2STAGE << 25) | (DEBUG_SMALLCIN_NOSLAB << 26)
                        | ((DEBUG_THINMF & 7) << 27) | (((DEBUG_WINO_NOCANVAS & 1) << 30 | (DEBUG_WINO_NOCANVAS >> 1 & 1) << 29) if tile in (70, 71) else 0))  # measurement / test switches
@@ -456,7 +499,11 @@ class ConvPlan:
                                                                                + (aux_out is not None) + (gate2 is not None))
                       + bi * self.alg_taps * self.cin_p * self.cout)
             nbytes += npx * self.cout // 4 * ((mask_out is not None) + (gate_bits is not None) + (gate2_bits is not None))
-            PROFILE.append((self.name, key, self.flops(b, hout, wout), e0, e1, tid, nbytes))
+            fl = self.flops(b, hout, wout)
+            if inp2 is not None:
+                nbytes += 4 * npx * self.cin2
+                fl += 2 * npx * self.cin2 * self.cout
+            PROFILE.append((self.name, key, fl, e0, e1, tid, nbytes))
         return out
 
     def wgrad(self, inp, gout, dbias=True, nchunk=None, out_coff=0, in_coff=0):

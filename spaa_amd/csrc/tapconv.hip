@@ -24,6 +24,7 @@ int spaa_launch_tapconv_h16(const spaa_tapconv_t& d, int tile, hipStream_t strea
 int spaa_launch_tapconv_h16p(const spaa_tapconv_t& d, hipStream_t stream);           // tapconv_h16p.hip
 int spaa_launch_tapconv_thinmf(const spaa_tapconv_t& d, hipStream_t stream);         // tapconv_thinmf.hip
 int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream);          // tapconv_wino.hip
+int spaa_launch_tapconv_x6p(const spaa_tapconv_t& d, hipStream_t stream);           // tapconv_x6p.hip
 int spaa_launch_thinpatch(const spaa_tapconv_t& d, hipStream_t stream);               // thinpatch.hip
 int spaa_launch_smallcin(const spaa_tapconv_t& d, hipStream_t stream);                // smallcin.hip
 
@@ -540,6 +541,8 @@ extern "C" int spaa_tapconv_offsetof(int field) {
         case 7: return (int)offsetof(spaa_tapconv_t, io_dtype);
         case 8: return (int)offsetof(spaa_tapconv_t, nclass);
         case 9: return (int)offsetof(spaa_tapconv_t, cls);
+        case 10: return (int)offsetof(spaa_tapconv_t, in2);
+        case 11: return (int)offsetof(spaa_tapconv_t, w2_split);
         default: return -1;
     }
 }
@@ -557,7 +560,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         // byte masks (1 byte per 4 channels): only the epilogues built on epilogue.hpp's store4 know them, and only in its
         // 4-channel-vector form
         const int t = d.tile;
-        if (!((t >= 15 && t <= 27) || (t >= 30 && t <= 46) || (t >= 48 && t <= 54) || (t >= 60 && t <= 65) || t == 68 || t == 70 || t == 71)) return hipErrorInvalidValue;
+        if (!((t >= 15 && t <= 27) || (t >= 30 && t <= 46) || (t >= 48 && t <= 54) || (t >= 60 && t <= 65) || t == 68 || t == 70 || t == 71 || t == 74)) return hipErrorInvalidValue;
         if ((d.Cout | d.out_cstride | d.out_coff) & 3) return hipErrorInvalidValue;
         if (d.add != nullptr && ((d.add_cstride | d.add_coff) & 3)) return hipErrorInvalidValue;
         if (d.gate_bits != nullptr && (d.gate != nullptr || ((d.gate_cstride | d.gate_coff) & 3))) return hipErrorInvalidValue;
@@ -579,6 +582,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
     for (int c = 0; c < d.nclass; ++c)
         if ((int64_t)((d.Cout + 127) & ~127) * d.cls[c].Kpad * 4 >= (int64_t)1 << 31) return hipErrorInvalidValue;
     int tile = d.tile;
+    if (d.in2 != nullptr && tile != 74) return hipErrorInvalidValue;   // (second source: the patch-staged stride-2 kernel only)
     // fp16-storage mode: fp16 inputs only through the h16 kernels; fp16 outputs only through the shared epilogue
     if ((d.io_dtype & SPAA_IO_IN_F16) && !((tile >= 60 && tile <= 65) || tile == 68 || ((tile == 29 || tile == 72) && !(d.io_dtype & SPAA_IO_OUT_F16)))) return hipErrorInvalidValue;
     if (!(d.io_dtype & SPAA_IO_IN_F16) && tile >= 60 && tile <= 63) return hipErrorInvalidValue;
@@ -659,6 +663,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         case 70:
         case 71: return spaa_launch_tapconv_wino(d, stream);
         case 72: return spaa_launch_tapconv_thinmf(d, stream);
+        case 74: return spaa_launch_tapconv_x6p(d, stream);
         default: return hipErrorInvalidValue;
     }
 }

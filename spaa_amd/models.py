@@ -23,6 +23,8 @@ from .synthetic import uniform_ctrl_pts
 
 USE_GATE_MASKS = os.environ.get('SPAA_GATE_MASKS', '1') != '0'   # 0: fp32 activations as ReLU gates (A/B measurements)
 FUSE_TAIL = os.environ.get('SPAA_FUSE_TAIL', '1') != '0'         # 0: transConv2 / conv6 as separate launches (A/B measurements)
+FUSE_SKIP2 = int(os.environ.get('SPAA_FUSE_SKIP2', '7'))         # bits: 1 transConv1 + skipConv2, 2 conv2^T + skipConv2^T, 4 conv2_s^T on the same kernel; 0: separate launches (A/B measurements)
+FUSE_SKIP2_MIN_PIXELS = int(os.environ.get('SPAA_FUSE_SKIP2_MIN', '16384'))   # B x H/4 x W/4 from which the fused kernel's 4 x 32-pixel regions fill the chip
 
 
 def C_ptr(t):
@@ -339,7 +341,9 @@ class PCNetEngine:
     """Packed weights, sampling grid and workspaces of one PCNet for a fixed batch size; HIP forward and
     input-gradient passes over NHWC4 tensors."""
 
-    def __init__(self, pcnet, batch, prj_size, storage='f32'):
+    def __init__(self, pcnet, batch, prj_size, storage='f32', fuse_skip2=None):
+        """`fuse_skip2`: None = where it applies (fp32 storage, enough pixels), False = never (the training step: weight gradients
+        and weight refreshes work on the separate layers' plans)."""
         if storage not in ('f32', 'f16'):
             raise ValueError("storage must be 'f32' or 'f16'")
         self.storage = storage
@@ -384,6 +388,24 @@ class PCNetEngine:
         f['transConv1'] = cp.deconv_fwd_plan(sn.transConv1.weight, sn.transConv1.bias, 2, 1, dev, 'transConv1',
                                              fold=True if storage == 'f16' else None)
         d['transConv1'] = cp.deconv_dgrad_plan(sn.transConv1.weight, 2, 1, dev, 'transConv1_dgrad')
+        # fp32 storage: `transConv1(x5) + skipConv2(x1)` (models.py:293,299) as ONE launch of the patch-staged stride-2 kernel with
+        # the 1 x 1 convolution as its second source (csrc/tapconv_x6p.hip: no R2 tensor, no separate launch), its mirror image in
+        # the backward pass (`conv2^T(g2) + skipConv2^T(g6)`), and the surface branch's conv2_s input gradient on the same kernel
+        self.fuse_skip2 = False
+        if FUSE_SKIP2 and fuse_skip2 is not False and storage == 'f32' and USE_GATE_MASKS and batch * (self.Hc // 4) * (self.Wc // 4) >= FUSE_SKIP2_MIN_PIXELS:
+            tc = cp.deconv_fwd_plan(sn.transConv1.weight, sn.transConv1.bias, 2, 1, dev, 'transConv1+skipConv2', fold=False)
+            c2 = cp.conv_dgrad_plan(sn.conv2.weight, 2, 1, dev, 'conv2_dgrad+skipConv2_dgrad', fold=False)
+            if tc.x6p_ok() and c2.x6p_ok() and tuple(sn.skipConv2.weight.shape) == (tc.cout, c2.cout, 1, 1) and c2.cout in (32, 64) and tc.cout in (32, 64):
+                tc.attach_second_source(sn.skipConv2.weight, sn.skipConv2.bias)
+                c2.attach_second_source(sn.skipConv2.weight.detach()[:, :, 0, 0].t().contiguous(), None)
+                if FUSE_SKIP2 & 1:
+                    f['transConv1x'] = tc
+                if FUSE_SKIP2 & 2:
+                    d['conv2x'] = c2
+                if self.rough and FUSE_SKIP2 & 4:
+                    d['conv2_s'] = cp.conv_dgrad_plan(sn.conv2_s.weight, 2, 1, dev, 'conv2_s_dgrad', fold=False)
+                    d['conv2_s'].fixed_tile = 74
+                self.fuse_skip2 = True
         f['transConv2'] = cp.deconv_fwd_plan(sn.transConv2.weight, sn.transConv2.bias, 2, 0, dev, 'transConv2')
         d['transConv2'] = cp.deconv_dgrad_plan(sn.transConv2.weight, 2, 0, dev, 'transConv2_dgrad')
         sk = sn.skipConv1
@@ -481,13 +503,17 @@ class PCNetEngine:
         if self.rough:
             self._surface_branch(a['cat8'])
         f['conv1'].run(a['xw'], a['X1'], add=a['S1'], act=R, mask_out=m['X1'])
-        f['skipConv2'].run(a['X1'], a['R2'], act=N)
+        if not (self.fuse_skip2 and 'transConv1x' in f):
+            f['skipConv2'].run(a['X1'], a['R2'], act=N)
         f['conv2'].run(a['X1'], a['X2'], add=a['S2'], act=R, mask_out=m['X2'])
         f['skipConv3'].run(a['X2'], a['R3'], act=N)
         f['conv3'].run(a['X2'], a['X3'], add=a['S3'], act=R, mask_out=m['X3'])
         f['conv4'].run(a['X3'], a['X4'], add=a['S4'], act=R, mask_out=m['X4'])
         f['conv5'].run(a['X4'], a['X5'], add=a['R3'], act=R, mask_out=m['X5'])
-        f['transConv1'].run(a['X5'], a['X6'], add=a['R2'], act=R, mask_out=m['X6'])
+        if self.fuse_skip2 and 'transConv1x' in f:
+            f['transConv1x'].run(a['X5'], a['X6'], inp2=a['X1'], act=R, mask_out=m['X6'])
+        else:
+            f['transConv1'].run(a['X5'], a['X6'], add=a['R2'], act=R, mask_out=m['X6'])
         if self.fuse_tail:
             t = self.tail
             f16 = self.storage == 'f16'   # (X6 fp16 in HBM; the activation kept in LDS and the arithmetic stay fp32)
@@ -525,8 +551,11 @@ class PCNetEngine:
         d['conv4'].run(g['P4'], g['P3'], gate_bits=m['X3'])
         d['skipConv3'].run(g['P5'], g['t2'])
         d['conv3'].run(g['P3'], g['P2'], add=g['t2'], gate_bits=m['X2'])
-        d['skipConv2'].run(g['P6'], g['t1'])
-        d['conv2'].run(g['P2'], g['P1'], add=g['t1'], gate_bits=m['X1'])
+        if self.fuse_skip2 and 'conv2x' in d:
+            d['conv2x'].run(g['P2'], g['P1'], inp2=g['P6'], gate_bits=m['X1'])
+        else:
+            d['skipConv2'].run(g['P6'], g['t1'])
+            d['conv2'].run(g['P2'], g['P1'], add=g['t1'], gate_bits=m['X1'])
         if not self.rough:   # the surface branch is a constant: the gradient reaches the warped image through conv1 alone
             d['conv1'].run(g['P1'], g['xw'])
             return self.warp_backward(g['xw'])

@@ -81,7 +81,7 @@ class PCNetTrainer:
         """PCNetEngine + index maps to refresh its packed weights, wgrad plans (unfolded geometry), refine-net plans."""
         wn, sn = self.pc.warping_net, self.pc.shading_net
         dev = self.dev
-        eng = PCNetEngine(self.pc, self.B, prj_size)
+        eng = PCNetEngine(self.pc, self.B, prj_size, fuse_skip2=False)
         eng.fuse_tail = False   # the weight gradients of conv6 / transConv2 read X7 and its gradient
         self.maps = []   # (plan, parameter, bias parameter or None)
 

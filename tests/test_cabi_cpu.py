@@ -41,11 +41,12 @@ def test_struct_layout_matches_c():
     # spaa_tapclass_t: 6 x int32 + int64 = 32 bytes
     assert ctypes.sizeof(_lib.TapClass) == 32
     assert _lib.TapConv.cls.offset % 8 == 0
-    assert ctypes.sizeof(_lib.TapConv) == _lib.TapConv.cls.offset + 4 * 32
+    assert _lib.TapConv.in2.offset == _lib.TapConv.cls.offset + 4 * 32      # (the second-source fields follow the classes)
+    assert ctypes.sizeof(_lib.TapConv) == _lib.TapConv.in2.offset + 32
     # the compiled struct itself (layout probes exported by the library)
     lib = _lib.load()
     assert lib.spaa_tapconv_sizeof() == ctypes.sizeof(_lib.TapConv)
-    for i, f in enumerate(('out', 'weights', 'taps', 'gate2', 'mask_out', 'tap_range', 'splitk_ws', 'io_dtype', 'nclass', 'cls')):
+    for i, f in enumerate(('out', 'weights', 'taps', 'gate2', 'mask_out', 'tap_range', 'splitk_ws', 'io_dtype', 'nclass', 'cls', 'in2', 'w2_split')):
         assert lib.spaa_tapconv_offsetof(i) == getattr(_lib.TapConv, f).offset, f
 
 

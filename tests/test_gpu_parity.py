@@ -264,6 +264,111 @@ def test_winograd_canvas_and_k_ranges(hip, ci, co, h, w, b, tile, ks):
         cp.DEBUG_WINO_NOCANVAS = old_nc
 
 
+@pytest.mark.parametrize('kind,ci,co,h,w,b,ci2', [('deconv', 128, 64, 64, 64, 2, 0), ('deconv', 128, 64, 13, 21, 3, 32), ('deconv', 64, 32, 9, 40, 2, 0),
+                                                  ('dgrad', 64, 32, 24, 24, 2, 64), ('dgrad', 64, 32, 17, 35, 3, 0), ('dgrad', 128, 64, 28, 28, 2, 0),
+                                                  ('dgrad', 256, 128, 14, 14, 4, 0), ('deconv', 32, 128, 8, 8, 5, 32)])
+def test_patch_staged_stride2_kernel(hip, kind, ci, co, h, w, b, ci2):
+    """csrc/tapconv_x6p.hip (tile 74): ConvTranspose2d(k3, s2, p1, op1) forward and the input gradient of a k3 / s2 / p1 convolution as
+    ONE launch over the four output-parity classes (input patch staged once, exactly the nine real (class, tap) products), with
+    an optional fused 1 x 1 second source at output resolution (models.py:293,299: transConv1(x) + skipConv2(x1)).  Against
+    fp64 at the exact-fp32 kernel's error level, every epilogue form, channel windows, bitwise run to run."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(ci + co + h + ci2)
+    if kind == 'deconv':   # x [b, ci, h, w] -> [b, co, 2h, 2w]
+        wt, bias = torch.randn(ci, co, 3, 3) / (ci * 2.25) ** 0.5, torch.randn(co)
+        x = torch.relu(torch.randn(b, ci, h, w))
+        plan = cp.deconv_fwd_plan(wt, bias, 2, 1, DEV, 'tc', fold=False)
+        truth = F.conv_transpose2d(x.double(), wt.double(), bias.double(), 2, 1, 1)
+        ho, wo = 2 * h, 2 * w
+    else:                  # gradient of conv(co -> ci channels ... ) : consumes [b, ci, h, w], produces [b, co, ~2h, ~2w]
+        ho, wo = 2 * h - (h % 2), 2 * w          # (an odd and an even output size)
+        wt, bias = torch.randn(ci, co, 3, 3) / (ci * 2.25) ** 0.5, None
+        x = torch.randn(b, ci, h, w)
+        assert (ho + 2 - 3) // 2 + 1 == h and (wo + 2 - 3) // 2 + 1 == w
+        plan = cp.conv_dgrad_plan(wt, 2, 1, DEV, 'dg', fold=False)
+        truth = torch.nn.grad.conv2d_input((b, co, ho, wo), wt.double(), x.double(), 2, 1)
+    assert plan.x6p_ok()
+    x2 = w2 = None
+    if ci2:
+        w2, b2 = torch.randn(co, ci2, 1, 1) / ci2 ** 0.5, torch.randn(co)
+        x2 = torch.randn(b, ci2 + 32, ho, wo)          # (a channel window of a wider tensor)
+        plan.attach_second_source(w2, b2)
+        truth = truth + F.conv2d(x2[:, 32:].double(), w2.double(), b2.double())
+    kw = dict(inp2=nhwc(x2).to(DEV), in2_coff=32) if ci2 else {}
+    xin = nhwc(x).to(DEV)
+    errs = {}
+    try:
+        for t in ((74,) if ci2 else (6, 34, 74)):
+            cp.FORCE_TILE = t
+            out = torch.zeros(b, ho, wo, co, device=DEV)
+            plan.run(xin, out, **kw)
+            assert plan.last_tile == t
+            errs[t] = (nchw(out.cpu()).double() - truth).abs().max().item() / truth.abs().max().item()
+        print(f'{kind} {ci}->{co} {h}x{w} second source {ci2}: rel err vs fp64 ' + ' '.join(f'tile {t}: {e:.1e}' for t, e in errs.items()))
+        assert errs[74] < (max(2 * errs[6], 3e-7) if not ci2 else 2e-6)
+        cp.FORCE_TILE = 74
+        ref = truth.float()
+        out = torch.zeros(b, ho, wo, co, device=DEV)
+        plan.run(xin, out, **kw)
+        out2 = torch.zeros_like(out)
+        plan.run(xin, out2, **kw)
+        assert torch.equal(out, out2)
+        add, gate = torch.randn(b, co, ho, wo), torch.randn(b, co, ho, wo)
+        mask = torch.zeros(b, ho, wo, co // 4, dtype=torch.uint8, device=DEV)
+        plan.run(xin, out, add=nhwc(add).to(DEV), act=lib.ACT_RELU, mask_out=mask, **kw)
+        assert rel_inf(nchw(out.cpu()), F.relu(ref + add)) < 1e-5 and torch.equal(mask, lib.pack_gate_mask(out))
+        gbits = lib.pack_gate_mask(nhwc(gate).to(DEV))
+        plan.run(xin, out, gate_bits=gbits, **kw)
+        assert rel_inf(nchw(out.cpu()), ref * (gate > 0)) < 1e-5
+        plan.run(xin, out, gate=nhwc(gate).to(DEV), **kw)          # float gate: the generic epilogue
+        assert rel_inf(nchw(out.cpu()), ref * (gate > 0)) < 1e-5
+        wide_in = torch.zeros(b, h, w, ci + 32, device=DEV)
+        wide_in[..., 32:] = xin
+        wide_in[..., :32] = 3.0
+        wide_out = torch.full((b, ho, wo, co + 64), 7.0, device=DEV)
+        plan.run(wide_in, wide_out, in_coff=32, out_coff=64, **kw)
+        assert rel_inf(nchw(wide_out.cpu())[:, 64:], ref) < 1e-5 and (wide_out[..., :64] == 7.0).all()
+    finally:
+        cp.FORCE_TILE = 0
+
+
+@pytest.mark.parametrize('ci,co,ci2', [(64, 32, 0), (64, 32, 64), (128, 64, 32)])
+def test_patch_staged_stride2_full_size_is_reproducible(hip, ci, co, ci2):
+    """Tile 74 at the benchmark's sizes (batch 64, 64 x 64 class grid: 2048 workgroups, two per compute unit, short K): every
+    image equal to the implicit-GEMM tile's result and bitwise run to run.  (A counted `vmcnt` that let a combo's weights stay in
+    flight corrupted one or two workgroups of 2048 per launch -- only at this size, only sometimes: caught by
+    test_benchmarked_configuration_first_iteration, pinned here.)"""
+    cp = hip['cp']
+    torch.manual_seed(ci)
+    b = 64
+    wt = torch.randn(ci, co, 3, 3) / (ci * 2.25) ** 0.5
+    plan = cp.conv_dgrad_plan(wt, 2, 1, DEV, 'dg', fold=False)
+    x = torch.randn(b, 64, 64, ci, device=DEV)
+    add = torch.randn(b, 128, 128, co, device=DEV)
+    gb = (torch.rand(b, 128, 128, co // 4, device=DEV) * 16).to(torch.uint8)
+    kw = {}
+    if ci2:
+        plan.attach_second_source(torch.randn(co, ci2) / ci2 ** 0.5, None)
+        x2 = torch.randn(b, 128, 128, ci2, device=DEV)
+        kw = dict(inp2=x2)
+    try:
+        outs = []
+        for rep in range(4):
+            cp.FORCE_TILE = 74
+            o = torch.zeros(b, 128, 128, co, device=DEV)
+            plan.run(x, o, add=add, gate_bits=gb, **kw)
+            outs.append(o)
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+        if not ci2:
+            cp.FORCE_TILE = 30
+            ref = torch.zeros(b, 128, 128, co, device=DEV)
+            plan.run(x, ref, add=add, gate_bits=gb)
+            d = (ref - outs[0]).abs().flatten(1).max(dim=1).values / ref.abs().max()
+            assert d.max() < 2e-6, [i for i, v in enumerate(d.tolist()) if v > 2e-6]
+    finally:
+        cp.FORCE_TILE = 0
+
+
 def test_winograd_epilogues_and_masks(hip):
     """The Winograd kernel shares the epilogue of the other bf16x6 kernels: bias, residual, ReLU, byte gate masks."""
     cp, lib = hip['cp'], hip['lib']
@@ -1666,6 +1771,47 @@ def test_engine_masks_match_activations(hip, golden_dir):
     for blk in body.blocks:
         assert torch.equal(blk['m_o1'], lib.pack_gate_mask(blk['o1'])) and torch.equal(blk['m_out'], lib.pack_gate_mask(blk['out']))
     assert torch.equal((body.mp_arg & 128) != 0, body.mp > 0)
+
+
+@pytest.mark.parametrize('cam_sz,prj_sz,b', [((64, 64), (64, 64), 3), ((48, 80), (64, 64), 2), ((240, 320), (256, 256), 2)])
+def test_fused_skipconv2_forward_and_backward(hip, cam_sz, prj_sz, b):
+    """`transConv1(x5) + skipConv2(x1)` and `conv2^T(g2) + skipConv2^T(g6)` as single launches of the patch-staged stride-2 kernel
+    (second source; spaa_amd/models.py PCNetEngine.fuse_skip2) against the engine with the three layers launched separately: the
+    same network output, gate masks and input gradient up to the summation order (one accumulation chain instead of two
+    rounded results added), and against the oracle's forward."""
+    M = hip['models']
+    sd = syn.pcnet_state_dict(5, cam_sz=cam_sz, mask='rect')
+    pc = make_pcnet(hip, sd, cam_sz)
+    old = M.FUSE_SKIP2_MIN_PIXELS
+    try:
+        M.FUSE_SKIP2_MIN_PIXELS = 0
+        e1 = M.PCNetEngine(pc, b, prj_sz)
+        e0 = M.PCNetEngine(pc, b, prj_sz, fuse_skip2=False)
+    finally:
+        M.FUSE_SKIP2_MIN_PIXELS = old
+    assert e1.fuse_skip2 and not e0.fuse_skip2 and e1.d['conv2_s'].fixed_tile == 74
+    torch.manual_seed(b)
+    scene = syn.scenes(3, b, cam_sz)
+    x = torch.rand(b, 3, *prj_sz)
+    g = torch.randn(b, *cam_sz, 4, device=DEV)
+    g[..., 3] = 0
+    outs = []
+    for e in (e1, e0):
+        e.set_scene(M.to_nhwc4(scene.to(DEV)))
+        y = e.forward(M.to_nhwc4(x.to(DEV))).clone()
+        gx = e.backward(g).clone()
+        outs.append((y, gx, e.a['X6'].clone(), e.m['X6'].clone(), e.g['P1'].clone()))
+    assert e1.f['transConv1x'].last_tile == 74 and e1.d['conv2x'].last_tile == 74 and e1.d['conv2_s'].last_tile == 74
+    (y1, gx1, x61, m61, p11), (y0, gx0, x60, m60, p10) = outs
+    flips = int((m61 != m60).sum())
+    print(f'fused vs separate at {cam_sz} B={b}: Y {rel_inf(y1, y0):.1e}, X6 {rel_inf(x61, x60):.1e}, gate bytes differing {flips} of {m60.numel()}, '
+          f'P1 {rel_l2(p11, p10):.1e}, input gradient rel L2 {rel_l2(gx1, gx0):.1e}')
+    assert rel_inf(y1, y0) < 2e-6 and rel_inf(x61, x60) < 2e-6 and flips <= 2e-5 * m60.numel()
+    assert rel_l2(p11, p10) < (1e-5 if flips == 0 else 1e-2) and rel_l2(gx1, gx0) < (1e-5 if flips == 0 else 1e-2)
+    with torch.no_grad():
+        xw = so.warp(sd, x.clamp(0, 1), cam_sz) * sd['mask']
+        ref = so.shading_net(sd, xw, (scene, xw * scene))
+    assert rel_inf(M.to_nchw(y1), ref) < 1e-5
 
 
 @pytest.mark.parametrize('storage', ['f32', 'f16'])

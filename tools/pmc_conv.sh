@@ -14,7 +14,7 @@ import csv,sys,collections,glob
 for f in sorted(glob.glob(sys.argv[1]+'/*/*counter_collection.csv')):
     agg=collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(f)):
-        if 'tapconv' in r['Kernel_Name'] or 'thin' in r['Kernel_Name'] or 'wino' in r['Kernel_Name']:
+        if any(k in r['Kernel_Name'] for k in ('tapconv', 'thin', 'wino', 'x6p')):
             agg[r['Counter_Name']][r['Dispatch_Id']]+=float(r['Counter_Value'])
     for c,d in agg.items():
         v=list(d.values()); print(f'{c:28s} {sum(v)/len(v):16.0f}  n={len(v)}')
