@@ -113,9 +113,13 @@ typedef struct {
     int32_t reserved1;
     int32_t nclass;
     spaa_tapclass_t cls[SPAA_MAX_CLASSES];
-    /* optional SECOND SOURCE (tile 74 only; NULL = none): a 1 x 1 convolution of a tensor at OUTPUT resolution, added to the
-     * accumulators before bias / residual / activation -- `transConv1(x) + skipConv2(x1)` (models.py:293,299) and its mirror
-     * image in the backward pass as ONE launch: out[b, oy, ox, n] += sum_c in2[b, oy, ox, in2_coff + c] * W2[n][c] */
+    /* optional SECOND SOURCE (NULL = none).
+     * Tile 74: a 1 x 1 convolution of a tensor at OUTPUT resolution, added to the accumulators before bias / residual / activation
+     * -- `transConv1(x) + skipConv2(x1)` (models.py:293,299) and its mirror image in the backward pass as ONE launch:
+     * out[b, oy, ox, n] += sum_c in2[b, oy, ox, in2_coff + c] * W2[n][c] (weights `w2_split`, Cin2 = 32 or 64).
+     * Tiles 70 / 71 (Winograd): the layer's LAST Cin2 input channels (Cin2 % 32 == 0, 0 < Cin2 < Cin) are read from `in2`
+     * ([B, Hin, Win, in2_cstride]) instead of `in` -- conv(a, Wa) + conv(b, Wb) as one convolution over the concatenated channels,
+     * `conv5(x4) + skipConv3(x2)` (models.py:294,298); `w2_split` unused (the weights are the layer's own, K = 16 x Cin). */
     const float* in2;         /* [B, Hout, Wout, in2_cstride] */
     int32_t in2_cstride, in2_coff, Cin2;   /* Cin2 = 32 or 64 */
     int32_t reserved2;

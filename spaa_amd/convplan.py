@@ -284,7 +284,10 @@ class ConvPlan:
                 raise ValueError(f'{self.name}: add / gate / aux_out / gate2 must have the storage type of `out` ({out.dtype})')
         b, hin, win, cs_in = inp.shape
         b2, hout, wout, cs_out = out.shape
-        assert b == b2 and cs_in % 4 == 0 and in_coff % 4 == 0 and in_coff + self.cin_p <= cs_in
+        cin2k = getattr(self, 'cin2_k', 0)   # (two-source Winograd plan: the last cin2_k input channels come from `inp2`)
+        if cin2k and (inp2 is None or inp2.shape[:3] != inp.shape[:3] or inp2.dtype != torch.float32 or in2_coff + cin2k > inp2.shape[3]):
+            raise ValueError(f'{self.name}: a two-source plan needs `inp2` [B, H, W, >= {cin2k} channels] (fp32)')
+        assert b == b2 and cs_in % 4 == 0 and in_coff % 4 == 0 and in_coff + self.cin_p - cin2k <= cs_in
         assert out_coff + self.cout <= cs_out
         d = _lib.TapConv()
         d.inp, d.Hin, d.Win, d.Cin, d.in_cstride, d.in_coff = inp.data_ptr(), hin, win, self.cin_p, cs_in, in_coff
@@ -346,6 +349,8 @@ class ConvPlan:
         tile = forced if forced else tuned_tile(key)
         if tile < 0:
             tile = self._default_tile(b * d.Hm * d.Wm)
+        if cin2k and self.wino is not None and tile % 100 not in (70, 71):
+            tile = 70      # (two sources: only the Winograd kernel reads them)
         thin_mf = (forced in (0, 72) and 'thinmf' not in DEFAULT_DISABLE and not out_f16 and not masked and self.thin_ok())
         if thin_mf and not in_f16:
             # fp32 input (bf16x6: the 3-way operand split costs as much as the products): the stride-2 layers, whose four classes fill
@@ -359,7 +364,7 @@ class ConvPlan:
             if self.wino is not None and WINOGRAD and not (in_f16 or out_f16) and (hin, win) == (hout, wout):
                 self.wino.fixed_tile, self.wino.wino_ksplit = tile % 100, tile // 100
                 return self.wino.run(inp, out, add, gate, gate_mode, act, aux_out, gate2, in_coff, out_coff, add_coff, gate_coff,
-                                     mask_out, gate_bits, gate2_bits)
+                                     mask_out, gate_bits, gate2_bits, inp2, in2_coff)
             tile = 0 if forced else self._default_tile(b * d.Hm * d.Wm, winograd=False)
         if in_f16:    # fp16 activations: the h16 kernels, N tile by the GEMM's width
             ngemm = self.cout * self.nfold
@@ -444,7 +449,11 @@ class ConvPlan:
                 d.w_half = self.thin_fold(True).data_ptr()
             else:
                 d.w_split = self.thin_fold(False).data_ptr()
-        if inp2 is not None:
+        if cin2k:
+            if tile not in (70, 71):
+                raise ValueError(f'{self.name}: a two-source plan runs on the Winograd kernel only (fp32 storage, same-size output)')
+            d.in2, d.in2_cstride, d.in2_coff, d.Cin2 = inp2.data_ptr(), inp2.shape[3], in2_coff, cin2k
+        elif inp2 is not None:
             # second source (attach_second_source): the patch-staged stride-2 kernel only, fp32 storage
             if getattr(self, 'w2_split', None) is None or in_f16 or out_f16 or not self.x6p_ok():
                 raise ValueError(f'{self.name}: a second source needs attach_second_source() on an fp32 stride-2 layer')
@@ -500,7 +509,7 @@ class ConvPlan:
                       + bi * self.alg_taps * self.cin_p * self.cout)
             nbytes += npx * self.cout // 4 * ((mask_out is not None) + (gate_bits is not None) + (gate2_bits is not None))
             fl = self.flops(b, hout, wout)
-            if inp2 is not None:
+            if inp2 is not None and not cin2k:   # (second source of the stride-2 kernel; a two-source plan's channels are in cin_p)
                 nbytes += 4 * npx * self.cin2
                 fl += 2 * npx * self.cin2 * self.cout
             PROFILE.append((self.name, key, fl, e0, e1, tid, nbytes))
@@ -646,6 +655,30 @@ def attach_winograd(plan):
     wino.flops_per_pixel, wino.alg_taps = plan.flops_per_pixel, 9   # algorithmic work = the direct convolution's
     _winograd_weights(plan, wino)
     plan.wino = wino
+    return plan
+
+
+def conv_fwd_plan_2src(weight_a, weight_b, bias, device='cuda', name=''):
+    """conv(a, Wa) + conv(b, Wb) + bias for two 3x3 / s1 / p1 convolutions of tensors a, b of the same size (`conv5(x4) +
+    skipConv3(x2)`, /root/reference/src/python/models.py:294,298) as ONE convolution over the channel-concatenated input, run by
+    the Winograd kernel whose patch DMA reads the channel blocks of `a` from `inp` and those of `b` from `inp2`: no concatenated
+    tensor, no second launch, one accumulation chain.  None when the layer has no Winograd form."""
+    w = torch.cat([_w2(weight_a), _w2(weight_b)], 1)
+    plan = conv_fwd_plan(w, bias, 1, 1, device, name)
+    if plan.wino is None or weight_a.shape[1] % 32 or weight_b.shape[1] % 32:
+        return None
+    plan.cin2_k = plan.wino.cin2_k = weight_b.shape[1]
+    return plan
+
+
+def conv_dgrad_plan_2src(weight_a, weight_b, device='cuda', name=''):
+    """conv_a^T(ga) + conv_b^T(gb): the input gradients of two 3x3 / s1 / p1 convolutions that read the SAME tensor (conv3 and
+    skipConv3 both read x2), as one launch (see conv_fwd_plan_2src); `inp` = ga, `inp2` = gb."""
+    w = torch.cat([_w2(weight_a), _w2(weight_b)], 0)
+    plan = conv_dgrad_plan(w, 1, 1, device, name)
+    if plan.wino is None or weight_a.shape[0] % 32 or weight_b.shape[0] % 32:
+        return None
+    plan.cin2_k = plan.wino.cin2_k = weight_b.shape[0]
     return plan
 
 

@@ -552,7 +552,9 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     // host-side shape checks: a faulting kernel can take the whole node down
     if (d.in == nullptr || d.out == nullptr || d.weights == nullptr || d.taps == nullptr) return hipErrorInvalidValue;
-    if (d.Cin <= 0 || (d.Cin & 3) || (d.in_cstride & 3) || (d.in_coff & 3) || d.in_coff + d.Cin > d.in_cstride)
+    // (Winograd with two sources: the last Cin2 of the Cin input channels are read from `in2`)
+    const int cin_main = (d.in2 != nullptr && (d.tile == 70 || d.tile == 71)) ? d.Cin - d.Cin2 : d.Cin;
+    if (d.Cin <= 0 || (d.Cin & 3) || (d.in_cstride & 3) || (d.in_coff & 3) || cin_main <= 0 || d.in_coff + cin_main > d.in_cstride)
         return hipErrorInvalidValue;
     if (d.Cout <= 0 || d.out_coff + d.Cout > d.out_cstride) return hipErrorInvalidValue;
     if (d.gate2 != nullptr && (d.aux_out == nullptr || d.act == SPAA_ACT_RELU_CLAMP1)) return hipErrorInvalidValue;
@@ -582,7 +584,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
     for (int c = 0; c < d.nclass; ++c)
         if ((int64_t)((d.Cout + 127) & ~127) * d.cls[c].Kpad * 4 >= (int64_t)1 << 31) return hipErrorInvalidValue;
     int tile = d.tile;
-    if (d.in2 != nullptr && tile != 74) return hipErrorInvalidValue;   // (second source: the patch-staged stride-2 kernel only)
+    if (d.in2 != nullptr && tile != 74 && tile != 70 && tile != 71) return hipErrorInvalidValue;   // (second source: the patch-staged stride-2 kernel and the Winograd kernel)
     // fp16-storage mode: fp16 inputs only through the h16 kernels; fp16 outputs only through the shared epilogue
     if ((d.io_dtype & SPAA_IO_IN_F16) && !((tile >= 60 && tile <= 65) || tile == 68 || ((tile == 29 || tile == 72) && !(d.io_dtype & SPAA_IO_OUT_F16)))) return hipErrorInvalidValue;
     if (!(d.io_dtype & SPAA_IO_IN_F16) && tile >= 60 && tile <= 63) return hipErrorInvalidValue;

@@ -105,7 +105,10 @@ struct wino_geo_t {
     int order;                 // 1: regions fastest in the workgroup order, 0: N tiles fastest (as in the image-aligned form)
 };
 
-template <int BN, int VAR, int DBG = 0, bool CV = false>   // DBG: timing-only ablations (wrong results): 1 no epilogue, 2 no fold, 4 no V, 8 no barrier, 16 no DMA; 32: raw barrier.  CV: canvas / split-K form
+// TWO: the layer's input channels come from TWO tensors of the same B x H x W (channel blocks [0, Cin - Cin2) from `in`, the rest from
+// `in2`): conv(a, Wa) + conv(b, Wb) as ONE convolution over the concatenated channels without the concatenated tensor --
+// ShadingNetSPAA's `conv5(x4) + skipConv3(x2)` (models.py:294,298) and its mirror image in the backward pass.
+template <int BN, int VAR, int DBG = 0, bool CV = false, bool TWO = false>   // DBG: timing-only ablations (wrong results): 1 no epilogue, 2 no fold, 4 no V, 8 no barrier, 16 no DMA; 32: raw barrier.  CV: canvas / split-K form
 __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p, const int wg_y, const int wg_x, const int n_tiles, const wino_geo_t geo) {
     constexpr int TJ = BN / 16;
     constexpr int W_PLANE = BN * 64;
@@ -158,6 +161,9 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
     const uint32_t in_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(in_addr >> 32));
     const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)in_hi << 32) | in_lo), 0,
                                                             (int)__builtin_amdgcn_readfirstlane(in_bytes), 0x00020000);
+    const int kb1 = TWO ? (Cin - p.Cin2) >> 5 : 0x7fffffff;   // first channel block of the second source
+    const int row_bytes2 = TWO ? p.in2_cstride * 4 : 0;
+    const auto rsrc_in2 = TWO ? rsrc_or_empty(p.in2, (int64_t)p.B * (H * W) * row_bytes2) : rsrc_in;
     const int npad = (p.Cout + 127) & ~127;
     const int plane_bytes = npad * cl.Kpad * 2;
     const uint64_t w_addr = reinterpret_cast<uint64_t>(p.w_split);
@@ -236,6 +242,15 @@ __global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p,
         if constexpr (CV) ok_ = canvas_pixel(iy_, ix_, pxi_) && pix_ < NPX;                                          \
         const int u_ = pc_ >> 1;                                                                                     \
         const int lc_ = ((((lane & 7) >> 1) - 2 * (u_ >> 2)) & 3) * 2 + ((lane & 1) ^ ((u_ >> 1) & 1));               \
+        if constexpr (TWO) {                                                                                         \
+            const bool s2_ = (kb_) >= kb1;   /* (uniform) */                                                           \
+            const int off2_ = ok_ ? pxi_ * (s2_ ? row_bytes2 : row_bytes) + lc_ * 16 +                                \
+                                        (s2_ ? p.in2_coff * 4 + ((kb_) - kb1) * 128 : p.in_coff * 4 + (kb_) * 128)   \
+                                  : (int)0x80000000;                                                                 \
+            if (s2_) dma16(rsrc_in2, smem + (wave + NW * i) * 1024, off2_, 0);                                       \
+            else dma16(rsrc_in, smem + (wave + NW * i) * 1024, off2_, 0);                                            \
+            continue;                                                                                                \
+        }                                                                                                            \
         const int off_ = ok_ ? pxi_ * row_bytes + p.in_coff * 4 + lc_ * 16 + (kb0 + (kb_)) * 128                     \
                              : (int)0x80000000;                                                                      \
         dma16(rsrc_in, smem + (wave + NW * i) * 1024, off_, 0);                                                      \
@@ -679,7 +694,8 @@ extern "C" int spaa_tapconv_wino_plan(const spaa_tapconv_t* desc, int32_t* plan)
     spaa_tapconv_t d = *desc;
     if (d.w_split == nullptr) d.w_split = reinterpret_cast<const uint16_t*>(desc);   // (the plan does not depend on the pointers)
     if (!wino_shape_ok(d) || (d.tile != 70 && d.tile != 71)) return hipErrorInvalidValue;
-    const wino_plan_t pl = wino_make_plan(d, wino_ncu(), d.tile == 71 ? 64 : 0, d.ksplit, true);
+    if (d.in2 != nullptr) d.reserved0 |= 1 << 30;
+    const wino_plan_t pl = wino_make_plan(d, wino_ncu(), d.tile == 71 ? 64 : 0, d.in2 != nullptr ? 1 : d.ksplit, d.in2 == nullptr);
     plan[0] = pl.bn, plan[1] = pl.ksplit, plan[2] = pl.canvas, plan[3] = pl.gy, plan[4] = pl.gx;
     plan[5] = (int32_t)(pl.nwg > 0x7fffffff ? 0x7fffffff : pl.nwg), plan[6] = pl.kb_per, plan[7] = pl.ncanvas;
     return 0;
@@ -693,11 +709,18 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     // K ranges: the caller's (with its workspace), or chosen here when a workspace is there to take them
     const bool has_ws = d.splitk_ws != nullptr;
     if (d.ksplit > 1 && !has_ws) return hipErrorInvalidValue;
-    const wino_plan_t pl = wino_make_plan(d, wino_ncu(), d.tile == 71 ? 64 : 0, has_ws ? d.ksplit : 1, has_ws);
+    spaa_tapconv_t dp = d;
+    if (d.in2 != nullptr) dp.reserved0 |= 1 << 30;   // (two sources: no canvas ...)
+    const wino_plan_t pl = wino_make_plan(dp, wino_ncu(), d.tile == 71 ? 64 : 0, (has_ws && d.in2 == nullptr) ? d.ksplit : 1, has_ws && d.in2 == nullptr);   // (... and no K ranges)
     if (pl.nwg > 0x7fffffff) return hipErrorInvalidValue;
     const int BN = pl.bn, n_tiles = pl.n_tiles, wg_y = pl.wg_y, wg_x = pl.wg_x;
     const int64_t nwg = pl.nwg;
+    const bool two = d.in2 != nullptr;
+    if (two && ((d.Cin2 % 32) != 0 || d.Cin2 <= 0 || d.Cin2 >= d.Cin || (d.in2_cstride & 3) || (d.in2_coff & 3) || d.in2_coff + d.Cin2 > d.in2_cstride ||
+                d.in_coff + d.Cin - d.Cin2 > d.in_cstride || (int64_t)d.B * d.Hin * d.Win * d.in2_cstride * 4 >= (int64_t)1 << 31))
+        return hipErrorInvalidValue;
     const bool cv = pl.canvas || pl.ksplit > 1;
+    if (two && cv) return hipErrorInvalidValue;   // (the plan below never asks for it: two sources keep the image-aligned form)
     wino_geo_t geo = {};
     geo.ksplit = pl.ksplit, geo.kb_per = pl.kb_per;
     geo.gy = pl.gy, geo.gx = pl.gx, geo.py = pl.canvas ? pl.py : (1 << 14), geo.px = pl.canvas ? pl.px : (1 << 14);
@@ -711,7 +734,7 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     if (cv && (int64_t)d.B * d.Hout * d.Wout >= ((int64_t)1 << 24)) return hipErrorInvalidValue;   // (the plan never asks for it: wino_make_plan)
     spaa_tapconv_t dd = d;
     dd.ksplit = pl.ksplit;
-    static bool attr_set[10][SPAA_MAX_DEVICES] = {};
+    static bool attr_set[12][SPAA_MAX_DEVICES] = {};
     // kernel variant: bit 0 = late V (waves 4-7 transform one step ahead), bit 1 = xi groups expanded.  Default 3 / 2 (measured:
     // conv4 500 -> 462 us, conv5 461 -> 415 us against variant 0); `reserved0` bits 16-17 flip bits for A/B measurements
     const int var = (BN == 64 ? 2 : 3) ^ ((d.reserved0 >> 16) & 3);   // (64-wide tile: late V does not pay: 168 / 167 / 159 us for 0 / 3 / 2)
@@ -723,6 +746,13 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
         hipLaunchKernelGGL((wino_x6_kernel<N, V, 0, C>), dim3((unsigned)nwg), dim3(512), smem, stream, dd, wg_y, wg_x, n_tiles, geo); \
     }
 #define WINO_LAUNCH(N, V, SLOT) WINO_LAUNCH_T(N, V, false, SLOT)
+#define WINO_LAUNCH_T2(N, V, SLOT)                                                                                        \
+    {                                                                                                                     \
+        const size_t smem = (size_t)PATCH_BYTES + 3 * (size_t)(((3 * N / 16 + 7) / 8) * 8 * 1024);                        \
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<N, V, 0, false, true>), (int)smem, attr_set[SLOT]); \
+        if (e != hipSuccess) return (int)e;                                                                               \
+        hipLaunchKernelGGL((wino_x6_kernel<N, V, 0, false, true>), dim3((unsigned)nwg), dim3(512), smem, stream, dd, wg_y, wg_x, n_tiles, geo); \
+    }
 #ifdef SPAA_WINO_ABLATE
     const int dbg = (d.reserved0 >> 18) & 127;
 #define WINO_LAUNCH_DBG(D)                                                                                                \
@@ -739,7 +769,9 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     }
 #undef WINO_LAUNCH_DBG
 #endif
-    if (cv) {   // canvas / K-split form: the default variants only
+    if (two) {   // two sources: the default variants only
+        if (BN == 64) WINO_LAUNCH_T2(64, 2, 10) else WINO_LAUNCH_T2(128, 3, 11)
+    } else if (cv) {   // canvas / K-split form: the default variants only
         if (BN == 64) WINO_LAUNCH_T(64, 2, true, 8) else WINO_LAUNCH_T(128, 3, true, 9)
         if (pl.ksplit > 1) {
             const int npad = (d.Cout + 127) & ~127;
@@ -751,5 +783,6 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     } else if (var == 3) WINO_LAUNCH(128, 3, 3) else if (var == 2) WINO_LAUNCH(128, 2, 2) else if (var == 1) WINO_LAUNCH(128, 1, 1) else WINO_LAUNCH(128, 0, 0)
 #undef WINO_LAUNCH
 #undef WINO_LAUNCH_T
+#undef WINO_LAUNCH_T2
     return (int)hipGetLastError();
 }

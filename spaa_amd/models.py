@@ -23,7 +23,7 @@ from .synthetic import uniform_ctrl_pts
 
 USE_GATE_MASKS = os.environ.get('SPAA_GATE_MASKS', '1') != '0'   # 0: fp32 activations as ReLU gates (A/B measurements)
 FUSE_TAIL = os.environ.get('SPAA_FUSE_TAIL', '1') != '0'         # 0: transConv2 / conv6 as separate launches (A/B measurements)
-FUSE_SKIP2 = int(os.environ.get('SPAA_FUSE_SKIP2', '7'))         # bits: 1 transConv1 + skipConv2, 2 conv2^T + skipConv2^T, 4 conv2_s^T on the same kernel; 0: separate launches (A/B measurements)
+FUSE_SKIP2 = int(os.environ.get('SPAA_FUSE_SKIP2', '15'))        # bits: 1 transConv1 + skipConv2, 2 conv2^T + skipConv2^T, 4 conv2_s^T on the same kernel, 8 conv5 + skipConv3 and conv3^T + skipConv3^T; 0: separate launches (A/B measurements)
 FUSE_SKIP2_MIN_PIXELS = int(os.environ.get('SPAA_FUSE_SKIP2_MIN', '16384'))   # B x H/4 x W/4 from which the fused kernel's 4 x 32-pixel regions fill the chip
 
 
@@ -406,6 +406,15 @@ class PCNetEngine:
                     d['conv2_s'] = cp.conv_dgrad_plan(sn.conv2_s.weight, 2, 1, dev, 'conv2_s_dgrad', fold=False)
                     d['conv2_s'].fixed_tile = 74
                 self.fuse_skip2 = True
+        # likewise `conv5(x4) + skipConv3(x2)` (models.py:294,298) and `conv3^T(g3) + skipConv3^T(g5)`: one Winograd launch each over
+        # the concatenated input channels, read from two tensors (cp.conv_fwd_plan_2src)
+        self.fuse_skip3 = False
+        if FUSE_SKIP2 & 8 and fuse_skip2 is not False and storage == 'f32' and USE_GATE_MASKS and cp.WINOGRAD and self.fuse_skip2:
+            c5 = cp.conv_fwd_plan_2src(sn.conv5.weight, sn.skipConv3.weight, sn.conv5.bias.detach() + sn.skipConv3.bias.detach(), dev, 'conv5+skipConv3')
+            c3 = cp.conv_dgrad_plan_2src(sn.conv3.weight, sn.skipConv3.weight, dev, 'conv3_dgrad+skipConv3_dgrad')
+            if c5 is not None and c3 is not None:
+                f['conv5x'], d['conv3x'] = c5, c3
+                self.fuse_skip3 = True
         f['transConv2'] = cp.deconv_fwd_plan(sn.transConv2.weight, sn.transConv2.bias, 2, 0, dev, 'transConv2')
         d['transConv2'] = cp.deconv_dgrad_plan(sn.transConv2.weight, 2, 0, dev, 'transConv2_dgrad')
         sk = sn.skipConv1
@@ -506,10 +515,14 @@ class PCNetEngine:
         if not (self.fuse_skip2 and 'transConv1x' in f):
             f['skipConv2'].run(a['X1'], a['R2'], act=N)
         f['conv2'].run(a['X1'], a['X2'], add=a['S2'], act=R, mask_out=m['X2'])
-        f['skipConv3'].run(a['X2'], a['R3'], act=N)
+        if not self.fuse_skip3:
+            f['skipConv3'].run(a['X2'], a['R3'], act=N)
         f['conv3'].run(a['X2'], a['X3'], add=a['S3'], act=R, mask_out=m['X3'])
         f['conv4'].run(a['X3'], a['X4'], add=a['S4'], act=R, mask_out=m['X4'])
-        f['conv5'].run(a['X4'], a['X5'], add=a['R3'], act=R, mask_out=m['X5'])
+        if self.fuse_skip3:
+            f['conv5x'].run(a['X4'], a['X5'], inp2=a['X2'], act=R, mask_out=m['X5'])
+        else:
+            f['conv5'].run(a['X4'], a['X5'], add=a['R3'], act=R, mask_out=m['X5'])
         if self.fuse_skip2 and 'transConv1x' in f:
             f['transConv1x'].run(a['X5'], a['X6'], inp2=a['X1'], act=R, mask_out=m['X6'])
         else:
@@ -549,8 +562,11 @@ class PCNetEngine:
         else:
             d['conv5'].run(g['P5'], g['P4'], gate_bits=m['X4'])
         d['conv4'].run(g['P4'], g['P3'], gate_bits=m['X3'])
-        d['skipConv3'].run(g['P5'], g['t2'])
-        d['conv3'].run(g['P3'], g['P2'], add=g['t2'], gate_bits=m['X2'])
+        if self.fuse_skip3:
+            d['conv3x'].run(g['P3'], g['P2'], inp2=g['P5'], gate_bits=m['X2'])
+        else:
+            d['skipConv3'].run(g['P5'], g['t2'])
+            d['conv3'].run(g['P3'], g['P2'], add=g['t2'], gate_bits=m['X2'])
         if self.fuse_skip2 and 'conv2x' in d:
             d['conv2x'].run(g['P2'], g['P1'], inp2=g['P6'], gate_bits=m['X1'])
         else:

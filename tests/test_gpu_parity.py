@@ -369,6 +369,50 @@ def test_patch_staged_stride2_full_size_is_reproducible(hip, ci, co, ci2):
         cp.FORCE_TILE = 0
 
 
+@pytest.mark.parametrize('ca,cb,co,h,w,b', [(256, 64, 128, 64, 64, 2), (128, 128, 64, 40, 70, 3), (64, 32, 192, 17, 33, 2)])
+def test_winograd_two_sources(hip, ca, cb, co, h, w, b):
+    """conv(a, Wa) + conv(b, Wb) as ONE Winograd launch over the concatenated input channels read from two tensors
+    (cp.conv_fwd_plan_2src: `conv5(x4) + skipConv3(x2)`, models.py:294,298), and the mirror image for input gradients
+    (cp.conv_dgrad_plan_2src): against fp64, epilogues, channel windows of wider tensors."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(ca + cb)
+    xa, xb = torch.randn(b, ca, h, w), torch.randn(b, cb, h, w)
+    wa, wb, bias = torch.randn(co, ca, 3, 3) / (3 * (ca + cb) ** 0.5), torch.randn(co, cb, 3, 3) / (3 * (ca + cb) ** 0.5), torch.randn(co)
+    truth = F.conv2d(xa.double(), wa.double(), bias.double(), 1, 1) + F.conv2d(xb.double(), wb.double(), None, 1, 1)
+    plan = cp.conv_fwd_plan_2src(wa, wb, bias, DEV, 'two')
+    assert plan is not None
+    wide_a = torch.randn(b, h, w, ca + 32, device=DEV)
+    wide_a[..., 32:] = nhwc(xa).to(DEV)
+    wide_b = torch.randn(b, h, w, cb + 64, device=DEV)
+    wide_b[..., 64:] = nhwc(xb).to(DEV)
+    out = torch.zeros(b, h, w, co, device=DEV)
+    plan.run(wide_a, out, inp2=wide_b, in_coff=32, in2_coff=64)
+    assert plan.wino.last_tile in (70, 71)
+    e = (nchw(out.cpu()).double() - truth).abs().max().item() / truth.abs().max().item()
+    print(f'two sources {ca}+{cb}->{co} {h}x{w}: rel err vs fp64 {e:.1e}, plan {plan.wino.last_wino_plan}')
+    assert e < 6e-7
+    add = torch.randn(b, co, h, w)
+    mask = torch.zeros(b, h, w, co // 4, dtype=torch.uint8, device=DEV)
+    plan.run(wide_a, out, inp2=wide_b, in_coff=32, in2_coff=64, add=nhwc(add).to(DEV), act=lib.ACT_RELU, mask_out=mask)
+    assert rel_inf(nchw(out.cpu()), F.relu(truth.float() + add)) < 1e-5 and torch.equal(mask, lib.pack_gate_mask(out))
+    with pytest.raises(ValueError):
+        plan.run(wide_a, out, in_coff=32)                    # the second tensor is not optional
+    # input gradients of two convolutions that read the same tensor: ga [co], gb [cb2] -> [ci]
+    ci, co_a, co_b = 64, ca, cb
+    wa2, wb2 = torch.randn(co_a, ci, 3, 3) / (3 * (ca + cb) ** 0.5), torch.randn(co_b, ci, 3, 3) / (3 * (ca + cb) ** 0.5)
+    ga, gb = torch.randn(b, co_a, h, w), torch.randn(b, co_b, h, w)
+    gt = (torch.nn.grad.conv2d_input((b, ci, h, w), wa2.double(), ga.double(), 1, 1)
+          + torch.nn.grad.conv2d_input((b, ci, h, w), wb2.double(), gb.double(), 1, 1))
+    dplan = cp.conv_dgrad_plan_2src(wa2, wb2, DEV, 'two_d')
+    gx = torch.zeros(b, h, w, ci, device=DEV)
+    gbits = (torch.rand(b, h, w, ci // 4, device=DEV) * 16).to(torch.uint8)
+    dplan.run(nhwc(ga).to(DEV), gx, inp2=nhwc(gb).to(DEV))
+    assert (nchw(gx.cpu()).double() - gt).abs().max().item() / gt.abs().max().item() < 6e-7
+    dplan.run(nhwc(ga).to(DEV), gx, inp2=nhwc(gb).to(DEV), gate_bits=gbits)
+    keep = torch.stack([(gbits.cpu() >> e_) & 1 for e_ in range(4)], -1).reshape(b, h, w, ci).permute(0, 3, 1, 2).bool()
+    assert rel_inf(nchw(gx.cpu()), gt.float() * keep) < 1e-5
+
+
 def test_winograd_epilogues_and_masks(hip):
     """The Winograd kernel shares the epilogue of the other bf16x6 kernels: bias, residual, ReLU, byte gate masks."""
     cp, lib = hip['cp'], hip['lib']
@@ -1789,7 +1833,7 @@ def test_fused_skipconv2_forward_and_backward(hip, cam_sz, prj_sz, b):
         e0 = M.PCNetEngine(pc, b, prj_sz, fuse_skip2=False)
     finally:
         M.FUSE_SKIP2_MIN_PIXELS = old
-    assert e1.fuse_skip2 and not e0.fuse_skip2 and e1.d['conv2_s'].fixed_tile == 74
+    assert e1.fuse_skip2 and e1.fuse_skip3 and not e0.fuse_skip2 and not e0.fuse_skip3 and e1.d['conv2_s'].fixed_tile == 74
     torch.manual_seed(b)
     scene = syn.scenes(3, b, cam_sz)
     x = torch.rand(b, 3, *prj_sz)
@@ -1800,11 +1844,12 @@ def test_fused_skipconv2_forward_and_backward(hip, cam_sz, prj_sz, b):
         e.set_scene(M.to_nhwc4(scene.to(DEV)))
         y = e.forward(M.to_nhwc4(x.to(DEV))).clone()
         gx = e.backward(g).clone()
-        outs.append((y, gx, e.a['X6'].clone(), e.m['X6'].clone(), e.g['P1'].clone()))
+        outs.append((y, gx, e.a['X6'].clone(), torch.cat([e.m[k].reshape(-1) for k in sorted(e.m)]), e.g['P1'].clone()))
     assert e1.f['transConv1x'].last_tile == 74 and e1.d['conv2x'].last_tile == 74 and e1.d['conv2_s'].last_tile == 74
+    assert e1.f['conv5x'].wino.last_tile in (70, 71) and e1.d['conv3x'].wino.last_tile in (70, 71)
     (y1, gx1, x61, m61, p11), (y0, gx0, x60, m60, p10) = outs
     flips = int((m61 != m60).sum())
-    print(f'fused vs separate at {cam_sz} B={b}: Y {rel_inf(y1, y0):.1e}, X6 {rel_inf(x61, x60):.1e}, gate bytes differing {flips} of {m60.numel()}, '
+    print(f'fused vs separate at {cam_sz} B={b}: Y {rel_inf(y1, y0):.1e}, X6 {rel_inf(x61, x60):.1e}, gate bytes differing (all eleven masks) {flips} of {m60.numel()}, '
           f'P1 {rel_l2(p11, p10):.1e}, input gradient rel L2 {rel_l2(gx1, gx0):.1e}')
     assert rel_inf(y1, y0) < 2e-6 and rel_inf(x61, x60) < 2e-6 and flips <= 2e-5 * m60.numel()
     assert rel_l2(p11, p10) < (1e-5 if flips == 0 else 1e-2) and rel_l2(gx1, gx0) < (1e-5 if flips == 0 else 1e-2)
