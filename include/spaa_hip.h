@@ -71,7 +71,7 @@ typedef struct {
     const float* gate;    /* indexed like `out`, or NULL */
     int32_t gate_cstride, gate_coff, gate_mode;
     int32_t act;
-    int32_t tile;         /* 0 = auto; 1..54, 60..65, 68, 70, 71, 72, 74 = explicit kernel / workgroup tile (the dispatcher in tapconv.hip lists them;
+    int32_t tile;         /* 0 = auto; 1..54, 60..65, 68, 70, 71, 72, 73, 74 = explicit kernel / workgroup tile (the dispatcher in tapconv.hip lists them;
                              spaa_amd/convplan.py: TILE_NAMES; chosen per layer shape by tools/autotune.py) */
     float* aux_out;       /* optional second output (indexed like `out`):
                              act == SPAA_ACT_RELU_CLAMP1: the value BEFORE the clamp;

@@ -34,12 +34,12 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               48: 'x6d16p_128x128', 49: 'x6d16p_128x64', 50: 'x6d16a3p_128x64', 51: 'x6da3p_128x64', 52: 'x6d16p_256x128',
               53: 'x6d16p_128x32', 54: 'x6dp_128x128',
               60: 'h16_128x128', 61: 'h16_128x64', 62: 'h16_128x32', 63: 'h16_128x16', 64: 'h16_256x128', 65: 'h16_256x256', 68: 'h16p_16x32x128', 72: 'thinmf_12x32',
-              74: 'x6p_8x32',
+              73: 'wino_x6_8x32x64', 74: 'x6p_4x32',
               70: 'wino_x6_16x32x128', 71: 'wino_x6_16x32x64'}   # (70: the launcher chooses the N tile -- reported as 71 when it took 64; 71: 64-wide forced)
 X6D_TILES = set(range(25, 28)) | set(range(30, 38)) | set(range(39, 47)) | set(range(48, 55))   # DMA-staged bf16x6 kernels (csrc/tapconv_x6d.hip)
 X6D_PERSISTENT = set(range(48, 55))      # ... of which the persistent ones (stream-K capable)
 H16_TILES = set(range(60, 66))           # fp16 implicit-GEMM kernels (csrc/tapconv_h16.hip); 68 = patch-staged 3x3 (tapconv_h16p.hip)
-STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 66)) | {68, 70, 71, 74}  # shared epilogue (epilogue.hpp)
+STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 66)) | {68, 70, 71, 73, 74}  # shared epilogue (epilogue.hpp)
 F16OUT_TILES = set(range(15, 25)) | {38} | set(range(60, 66))  # ... of which these may write fp16 (fp32 image in, fp16 activation out)
 DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
 DEBUG_TAPMAJOR = int(os.environ.get('SPAA_X6D_TAPMAJOR', '0'))      # 1: tap-major K order (A/B measurements only)
@@ -349,7 +349,7 @@ class ConvPlan:
         tile = forced if forced else tuned_tile(key)
         if tile < 0:
             tile = self._default_tile(b * d.Hm * d.Wm)
-        if cin2k and self.wino is not None and tile % 100 not in (70, 71):
+        if cin2k and self.wino is not None and tile % 100 not in (70, 71, 73):
             tile = 70      # (two sources: only the Winograd kernel reads them)
         thin_mf = (forced in (0, 72) and 'thinmf' not in DEFAULT_DISABLE and not out_f16 and not masked and self.thin_ok())
         if thin_mf and not in_f16:
@@ -359,8 +359,8 @@ class ConvPlan:
             # always (55 against 306 us).
             if forced == 72 or self.s_out == 2:
                 tile = 72   # thin output: the parity classes folded into the N dimension of a matrix-core tile (csrc/tapconv_thinmf.hip)
-        if tile % 100 in (70, 71):   # Winograd form of a 3x3 / stride-1 layer (csrc/tapconv_wino.hip): fp32 storage, same-size output
-            # (tune values: 70 = the launcher's choice of N tile and K ranges, 71 = 64-wide N tile; + 100 k = k K ranges, k = 1: none)
+        if tile % 100 in (70, 71, 73):   # Winograd form of a 3x3 / stride-1 layer (csrc/tapconv_wino.hip): fp32 storage, same-size output
+            # (tune values: 70 = the launcher's choice of N tile and K ranges, 71 = 64-wide N tile, 73 = 64-wide, four-wave workgroups; + 100 k = k K ranges, k = 1: none)
             if self.wino is not None and WINOGRAD and not (in_f16 or out_f16) and (hin, win) == (hout, wout):
                 self.wino.fixed_tile, self.wino.wino_ksplit = tile % 100, tile // 100
                 return self.wino.run(inp, out, add, gate, gate_mode, act, aux_out, gate2, in_coff, out_coff, add_coff, gate_coff,
@@ -450,7 +450,7 @@ class ConvPlan:
             else:
                 d.w_split = self.thin_fold(False).data_ptr()
         if cin2k:
-            if tile not in (70, 71):
+            if tile not in (70, 71, 73):
                 raise ValueError(f'{self.name}: a two-source plan runs on the Winograd kernel only (fp32 storage, same-size output)')
             d.in2, d.in2_cstride, d.in2_coff, d.Cin2 = inp2.data_ptr(), inp2.shape[3], in2_coff, cin2k
         elif inp2 is not None:
@@ -466,14 +466,14 @@ class ConvPlan:
             tile = 0 if forced else self._default_tile(b * d.Hm * d.Wm, winograd=False) % 100
         d.tile = self.last_tile = tile     # (last_tile: for tests and reports)
         d.reserved0 = (DEBUG_TAPMAJOR | (DEBUG_PERSIST_CAP << 8) | (DEBUG_WINO << 16) | (DEBUG_H16_2STAGE << 25) | (DEBUG_SMALLCIN_NOSLAB << 26)
-                       | ((DEBUG_THINMF & 7) << 27) | (((DEBUG_WINO_NOCANVAS & 1) << 30 | (DEBUG_WINO_NOCANVAS >> 1 & 1) << 29) if tile in (70, 71) else 0))  # measurement / test switches
+                       | ((DEBUG_THINMF & 7) << 27) | (((DEBUG_WINO_NOCANVAS & 1) << 30 | (DEBUG_WINO_NOCANVAS >> 1 & 1) << 29) if tile in (70, 71, 73) else 0))  # measurement / test switches
         d.nclass = len(self.cls)
         d.tap_range[:] = self.tap_range
         for i, c in enumerate(self.cls):
             for k, v in c.items():
                 setattr(d.cls[i], k, v)
         wino_bn = 0
-        if tile in (70, 71):
+        if tile in (70, 71, 73):
             # the launcher's plan (csrc/tapconv_wino.hip: N tile, canvas layout for small images, K ranges for few workgroups with
             # long K) -- asked for here because the K ranges need a workspace; its K-range count is then passed back explicitly
             want = getattr(self, 'wino_ksplit', 0)

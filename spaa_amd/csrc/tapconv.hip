@@ -553,7 +553,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
     // host-side shape checks: a faulting kernel can take the whole node down
     if (d.in == nullptr || d.out == nullptr || d.weights == nullptr || d.taps == nullptr) return hipErrorInvalidValue;
     // (Winograd with two sources: the last Cin2 of the Cin input channels are read from `in2`)
-    const int cin_main = (d.in2 != nullptr && (d.tile == 70 || d.tile == 71)) ? d.Cin - d.Cin2 : d.Cin;
+    const int cin_main = (d.in2 != nullptr && (d.tile == 70 || d.tile == 71 || d.tile == 73)) ? d.Cin - d.Cin2 : d.Cin;
     if (d.Cin <= 0 || (d.Cin & 3) || (d.in_cstride & 3) || (d.in_coff & 3) || cin_main <= 0 || d.in_coff + cin_main > d.in_cstride)
         return hipErrorInvalidValue;
     if (d.Cout <= 0 || d.out_coff + d.Cout > d.out_cstride) return hipErrorInvalidValue;
@@ -562,7 +562,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         // byte masks (1 byte per 4 channels): only the epilogues built on epilogue.hpp's store4 know them, and only in its
         // 4-channel-vector form
         const int t = d.tile;
-        if (!((t >= 15 && t <= 27) || (t >= 30 && t <= 46) || (t >= 48 && t <= 54) || (t >= 60 && t <= 65) || t == 68 || t == 70 || t == 71 || t == 74)) return hipErrorInvalidValue;
+        if (!((t >= 15 && t <= 27) || (t >= 30 && t <= 46) || (t >= 48 && t <= 54) || (t >= 60 && t <= 65) || t == 68 || t == 70 || t == 71 || t == 73 || t == 74)) return hipErrorInvalidValue;
         if ((d.Cout | d.out_cstride | d.out_coff) & 3) return hipErrorInvalidValue;
         if (d.add != nullptr && ((d.add_cstride | d.add_coff) & 3)) return hipErrorInvalidValue;
         if (d.gate_bits != nullptr && (d.gate != nullptr || ((d.gate_cstride | d.gate_coff) & 3))) return hipErrorInvalidValue;
@@ -584,7 +584,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
     for (int c = 0; c < d.nclass; ++c)
         if ((int64_t)((d.Cout + 127) & ~127) * d.cls[c].Kpad * 4 >= (int64_t)1 << 31) return hipErrorInvalidValue;
     int tile = d.tile;
-    if (d.in2 != nullptr && tile != 74 && tile != 70 && tile != 71) return hipErrorInvalidValue;   // (second source: the patch-staged stride-2 kernel and the Winograd kernel)
+    if (d.in2 != nullptr && tile != 74 && tile != 70 && tile != 71 && tile != 73) return hipErrorInvalidValue;   // (second source: the patch-staged stride-2 kernel and the Winograd kernel)
     // fp16-storage mode: fp16 inputs only through the h16 kernels; fp16 outputs only through the shared epilogue
     if ((d.io_dtype & SPAA_IO_IN_F16) && !((tile >= 60 && tile <= 65) || tile == 68 || ((tile == 29 || tile == 72) && !(d.io_dtype & SPAA_IO_OUT_F16)))) return hipErrorInvalidValue;
     if (!(d.io_dtype & SPAA_IO_IN_F16) && tile >= 60 && tile <= 63) return hipErrorInvalidValue;
@@ -663,7 +663,8 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         case 65: return spaa_launch_tapconv_h16(d, tile, stream);
         case 68: return spaa_launch_tapconv_h16p(d, stream);
         case 70:
-        case 71: return spaa_launch_tapconv_wino(d, stream);
+        case 71:
+        case 73: return spaa_launch_tapconv_wino(d, stream);
         case 72: return spaa_launch_tapconv_thinmf(d, stream);
         case 74: return spaa_launch_tapconv_x6p(d, stream);
         default: return hipErrorInvalidValue;

@@ -108,11 +108,17 @@ struct wino_geo_t {
 // TWO: the layer's input channels come from TWO tensors of the same B x H x W (channel blocks [0, Cin - Cin2) from `in`, the rest from
 // `in2`): conv(a, Wa) + conv(b, Wb) as ONE convolution over the concatenated channels without the concatenated tensor --
 // ShadingNetSPAA's `conv5(x4) + skipConv3(x2)` (models.py:294,298) and its mirror image in the backward pass.
-template <int BN, int VAR, int DBG = 0, bool CV = false, bool TWO = false>   // DBG: timing-only ablations (wrong results): 1 no epilogue, 2 no fold, 4 no V, 8 no barrier, 16 no DMA; 32: raw barrier.  CV: canvas / split-K form
-__global__ __launch_bounds__(512, 1) void wino_x6_kernel(const spaa_tapconv_t p, const int wg_y, const int wg_x, const int n_tiles, const wino_geo_t geo) {
+// NWT = 4 (tile 73, 64-wide N tile): a workgroup of FOUR waves (4 x 16 tiles = 8 x 32 output pixels, 80 KB of LDS), TWO workgroups per
+// compute unit -- the two waves of a SIMD belong to different workgroups, so one's prologue / epilogue runs under the other's main
+// loop (short-K layers: ResNet-18 layer1 spends a third of a launch in them).
+template <int BN, int VAR, int DBG = 0, bool CV = false, bool TWO = false, int NWT = 8>   // DBG: timing-only ablations (wrong results): 1 no epilogue, 2 no fold, 4 no V, 8 no barrier, 16 no DMA; 32: raw barrier.  CV: canvas / split-K form
+__global__ __launch_bounds__(64 * NWT, NWT == 4 ? 2 : 1) void wino_x6_kernel(const spaa_tapconv_t p, const int wg_y, const int wg_x, const int n_tiles, const wino_geo_t geo) {
     constexpr int TJ = BN / 16;
     constexpr int W_PLANE = BN * 64;
-    constexpr int NW = 8;
+    constexpr int NW = NWT;
+    // (these shadow the 8-wave constants of the same names above)
+    constexpr int TY = NWT, PH = 2 * TY + 2, NPX = PH * PW, NPIECE = (NPX + 7) / 8, PPW = (NPIECE + NW - 1) / NW, PATCH_BYTES = PPW * NW * 1024;
+    static_assert(NWT == 8 || (NWT == 4 && !(VAR & 1)), "the late-V variants pair waves w and w + 4");
     constexpr int W_PIECES = 3 * BN / 16;
     constexpr int WPW = (W_PIECES + NW - 1) / NW;
     constexpr int WS_BYTES = WPW * NW * 1024;   // (every wave issues WPW DMAs per step: pieces past the planes land in the pad)
@@ -693,9 +699,11 @@ extern "C" int spaa_tapconv_wino_plan(const spaa_tapconv_t* desc, int32_t* plan)
     if (desc == nullptr || plan == nullptr) return hipErrorInvalidValue;
     spaa_tapconv_t d = *desc;
     if (d.w_split == nullptr) d.w_split = reinterpret_cast<const uint16_t*>(desc);   // (the plan does not depend on the pointers)
-    if (!wino_shape_ok(d) || (d.tile != 70 && d.tile != 71)) return hipErrorInvalidValue;
-    if (d.in2 != nullptr) d.reserved0 |= 1 << 30;
-    const wino_plan_t pl = wino_make_plan(d, wino_ncu(), d.tile == 71 ? 64 : 0, d.in2 != nullptr ? 1 : d.ksplit, d.in2 == nullptr);
+    if (!wino_shape_ok(d) || (d.tile != 70 && d.tile != 71 && d.tile != 73)) return hipErrorInvalidValue;
+    if (d.in2 != nullptr || d.tile == 73) d.reserved0 |= 1 << 30;
+    const bool nosplit = d.in2 != nullptr || d.tile == 73;
+    wino_plan_t pl = wino_make_plan(d, wino_ncu(), d.tile == 70 ? 0 : 64, nosplit ? 1 : d.ksplit, !nosplit);
+    if (d.tile == 73) pl.nwg = (int64_t)d.B * cdiv(d.Hout, 8) * pl.wg_x * pl.n_tiles;
     plan[0] = pl.bn, plan[1] = pl.ksplit, plan[2] = pl.canvas, plan[3] = pl.gy, plan[4] = pl.gx;
     plan[5] = (int32_t)(pl.nwg > 0x7fffffff ? 0x7fffffff : pl.nwg), plan[6] = pl.kb_per, plan[7] = pl.ncanvas;
     return 0;
@@ -710,8 +718,13 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     const bool has_ws = d.splitk_ws != nullptr;
     if (d.ksplit > 1 && !has_ws) return hipErrorInvalidValue;
     spaa_tapconv_t dp = d;
-    if (d.in2 != nullptr) dp.reserved0 |= 1 << 30;   // (two sources: no canvas ...)
-    const wino_plan_t pl = wino_make_plan(dp, wino_ncu(), d.tile == 71 ? 64 : 0, (has_ws && d.in2 == nullptr) ? d.ksplit : 1, has_ws && d.in2 == nullptr);   // (... and no K ranges)
+    if (d.in2 != nullptr || d.tile == 73) dp.reserved0 |= 1 << 30;   // (two sources, four-wave form: no canvas ...)
+    const bool nosplit = d.in2 != nullptr || d.tile == 73;
+    wino_plan_t pl = wino_make_plan(dp, wino_ncu(), d.tile == 70 ? 0 : 64, (has_ws && !nosplit) ? d.ksplit : 1, has_ws && !nosplit);   // (... and no K ranges)
+    if (d.tile == 73) {
+        pl.wg_y = cdiv(d.Hout, 8);
+        pl.nwg = (int64_t)d.B * pl.wg_y * pl.wg_x * pl.n_tiles;
+    }
     if (pl.nwg > 0x7fffffff) return hipErrorInvalidValue;
     const int BN = pl.bn, n_tiles = pl.n_tiles, wg_y = pl.wg_y, wg_x = pl.wg_x;
     const int64_t nwg = pl.nwg;
@@ -734,7 +747,7 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     if (cv && (int64_t)d.B * d.Hout * d.Wout >= ((int64_t)1 << 24)) return hipErrorInvalidValue;   // (the plan never asks for it: wino_make_plan)
     spaa_tapconv_t dd = d;
     dd.ksplit = pl.ksplit;
-    static bool attr_set[12][SPAA_MAX_DEVICES] = {};
+    static bool attr_set[14][SPAA_MAX_DEVICES] = {};
     // kernel variant: bit 0 = late V (waves 4-7 transform one step ahead), bit 1 = xi groups expanded.  Default 3 / 2 (measured:
     // conv4 500 -> 462 us, conv5 461 -> 415 us against variant 0); `reserved0` bits 16-17 flip bits for A/B measurements
     const int var = (BN == 64 ? 2 : 3) ^ ((d.reserved0 >> 16) & 3);   // (64-wide tile: late V does not pay: 168 / 167 / 159 us for 0 / 3 / 2)
@@ -769,7 +782,18 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     }
 #undef WINO_LAUNCH_DBG
 #endif
-    if (two) {   // two sources: the default variants only
+    if (d.tile == 73) {   // four-wave workgroups, two per compute unit
+        const size_t smem = (size_t)(((2 * 4 + 2) * PW + 7) / 8 + 3) / 4 * 4 * 1024 + 3 * (size_t)(12 * 1024);
+        if (two) {
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<64, 2, 0, false, true, 4>), (int)smem, attr_set[13]);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((wino_x6_kernel<64, 2, 0, false, true, 4>), dim3((unsigned)nwg), dim3(256), smem, stream, dd, wg_y, wg_x, n_tiles, geo);
+        } else {
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<64, 2, 0, false, false, 4>), (int)smem, attr_set[12]);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((wino_x6_kernel<64, 2, 0, false, false, 4>), dim3((unsigned)nwg), dim3(256), smem, stream, dd, wg_y, wg_x, n_tiles, geo);
+        }
+    } else if (two) {   // two sources: the default variants only
         if (BN == 64) WINO_LAUNCH_T2(64, 2, 10) else WINO_LAUNCH_T2(128, 3, 11)
     } else if (cv) {   // canvas / K-split form: the default variants only
         if (BN == 64) WINO_LAUNCH_T(64, 2, true, 8) else WINO_LAUNCH_T(128, 3, true, 9)

@@ -413,6 +413,40 @@ def test_winograd_two_sources(hip, ca, cb, co, h, w, b):
     assert rel_inf(nchw(gx.cpu()), gt.float() * keep) < 1e-5
 
 
+@pytest.mark.parametrize('ci,co,h,w,b', [(64, 64, 56, 56, 3), (128, 128, 28, 28, 5), (128, 64, 21, 45, 2), (64, 192, 9, 70, 2)])
+def test_winograd_four_wave_workgroups(hip, ci, co, h, w, b):
+    """Tile 73: the Winograd kernel with four-wave workgroups (8 x 32 output pixels, two workgroups per compute unit).  The same
+    per-tile arithmetic in the same order as the eight-wave form with the 64-wide N tile (tile 71): bitwise equal, every epilogue."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(ci + h)
+    x, wt, bias = torch.randn(b, ci, h, w), torch.randn(co, ci, 3, 3) / (3 * ci ** 0.5), torch.randn(co)
+    add, gate = torch.randn(b, co, h, w), torch.randn(b, co, h, w)
+    plan = cp.conv_fwd_plan(wt, bias, 1, 1, DEV)
+    xin, addn = nhwc(x).to(DEV), nhwc(add).to(DEV)
+    gbits = lib.pack_gate_mask(nhwc(gate).to(DEV))
+    res = {}
+    old_nc = cp.DEBUG_WINO_NOCANVAS
+    try:
+        cp.DEBUG_WINO_NOCANVAS = 1
+        for tile in (171, 73):
+            cp.FORCE_TILE = tile
+            o1, o2, o3 = (torch.zeros(b, h, w, co, device=DEV) for _ in range(3))
+            mask = torch.zeros(b, h, w, co // 4, dtype=torch.uint8, device=DEV)
+            plan.run(xin, o1)
+            assert plan.wino.last_tile == tile % 100
+            plan.run(xin, o2, add=addn, act=lib.ACT_RELU, mask_out=mask)
+            plan.run(xin, o3, gate=nhwc(gate).to(DEV))
+            o4 = torch.zeros_like(o1)
+            plan.run(xin, o4, gate_bits=gbits)
+            res[tile] = (o1, o2, o3, o4, mask)
+    finally:
+        cp.FORCE_TILE = 0
+        cp.DEBUG_WINO_NOCANVAS = old_nc
+    for a, c in zip(res[171], res[73]):
+        assert torch.equal(a, c)
+    assert rel_inf(nchw(res[73][0].cpu()), F.conv2d(x, wt, bias, 1, 1)) < 1e-5
+
+
 def test_winograd_epilogues_and_masks(hip):
     """The Winograd kernel shares the epilogue of the other bf16x6 kernels: bias, residual, ReLU, byte gate masks."""
     cp, lib = hip['cp'], hip['lib']

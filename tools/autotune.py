@@ -46,7 +46,7 @@ def main():
     torch.cuda.synchronize()
     res = {}
     names = {}
-    tiles = [int(t) for t in os.environ.get('SPAA_TUNE_TILES', '').split(',') if t] or (list(range(1, 55)) + [70, 71, 170, 171, 270, 271, 470, 471, 870, 871] + [s * 100 + t for s in (2, 4, 8) for t in (25, 27, 31, 34, 35, 36, 42, 48, 50, 52)] + [900 + t for t in (48, 49, 50, 51, 52, 53, 54)])
+    tiles = [int(t) for t in os.environ.get('SPAA_TUNE_TILES', '').split(',') if t] or (list(range(1, 55)) + [70, 71, 73, 170, 171, 270, 271, 470, 471, 870, 871] + [s * 100 + t for s in (2, 4, 8) for t in (25, 27, 31, 34, 35, 36, 42, 48, 50, 52)] + [900 + t for t in (48, 49, 50, 51, 52, 53, 54)])
     # the current choice (tune table / heuristic) per launch, measured in this same process: a candidate must beat it by 2 %
     cur = {}
     convplan.FORCE_TILE = 0
@@ -66,7 +66,7 @@ def main():
             st.iteration(**hp)
         torch.cuda.synchronize()
         for name, key, flops, e0, e1, used, _nbytes in convplan.PROFILE:
-            if (used % 100 not in (70, 71)) if tile % 100 in (70, 71) else used != tile:   # (Winograd: the launcher's N tile / K ranges are reported, not the request)
+            if (used % 100 not in (70, 71, 73) or (used % 100 == 73) != (tile % 100 == 73)) if tile % 100 in (70, 71, 73) else used != tile:   # (Winograd: the launcher's N tile / K ranges are reported, not the request)
                 continue  # this tile is not valid for the layer (ConvPlan.run fell back)
             res.setdefault(key, {}).setdefault(tile, []).append(e0.elapsed_time(e1))
             names.setdefault(key, set()).add(name)

@@ -30,9 +30,9 @@ for ci, co, h, w, b in SHAPES:
         cp.FORCE_TILE, cp.DEBUG_WINO_NOCANVAS = tile, nocanvas
         try:
             a = t(lambda: plan.run(x, out))
-            pl = getattr(plan.wino, 'last_wino_plan', None) if tile % 100 in (70, 71) else None
+            pl = getattr(plan.wino, 'last_wino_plan', None) if tile % 100 in (70, 71, 73) else None
             bb = t(lambda: plan.run(x, out, add=add, act=_lib.ACT_RELU, mask_out=mask))
-            used = plan.wino.last_tile if (tile % 100 in (70, 71) and plan.wino is not None) else plan.last_tile
+            used = plan.wino.last_tile if (tile % 100 in (70, 71, 73) and plan.wino is not None) else plan.last_tile
             res[label] = (a, bb, used, pl)
         except Exception as e:   # noqa
             res[label] = (float('nan'), float('nan'), -1, str(e)[:40])
@@ -43,6 +43,7 @@ for ci, co, h, w, b in SHAPES:
     run('wino_plain', 170, 1)
     run('wino64_plain', 171, 1)
     run('wino_auto', 70)
+    run('wino_4wave', 73, 1)
     for ks in (1, 2, 4, 8):
         run(f'wino128_ks{ks}', 70 + 100 * ks, 2)
         run(f'wino64_ks{ks}', 71 + 100 * ks, 2)
