@@ -140,13 +140,16 @@ def cpu_baseline(sd, csd, setup, scenes, budget_b=16, iters=8):
 def pmc_traffic(tile):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py), or None."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
-    path = next((os.path.join(prof, f) for f in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+    path = next((os.path.join(prof, f) for f in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
                  if os.path.exists(os.path.join(prof, f))), None)
     if path is None:
         return None, None
     m = re.match(r'(x6d(?:16)?(?:co)?(?:a3)?|x6v\d|x6)_(\d+)x(\d+)(?:g(\d))?', tile)
     if tile.startswith('wino'):
-        want = 'wino_x6_kernel<64, 2' if tile.endswith('x64') else 'wino_x6_kernel<128, 3'   # (template arguments: N tile, kernel variant)
+        # template arguments: N tile, kernel variant, 0, canvas / K-range form, two input tensors, waves per workgroup
+        plain = tile.replace('_canvas', '').replace('_2src', '')
+        bn, var, nw = (64, 2, 4) if '_8x32x64' in plain else (64, 2, 8) if plain.endswith('x64') else (128, 3, 8)
+        want = f"wino_x6_kernel<{bn}, {var}, 0, {'true' if '_canvas' in tile else 'false'}, {'true' if '_2src' in tile else 'false'}, {nw}>"
     elif not m:
         return None, None
     else:
@@ -255,6 +258,19 @@ def rehearse_glue(args, world, rank, json_out):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def tile_names(tile_id):
+    """(kernel instantiation as rocprofv3 reports it, tile label of the per-layer table) of a reported tile id (spaa_amd/convplan.py:
+    tile + 100 x K ranges (9 = stream-K); Winograd: + 1000 canvas / K-range form, + 2000 two input tensors)."""
+    from spaa_amd import convplan
+    form, tid = tile_id // 1000, tile_id % 1000
+    # (persistent launches 48..54 run the same instantiations as 34, 36, 42, 44, 35, 37, 25)
+    kern = {48: 34, 49: 36, 50: 42, 51: 44, 52: 35, 53: 37, 54: 25}.get(tid % 100, tid % 100)
+    suffix = {1: '_canvas', 2: '_2src'}.get(form, '')
+    base = convplan.TILE_NAMES.get(kern, 'auto') + suffix
+    tile = convplan.TILE_NAMES.get(tid % 100, 'auto') + suffix + (('_streamk' if tid // 100 == 9 else f'_splitk{tid // 100}') if tid >= 100 else '')
+    return base, tile
+
+
 def instrumented_pass(st, args, n_prof=3):
     """Per-kernel event timing (HIP events on the launch stream): every tapconv launch, then every other entry point."""
     from spaa_amd import convplan, _lib
@@ -269,10 +285,7 @@ def instrumented_pass(st, args, n_prof=3):
     for name, key, flops, e0, e1, tile_id, nbytes in conv_events:
         ms = e0.elapsed_time(e1)
         # roofline groups = kernel instantiations (as rocprofv3 reports them): split-K launches of a tile belong to it
-        # (persistent launches 48..54 run the same instantiations as 34, 36, 42, 44, 35, 37, 25)
-        kern = {48: 34, 49: 36, 50: 42, 51: 44, 52: 35, 53: 37, 54: 25}.get(tile_id % 100, tile_id % 100)
-        base = convplan.TILE_NAMES.get(kern, 'auto')
-        tile = convplan.TILE_NAMES.get(tile_id % 100, 'auto') + (('_streamk' if tile_id // 100 == 9 else f'_splitk{tile_id // 100}') if tile_id >= 100 else '')
+        base, tile = tile_names(tile_id)
         a = per_tile.setdefault(base, [0.0, 0.0, 0, 0.0])
         a[0] += flops
         a[1] += ms
@@ -461,8 +474,7 @@ def main():
             per[tid] = per.get(tid, 0.0) + e0.elapsed_time(e1)
         names = {}
         for tid, ms in per.items():
-            kern = {48: 34, 49: 36, 50: 42, 51: 44, 52: 35, 53: 37, 54: 25}.get(tid % 100, tid % 100)
-            names.setdefault(convplan.TILE_NAMES.get(kern, 'auto'), []).append((tid, ms))
+            names.setdefault(tile_names(tid)[0], []).append((tid, ms))
         dom_name = max(names, key=lambda k: sum(m for _, m in names[k]))
         dom_ids = {tid for tid, _ in names[dom_name]}
         convplan.PROFILE, convplan.PROFILE_ONLY = timed_events, dom_ids

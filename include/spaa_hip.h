@@ -229,6 +229,16 @@ int spaa_shading_tail_fwd_f16(const void* x6, const uint16_t* w2_split, const fl
 int spaa_shading_head_bwd_f16(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7,
                               const uint8_t* mask6, void* p6, int B, int H2, int W2, spaa_stream_t stream);
 
+/* the backward head with spaa_select_grad folded into its first phase (one launch and one [B,H,W,4] round trip less per iteration):
+ * the cotangent of sample b is g_col (state[4 b + 1] != 0: the sample takes the colour step, projector_based_attack.py:310-315)
+ * or g_adv (:302-307), gated by 0 < ypre <= 1 (backward of clamp(relu(.), max = 1), models.py:301); all three [B,2 H2,2 W2,4] */
+int spaa_shading_head_bwd_select(const float* g_adv, const float* g_col, const int32_t* state, const float* ypre, const float* w6t,
+                                 const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6, float* p6, int B, int H2,
+                                 int W2, spaa_stream_t stream);
+int spaa_shading_head_bwd_select_f16(const float* g_adv, const float* g_col, const int32_t* state, const float* ypre, const float* w6t,
+                                     const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6, void* p6, int B, int H2,
+                                     int W2, spaa_stream_t stream);
+
 /* ReLU backward as a stand-alone op: out = (act > 0) ? g : 0, n floats (n % 4 == 0, 16-byte aligned) */
 int spaa_relu_gate(const float* g, const float* act, float* out, int64_t n, spaa_stream_t stream);
 /* torch.optim.Adam step on one flat parameter tensor (train_network.py:252-254: betas (0.9, 0.999), eps 1e-8, L2 weight

@@ -494,6 +494,8 @@ class ConvPlan:
             tid = d.tile + 100 * (d.ksplit if d.ksplit > 1 else (9 if d.ksplit == -1 else 0))
             if d.tile == 70 and wino_bn == 64:   # the launcher's choice of the N tile: a kernel of its own for rocprofv3
                 tid += 1
+            if d.tile in (70, 71, 73):           # ... and so are the canvas / K-range form (+ 1000) and the two-source form (+ 2000)
+                tid += 2000 if cin2k else (1000 if (self.last_wino_plan[2] or d.ksplit > 1) else 0)
         if PROFILE is None or (PROFILE_ONLY is not None and tid not in PROFILE_ONLY):
             _lib.call('spaa_tapconv_f32', C.byref(d))
         else:  # bench.py's instrumented pass: HIP events on the launch stream around this one kernel

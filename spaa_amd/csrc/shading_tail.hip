@@ -276,7 +276,9 @@ constexpr int GP_BYTES = GP_W * GP_H * 16;    // 9792 B
 // 0-15, waves 8-15: 16-31; per tap 3 inputs x 16 weights = three scalar loads feeding 24 packed FMAs); phase 2 gives wave w the X6
 // row w & 7 and the N half w >> 3 (two of the four 16-channel blocks of P6).
 template <typename T6>   // storage type of P6 (float / _Float16)
-__global__ __launch_bounds__(1024, 1) void shading_head_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ w6t,
+__global__ __launch_bounds__(1024, 1) void shading_head_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ gcol,
+                                                                   const int32_t* __restrict__ state, const float* __restrict__ ypre,
+                                                                   const float* __restrict__ w6t,
                                                                    const uint16_t* __restrict__ w2ts,
                                                                    const uint8_t* __restrict__ mask7,
                                                                    const uint8_t* __restrict__ mask6, T6* __restrict__ p6,
@@ -317,8 +319,20 @@ __global__ __launch_bounds__(1024, 1) void shading_head_bwd_kernel(const float* 
             const int qy = tid / GP_W, qx = tid - qy * GP_W;
             const int gy = 2 * a0 - 1 + qy, gx = 2 * b0 - 1 + qx;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-                v = *reinterpret_cast<const f32x4*>(gp + (((size_t)img * H + gy) * W + gx) * 4);
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+                const size_t o = (((size_t)img * H + gy) * W + gx) * 4;
+                if (state != nullptr) {
+                    // spaa_select_grad folded in (projector_based_attack.py:302,310: the sample's cotangent is the classifier
+                    // path's gradient `gp` or the stealth loss's `gcol`; models.py:301: backward of clamp(relu(.), max = 1))
+                    v = *reinterpret_cast<const f32x4*>((state[4 * img + 1] != 0 ? gcol : gp) + o);
+                    const f32x4 y = *reinterpret_cast<const f32x4*>(ypre + o);
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) v[e] = (y[e] > 0.f && y[e] <= 1.f) ? v[e] : 0.f;
+                    v[3] = 0.f;
+                } else {
+                    v = *reinterpret_cast<const f32x4*>(gp + o);
+                }
+            }
             *reinterpret_cast<f32x4*>(gl + tid * 16) = v;
         }
         // this pixel's gate bytes of the thread's channel half (requested before the barrier)
@@ -417,7 +431,7 @@ static int launch_tail_fwd(const T6* x6, const uint16_t* w2_split, const float* 
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&shading_tail_fwd_kernel<T6>), (int)smem, attr_set);
     if (e != hipSuccess) return (int)e;
     int dev = 0, ncu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
     const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);
     hipLaunchKernelGGL(shading_tail_fwd_kernel<T6>, dim3(grid), dim3(64 * FWD_WAVES), smem, stream, x6, w2_split, bias2, w6, bias6, res1,
                        y, ypre, mask7, B, H2, W2, tiles_y, tiles_x);
@@ -425,9 +439,11 @@ static int launch_tail_fwd(const T6* x6, const uint16_t* w2_split, const float* 
 }
 
 template <typename T6>
-static int launch_head_bwd(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6,
+static int launch_head_bwd(const float* gp, const float* gcol, const int32_t* state, const float* ypre, const float* w6t,
+                           const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6,
                            T6* p6, int B, int H2, int W2, spaa_stream_t stream_) {
     if (!gp || !w6t || !w2t_split || !mask7 || !mask6 || !p6 || B <= 0 || H2 <= 0 || W2 <= 0) return hipErrorInvalidValue;
+    if (state != nullptr && (!gcol || !ypre)) return hipErrorInvalidValue;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const int tiles_y = (H2 + RY - 1) / RY, tiles_x = (W2 + RX - 1) / RX;
     const int64_t ntiles = (int64_t)B * tiles_y * tiles_x;
@@ -437,10 +453,10 @@ static int launch_head_bwd(const float* gp, const float* w6t, const uint16_t* w2
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&shading_head_bwd_kernel<T6>), (int)smem, attr_set);
     if (e != hipSuccess) return (int)e;
     int dev = 0, ncu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
     const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);
-    hipLaunchKernelGGL(shading_head_bwd_kernel<T6>, dim3(grid), dim3(1024), smem, stream, gp, w6t, w2t_split, mask7, mask6, p6, B, H2, W2,
-                       tiles_y, tiles_x);
+    hipLaunchKernelGGL(shading_head_bwd_kernel<T6>, dim3(grid), dim3(1024), smem, stream, gp, gcol, state, ypre, w6t, w2t_split, mask7, mask6, p6,
+                       B, H2, W2, tiles_y, tiles_x);
     return (int)hipGetLastError();
 }
 
@@ -457,11 +473,23 @@ int spaa_shading_tail_fwd_f16(const void* x6, const uint16_t* w2_split, const fl
 }
 int spaa_shading_head_bwd(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6,
                           float* p6, int B, int H2, int W2, spaa_stream_t stream) {
-    return launch_head_bwd<float>(gp, w6t, w2t_split, mask7, mask6, p6, B, H2, W2, stream);
+    return launch_head_bwd<float>(gp, nullptr, nullptr, nullptr, w6t, w2t_split, mask7, mask6, p6, B, H2, W2, stream);
+}
+int spaa_shading_head_bwd_select(const float* g_adv, const float* g_col, const int32_t* state, const float* ypre, const float* w6t,
+                                 const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6, float* p6, int B, int H2, int W2,
+                                 spaa_stream_t stream) {
+    if (!state) return hipErrorInvalidValue;
+    return launch_head_bwd<float>(g_adv, g_col, state, ypre, w6t, w2t_split, mask7, mask6, p6, B, H2, W2, stream);
+}
+int spaa_shading_head_bwd_select_f16(const float* g_adv, const float* g_col, const int32_t* state, const float* ypre, const float* w6t,
+                                     const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6, void* p6, int B, int H2, int W2,
+                                     spaa_stream_t stream) {
+    if (!state) return hipErrorInvalidValue;
+    return launch_head_bwd<_Float16>(g_adv, g_col, state, ypre, w6t, w2t_split, mask7, mask6, reinterpret_cast<_Float16*>(p6), B, H2, W2, stream);
 }
 int spaa_shading_head_bwd_f16(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6,
                               void* p6, int B, int H2, int W2, spaa_stream_t stream) {
-    return launch_head_bwd<_Float16>(gp, w6t, w2t_split, mask7, mask6, reinterpret_cast<_Float16*>(p6), B, H2, W2, stream);
+    return launch_head_bwd<_Float16>(gp, nullptr, nullptr, nullptr, w6t, w2t_split, mask7, mask6, reinterpret_cast<_Float16*>(p6), B, H2, W2, stream);
 }
 
 }  // extern "C"

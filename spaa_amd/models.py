@@ -23,6 +23,7 @@ from .synthetic import uniform_ctrl_pts
 
 USE_GATE_MASKS = os.environ.get('SPAA_GATE_MASKS', '1') != '0'   # 0: fp32 activations as ReLU gates (A/B measurements)
 FUSE_TAIL = os.environ.get('SPAA_FUSE_TAIL', '1') != '0'         # 0: transConv2 / conv6 as separate launches (A/B measurements)
+FUSE_SELECT = os.environ.get('SPAA_FUSE_SELECT', '1') != '0'     # 0: spaa_select_grad as its own launch (A/B measurements)
 FUSE_SKIP2 = int(os.environ.get('SPAA_FUSE_SKIP2', '15'))        # bits: 1 transConv1 + skipConv2, 2 conv2^T + skipConv2^T, 4 conv2_s^T on the same kernel, 8 conv5 + skipConv3 and conv3^T + skipConv3^T; 0: separate launches (A/B measurements)
 FUSE_SKIP2_MIN_PIXELS = int(os.environ.get('SPAA_FUSE_SKIP2_MIN', '16384'))   # B x H/4 x W/4 from which the fused kernel's 4 x 32-pixel regions fill the chip
 
@@ -540,19 +541,36 @@ class PCNetEngine:
         self._x7_version = self.version
         return a['Y']
 
-    def backward(self, gP):
-        """gP: gradient w.r.t. conv6's pre-activation (already gated by 0 < Ypre <= 1), [B,Hc,Wc,4].
+    def can_select(self):
+        """True when `backward(None, select=...)` is served: the fused head kernel takes the per-sample choice between the two
+        cotangents and the clamp gate itself (spaa_shading_head_bwd_select), no spaa_select_grad launch."""
+        return bool(self.fuse_tail and (USE_GATE_MASKS or self.storage == 'f16') and FUSE_SELECT)
+
+    def backward(self, gP, select=None):
+        """gP: gradient w.r.t. conv6's pre-activation (already gated by 0 < Ypre <= 1), [B,Hc,Wc,4]; or None with
+        `select` = (g_adv, g_col, state): the two candidate cotangents at the network output [B,Hc,Wc,4] and the loop's state
+        int32 [B,4] (projector_based_attack.py:302-315), see `can_select`.
         Returns the gradient w.r.t. the projector image x4 [B,Hp,Wp,4] (workspace)."""
         if not USE_GATE_MASKS and self.storage == 'f32':
             return self._backward_float_gates(gP)
         g, d, m = self.g, self.d, self.m
         if self.fuse_tail:
             t = self.tail
-            _lib.check_dev(gP)
-            assert gP.shape == (self.B, self.Hc, self.Wc, 4) and gP.dtype == torch.float32
-            _lib.call('spaa_shading_head_bwd' if self.storage == 'f32' else 'spaa_shading_head_bwd_f16', _lib.ptr(gP), _lib.ptr(t['w6t']),
-                      _lib.ptr(t['w2ts']), _lib.ptr(m['X7']), _lib.ptr(m['X6']),
-                      _lib.hptr(g['P6']) if self.storage == 'f16' else _lib.ptr(g['P6']), self.B, self.Hc // 2, self.Wc // 2)
+            p6 = _lib.hptr(g['P6']) if self.storage == 'f16' else _lib.ptr(g['P6'])
+            if select is not None:
+                assert gP is None and self.can_select()
+                ga, gc, state = select
+                _lib.check_dev(ga, gc)
+                assert ga.shape == gc.shape == (self.B, self.Hc, self.Wc, 4)
+                assert state.shape == (self.B, 4) and state.dtype == torch.int32 and state.is_contiguous() and state.device == ga.device
+                _lib.call('spaa_shading_head_bwd_select' if self.storage == 'f32' else 'spaa_shading_head_bwd_select_f16', _lib.ptr(ga),
+                          _lib.ptr(gc), _lib.ptr(state), _lib.ptr(self.a['Ypre']), _lib.ptr(t['w6t']), _lib.ptr(t['w2ts']),
+                          _lib.ptr(m['X7']), _lib.ptr(m['X6']), p6, self.B, self.Hc // 2, self.Wc // 2)
+            else:
+                _lib.check_dev(gP)
+                assert gP.shape == (self.B, self.Hc, self.Wc, 4) and gP.dtype == torch.float32
+                _lib.call('spaa_shading_head_bwd' if self.storage == 'f32' else 'spaa_shading_head_bwd_f16', _lib.ptr(gP), _lib.ptr(t['w6t']),
+                          _lib.ptr(t['w2ts']), _lib.ptr(m['X7']), _lib.ptr(m['X6']), p6, self.B, self.Hc // 2, self.Wc // 2)
         else:
             d['conv6'].run(gP, g['P7'], gate_bits=m['X7'])
             d['transConv2'].run(g['P7'], g['P6'], gate_bits=m['X6'])

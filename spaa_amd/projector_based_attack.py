@@ -132,9 +132,12 @@ class AttackState:
     def _backward_step(self, adv_lr, col_lr):
         B, p, y = self.B, _lib.ptr, self._y
         g_adv = self.clf.backward(self.g_logits)                                     # :302 (classifier part)
-        _lib.call('spaa_select_grad', p(g_adv), p(self.g_col), p(self.state), p(self.eng.a['Ypre']), p(self.gP), B,
-                  self.HWc)
-        gx = self.eng.backward(self.gP)                                              # :302 / :310 (PCNet part)
+        if self.eng.can_select():   # (the per-sample choice and the clamp gate as the first phase of the fused head kernel)
+            gx = self.eng.backward(None, select=(g_adv, self.g_col, self.state))     # :302 / :310 (PCNet part)
+        else:
+            _lib.call('spaa_select_grad', p(g_adv), p(self.g_col), p(self.state), p(self.eng.a['Ypre']), p(self.gP), B,
+                      self.HWc)
+            gx = self.eng.backward(self.gP)                                          # :302 / :310 (PCNet part)
         _lib.call('spaa_grad_sumsq', p(gx), p(self.x), self.gray, self.prjl2_w / (B * self.HWp) * self.gs_col, p(self.state),
                   p(self.partial_ss), B, self.HWp)
         _lib.call('spaa_step_and_track', p(self.x), p(gx), p(self.partial_ss), p(self.state), float(adv_lr),

@@ -49,7 +49,12 @@ def test_rocprof_summary_agrees_with_bench_roofline():
     assert os.path.exists(stats), stats
     kern = b['roofline']['kernel']
     if kern.startswith('tapconv_wino'):
-        want = 'wino_x6_kernel<64, ' if 'x64 ' in kern or kern.split(' ')[0].endswith('x64') else 'wino_x6_kernel<128, '
+        nm = kern.split(' ')[0]
+        if 'false, 8>' in open(stats).read() or 'false, 4>' in open(stats).read():   # (round 4 on: <N tile, variant, 0, canvas, two sources, waves>)
+            bn, var, nw = ((64, 2, 4) if '_8x32x64' in nm else (64, 2, 8) if 'x64' in nm.replace('_canvas', '').replace('_2src', '')[-4:] else (128, 3, 8))
+            want = f"wino_x6_kernel<{bn}, {var}, 0, {'true' if '_canvas' in nm else 'false'}, {'true' if '_2src' in nm else 'false'}, {nw}>"
+        else:
+            want = 'wino_x6_kernel<64, ' if 'x64 ' in kern or nm.endswith('x64') else 'wino_x6_kernel<128, '
     else:
         m = re.match(r'tapconv_(x6d(?:16)?(?:co)?(?:a3)?)_(\d+)x(\d+)', kern)
         assert m, kern
