@@ -605,9 +605,14 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // split adds its second pass (5 us + the partial sums at 12 TB/s: L2 / MALL).  Predicted / measured: conv4 438 / 420-457, conv3_s 130 /
 // 128, ResNet layer2 63 / 65, layer1 75 / 75, layer3 (canvas, 4 ranges) 74 / 77, layer4 (8 ranges) 74 / 76, VGG-16 14 x 14 x 512
 // (2 ranges) 210 / 205 (tools/lab/wino_small.py).
-inline wino_plan_t wino_make_plan(const spaa_tapconv_t& d, const int ncu, const int force_bn, const int force_ks, const bool allow_split) {
+// `nw` = waves per workgroup: 8 (16 x 32-pixel regions, one workgroup per CU) or 4 (tile 73: 8 x 32-pixel regions, two per CU: `ncu`
+// counts slots, the prologue + epilogue of one workgroup mostly hides under the other's main loop).
+inline wino_plan_t wino_make_plan(const spaa_tapconv_t& d, const int ncu_, const int force_bn, const int force_ks, const bool allow_split,
+                                  const int nw = 8) {
     wino_plan_t pl = {};
     const int H = d.Hout, W = d.Wout, B = d.B;
+    const int TY = nw;                       // (shadows the 8-wave constant: tile rows of a region)
+    const int ncu = nw == 4 ? 2 * ncu_ : ncu_;
     // plain regions: per image
     const int pwy = cdiv(H, 2 * TY), pwx = cdiv(W, 2 * TX);
     const int64_t plain = (int64_t)B * pwy * pwx;
@@ -647,8 +652,9 @@ inline wino_plan_t wino_make_plan(const spaa_tapconv_t& d, const int ncu, const 
                 // VGG-16's 28 x 28 x 512 layers, 432 against 512 workgroups, 720 against 780 us)
                 const double rounds = 0.5 * (double)((nwg + ncu - 1) / ncu) + 0.5 * (double)nwg / ncu;
                 double cost = rounds * (kb_per * (bn == 128 ? 22.4 : 12.8) + (bn == 128 ? 20.0 : 12.0) + ((cv || ksr > 1) && bn == 64 ? 6.0 : 0.0));
+                if (nw == 4) cost = rounds * (kb_per * 12.8 + 6.0);   // (two half-size workgroups per CU share its rate: per slot the same time per block)
                 if (ksr > 1) cost += 5.0 + (double)ksr * (double)M * npad * 4.0 / 12e6;   // (second pass: the partial sums come from L2 / MALL)
-                if (cv && !((d.reserved0 >> 29) & 1)) cost *= 1.05;   // (the canvas form must win by 5 %: else the image-aligned regions, unchanged since round 2)
+                if (cv && !((d.reserved0 >> 29) & 1)) cost *= nw == 4 ? 1.15 : 1.05;   // (the canvas form must win by 5 % -- 15 % with four-wave workgroups: 56 x 56, 798 against 896 workgroups, 73 against 69 us -- else the image-aligned regions)
                 if (!cv && best < plain && ((d.reserved0 >> 29) & 1)) cost *= 1e6;   // (tests: canvas wherever it has fewer regions)
                 if (ksr > 1) cost *= 1.02;  // (ties: no split)
                 if (cost < best_cost) {
@@ -658,7 +664,7 @@ inline wino_plan_t wino_make_plan(const spaa_tapconv_t& d, const int ncu, const 
             }
         }
     }
-    if (!pl.canvas && pl.ksplit == 1 && force_bn == 0) {
+    if (!pl.canvas && pl.ksplit == 1 && force_bn == 0 && nw == 8) {
         // image-aligned regions without a split: the N tile by the rule the round-2 / round-3 tune tables were measured with (64
         // wide for at most 64 output channels and where the 128-wide grid would leave compute units without a workgroup)
         pl.bn = (d.Cout <= 64 || plain * cdiv(d.Cout, 128) < ncu) ? 64 : 128;
@@ -700,10 +706,9 @@ extern "C" int spaa_tapconv_wino_plan(const spaa_tapconv_t* desc, int32_t* plan)
     spaa_tapconv_t d = *desc;
     if (d.w_split == nullptr) d.w_split = reinterpret_cast<const uint16_t*>(desc);   // (the plan does not depend on the pointers)
     if (!wino_shape_ok(d) || (d.tile != 70 && d.tile != 71 && d.tile != 73)) return hipErrorInvalidValue;
-    if (d.in2 != nullptr || d.tile == 73) d.reserved0 |= 1 << 30;
-    const bool nosplit = d.in2 != nullptr || d.tile == 73;
-    wino_plan_t pl = wino_make_plan(d, wino_ncu(), d.tile == 70 ? 0 : 64, nosplit ? 1 : d.ksplit, !nosplit);
-    if (d.tile == 73) pl.nwg = (int64_t)d.B * cdiv(d.Hout, 8) * pl.wg_x * pl.n_tiles;
+    if (d.in2 != nullptr) d.reserved0 |= 1 << 30;
+    const bool nosplit = d.in2 != nullptr;
+    const wino_plan_t pl = wino_make_plan(d, wino_ncu(), d.tile == 70 ? 0 : 64, nosplit ? 1 : d.ksplit, !nosplit, d.tile == 73 ? 4 : 8);
     plan[0] = pl.bn, plan[1] = pl.ksplit, plan[2] = pl.canvas, plan[3] = pl.gy, plan[4] = pl.gx;
     plan[5] = (int32_t)(pl.nwg > 0x7fffffff ? 0x7fffffff : pl.nwg), plan[6] = pl.kb_per, plan[7] = pl.ncanvas;
     return 0;
@@ -718,13 +723,10 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     const bool has_ws = d.splitk_ws != nullptr;
     if (d.ksplit > 1 && !has_ws) return hipErrorInvalidValue;
     spaa_tapconv_t dp = d;
-    if (d.in2 != nullptr || d.tile == 73) dp.reserved0 |= 1 << 30;   // (two sources, four-wave form: no canvas ...)
-    const bool nosplit = d.in2 != nullptr || d.tile == 73;
-    wino_plan_t pl = wino_make_plan(dp, wino_ncu(), d.tile == 70 ? 0 : 64, (has_ws && !nosplit) ? d.ksplit : 1, has_ws && !nosplit);   // (... and no K ranges)
-    if (d.tile == 73) {
-        pl.wg_y = cdiv(d.Hout, 8);
-        pl.nwg = (int64_t)d.B * pl.wg_y * pl.wg_x * pl.n_tiles;
-    }
+    if (d.in2 != nullptr) dp.reserved0 |= 1 << 30;   // (two sources: no canvas ...)
+    const bool nosplit = d.in2 != nullptr;
+    const wino_plan_t pl = wino_make_plan(dp, wino_ncu(), d.tile == 70 ? 0 : 64, (has_ws && !nosplit) ? d.ksplit : 1, has_ws && !nosplit,
+                                          d.tile == 73 ? 4 : 8);   // (... and no K ranges)
     if (pl.nwg > 0x7fffffff) return hipErrorInvalidValue;
     const int BN = pl.bn, n_tiles = pl.n_tiles, wg_y = pl.wg_y, wg_x = pl.wg_x;
     const int64_t nwg = pl.nwg;
@@ -747,7 +749,7 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     if (cv && (int64_t)d.B * d.Hout * d.Wout >= ((int64_t)1 << 24)) return hipErrorInvalidValue;   // (the plan never asks for it: wino_make_plan)
     spaa_tapconv_t dd = d;
     dd.ksplit = pl.ksplit;
-    static bool attr_set[14][SPAA_MAX_DEVICES] = {};
+    static bool attr_set[15][SPAA_MAX_DEVICES] = {};
     // kernel variant: bit 0 = late V (waves 4-7 transform one step ahead), bit 1 = xi groups expanded.  Default 3 / 2 (measured:
     // conv4 500 -> 462 us, conv5 461 -> 415 us against variant 0); `reserved0` bits 16-17 flip bits for A/B measurements
     const int var = (BN == 64 ? 2 : 3) ^ ((d.reserved0 >> 16) & 3);   // (64-wide tile: late V does not pay: 168 / 167 / 159 us for 0 / 3 / 2)
@@ -788,6 +790,15 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
             hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<64, 2, 0, false, true, 4>), (int)smem, attr_set[13]);
             if (e != hipSuccess) return (int)e;
             hipLaunchKernelGGL((wino_x6_kernel<64, 2, 0, false, true, 4>), dim3((unsigned)nwg), dim3(256), smem, stream, dd, wg_y, wg_x, n_tiles, geo);
+        } else if (cv) {
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<64, 2, 0, true, false, 4>), (int)smem, attr_set[14]);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((wino_x6_kernel<64, 2, 0, true, false, 4>), dim3((unsigned)nwg), dim3(256), smem, stream, dd, wg_y, wg_x, n_tiles, geo);
+            if (pl.ksplit > 1) {
+                const int npad = (d.Cout + 127) & ~127;
+                const int64_t M = (int64_t)d.B * d.Hout * d.Wout, nthr = M * ((d.Cout + 3) >> 2);
+                hipLaunchKernelGGL(wino_splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, dd, (int)M, npad);
+            }
         } else {
             hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<64, 2, 0, false, false, 4>), (int)smem, attr_set[12]);
             if (e != hipSuccess) return (int)e;

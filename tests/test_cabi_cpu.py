@@ -120,21 +120,25 @@ def _wino_plan(b, h, w, cin, cout, tile=70, ksplit=0, force_canvas=False):
     return dict(zip(('bn', 'ksplit', 'canvas', 'gy', 'gx', 'nwg', 'kb_per', 'ncanvas'), wp))
 
 
+@pytest.mark.parametrize('tile', [70, 73])
 @pytest.mark.parametrize('b,h,w,cin,cout', [(64, 14, 14, 256, 256), (64, 7, 7, 512, 512), (64, 35, 35, 96, 96), (5, 14, 14, 64, 64),
                                              (64, 17, 17, 128, 128), (3, 7, 9, 512, 512), (64, 14, 14, 512, 512)])
-def test_winograd_canvas_plan_covers_every_pixel_once(b, h, w, cin, cout):
+def test_winograd_canvas_plan_covers_every_pixel_once(b, h, w, cin, cout, tile):
     """csrc/tapconv_wino.hip, canvas form (small images laid out on virtual canvases, host-side plan through
     spaa_tapconv_wino_plan): the kernel's index arithmetic restated here -- division by the period as a multiplication by
     ceil(2^20 / period) -- maps the workgroup regions onto every output pixel exactly once, and the 3 x 3 neighbourhood of every
     output pixel onto the same image's pixels or onto the zero padding (never onto a neighbouring image)."""
     import numpy as np
-    pl = _wino_plan(b, h, w, cin, cout, force_canvas=True)
+    pl = _wino_plan(b, h, w, cin, cout, tile=tile, force_canvas=True)
+    rh = 8 if tile == 73 else 16          # region height: four-wave workgroups own 4 x 16 tiles
+    if tile == 73 and pl['canvas'] == 0:
+        pytest.skip('8-row regions: the image-aligned form already has no fewer regions')
     assert pl['canvas'] == 1 and pl['ksplit'] * pl['kb_per'] >= cin // 32 > (pl['ksplit'] - 1) * pl['kb_per']
     gy, gx, nc = pl['gy'], pl['gx'], pl['ncanvas']
     py, px = h + 1, w + 1
     assert gy * gx * nc >= b and gy * py - 1 <= 4095 and gx * px - 1 <= 4095 and py <= 255 and px <= 255
     my, mx = ((1 << 20) + py - 1) // py, ((1 << 20) + px - 1) // px
-    wg_y, wg_x = (gy * py - 1 + 15) // 16, (gx * px - 1 + 31) // 32
+    wg_y, wg_x = (gy * py - 1 + rh - 1) // rh, (gx * px - 1 + 31) // 32
     n_tiles = (cout + pl['bn'] - 1) // pl['bn']
     assert pl['nwg'] == nc * wg_y * wg_x * n_tiles * pl['ksplit']
 
@@ -149,7 +153,7 @@ def test_winograd_canvas_plan_covers_every_pixel_once(b, h, w, cin, cout):
 
     count = np.zeros((b, h, w), dtype=np.int64)
     for cv in range(nc):
-        vy, vx = np.meshgrid(np.arange(16 * wg_y), np.arange(32 * wg_x), indexing='ij')
+        vy, vx = np.meshgrid(np.arange(rh * wg_y), np.arange(32 * wg_x), indexing='ij')
         ok, im, iy, ix = canvas_pixel(cv, vy, vx)
         assert (iy[ok] >= 0).all() and (ix[ok] >= 0).all()
         np.add.at(count, (im[ok], iy[ok], ix[ok]), 1)

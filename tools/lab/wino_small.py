@@ -43,7 +43,10 @@ for ci, co, h, w, b in SHAPES:
     run('wino_plain', 170, 1)
     run('wino64_plain', 171, 1)
     run('wino_auto', 70)
-    run('wino_4wave', 73, 1)
+    run('wino_4wave_plain', 173, 1)
+    run('wino_4wave_auto', 73)
+    for ks in (2, 4):
+        run(f'wino_4wave_ks{ks}', 73 + 100 * ks, 2)
     for ks in (1, 2, 4, 8):
         run(f'wino128_ks{ks}', 70 + 100 * ks, 2)
         run(f'wino64_ks{ks}', 71 + 100 * ks, 2)
