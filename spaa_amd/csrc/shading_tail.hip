@@ -128,49 +128,43 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void shading_tail_fwd_kernel(
     __syncthreads();
 
     const int rx = lane & 15, g = lane >> 4;
-    // phase 1: wave = (X6 row PAIR rp, N quarter q4 = two of the eight 16-channel blocks): a weight fragment read from LDS feeds the
-    // products of two pixel rows (one row x four blocks per wave read 24 fragments per 48 MFMAs: the phase was LDS-bound,
-    // tools/lab/tail_time.py: 147 of the kernel's 311 us)
-    const int rp = wave & 3, q4 = wave >> 2;
+    const int row = wave & 7, nh = wave >> 3;       // phase 1: X6 row and N half of this wave
     const int ph = wave >= PW2 ? 1 : 0;             // phase 2: channel half (waves 14, 15: idle)
     const int pix = (wave - ph * PW2) * 64 + lane;  // ... and pixel of the owned interior
     const bool p2 = wave < 2 * PW2 && pix < OY * OX;
     const int oy_l = p2 ? pix / OX : 0, ox_l = p2 ? pix - oy_l * OX : 0;
     const unsigned char* p2base = tl + 4 * ph * PLANE + (oy_l * TX + ox_l) * 16;
     // per-lane constants of the phase-1 epilogue: LDS address and bias of its four 16-channel blocks
-    int wofs[2];    // (row 2 rp; row 2 rp + 1 sits 2 TX pixels further)
-    f32x4 bq[2];
+    int wofs[4];
+    f32x4 bq[4];
 #pragma unroll
-    for (int nq = 0; nq < 2; ++nq) {
-        const int nb = 2 * q4 + nq, par = nb >> 1, c0 = 16 * (nb & 1) + 4 * g;
-        wofs[nq] = (c0 >> 2) * PLANE + ((4 * rp + (par >> 1)) * TX + 2 * rx + (par & 1)) * 16;
+    for (int nq = 0; nq < 4; ++nq) {
+        const int nb = 4 * nh + nq, par = nb >> 1, c0 = 16 * (nb & 1) + 4 * g;
+        wofs[nq] = (c0 >> 2) * PLANE + ((2 * row + (par >> 1)) * TX + 2 * rx + (par & 1)) * 16;
         bq[nq] = *reinterpret_cast<const f32x4*>(bias2 + c0);
     }
     const int ntiles = B * tiles_y * tiles_x;
     // X6 operands of a tile (this wave's row; lane = (column, 8-channel chunk)), loaded one tile ahead
-    f32x4 xin[2][4];
+    f32x4 xin[4];
     auto load_x6 = [&](const int tile_) {
         const int tx_ = tile_ % tiles_x, ty_ = (tile_ / tiles_x) % tiles_y, img = tile_ / (tiles_x * tiles_y);
+        const int ay = (OY / 2) * ty_ - 1 + row, ax = (OX / 2) * tx_ - 1 + rx;
+        const bool in6 = tile_ < ntiles && (unsigned)ay < (unsigned)H2 && (unsigned)ax < (unsigned)W2;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int ay = (OY / 2) * ty_ - 1 + 2 * rp + r, ax = (OX / 2) * tx_ - 1 + rx;
-            const bool in6 = tile_ < ntiles && (unsigned)ay < (unsigned)H2 && (unsigned)ax < (unsigned)W2;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xin[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (in6) {
-                const T6* src = x6 + (((size_t)img * H2 + ay) * W2 + ax) * C6 + g * 8;
-                if constexpr (sizeof(T6) == 4) {
-                    xin[r][0] = *reinterpret_cast<const f32x4*>(src);
-                    xin[r][1] = *reinterpret_cast<const f32x4*>(src + 4);
-                    xin[r][2] = *reinterpret_cast<const f32x4*>(src + 32);
-                    xin[r][3] = *reinterpret_cast<const f32x4*>(src + 36);
-                } else {
-                    const h8 a = *reinterpret_cast<const h8*>(src), b = *reinterpret_cast<const h8*>(src + 32);
-                    xin[r][0] = f32x4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
-                    xin[r][1] = f32x4{(float)a[4], (float)a[5], (float)a[6], (float)a[7]};
-                    xin[r][2] = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
-                    xin[r][3] = f32x4{(float)b[4], (float)b[5], (float)b[6], (float)b[7]};
-                }
+        for (int i = 0; i < 4; ++i) xin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (in6) {
+            const T6* src = x6 + (((size_t)img * H2 + ay) * W2 + ax) * C6 + g * 8;
+            if constexpr (sizeof(T6) == 4) {
+                xin[0] = *reinterpret_cast<const f32x4*>(src);
+                xin[1] = *reinterpret_cast<const f32x4*>(src + 4);
+                xin[2] = *reinterpret_cast<const f32x4*>(src + 32);
+                xin[3] = *reinterpret_cast<const f32x4*>(src + 36);
+            } else {
+                const h8 a = *reinterpret_cast<const h8*>(src), b = *reinterpret_cast<const h8*>(src + 32);
+                xin[0] = f32x4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
+                xin[1] = f32x4{(float)a[4], (float)a[5], (float)a[6], (float)a[7]};
+                xin[2] = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                xin[3] = f32x4{(float)b[4], (float)b[5], (float)b[6], (float)b[7]};
             }
         }
     };
@@ -180,50 +174,37 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void shading_tail_fwd_kernel(
         // owned output rows [OY ty - 1, OY ty + OY - 1), X7 rows [OY ty - 2, + TY), X6 rows [(OY/2) ty - 1, + RY)
         const int a0 = (OY / 2) * ty_ - 1, b0 = (OX / 2) * tx_ - 1;   // first X6 row / column of the tile
         const bool interior = a0 >= 0 && 2 * a0 + TY <= H && b0 >= 0 && 2 * b0 + TX <= W;
-        // ---- phase 1: X7 tile = relu(transConv2(X6) + bias); lane = (X6 column, 8-channel chunk); two X6 rows x two 16-channel blocks
+        // ---- phase 1: X7 tile = relu(transConv2(X6) + bias); lane = (X6 column, 8-channel chunk)
         {
-            f32x4 acc[2][2];   // [block][row]
+            bf16x8 pf[2][3];
 #pragma unroll
-            for (int nq = 0; nq < 2; ++nq)
+            for (int s = 0; s < 2; ++s) split8(xin[2 * s], xin[2 * s + 1], pf[s][0], pf[s][1], pf[s][2]);
+            load_x6(tile + gridDim.x);   // the next tile's operands fly during this tile's arithmetic
 #pragma unroll
-                for (int r = 0; r < 2; ++r) acc[nq][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nq = 0; nq < 4; ++nq) {
+                const int nb = 4 * nh + nq;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 pf[2][3];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) split8(xin[r][2 * s], xin[r][2 * s + 1], pf[r][0], pf[r][1], pf[r][2]);
-                if (s == 1) load_x6(tile + gridDim.x);   // the next tile's operands fly during this tile's arithmetic
-#pragma unroll
-                for (int nq = 0; nq < 2; ++nq) {
-#ifdef SPAA_TAIL_ABLATE
-                    if (SPAA_TAIL_ABLATE == 2) continue;   // (timing-only ablation: no MFMAs)
-#endif
+                for (int s = 0; s < 2; ++s) {
                     // A operand: row n = 16 nb + (lane & 15), k chunk 4 s + (lane >> 4)
-                    const int r_ = 16 * (2 * q4 + nq) + rx;
-                    const unsigned char* wp = wl + r_ * 128 + (((4 * s + g) ^ ((r_ >> 1) & 7)) << 4);
+                    const int r = 16 * nb + rx;
+                    const unsigned char* wp = wl + r * 128 + (((4 * s + g) ^ ((r >> 1) & 7)) << 4);
                     const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wp);
                     const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wp + 128 * 128);
                     const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wp + 2 * 128 * 128);
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) acc[nq][r] = mfma6(w0, w1, w2, pf[r][0], pf[r][1], pf[r][2], acc[nq][r]);
+                    acc = mfma6(w0, w1, w2, pf[s][0], pf[s][1], pf[s][2], acc);
                 }
+                // D: column = X6 pixel (lane & 15), rows n = 16 nb + 4 g + e: parity nb >> 1, channels 16 (nb & 1) + 4 g + e
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[e] + bq[nq][e], 0.f);
+                if (!interior) {   // (uniform) a tile at the image border: pixels outside are conv6's zero padding
+                    const int par = nb >> 1;
+                    const int gy = 2 * a0 + 2 * row + (par >> 1), gx = 2 * b0 + 2 * rx + (par & 1);
+                    if (!((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                *reinterpret_cast<f32x4*>(tl + wofs[nq]) = v;
             }
-#pragma unroll
-            for (int nq = 0; nq < 2; ++nq)
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    // D: column = X6 pixel (lane & 15), rows n = 16 nb + 4 g + e: parity nb >> 1, channels 16 (nb & 1) + 4 g + e
-                    const int nb = 2 * q4 + nq;
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[nq][r][e] + bq[nq][e], 0.f);
-                    if (!interior) {   // (uniform) a tile at the image border: pixels outside are conv6's zero padding
-                        const int par = nb >> 1;
-                        const int gy = 2 * a0 + 2 * (2 * rp + r) + (par >> 1), gx = 2 * b0 + 2 * rx + (par & 1);
-                        if (!((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                    *reinterpret_cast<f32x4*>(tl + wofs[nq] + r * (2 * TX * 16)) = v;
-                }
         }
         __syncthreads();
         // ---- phase 2: conv6 (3x3, 32 -> 3) over this wave's 16 channels; X7's gate bytes from the centre tap (relu(t) > 0 <=> t > 0)
@@ -236,11 +217,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void shading_tail_fwd_kernel(
         if (p2) {
             unsigned int bits = 0;
 #pragma unroll 1
-#ifdef SPAA_TAIL_ABLATE
-            for (int t = 0; t < (SPAA_TAIL_ABLATE == 1 ? 1 : 9); ++t) {   // (timing-only ablation: one tap instead of nine)
-#else
             for (int t = 0; t < 9; ++t) {   // (not unrolled: 48 weight SGPRs per tap is what the scalar file holds)
-#endif
                 // (chunk-planar tile: the four reads of a tap are one address + immediates, neighbouring lanes 16 bytes apart)
                 const unsigned char* pp = p2base + ((t / 3) * TX + t % 3) * 16;
                 f16v w[3];                  // 16 channels x 3 outputs of this tap: one s_load_dwordx16 per output channel
@@ -328,7 +305,7 @@ __global__ __launch_bounds__(1024, 1) void shading_head_bwd_kernel(const float* 
     }
     __syncthreads();
     const int rx = lane & 15, g = lane >> 4;
-    const int nh = wave >> 3;                        // phase 1: channel half
+    const int row = wave & 7, nh = wave >> 3;        // phase 2: X6 row and N half; phase 1: nh = channel half
     const int pix = (tid & 511);                     // phase 1: X7 pixel of the 16 x 32 tile
     const int py = pix >> 5, px = pix & 31;
     // GEMM operand row m = 16 (py >> 1) + (px >> 1), columns k = 32 (2 (py & 1) + (px & 1)) + 16 nh + ...
@@ -393,43 +370,42 @@ __global__ __launch_bounds__(1024, 1) void shading_head_bwd_kernel(const float* 
             }
         }
         __syncthreads();
-        // ---- phase 2: P6[m][n] = gate6 . sum_k P7[m][k] W[n][k];  lane = (X6 column, k chunk); wave = (X6 row PAIR, one 16-channel
-        // block of P6): a weight fragment read from LDS feeds two pixel rows (as the forward kernel's phase 1)
+        // ---- phase 2: P6[m][n] = gate6 . sum_k P7[m][k] W[n][k];  lane = (X6 column, k chunk)
         {
-            const int rp2 = wave & 3, nb = wave >> 2;
-            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            const int r_ = 16 * nb + rx;   // weight row n
+            const int m = 16 * row + rx;
+            bf16x8 pf[4][3];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {   // k step s: columns 32 s + 8 g .. + 7 = chunks 8 s + 2 g, + 1
-                bf16x8 pf[2][3];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int m = 16 * (2 * rp2 + r) + rx;
-                    const f32x4 u0 = *reinterpret_cast<const f32x4*>(pl + m * 512 + (((8 * s + 2 * g) ^ (m & 31)) << 4));
-                    const f32x4 u1 = *reinterpret_cast<const f32x4*>(pl + m * 512 + (((8 * s + 2 * g + 1) ^ (m & 31)) << 4));
-                    split8(u0, u1, pf[r][0], pf[r][1], pf[r][2]);
-                }
-                const unsigned char* wp = wl + r_ * 256 + (((4 * s + g) ^ (r_ & 15)) << 4);
-                const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wp);
-                const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wp + 64 * 256);
-                const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wp + 2 * 64 * 256);
-#pragma unroll
-                for (int r = 0; r < 2; ++r) acc[r] = mfma6(w0, w1, w2, pf[r][0], pf[r][1], pf[r][2], acc[r]);
+                const f32x4 u0 = *reinterpret_cast<const f32x4*>(pl + m * 512 + (((8 * s + 2 * g) ^ (m & 31)) << 4));
+                const f32x4 u1 = *reinterpret_cast<const f32x4*>(pl + m * 512 + (((8 * s + 2 * g + 1) ^ (m & 31)) << 4));
+                split8(u0, u1, pf[s][0], pf[s][1], pf[s][2]);
             }
-            // D: column = X6 pixel (lane & 15), rows n = 16 nb + 4 g + e: gate byte 4 nb + g of the pixel
-            const int n0 = 16 * nb + 4 * g;
+            const int ay = a0 + row, ax = b0 + rx;
+            const bool in6 = ay < H2 && ax < W2;
+            uint64_t g6 = 0;   // the 8 gate bytes of this X6 pixel's channel half
+            if (in6) g6 = *reinterpret_cast<const uint64_t*>(mask6 + (((size_t)img * H2 + ay) * W2 + ax) * (C6 / 4) + 8 * nh);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int ay = a0 + 2 * rp2 + r, ax = b0 + rx;
-                if (ay < H2 && ax < W2) {
-                    const size_t o6 = ((size_t)img * H2 + ay) * W2 + ax;
-                    const unsigned int nib = mask6[o6 * (C6 / 4) + 4 * nb + g] & 15u;
-                    f32x4 v = acc[r];
+            for (int nq = 0; nq < 2; ++nq) {
+                const int nb = 2 * nh + nq;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = ((nib >> e) & 1u) ? v[e] : 0.f;
-                    T6* dst = p6 + o6 * C6 + n0;
-                    if constexpr (sizeof(T6) == 4) *reinterpret_cast<f32x4*>(dst) = v;
-                    else *reinterpret_cast<h4*>(dst) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                for (int s = 0; s < 4; ++s) {
+                    const int r = 16 * nb + rx;   // weight row n
+                    const unsigned char* wp = wl + r * 256 + (((4 * s + g) ^ (r & 15)) << 4);
+                    const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wp);
+                    const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wp + 64 * 256);
+                    const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wp + 2 * 64 * 256);
+                    acc = mfma6(w0, w1, w2, pf[s][0], pf[s][1], pf[s][2], acc);
+                }
+                // D: column = X6 pixel (lane & 15), rows n = 16 nb + 4 g + e: byte 4 nq + g of this half's gate bytes
+                const int n0 = 16 * nb + 4 * g;
+                const unsigned int nib = (unsigned int)(g6 >> (8 * (4 * nq + g))) & 15u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = ((nib >> e) & 1u) ? acc[e] : 0.f;
+                if (in6) {
+                    T6* dst = p6 + (((size_t)img * H2 + ay) * W2 + ax) * C6 + n0;
+                    if constexpr (sizeof(T6) == 4) *reinterpret_cast<f32x4*>(dst) = acc;
+                    else *reinterpret_cast<h4*>(dst) = h4{(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};
                 }
             }
         }
