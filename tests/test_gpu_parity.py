@@ -1707,6 +1707,26 @@ def test_inception_v3_full_input_size_first_iteration(hip):
     assert st.B == 8
 
 
+def _hip_gates(st, rows):
+    """Every gate of one HIP attack state for the samples `rows` (a slice), as a list of (name, tensor): the engine's byte masks,
+    the clamp gate of the output, the classifier body's ReLU signs and arg-max bytes (VGG-16 / Inception-v3 op lists)."""
+    out = [(f'pcnet.{k}', st.eng.m[k][rows]) for k in sorted(st.eng.m)]
+    yp = st.eng.a['Ypre'][rows]
+    out.append(('pcnet.ypre', (yp > 0) & (yp <= 1)))
+    body = st.clf.body
+    for n, op in enumerate(getattr(body, 'ops', [])):
+        if op['kind'] == 'conv':
+            t = op['out']
+            buf = t.buf[..., t.coff:t.coff + t.c] if hasattr(t, 'buf') else t
+            out.append((f'clf.conv{n}', buf[rows] > 0))
+        elif 'arg' in op:
+            out.append((f'clf.pool{n}', op['arg'][rows]))
+    for nm in ('h1', 'h2'):
+        if hasattr(body, nm):
+            out.append((f'clf.{nm}', getattr(body, nm)[rows] > 0))
+    return out
+
+
 @pytest.mark.parametrize('body', ['inception_v3', 'vgg16'])
 def test_full_size_properties_other_classifiers(hip, body):
     """BASELINE.json configs[2] (Inception-v3, 299x299) and the SPAA loop with configs[4]'s VGG-16 at full size:
@@ -1726,15 +1746,26 @@ def test_full_size_properties_other_classifiers(hip, body):
     step = (x1[..., :3] - 0.5).flatten(1).norm(dim=1).cpu()
     lr = torch.where(st.state[:, 1].cpu() != 0, torch.tensor(1.0), torch.tensor(2.0))
     assert torch.allclose(step, lr, rtol=1e-4)                       # prescribed step length per sample
-    st8 = A.AttackState(pc, clf, targets[8:16], scenes[8:16], 'camdE_caml2', setup, DEV)
+    st_gates = st       # (its buffers hold the first iteration's activations until it is stepped again below)
+    rows8 = list(range(3, 64, 8))          # one sample of each of the eight scenes (the eight targets of a scene share its PCNet gates)
+    st8 = A.AttackState(pc, clf, [targets[i] for i in rows8], scenes[rows8], 'camdE_caml2', setup, DEV)
     st8.iteration(True, 5, 2, 1, 0.9)
-    assert rel_inf(st8.eng.a['Y'], y1[8:16]) < 1e-6                  # samples are independent
-    assert torch.allclose(st8.stats[:, 6], logit1[8:16], rtol=1e-4, atol=1e-4)
+    assert rel_inf(st8.eng.a['Y'], y1[rows8]) < 1e-6                 # samples are independent
+    assert torch.allclose(st8.stats[:, 6], logit1[rows8], rtol=1e-4, atol=1e-4)
     # (a batch of 8 takes other tiles / split-K factors than a batch of 64: another summation order, hence possibly another
     # side for a ReLU gate within rounding of zero -- sparse differences)
-    e8 = rel_inf(st8.x, x1[8:16])
-    # (one flipped gate moves a sample's step by up to 8.3e-3: the teacher-forced cases of profiles/r02_parity.txt; 8.0e-3 seen here)
-    assert e8 < 1e-4 or (e8 < 2.5e-2 and outlier_fraction(st8.x, x1[8:16], 1e-4) < 0.2), e8
+    # ... so a sample is compared at 1e-4 where ALL its gates (PCNet byte masks, clamp gate, the body's ReLU signs and arg-max bytes)
+    # are the same in the two runs, and within the measured effect of a flipped gate otherwise (8.3e-3: profiles/r02_parity.txt)
+    g64 = _hip_gates(st_gates, rows8)
+    g8 = _hip_gates(st8, slice(0, 8))
+    assert [n for n, _ in g64] == [n for n, _ in g8] and len(g8) > 20
+    differing = torch.zeros(8, dtype=torch.long)
+    for (_, a), (_, b_) in zip(g64, g8):
+        differing += (a != b_).flatten(1).sum(dim=1).cpu()
+    e8 = torch.tensor([rel_inf(st8.x[i], x1[rows8[i]]) for i in range(8)])
+    print(f'{body}: sub-batch of 8 (one sample per scene) against its rows of the batch of 64: differing gates per sample {differing.tolist()}, '
+          f'projector image rel Linf {[f"{v:.1e}" for v in e8.tolist()]}')
+    assert (e8[differing == 0] < 1e-4).all() and (e8 < 2.5e-2).all() and int(differing.max()) < 64
     st2 = A.AttackState(pc, clf, targets, scenes, 'camdE_caml2', setup, DEV)
     st2.iteration(True, 5, 2, 1, 0.9)
     assert torch.equal(st2.x, x1)                                    # bitwise reproducible
