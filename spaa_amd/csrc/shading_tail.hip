@@ -98,7 +98,7 @@ __device__ __forceinline__ void stage_planes(const uint16_t* w, unsigned char* d
 // 16-31; the weights stay wave-uniform = scalar loads), the halves meet through LDS.  Twice the waves of the 8-wave form hide the
 // scalar-load and LDS latencies of the VALU phase.
 constexpr int FWD_WAVES = 16;
-constexpr int PW2 = (OY * OX + 63) / 64;            // waves per channel half in phase 2 (7)
+constexpr int PW2 = (OY * TX + 63) / 64;            // waves per channel half in phase 2 (7: 14 rows of 32 lanes, 30 of them pixels)
 constexpr int RED_BYTES = PW2 * 64 * 16;            // partial sums of the second half
 
 template <typename T6>   // storage type of X6: float, or _Float16 in fp16-storage mode (the arithmetic is the same: exact operands)
@@ -130,9 +130,13 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void shading_tail_fwd_kernel(
     const int rx = lane & 15, g = lane >> 4;
     const int row = wave & 7, nh = wave >> 3;       // phase 1: X6 row and N half of this wave
     const int ph = wave >= PW2 ? 1 : 0;             // phase 2: channel half (waves 14, 15: idle)
-    const int pix = (wave - ph * PW2) * 64 + lane;  // ... and pixel of the owned interior
-    const bool p2 = wave < 2 * PW2 && pix < OY * OX;
-    const int oy_l = p2 ? pix / OX : 0, ox_l = p2 ? pix - oy_l * OX : 0;
+    // ... and pixel of the owned interior, enumerated over 14 rows of 32 (columns 30, 31 idle): a wave = two whole tile rows, so the
+    // 16-lane groups of its ds_read_b128 cover 16 consecutive 16-byte slots (rows of 30 wrapped inside the groups: 35 % of the
+    // kernel's LDS cycles were bank conflicts, profiles/r04_pmc_tail.txt)
+    const int pix = (wave - ph * PW2) * 64 + lane;
+    const int oy_r = pix / TX, ox_r = pix - oy_r * TX;
+    const bool p2 = wave < 2 * PW2 && oy_r < OY && ox_r < OX;
+    const int oy_l = p2 ? oy_r : 0, ox_l = p2 ? ox_r : 0;
     const unsigned char* p2base = tl + 4 * ph * PLANE + (oy_l * TX + ox_l) * 16;
     // per-lane constants of the phase-1 epilogue: LDS address and bias of its four 16-channel blocks
     int wofs[4];

@@ -14,8 +14,12 @@ import csv,sys,collections,glob
 for f in sorted(glob.glob(sys.argv[1]+'/*/*counter_collection.csv')):
     agg=collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(f)):
-        if any(k in r['Kernel_Name'] for k in ('tapconv', 'thin', 'wino', 'x6p')):
-            agg[r['Counter_Name']][r['Dispatch_Id']]+=float(r['Counter_Value'])
+        import os
+        flt = tuple(os.environ.get('PMC_FILTER', 'tapconv,thin,wino,x6p').split(','))
+        if any(k in r['Kernel_Name'] for k in flt):
+            agg[r['Counter_Name']][r['Kernel_Name'][:60] + '#' + r['Dispatch_Id']]+=float(r['Counter_Value'])
     for c,d in agg.items():
-        v=list(d.values()); print(f'{c:28s} {sum(v)/len(v):16.0f}  n={len(v)}')
+        byk=collections.defaultdict(list)
+        for k,v in d.items(): byk[k.split('#')[0]].append(v)
+        for k,v in byk.items(): print(f'{c:28s} {sum(v)/len(v):16.0f}  n={len(v)}  {k}')
 PY
