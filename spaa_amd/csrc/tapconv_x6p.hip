@@ -67,7 +67,7 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& h, 
 // A workgroup = FOUR waves (one per SIMD), TWO workgroups per compute unit (79 KB of LDS each): the two waves of a SIMD belong
 // to different workgroups, so one's fragment splits, barriers, prologue and epilogue (256 KB of stores per workgroup) run under
 // the other's matrix-core work -- with one 8-wave workgroup per CU every wave reaches those phases at the same time (measured:
-// transConv1 329 -> see profiles/r04_x6p.txt).
+// transConv1 288 -> 260 us; profiles/r04_x6p_time.txt).
 constexpr int NW = 4;
 constexpr int RY = NW, RX = 32;                // class-grid pixels of a workgroup (rows x columns): 8 x 64 output pixels
 constexpr int PH = RY + 1, PW = RX + 1;        // input patch 5 x 33 (taps in a 2 x 2 window)
