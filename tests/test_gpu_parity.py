@@ -825,7 +825,7 @@ def test_free_running_drift_vs_fp64_oracle(hip, golden_dir):
             # within rounding of zero) says nothing about drift; take the first of a few candidate scenes with a clean start
             # (the golden's own scene first where the case names one)
             first = int(z['scene_seed']) if scene_seed is None else scene_seed
-            for cand in ((first, first + 21) if int(z['sz'][0]) > 64 else (first, first + 20, first + 21, first + 22)):
+            for cand in ((first,) if int(z['sz'][0]) > 64 else (first, first + 20, first + 21, first + 22)):   # (256 x 256: the golden's own scene only -- scenes 21, 22, 23 were tried in round 4: none clean, profiles/r04_parity.txt)
                 scene = syn.scenes(cand, 1, tuple(int(v) for v in z['sz']))
                 r64 = _oracle_fp64(sd, csd, insz, targets, True, scene, d_thr, stealth, setup, 1)[0]['prj_adv']
                 t32 = []
