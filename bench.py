@@ -34,6 +34,9 @@ MB_PER_SCENE_256 = {'warp_fwd': 1.57 + 2.36,    # grid_sample (read x, write x_w
                     'warp_bwd_gather': 1.57,   # read g, write g_x
                     'stealth_loss': 2.36,      # read cam_infer, scene; write gradient
                     'step_and_track': 3.9}     # read g, read/write x, conditional copies of x and cam_infer
+# with the two entry layers fused (csrc/conv1pair.hip) the warp kernel writes x_w only, and the fused launch reads x_w and s
+# (2 x 0.79 MB) and writes res1_s and x1 (2 x 2.10 MB: 128 x 128 x 32 fp32)
+MB_WARP_FWD_NO_CAT, MB_CONV1_PAIR = 1.57, 1.57 + 4.19
 
 
 def build_attack(rank, batch, size, n_scenes, dev, classifier='resnet18', storage='f32', attack='spaa'):
@@ -317,7 +320,7 @@ def instrumented_pass(st, args, n_prof=3):
 
 PCNET_LAYERS = ('conv1', 'conv2', 'conv3', 'conv4', 'conv5', 'conv1_s', 'conv2_s', 'conv3_s', 'conv4_s', 'conv6', 'skipConv2',
                 'skipConv3', 'transConv1', 'transConv2')
-PCNET_ENTRY_POINTS = ('spaa_warp_fwd', 'spaa_warp_bwd_gather', 'spaa_warp_bwd_tiled', 'spaa_shading_tail_fwd', 'spaa_shading_tail_fwd_f16',
+PCNET_ENTRY_POINTS = ('spaa_conv1_pair_fwd', 'spaa_warp_fwd', 'spaa_warp_bwd_gather', 'spaa_warp_bwd_tiled', 'spaa_shading_tail_fwd', 'spaa_shading_tail_fwd_f16',
                       'spaa_shading_head_bwd', 'spaa_shading_head_bwd_f16', 'spaa_stealth_loss_fwd_bwd')
 MB_PCNET_DE_PER_SCENE_256 = 214.0   # PCNet + dE2000 forward / backward, fp32, per scene-iteration
 
@@ -523,17 +526,20 @@ def main():
         # HBM-bound kernel groups named by north_star (grid_sample, dE2000 loss, PGD step): algorithmic bytes of SURVEY 8(d)
         scale = args.batch * (args.size * args.size) / 65536.0 * 1e6
         groups = {}
-        for gname, entry in (('warp_fwd', 'spaa_warp_fwd'), ('warp_bwd_gather', 'spaa_warp_bwd_gather'),
+        mb_group = dict(MB_PER_SCENE_256)
+        if 'spaa_conv1_pair_fwd' in other:
+            mb_group['warp_fwd'], mb_group['conv1_pair'] = MB_WARP_FWD_NO_CAT, MB_CONV1_PAIR
+        for gname, entry in (('conv1_pair', 'spaa_conv1_pair_fwd'), ('warp_fwd', 'spaa_warp_fwd'), ('warp_bwd_gather', 'spaa_warp_bwd_gather'),
                              ('warp_bwd_gather', 'spaa_warp_bwd_tiled'),   # (the LDS-staged form of the same adjoint)
                              ('stealth_loss', 'spaa_stealth_loss_fwd_bwd'), ('step_and_track', 'spaa_step_and_track')):
             if entry in other:
                 us = other[entry][0] * 1e3 / other[entry][1]
-                gb = MB_PER_SCENE_256[gname] * scale
+                gb = mb_group[gname] * scale
                 groups[gname] = {'bound': 'hbm', 'achieved': round(gb / (us * 1e-6) / 1e9, 1), 'peak': PEAK_HBM_TBS * 1e3,
                                  'unit': 'GB/s', 'frac': round(gb / (us * 1e-6) / 1e12 / PEAK_HBM_TBS, 4),
                                  'avg_launch_us': round(us, 2), 'algorithmic_bytes_per_launch': round(gb)}
         other_ms = sum(v[0] for v in other.values()) / n_prof
-        other_roof = sum(MB_PER_SCENE_256[g] for g in MB_PER_SCENE_256) * scale / (PEAK_HBM_TBS * 1e12) * 1e3
+        other_roof = sum(mb_group.values()) * scale / (PEAK_HBM_TBS * 1e12) * 1e3
         ms_step = dt / args.steps * 1e3
         roof = {'kernel': kname, 'bound': 'mfma',
                 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',

@@ -168,6 +168,14 @@ int spaa_warp_finish_grid(const float* coarse, const float* refine, float* fine,
  * xw: [B,Hc,Wc,4]; cat8: [B,Hc,Wc,8] = (s.rgb, xw*s .rgb, 0, 0) or NULL. */
 int spaa_warp_fwd(const float* x, const float* grid, const float* mask, const float* s, float* xw, float* cat8,
                   int B, int Hp, int Wp, int Hc, int Wc, int clamp01, spaa_stream_t stream);
+/* ShadingNetSPAA's two stride-2 entry layers with use_rough in one launch (models.py:284-285,295 of the reference):
+ *   S1 = relu(conv1_s(cat[s, xw * s]) + bias_s),  X1 = relu(conv1(xw) + bias1 + S1)
+ * xw, s: [B,H,W,4] fp32 (channel 3 = 0), H and W even; S1, X1: [B,H/2,W/2,32] fp32 (out_f16 = 0) or fp16 (1: the residual is
+ * the rounded S1); mask_S1 / mask_X1: [B,H/2,W/2,8] ReLU gate bits of the stored values (1 byte per 4 channels) or NULL.
+ * w_pair: [3][32][9][4] fp32 = conv1.weight, conv1_s.weight[:, 0:3], conv1_s.weight[:, 3:6] as [n][3 ky + kx][c], c = 3 zero. */
+int spaa_conv1_pair_fwd(const float* xw, const float* s, const float* w_pair, const float* bias1, const float* bias_s,
+                        void* S1, void* X1, uint8_t* mask_S1, uint8_t* mask_X1, int B, int H, int W, int out_f16,
+                        spaa_stream_t stream);
 /* Backward of the above w.r.t. x (grid_sampler_2d_backward + clamp mask): g_x must be zeroed by the caller
  * (spaa_zero); contributions are accumulated with float atomics.
  * g_xw: [B,Hc,Wc,4] gradient w.r.t. xw (conv1 path); g_xs: [B,Hc,Wc,4] gradient w.r.t. xw*s (channels 3..5 of

@@ -1,0 +1,215 @@
+// conv1pair.hip — the two stride-2 entry layers of ShadingNetSPAA with use_rough in ONE launch:
+//     S1 = relu(conv1_s(cat[s, xw * s]))          (models.py:284-285 of the reference: res1_s)
+//     X1 = relu(conv1(xw) + S1)                   (models.py:295)
+// Both layers read the same 3-channel camera-resolution images and write 32 channels at half resolution, so they are
+// HBM-bound on their outputs.  Run separately they read xw twice, the 8-channel concatenation [s, xw * s] (which the
+// warp kernel had to write first) and S1 back as conv1's residual; fused, a workgroup stages the xw and s patches of
+// its 32 x 8 output tile once (LDS-DMA, zero padding as out-of-range offsets), forms xw * s in registers, and keeps
+// S1 in registers for conv1's epilogue.  Per camera pixel: 32 B read, and per output pixel 2 x 128 B + 16 mask bytes
+// written — 410 MB at batch 64 instead of 870 MB (+ the 134 MB the warp kernel no longer writes).
+//
+// Arithmetic is the exact fp32 matrix instruction of smallcin.hip (v_mfma_f32_32x32x2_f32), weights in registers:
+// per tap 2 MFMAs for conv1 and 4 for conv1_s (s quad, xw * s quad).
+#include <hip/hip_runtime.h>
+#include "launch_util.hpp"
+#include <stdint.h>
+#include "../../include/spaa_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int TW = 32, TH = 8;                 // output pixels per workgroup (4 waves x 2 rows of 32)
+constexpr int PH = 2 * (TH - 1) + 3;           // 17 input rows
+constexpr int PW = 2 * (TW - 1) + 3;           // 65 input columns
+constexpr int NPIX = PH * PW;                  // 1105 staged pixels of 16 B per source
+constexpr int NPIECE = (NPIX + 63) / 64;       // 18 one-KiB DMA pieces per source
+constexpr int SRC_BYTES = NPIECE * 1024;
+constexpr int LDS_BYTES = 2 * SRC_BYTES;       // 36 KiB
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct c1p_args {
+    const float* xw;
+    const float* s;
+    const float* w;      // [3 groups: conv1 | conv1_s on s | conv1_s on xw*s][32 n][9 taps][4 channels]
+    const float* b1;
+    const float* bs;
+    void* S1;
+    void* X1;
+    uint8_t* mS1;
+    uint8_t* mX1;
+    int B, H, W, Hm, Wm, tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rsrc, unsigned char* dst, int voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* ptr, uint32_t bytes) {
+    const uint64_t addr = reinterpret_cast<uint64_t>(ptr);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)addr);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)hi << 32) | lo), 0,
+                                             (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const void* base, const size_t byte_off, const int bytes) {
+    const uint64_t addr = reinterpret_cast<uint64_t>(base) + byte_off;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)addr);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0,
+                                             (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+// nibble q of u (q = 0..3) -> byte q: the gate format is one byte per 4 channels
+__device__ __forceinline__ uint32_t spread_nibbles(const uint32_t u) {
+    return (u & 0xFu) | ((u & 0xF0u) << 4) | ((u & 0xF00u) << 8) | ((u & 0xF000u) << 12);
+}
+// lane `l` of `old` := the wave-uniform value `v` (v_writelane_b32 through the compiler, which then keeps the wait states between
+// the compare that produces `v` and this read of it; clang has no builtin of that name for the intrinsic)
+extern "C" __device__ uint32_t spaa_llvm_writelane(uint32_t v, uint32_t l, uint32_t old) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ uint32_t writelane(const uint32_t v, const int l, const uint32_t old) { return spaa_llvm_writelane(v, (uint32_t)l, old); }
+template <typename T>
+__device__ __forceinline__ void st1(const __amdgpu_buffer_rsrc_t r, const int voff, const int imm, const float v) {
+    if constexpr (sizeof(T) == 2)
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), r, voff, imm, 0);
+    else
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, imm, 0);
+}
+
+// T = storage type of S1 / X1 (fp32, or fp16 in the fp16-storage mode: the residual added is then the ROUNDED S1, as
+// when conv1 reads it back from memory)
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv1pair_kernel(const c1p_args p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int tile;
+    {   // consecutive tiles on the same XCD (workgroups are dealt round-robin over the 8 XCDs): neighbours share halo rows in L2
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int tx = tile % p.tiles_x;
+    const int ty = (tile / p.tiles_x) % p.tiles_y;
+    const int b = tile / (p.tiles_x * p.tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    // ---- stage the two input patches: rows 2 y0 - 1 .., columns 2 x0 - 1 .. (one 16-byte pixel per lane)
+    {
+        const uint32_t bytes = (uint32_t)p.B * (uint32_t)(p.H * p.W) * 16u;
+        const auto rx = make_rsrc(p.xw, bytes), rs = make_rsrc(p.s, bytes);
+        for (int i = wave; i < NPIECE; i += 4) {
+            const int q = i * 64 + lane;
+            const int py = q / PW, px = q - py * PW;
+            const int iy = 2 * y0 - 1 + py, ix = 2 * x0 - 1 + px;
+            const bool v = q < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const int off = v ? ((b * p.H + iy) * p.W + ix) * 16 : (int)0x80000000;
+            dma16(rx, smem + i * 1024, off);
+            dma16(rs, smem + SRC_BYTES + i * 1024, off);
+        }
+    }
+
+    // ---- weights in registers: lane -> output channel (lane & 31), channels 2 * (lane >> 5) + {0, 1} of every tap
+    float wA[3][9], wB[3][9];
+    {
+        const float* wr = p.w + (size_t)(lane & 31) * 36 + 2 * (lane >> 5);
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const f2 w2 = *reinterpret_cast<const f2*>(wr + g * (32 * 36) + t * 4);
+                wA[g][t] = w2.x;
+                wB[g][t] = w2.y;
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int lx = lane & 31, h = lane >> 5, n = lane & 31;
+    const float b1n = p.b1[n], bsn = p.bs[n];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int ly = wave * 2 + r;
+        const unsigned char* pp = smem + ((2 * ly) * PW + 2 * lx) * 16 + h * 8;
+        f32x16 acc1, acc2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc1[i] = acc2[i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * PW + (t % 3)) * 16;
+            const f2 vx = *reinterpret_cast<const f2*>(pp + toff);
+            const f2 vs = *reinterpret_cast<const f2*>(pp + SRC_BYTES + toff);
+            const f2 vxs = vx * vs;
+            // pixels as the ROWS of the product (A operand), channels as its columns: a lane then holds ONE channel of 16 pixels
+            // and a store instruction writes two complete 128-byte channel rows
+            acc1 = mfma2(vx.x, wA[0][t], acc1);
+            acc2 = mfma2(vs.x, wA[1][t], acc2);
+            acc1 = mfma2(vx.y, wB[0][t], acc1);
+            acc2 = mfma2(vs.y, wB[1][t], acc2);
+            acc2 = mfma2(vxs.x, wA[2][t], acc2);
+            acc2 = mfma2(vxs.y, wB[2][t], acc2);
+        }
+        // ---- epilogue: lane = channel n (both halves), element 4 g + e = pixel 8 g + 4 h + e of the row.  Out-of-image pixels fall
+        // outside the row's buffer descriptor (its records end at the last valid pixel) and are dropped by the hardware.
+        const int y = y0 + ly;
+        const int npx = y < p.Hm ? (p.Wm - x0 < TW ? p.Wm - x0 : TW) : 0;
+        const size_t o0 = ((size_t)b * p.Hm + (y < p.Hm ? y : 0)) * p.Wm + x0;
+        const auto rS = row_rsrc(p.S1, o0 * 32 * sizeof(T), npx * 32 * (int)sizeof(T));
+        const auto rX = row_rsrc(p.X1, o0 * 32 * sizeof(T), npx * 32 * (int)sizeof(T));
+        const int voff = (h * 4 * 32 + n) * (int)sizeof(T);
+        uint32_t gS = 0, gX = 0;      // lane j < 32: the 32 gate bits of pixel j
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = fmaxf(acc2[4 * g + e] + bsn, 0.f);
+                if constexpr (sizeof(T) == 2) a = (float)(_Float16)a;
+                float v = fmaxf(acc1[4 * g + e] + b1n + a, 0.f);
+                if constexpr (sizeof(T) == 2) v = (float)(_Float16)v;
+                st1<T>(rS, voff, (8 * g + e) * 32 * (int)sizeof(T), a);
+                st1<T>(rX, voff, (8 * g + e) * 32 * (int)sizeof(T), v);
+                const uint64_t ba = __builtin_amdgcn_ballot_w64(a > 0.f), bv = __builtin_amdgcn_ballot_w64(v > 0.f);
+                gS = writelane((uint32_t)ba, 8 * g + e, gS);
+                gS = writelane((uint32_t)(ba >> 32), 8 * g + 4 + e, gS);
+                gX = writelane((uint32_t)bv, 8 * g + e, gX);
+                gX = writelane((uint32_t)(bv >> 32), 8 * g + 4 + e, gX);
+            }
+        const int moff = lane < 32 ? lane * 8 : (int)0x80000000;
+        if (p.mS1 != nullptr) {
+            const auto rm = row_rsrc(p.mS1, o0 * 8, npx * 8);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{spread_nibbles(gS & 0xFFFFu), spread_nibbles(gS >> 16)}, rm, moff, 0, 0);
+        }
+        if (p.mX1 != nullptr) {
+            const auto rm = row_rsrc(p.mX1, o0 * 8, npx * 8);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{spread_nibbles(gX & 0xFFFFu), spread_nibbles(gX >> 16)}, rm, moff, 0, 0);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int spaa_conv1_pair_fwd(const float* xw, const float* s, const float* w_pair, const float* bias1, const float* bias_s,
+                                   void* S1, void* X1, uint8_t* mask_S1, uint8_t* mask_X1, int B, int H, int W, int out_f16,
+                                   spaa_stream_t stream) {
+    if (!xw || !s || !w_pair || !bias1 || !bias_s || !S1 || !X1 || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return hipErrorInvalidValue;
+    if ((uint64_t)B * H * W * 16u >= (1ull << 31)) return hipErrorInvalidValue;   // 32-bit buffer offsets
+    c1p_args a;
+    a.xw = xw, a.s = s, a.w = w_pair, a.b1 = bias1, a.bs = bias_s;
+    a.S1 = S1, a.X1 = X1, a.mS1 = mask_S1, a.mX1 = mask_X1;
+    a.B = B, a.H = H, a.W = W, a.Hm = H / 2, a.Wm = W / 2;
+    a.tiles_x = (a.Wm + TW - 1) / TW, a.tiles_y = (a.Hm + TH - 1) / TH;
+    const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * B), 1, 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (out_f16)
+        hipLaunchKernelGGL(conv1pair_kernel<_Float16>, grid, dim3(256), LDS_BYTES, st, a);
+    else
+        hipLaunchKernelGGL(conv1pair_kernel<float>, grid, dim3(256), LDS_BYTES, st, a);
+    return (int)hipGetLastError();
+}

@@ -24,7 +24,7 @@ from .synthetic import uniform_ctrl_pts
 USE_GATE_MASKS = os.environ.get('SPAA_GATE_MASKS', '1') != '0'   # 0: fp32 activations as ReLU gates (A/B measurements)
 FUSE_TAIL = os.environ.get('SPAA_FUSE_TAIL', '1') != '0'         # 0: transConv2 / conv6 as separate launches (A/B measurements)
 FUSE_SELECT = os.environ.get('SPAA_FUSE_SELECT', '1') != '0'     # 0: spaa_select_grad as its own launch (A/B measurements)
-FUSE_SKIP2 = int(os.environ.get('SPAA_FUSE_SKIP2', '15'))        # bits: 1 transConv1 + skipConv2, 2 conv2^T + skipConv2^T, 4 conv2_s^T on the same kernel, 8 conv5 + skipConv3 and conv3^T + skipConv3^T; 0: separate launches (A/B measurements)
+FUSE_SKIP2 = int(os.environ.get('SPAA_FUSE_SKIP2', '31'))        # bits: 1 transConv1 + skipConv2, 2 conv2^T + skipConv2^T, 4 conv2_s^T on the same kernel, 8 conv5 + skipConv3 and conv3^T + skipConv3^T, 16 conv1_s + conv1 (csrc/conv1pair.hip); 0: separate launches (A/B measurements)
 FUSE_SKIP2_MIN_PIXELS = int(os.environ.get('SPAA_FUSE_SKIP2_MIN', '16384'))   # B x H/4 x W/4 from which the fused kernel's 4 x 32-pixel regions fill the chip
 
 
@@ -416,6 +416,18 @@ class PCNetEngine:
             if c5 is not None and c3 is not None:
                 f['conv5x'], d['conv3x'] = c5, c3
                 self.fuse_skip3 = True
+        # use_rough: `relu(conv1_s(cat[s, xw * s]))` and `relu(conv1(xw) + res1_s)` (models.py:284-285,295) as ONE launch that reads xw and
+        # s once, forms xw * s in registers and keeps res1_s there for conv1's epilogue (csrc/conv1pair.hip); the warp kernel then
+        # no longer writes the 8-channel concatenation.  Frozen weights only (the training step refreshes the separate plans).
+        self.pair1 = None
+        if FUSE_SKIP2 & 16 and fuse_skip2 is not False and self.rough and (USE_GATE_MASKS or storage == 'f16') \
+                and tuple(sn.conv1.weight.shape) == (32, 3, 3, 3) and tuple(sn.conv1_s.weight.shape) == (32, 6, 3, 3):
+            w1, ws = sn.conv1.weight.detach().float(), sn.conv1_s.weight.detach().float()
+            wp = torch.zeros(3, 32, 9, 4, device=dev)
+            for gi, wsrc in enumerate((w1, ws[:, 0:3], ws[:, 3:6])):
+                wp[gi, :, :, :3] = wsrc.permute(0, 2, 3, 1).reshape(32, 9, 3)
+            self.pair1 = (wp.contiguous(), sn.conv1.bias.detach().float().contiguous().to(dev),
+                          sn.conv1_s.bias.detach().float().contiguous().to(dev))
         f['transConv2'] = cp.deconv_fwd_plan(sn.transConv2.weight, sn.transConv2.bias, 2, 0, dev, 'transConv2')
         d['transConv2'] = cp.deconv_dgrad_plan(sn.transConv2.weight, 2, 0, dev, 'transConv2_dgrad')
         sk = sn.skipConv1
@@ -486,7 +498,8 @@ class PCNetEngine:
     def _surface_branch(self, inp):
         a, f, R = self.a, self.f, _lib.ACT_RELU
         m = self.m if (USE_GATE_MASKS or self.storage == 'f16') else {k: None for k in self.m}
-        f['conv1_s'].run(inp, a['S1'], act=R, mask_out=m['S1'])
+        if inp is not None:   # (None: S1 already written by the fused conv1 pair)
+            f['conv1_s'].run(inp, a['S1'], act=R, mask_out=m['S1'])
         f['conv2_s'].run(a['S1'], a['S2'], act=R, mask_out=m['S2'])
         f['conv3_s'].run(a['S2'], a['S3'], act=R, mask_out=m['S3'])
         f['conv4_s'].run(a['S3'], a['S4'], act=R, mask_out=m['S4'])
@@ -496,7 +509,7 @@ class PCNetEngine:
         _lib.check_dev(x4)
         assert x4.shape == (self.B, self.Hp, self.Wp, 4)
         _lib.call('spaa_warp_fwd', _lib.ptr(x4), _lib.ptr(self.grid), _lib.ptr(self.mask), _lib.ptr(self.scene),
-                  _lib.ptr(a['xw']), _lib.ptr(a['cat8']) if self.scene is not None else None, self.B, self.Hp,
+                  _lib.ptr(a['xw']), _lib.ptr(a['cat8']) if (self.scene is not None and self.pair1 is None) else None, self.B, self.Hp,
                   self.Wp, self.Hc, self.Wc, int(clamp01))
         self._x, self._clamp = x4, int(clamp01)
         return a['xw']
@@ -510,9 +523,16 @@ class PCNetEngine:
         self.version += 1
         self.warp(x4, clamp01)
         m = self.m if (USE_GATE_MASKS or self.storage == 'f16') else {k: None for k in self.m}
-        if self.rough:
-            self._surface_branch(a['cat8'])
-        f['conv1'].run(a['xw'], a['X1'], add=a['S1'], act=R, mask_out=m['X1'])
+        if self.pair1 is not None:
+            wp, b1, bs = self.pair1
+            _lib.call('spaa_conv1_pair_fwd', _lib.ptr(a['xw']), _lib.ptr(self.scene), _lib.ptr(wp), _lib.ptr(b1), _lib.ptr(bs),
+                      _lib.ptr(a['S1']), _lib.ptr(a['X1']), C_ptr(m['S1']), C_ptr(m['X1']), self.B, self.Hc, self.Wc,
+                      int(self.storage == 'f16'))
+            self._surface_branch(None)
+        else:
+            if self.rough:
+                self._surface_branch(a['cat8'])
+            f['conv1'].run(a['xw'], a['X1'], add=a['S1'], act=R, mask_out=m['X1'])
         if not (self.fuse_skip2 and 'transConv1x' in f):
             f['skipConv2'].run(a['X1'], a['R2'], act=N)
         f['conv2'].run(a['X1'], a['X2'], add=a['S2'], act=R, mask_out=m['X2'])
