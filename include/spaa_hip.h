@@ -168,6 +168,11 @@ int spaa_warp_finish_grid(const float* coarse, const float* refine, float* fine,
  * xw: [B,Hc,Wc,4]; cat8: [B,Hc,Wc,8] = (s.rgb, xw*s .rgb, 0, 0) or NULL. */
 int spaa_warp_fwd(const float* x, const float* grid, const float* mask, const float* s, float* xw, float* cat8,
                   int B, int Hp, int Wp, int Hc, int Wc, int clamp01, spaa_stream_t stream);
+/* nn.Linear on a few rows (classifier.py:60: torchvision's `fc` = ATen addmm; its input gradient = mm with the weight):
+ * out[m][n] = bias[n] + sum_k x[m][k] * w[n][k], fp32, M <= 256, K <= 4096, K % 4 == 0; x / w rows 16-byte aligned (ldx, ldw % 4 == 0),
+ * bias may be NULL.  The input gradient is the same call with the transposed weight. */
+int spaa_linear_small(const float* x, const float* w, const float* bias, float* out, int M, int K, int N, int ldx, int ldw, int ldo,
+                      spaa_stream_t stream);
 /* ShadingNetSPAA's two stride-2 entry layers with use_rough in one launch (models.py:284-285,295 of the reference):
  *   S1 = relu(conv1_s(cat[s, xw * s]) + bias_s),  X1 = relu(conv1(xw) + bias1 + S1)
  * xw, s: [B,H,W,4] fp32 (channel 3 = 0), H and W even; S1, X1: [B,H/2,W/2,32] fp32 (out_f16 = 0) or fp16 (1: the residual is

@@ -830,19 +830,56 @@ def attach_maps(plan, builder, weight):
     return plan
 
 
+SMALL_LINEAR = os.environ.get('SPAA_SMALL_LINEAR', '1') != '0'   # 0: the classifiers' last layer on the implicit-GEMM tiles (A/B measurements)
+
+
+class SmallLinearPlan:
+    """nn.Linear on at most 64 rows as a wave-per-output kernel (csrc/linear_small.hip); more rows, fp16 tensors or a fused
+    epilogue go to the 1 x 1 convolution plan it wraps.  `w_rows` [N, K]: row n holds the weights of output n."""
+
+    def __init__(self, conv_plan, w_rows, bias, device):
+        self.conv, self.name = conv_plan, conv_plan.name
+        self.w = w_rows.detach().float().contiguous().to(device)
+        self.bias = bias.detach().float().contiguous().to(device) if bias is not None else None
+        self.n, self.k = self.w.shape
+        self.last_tile = -1
+
+    def applies(self, inp, out, kw):
+        m = inp.shape[0] * inp.shape[1] * inp.shape[2]
+        return (SMALL_LINEAR and not kw and m <= 64 and inp.dtype == out.dtype == torch.float32 and inp.shape[3] == self.k
+                and out.shape[3] == self.n and self.k % 4 == 0 and 4 <= self.k <= 4096 and inp.is_contiguous() and out.is_contiguous())
+
+    def run(self, inp, out, **kw):
+        if not self.applies(inp, out, kw):
+            r = self.conv.run(inp, out, **kw)
+            self.last_tile = self.conv.last_tile
+            return r
+        _lib.check_dev(inp, out)
+        m = inp.shape[0] * inp.shape[1] * inp.shape[2]
+        _lib.call('spaa_linear_small', _lib.ptr(inp), _lib.ptr(self.w), _lib.ptr(self.bias) if self.bias is not None else None, _lib.ptr(out),
+                  m, self.k, self.n, self.k, self.k, self.n)
+        self.last_tile = 75
+        return out
+
+    def __getattr__(self, item):      # (flops(), refresh(), tune keys ...: the wrapped plan's)
+        return getattr(self.conv, item)
+
+
 def linear_fwd_plan(weight, bias, device='cuda', name=''):
     """nn.Linear as a 1x1 convolution over a [B,1,1,C] activation."""
     w = _w2(weight)
     c = TapClassSpec(0, 0)
     c.add(0, 0, w)
-    return ConvPlan([c], w.shape[1], w.shape[0], 1, 1, bias, device, name)
+    plan = ConvPlan([c], w.shape[1], w.shape[0], 1, 1, bias, device, name)
+    return SmallLinearPlan(plan, w, bias, device) if w.numel() <= (1 << 22) and w.shape[1] % 4 == 0 else plan
 
 
 def linear_dgrad_plan(weight, device='cuda', name=''):
     w = _w2(weight)
     c = TapClassSpec(0, 0)
     c.add(0, 0, w.t().contiguous())
-    return ConvPlan([c], w.shape[0], w.shape[1], 1, 1, None, device, name)
+    plan = ConvPlan([c], w.shape[0], w.shape[1], 1, 1, None, device, name)
+    return SmallLinearPlan(plan, w.t().contiguous(), None, device) if w.numel() <= (1 << 22) and w.shape[0] % 4 == 0 else plan
 
 
 def fold_bn(weight, bn_w, bn_b, bn_mean, bn_var, eps=1e-5):

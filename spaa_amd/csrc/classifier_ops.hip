@@ -113,6 +113,59 @@ __global__ void preproc_bwd_kernel(const float4* __restrict__ g_out, float4* __r
     g_y[idx] = make_float4(a0 / s0, a1 / s1, a2 / s2, 0.f);
 }
 
+// The down-sampling case of the above (the attack's 240 -> 224), restructured: a thread owns ONE column of PRE_ROWS consecutive rows,
+// finds its (at most two) covering output columns once, and the covering output rows are wave-uniform (scalar arithmetic); per
+// pixel that leaves four gradient loads and four fused multiply-adds in the same row-major order (the same bits as the per-pixel
+// kernel: 58 -> about 30 us at batch 64, 256 x 256, where the candidate search was 90 % of the instructions).
+constexpr int PRE_ROWS = 8;
+__device__ __forceinline__ void covering2(const int p, const int in, const int out, const bool inside, int (&o2)[2], int (&l2)[2]) {
+    o2[0] = o2[1] = -1;
+    l2[0] = l2[1] = 1;
+    const int lo = max((p * out) / in - 1, 0), hi = min(((p + 1) * out + in - 1) / in, out - 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int o = lo + k;
+        const int s = win_start(min(o, out - 1), out, in), e = win_end(min(o, out - 1), out, in);
+        const bool c = inside && o <= hi && p >= s && p < e;
+        const bool c0 = c && o2[0] < 0, c1 = c && !c0 && o2[1] < 0;
+        o2[0] = c0 ? o : o2[0]; l2[0] = c0 ? e - s : l2[0];
+        o2[1] = c1 ? o : o2[1]; l2[1] = c1 ? e - s : l2[1];
+    }
+}
+__global__ void preproc_bwd_down_kernel(const float4* __restrict__ g_out, float4* __restrict__ g_y, int B, int H, int W,
+                                        int cy0, int cx0, int ch, int cw, int oh, int ow, float s0, float s1, float s2) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.z;
+    if (x >= W) return;
+    const int px = x - cx0;
+    int ox2[2], xl2[2];
+    covering2(px, cw, ow, (unsigned)px < (unsigned)cw, ox2, xl2);
+    for (int r = 0; r < PRE_ROWS; ++r) {
+        const int yy = blockIdx.y * PRE_ROWS + r;     // (uniform)
+        if (yy >= H) break;
+        const int py = yy - cy0;
+        int oy2[2], yl2[2];
+        covering2(py, ch, oh, (unsigned)py < (unsigned)ch, oy2, yl2);
+        float4 gv[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) gv[2 * i + j] = g_out[((size_t)b * oh + max(oy2[i], 0)) * ow + max(ox2[j], 0)];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool ok = oy2[i] >= 0 && ox2[j] >= 0;
+                const float inv = 1.f / (float)(yl2[i] * xl2[j]);
+                a0 = ok ? fmaf(gv[2 * i + j].x, inv, a0) : a0;
+                a1 = ok ? fmaf(gv[2 * i + j].y, inv, a1) : a1;
+                a2 = ok ? fmaf(gv[2 * i + j].z, inv, a2) : a2;
+            }
+        g_y[((size_t)b * H + yy) * W + x] = make_float4(a0 / s0, a1 / s1, a2 / s2, 0.f);
+    }
+}
+
 // max_pool2d(kernel 3, stride 2, padding 1), NHWC, 4 channels per thread; first maximum in row-major window order
 // wins (ATen CPU kernel: `val > maxval || isnan(val)`).
 __global__ void maxpool_fwd_kernel(const float4* __restrict__ in, float4* __restrict__ out,
@@ -278,6 +331,12 @@ int spaa_preproc_bwd(const float* g_out, float* g_y, int B, int H, int W, int cy
     if (ch > 2 * oh || cw > 2 * ow) return hipErrorInvalidValue;
     // ... and an input pixel is covered by at most 5 outputs per axis (the gather's list length) up to 4x upscaling
     if (oh > 4 * ch || ow > 4 * cw) return hipErrorInvalidValue;
+    if (ch >= oh && cw >= ow && B <= 65535) {   // down-sampling: a column of PRE_ROWS rows per thread
+        hipLaunchKernelGGL(preproc_bwd_down_kernel, dim3((W + 255) / 256, (H + PRE_ROWS - 1) / PRE_ROWS, B), dim3(256), 0,
+                           (hipStream_t)stream, (const float4*)g_out, (float4*)g_y, B, H, W, cy0, cx0, ch, cw, oh, ow, std3[0],
+                           std3[1], std3[2]);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(preproc_bwd_kernel, dim3(nblk((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)g_out, (float4*)g_y, B, H, W, cy0, cx0, ch, cw, oh, ow, std3[0], std3[1],
                        std3[2]);

@@ -2127,6 +2127,35 @@ def test_tapconv_fp16_storage(hip, tile):
         cp.FORCE_TILE = 0
 
 
+@pytest.mark.parametrize('m,k,n', [(64, 512, 1000), (8, 2048, 1000), (3, 4096, 1000), (5, 12, 10), (64, 1000, 512)])
+def test_small_linear(hip, m, k, n):
+    """csrc/linear_small.hip (the classifiers' last layer and its input gradient at batch <= 64: classifier.py:60 of the reference,
+    torchvision `fc`): against fp64, at the error of an fp32 dot product, bitwise run to run, and through the plan wrapper
+    (convplan.SmallLinearPlan: the kernel for a plain call, the 1 x 1 convolution tiles when an epilogue is asked for)."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(m + k)
+    w, bias, x = torch.randn(n, k) / k ** 0.5, torch.randn(n), torch.randn(m, k)
+    ref = x.double() @ w.double().t() + bias.double()
+    plan = cp.linear_fwd_plan(w, bias, DEV, 'fc')
+    assert isinstance(plan, cp.SmallLinearPlan)
+    y = torch.full((m, 1, 1, n), float('nan'), device=DEV)
+    plan.run(x.view(m, 1, 1, k).to(DEV), y)
+    assert plan.last_tile == 75
+    y2 = torch.zeros_like(y)
+    plan.run(x.view(m, 1, 1, k).to(DEV), y2)
+    assert torch.equal(y, y2) and rel_inf(y.cpu().view(m, n), ref.float()) < 2e-6
+    if k % 32 == 0:
+        y3 = torch.zeros_like(y)
+        plan.run(x.view(m, 1, 1, k).to(DEV), y3, act=lib.ACT_RELU)
+        assert plan.last_tile != 75 and rel_inf(y3.cpu().view(m, n), F.relu(ref).float()) < 2e-6
+    if n % 4 == 0:
+        g = torch.randn(m, n)
+        dplan = cp.linear_dgrad_plan(w, DEV, 'fc_dgrad')
+        gx = torch.zeros(m, 1, 1, k, device=DEV)
+        dplan.run(g.view(m, 1, 1, n).to(DEV), gx)
+        assert dplan.last_tile == 75 and rel_inf(gx.cpu().view(m, k), (g.double() @ w.double()).float()) < 2e-6
+
+
 def test_tapconv_fp16_split_k(hip):
     """Split-K of the fp16 implicit-GEMM kernel (skinny GEMMs: a fully connected layer at batch 64, a 7 x 7 x 512 layer): raw fp32
     partial sums + a fixed-order second pass with the epilogue; against fp64 on the same fp16-rounded operands and against the
