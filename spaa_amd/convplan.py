@@ -361,7 +361,7 @@ class ConvPlan:
                 tile = 72   # thin output: the parity classes folded into the N dimension of a matrix-core tile (csrc/tapconv_thinmf.hip)
         if tile % 100 in (70, 71, 73):   # Winograd form of a 3x3 / stride-1 layer (csrc/tapconv_wino.hip): fp32 storage, same-size output
             # (tune values: 70 = the launcher's choice of N tile and K ranges, 71 = 64-wide N tile, 73 = 64-wide, four-wave workgroups; + 100 k = k K ranges, k = 1: none)
-            if self.wino is not None and WINOGRAD and not (in_f16 or out_f16) and (hin, win) == (hout, wout):
+            if self.wino is not None and WINOGRAD and not (in_f16 or out_f16) and (hout, wout) == (hin + 2 * self.wino_pad - 2, win + 2 * self.wino_pad - 2):
                 self.wino.fixed_tile, self.wino.wino_ksplit = tile % 100, tile // 100
                 return self.wino.run(inp, out, add, gate, gate_mode, act, aux_out, gate2, in_coff, out_coff, add_coff, gate_coff,
                                      mask_out, gate_bits, gate2_bits, inp2, in2_coff)
@@ -466,7 +466,8 @@ class ConvPlan:
             tile = 0 if forced else self._default_tile(b * d.Hm * d.Wm, winograd=False) % 100
         d.tile = self.last_tile = tile     # (last_tile: for tests and reports)
         d.reserved0 = (DEBUG_TAPMAJOR | (DEBUG_PERSIST_CAP << 8) | (DEBUG_WINO << 16) | (DEBUG_H16_2STAGE << 25) | (DEBUG_SMALLCIN_NOSLAB << 26)
-                       | ((DEBUG_THINMF & 7) << 27) | (((DEBUG_WINO_NOCANVAS & 1) << 30 | (DEBUG_WINO_NOCANVAS >> 1 & 1) << 29) if tile in (70, 71, 73) else 0))  # measurement / test switches
+                       | (((DEBUG_THINMF & 7) << 27) if tile == 72 else 0)
+                       | (((DEBUG_WINO_NOCANVAS & 1) << 30 | (DEBUG_WINO_NOCANVAS >> 1 & 1) << 29 | {1: 0, 0: 1, 2: 2}[getattr(self, 'wino_pad', 1)] << 27) if tile in (70, 71, 73) else 0))  # measurement / test switches; bits 27-28 of a Winograd launch: its zero padding (1 / 0 / 2)
         d.nclass = len(self.cls)
         d.tap_range[:] = self.tap_range
         for i, c in enumerate(self.cls):
@@ -636,8 +637,12 @@ def attach_winograd(plan):
             or plan.cin_p % 32 or plan.cin != plan.cin_p or plan.w_split is None or plan.cout < 64):
         return plan
     taps = [(dy, dx) for dy, dx, _ in plan.classes_host[0].taps]
-    if sorted(taps) != [(dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]:
+    # pad 1 (taps -1..1: same-size output), pad 0 (taps 0..2: the unpadded layer, output 2 smaller: Inception-v3's Conv2d_2a / 4a) or
+    # pad 2 (taps -2..0: that layer's input gradient, output 2 larger): the kernel's patch origin moves, nothing else
+    sh = min(dy for dy, _ in taps) + 1
+    if sh not in (-1, 0, 1) or sorted(taps) != [(dy + sh, dx + sh) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]:
         return plan
+    taps = [(dy - sh, dx - sh) for dy, dx in taps]
     t = torch.zeros(16, 9, dtype=torch.float64)  # U[pos] = sum_t T[pos, t] g_t,  g_t = the tap at offset (dy, dx)
     for i, (dy, dx) in enumerate(taps):
         for xi in range(4):
@@ -654,6 +659,7 @@ def attach_winograd(plan):
     wino.bias = plan.bias            # (shared tensor: refresh() updates both)
     wino._wino_t = t
     wino.fixed_tile = 70
+    wino.wino_pad = plan.wino_pad = 1 - sh
     wino.flops_per_pixel, wino.alg_taps = plan.flops_per_pixel, 9   # algorithmic work = the direct convolution's
     _winograd_weights(plan, wino)
     plan.wino = wino

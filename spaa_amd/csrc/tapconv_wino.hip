@@ -111,6 +111,10 @@ struct wino_geo_t {
 // NWT = 4 (tile 73, 64-wide N tile): a workgroup of FOUR waves (4 x 16 tiles = 8 x 32 output pixels, 80 KB of LDS), TWO workgroups per
 // compute unit -- the two waves of a SIMD belong to different workgroups, so one's prologue / epilogue runs under the other's main
 // loop (short-K layers: ResNet-18 layer1 spends a third of a launch in them).
+__host__ __device__ __forceinline__ int wino_pad(const int reserved0) {
+    const int c = (reserved0 >> 27) & 3;
+    return c == 0 ? 1 : (c == 1 ? 0 : 2);
+}
 template <int BN, int VAR, int DBG = 0, bool CV = false, bool TWO = false, int NWT = 8>   // DBG: timing-only ablations (wrong results): 1 no epilogue, 2 no fold, 4 no V, 8 no barrier, 16 no DMA; 32: raw barrier.  CV: canvas / split-K form
 __global__ __launch_bounds__(64 * NWT, NWT == 4 ? 2 : 1) void wino_x6_kernel(const spaa_tapconv_t p, const int wg_y, const int wg_x, const int n_tiles, const wino_geo_t geo) {
     constexpr int TJ = BN / 16;
@@ -130,6 +134,9 @@ __global__ __launch_bounds__(64 * NWT, NWT == 4 ? 2 : 1) void wino_x6_kernel(con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const spaa_tapclass_t cl = p.cls[0];
     const int Cin = p.Cin, H = p.Hin, W = p.Win;
+    // zero padding of the layer: 1 (same size), 0 (unpadded: the output is 2 smaller) or 2 (the unpadded layer's input gradient: 2 larger);
+    // `reserved0` bits 27-28 = 0 / 1 / 2.  The canvas / K-range form (CV) shares its gaps as padding: pad 1 only (the launcher sees to it).
+    const int pad_ = CV ? 1 : wino_pad(p.reserved0);
 
     // XCD-aware order over (image, patch row, patch column, n tile): an XCD takes a contiguous range
     int n_blk, img, oy0, ox0, ks = 0;   // (CV: img = the canvas, (oy0, ox0) = the region's origin on it)
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(64 * NWT, NWT == 4 ? 2 : 1) void wino_x6_kernel(con
         const int slot_ = (wave + NW * i) * 8 + (lane >> 3);                                                         \
         const int pix_ = slot_ ^ ((slot_ >> 1) & 1);                                                                 \
         const int pr_ = pix_ / PW, pc_ = pix_ - pr_ * PW;                                                            \
-        const int iy_ = oy0 - 1 + pr_, ix_ = ox0 - 1 + pc_;                                                          \
+        const int iy_ = oy0 - pad_ + pr_, ix_ = ox0 - pad_ + pc_;                                                    \
         int pxi_ = (img * H + iy_) * W + ix_;                                                                        \
         bool ok_ = pix_ < NPX && (unsigned)iy_ < (unsigned)H && (unsigned)ix_ < (unsigned)W;                         \
         if constexpr (CV) ok_ = canvas_pixel(iy_, ix_, pxi_) && pix_ < NPX;                                          \
@@ -687,7 +694,7 @@ inline int wino_ncu() {
 
 inline bool wino_shape_ok(const spaa_tapconv_t& d) {
     if (d.w_split == nullptr || (d.Cin % 32) != 0 || d.Cin < 32 || d.nclass != 1 || d.cls[0].ntaps != 16 || d.cls[0].K != 16 * d.Cin || d.cls[0].Kpad < d.cls[0].K || (d.cls[0].Kpad & 7) ||
-        d.s_in != 1 || d.s_out != 1 || d.Hin != d.Hout || d.Win != d.Wout || d.Hm != d.Hout || d.Wm != d.Wout || d.nfold > 1 ||
+        d.s_in != 1 || d.s_out != 1 || d.Hout != d.Hin + 2 * wino_pad(d.reserved0) - 2 || d.Wout != d.Win + 2 * wino_pad(d.reserved0) - 2 || d.Hm != d.Hout || d.Wm != d.Wout || d.nfold > 1 ||
         d.ksplit < 0 || d.io_dtype != 0 || d.B < 1 || d.Hout < 1 || d.Wout < 1 || d.Cout < 1)
         return false;
     if ((int64_t)((d.Cout + 127) & ~127) * d.cls[0].Kpad * 6 >= (int64_t)1 << 31) return false;
@@ -706,8 +713,8 @@ extern "C" int spaa_tapconv_wino_plan(const spaa_tapconv_t* desc, int32_t* plan)
     spaa_tapconv_t d = *desc;
     if (d.w_split == nullptr) d.w_split = reinterpret_cast<const uint16_t*>(desc);   // (the plan does not depend on the pointers)
     if (!wino_shape_ok(d) || (d.tile != 70 && d.tile != 71 && d.tile != 73)) return hipErrorInvalidValue;
-    if (d.in2 != nullptr) d.reserved0 |= 1 << 30;
-    const bool nosplit = d.in2 != nullptr;
+    const bool nosplit = d.in2 != nullptr || wino_pad(d.reserved0) != 1;   // (two sources / unpadded layers: image-aligned regions, no K ranges)
+    if (nosplit) d.reserved0 |= 1 << 30;
     const wino_plan_t pl = wino_make_plan(d, wino_ncu(), d.tile == 70 ? 0 : 64, nosplit ? 1 : d.ksplit, !nosplit, d.tile == 73 ? 4 : 8);
     plan[0] = pl.bn, plan[1] = pl.ksplit, plan[2] = pl.canvas, plan[3] = pl.gy, plan[4] = pl.gx;
     plan[5] = (int32_t)(pl.nwg > 0x7fffffff ? 0x7fffffff : pl.nwg), plan[6] = pl.kb_per, plan[7] = pl.ncanvas;
@@ -723,8 +730,9 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     const bool has_ws = d.splitk_ws != nullptr;
     if (d.ksplit > 1 && !has_ws) return hipErrorInvalidValue;
     spaa_tapconv_t dp = d;
-    if (d.in2 != nullptr) dp.reserved0 |= 1 << 30;   // (two sources: no canvas ...)
-    const bool nosplit = d.in2 != nullptr;
+    const bool nosplit = d.in2 != nullptr || wino_pad(d.reserved0) != 1;
+    if (nosplit) dp.reserved0 |= 1 << 30;   // (two sources, unpadded layers: no canvas ...)
+    if (nosplit && d.ksplit > 1) return hipErrorInvalidValue;
     const wino_plan_t pl = wino_make_plan(dp, wino_ncu(), d.tile == 70 ? 0 : 64, (has_ws && !nosplit) ? d.ksplit : 1, has_ws && !nosplit,
                                           d.tile == 73 ? 4 : 8);   // (... and no K ranges)
     if (pl.nwg > 0x7fffffff) return hipErrorInvalidValue;

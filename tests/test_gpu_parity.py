@@ -208,6 +208,42 @@ def test_winograd_is_fp32_accurate(hip, ci, co, h, w, b):
     assert errs[70][0] < max(3 * errs[6][0], 6e-7) and errs[70][1] < max(3 * errs[6][1], 6e-7)
 
 
+@pytest.mark.parametrize('ci,co,h,w,b', [(64, 96, 23, 37, 3), (80, 192, 33, 31, 2), (96, 192, 73, 73, 2)])   # (80 -> 192 = Conv2d_4a: its 80 input channels keep the forward off this kernel, the gradient's 192 do not)
+@pytest.mark.parametrize('tile', [70, 73])
+def test_winograd_unpadded_layers(hip, ci, co, h, w, b, tile):
+    """An UNPADDED 3x3 / s1 convolution (Inception-v3's Conv2d_2a / Conv2d_4a: classifier.py:29-33 of the reference) and its
+    input gradient through the Winograd kernel: the output is 2 smaller (pad 0) resp. 2 larger (pad 2) than the input, which only
+    moves the patch origin (csrc/tapconv_wino.hip: `reserved0` bits 27-28).  Against fp64 at the padded layers' bound, bias + ReLU +
+    byte mask on the forward, byte-mask gate on the gradient."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(ci + co + h)
+    x = torch.relu(torch.randn(b, ci, h, w))
+    wt, bias = torch.randn(co, ci, 3, 3) / (ci * 9) ** 0.5, torch.randn(co)
+    truth = F.relu(F.conv2d(x.double(), wt.double(), bias.double(), 1, 0))
+    gy = torch.randn(b, co, h - 2, w - 2)
+    keep = torch.rand(b, ci, h, w) > 0.3
+    g_truth = torch.nn.grad.conv2d_input(x.shape, wt.double(), gy.double(), 1, 0) * keep
+    fplan, dplan = cp.conv_fwd_plan(wt, bias, 1, 0, DEV), cp.conv_dgrad_plan(wt, 1, 0, DEV)
+    assert (fplan.wino is not None and fplan.wino_pad == 0) == (ci % 32 == 0) and dplan.wino is not None and dplan.wino_pad == 2
+    errs = {}
+    try:
+        for t in (34, tile):
+            cp.FORCE_TILE = t
+            out = torch.zeros(b, h - 2, w - 2, co, device=DEV)
+            m_out = torch.zeros(b, h - 2, w - 2, co // 4, dtype=torch.uint8, device=DEV)
+            fplan.run(nhwc(x, ci).to(DEV), out, act=lib.ACT_RELU, mask_out=m_out)
+            gx = torch.zeros(b, h, w, ci, device=DEV)
+            dplan.run(nhwc(gy, co).to(DEV), gx, gate_bits=lib.pack_gate_mask(nhwc(keep.float(), ci).to(DEV)))
+            if t == tile:
+                assert (fplan.wino is None or fplan.wino.last_tile == tile) and dplan.wino.last_tile == tile and torch.equal(m_out, lib.pack_gate_mask(out))
+            errs[t] = (((nchw(out.cpu(), co).double() - truth).abs().max() / truth.abs().max()).item(),
+                       ((nchw(gx.cpu(), ci).double() - g_truth).abs().max() / g_truth.abs().max()).item())
+    finally:
+        cp.FORCE_TILE = 0
+    print(f'unpadded {ci}->{co} {h}x{w}: rel err vs fp64 direct bf16x6 {errs[34][0]:.1e}/{errs[34][1]:.1e}, winograd {errs[tile][0]:.1e}/{errs[tile][1]:.1e}')
+    assert errs[tile][0] < max(3 * errs[34][0], 6e-7) and errs[tile][1] < max(3 * errs[34][1], 6e-7)
+
+
 @pytest.mark.parametrize('ci,co,h,w,b,tile,ks', [(256, 256, 14, 14, 64, 70, 0), (512, 512, 7, 7, 64, 70, 0), (64, 96, 35, 35, 9, 70, 0),
                                                  (128, 128, 14, 14, 5, 71, 2), (96, 64, 17, 17, 7, 70, 3), (64, 128, 7, 9, 3, 70, 1),
                                                  (128, 256, 20, 38, 2, 70, 4), (64, 64, 15, 20, 10, 71, 2),
