@@ -98,7 +98,9 @@ typedef struct {
                              a kernel-2 stride-2 ConvTranspose2d share their single tap, so they are folded into the GEMM N
                              dimension: weight rows [nfold*Cout], row c*Cout + n -> output pixel (2y + c/2, 2x + c%2),
                              channel n.  The input is read once instead of once per class. */
-    int32_t reserved0;    /* measurement switches (A/B runs of kernel variants: spaa_amd/convplan.py DEBUG_*); 0 in production */
+    int32_t reserved0;    /* measurement switches (A/B runs of kernel variants: spaa_amd/convplan.py DEBUG_*); 0 in production,
+                           * except bits 27-28 of a Winograd launch (tiles 70 / 71 / 73): the layer's zero padding, 0 = 1 (same-size
+                           * output), 1 = 0 (unpadded: output 2 smaller), 2 = 2 (that layer's input gradient: 2 larger) */
     int32_t io_dtype;     /* fp16-STORAGE mode (BASELINE.json configs[4]: "fp16 with fp32 dE2000"), bit flags:
                              SPAA_IO_IN_F16  (tiles 60..65; tile 68: 3x3 / stride-1 layers with the input patch staged once in LDS;
                                              tile 72: thin outputs with the parity classes folded into N, fp32 out (with a
