@@ -83,6 +83,13 @@ class ResNet18Body:
                 w2_, b2_ = folded(p + '.conv2', p + '.bn2')
                 blk['f1'] = cp.conv_fwd_plan(w1_, b1_, stride, 1, dev, p + '.conv1')
                 blk['d1'] = cp.conv_dgrad_plan(w1_, stride, 1, dev, p + '.conv1_dgrad')
+                if stride == 2 and cin in (32, 64) and storage == 'f32' and batch * hh * ww >= 100000:
+                    # layer2.0.conv1's input gradient (128 -> 64 channels, 28^2 -> 56^2) at benchmark batches: the patch-staged
+                    # stride-2 kernel with its four parity classes in one launch (tools/lab/x6p_resnet.py: 79 -> 71 us)
+                    d74 = cp.conv_dgrad_plan(w1_, stride, 1, dev, p + '.conv1_dgrad', fold=False)
+                    if d74.x6p_ok():
+                        d74.fixed_tile = 74
+                        blk['d1'] = d74
                 blk['f2'] = cp.conv_fwd_plan(w2_, b2_, 1, 1, dev, p + '.conv2')
                 blk['d2'] = cp.conv_dgrad_plan(w2_, 1, 1, dev, p + '.conv2_dgrad')
                 if p + '.downsample.0.weight' in sd:
