@@ -305,6 +305,71 @@ __global__ void avgpool_bwd_h_kernel(const float* __restrict__ g_out, const _Flo
     g_in[idx] = (_Float16)((act == nullptr || (float)act[idx] > 0.f) ? g : 0.f);
 }
 
+// The same adjoint with a thread per 2 x 2 block of input pixels (4 channels): the block's pixels draw on the same four windows
+// (oy in {a, a + 1}, ox in {b, b + 1}), so four (arg-max byte, gradient) pairs serve four outputs instead of four pairs per output
+// (the per-pixel kernel above loads all four candidates of every pixel, 2.25 of them live on average).  Same summation order.
+__global__ void maxpool_bwd_quad_kernel(const float4* __restrict__ g_out, const uchar4* __restrict__ argmax, const int relu_gate,
+                                        float4* __restrict__ g_in, int B, int Hin, int Win, int C4, int Hout, int Wout, int Hq, int Wq) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * Hq * Wq * C4) return;
+    const int c = idx % C4;
+    int r = idx / C4;
+    const int bq = r % Wq;
+    r /= Wq;
+    const int a = r % Hq;
+    const int b = r / Hq;
+    const unsigned char need = relu_gate ? 0x80 : 0x00;
+    uchar4 am[2][2];
+    float4 g[2][2];
+    bool wok[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            wok[p][q] = a + p < Hout && bq + q < Wout;
+            const size_t o = (((size_t)b * Hout + (wok[p][q] ? a + p : 0)) * Wout + (wok[p][q] ? bq + q : 0)) * C4 + c;
+            am[p][q] = argmax[o];
+            g[p][q] = g_out[o];
+        }
+    auto take = [&](float4& acc, const int p, const int q, const unsigned char k) {
+        const uchar4 m = am[p][q];
+        const float4 v = g[p][q];
+        if (wok[p][q] && (m.x & 0x7f) == k && (m.x & need) == need) acc.x += v.x;
+        if (wok[p][q] && (m.y & 0x7f) == k && (m.y & need) == need) acc.y += v.y;
+        if (wok[p][q] && (m.z & 0x7f) == k && (m.z & need) == need) acc.z += v.z;
+        if (wok[p][q] && (m.w & 0x7f) == k && (m.w & need) == need) acc.w += v.w;
+    };
+    const int iy = 2 * a, ix = 2 * bq;
+    const size_t base = (((size_t)b * Hin + iy) * Win + ix) * C4 + c;
+    {   // (even row, even column): window (a, b), tap (1, 1)
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        take(acc, 0, 0, 4);
+        g_in[base] = acc;
+    }
+    if (ix + 1 < Win) {   // (even, odd): (a, b + 1) tap (1, 0), then (a, b) tap (1, 2)
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        take(acc, 0, 1, 3);
+        take(acc, 0, 0, 5);
+        g_in[base + C4] = acc;
+    }
+    if (iy + 1 < Hin) {
+        {   // (odd, even): (a + 1, b) tap (0, 1), then (a, b) tap (2, 1)
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            take(acc, 1, 0, 1);
+            take(acc, 0, 0, 7);
+            g_in[base + (size_t)Win * C4] = acc;
+        }
+        if (ix + 1 < Win) {   // (odd, odd): taps (0, 0), (0, 2), (2, 0), (2, 2)
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            take(acc, 1, 1, 0);
+            take(acc, 1, 0, 2);
+            take(acc, 0, 1, 6);
+            take(acc, 0, 0, 8);
+            g_in[base + (size_t)Win * C4 + C4] = acc;
+        }
+    }
+}
+
 inline int nblk(int64_t n) { return (int)((n + 255) / 256); }
 
 }  // namespace
@@ -358,9 +423,9 @@ int spaa_maxpool3s2_bwd(const float* g_out, const uint8_t* argmax, int relu_gate
     if (!g_out || !argmax || !g_in || (C & 3) || B < 1 || Hout != (Hin + 2 - 3) / 2 + 1 ||
         Wout != (Win + 2 - 3) / 2 + 1)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk((int64_t)B * Hin * Win * (C / 4))), dim3(256), 0,
-                       (hipStream_t)stream, (const float4*)g_out, (const uchar4*)argmax, relu_gate,
-                       (float4*)g_in, B, Hin, Win, C / 4, Hout, Wout);
+    const int Hq = (Hin + 1) / 2, Wq = (Win + 1) / 2;
+    hipLaunchKernelGGL(maxpool_bwd_quad_kernel, dim3(nblk((int64_t)B * Hq * Wq * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)g_out, (const uchar4*)argmax, relu_gate, (float4*)g_in, B, Hin, Win, C / 4, Hout, Wout, Hq, Wq);
     return (int)hipGetLastError();
 }
 

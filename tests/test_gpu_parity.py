@@ -661,6 +661,35 @@ def test_pcnet_forward_and_input_gradient(hip, golden_dir, name):
         assert rel_l2(xg.grad, xc.grad) < 2e-3 and outlier_fraction(xg.grad, xc.grad, 1e-3) < 5e-3
 
 
+@pytest.mark.parametrize('b,c,h,w', [(2, 8, 13, 9), (3, 64, 28, 28), (1, 16, 7, 12)])
+def test_maxpool3s2_adjoint_blocks(hip, b, c, h, w):
+    """spaa_maxpool3s2_fwd / _bwd (ResNet's stem pool, classifier.py:59-60 of the reference: torchvision maxpool after ReLU): the
+    adjoint's thread-per-2x2-block form against autograd of max_pool2d(relu(x)) -- odd sizes (partial blocks, windows past the
+    border), with and without the fused ReLU gate."""
+    lib = hip['lib']
+    torch.manual_seed(h * w)
+    x = torch.randn(b, c, h, w)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    g = torch.randn(b, c, ho, wo)
+    xr = x.clone().requires_grad_(True)
+    F.max_pool2d(F.relu(xr), 3, 2, 1).backward(g)
+    xp = F.relu(x).clone().requires_grad_(True)
+    F.max_pool2d(xp, 3, 2, 1).backward(g)
+    xin = nhwc(F.relu(x), c).to(DEV)
+    out = torch.zeros(b, ho, wo, c, device=DEV)
+    arg = torch.zeros(b, ho, wo, c, dtype=torch.uint8, device=DEV)
+    lib.call('spaa_maxpool3s2_fwd', lib.ptr(xin), lib.ptr(out), lib.ptr(arg), b, h, w, c, ho, wo)
+    assert torch.equal(nchw(out.cpu(), c), F.max_pool2d(F.relu(x), 3, 2, 1))
+    for gate, ref in ((1, xr.grad), (0, xp.grad)):
+        gin = torch.full((b, h, w, c), float('nan'), device=DEV)
+        lib.call('spaa_maxpool3s2_bwd', lib.ptr(nhwc(g, c).to(DEV)), lib.ptr(arg), gate, lib.ptr(gin), b, h, w, c, ho, wo)
+        got = nchw(gin.cpu(), c)
+        if gate:
+            assert torch.allclose(got, ref, atol=1e-6), gate
+        else:   # (ungated: windows of zeros send their gradient to the first element, as ATen does)
+            assert torch.allclose(got, ref, atol=1e-6), gate
+
+
 def test_resnet18_classifier_vs_oracle(hip):
     csd = syn.resnet18_state_dict(2, logit_gain=20.0)
     for (h, crop, insz, b) in [(64, (60, 60), (56, 56), 3), (256, (240, 240), (224, 224), 2)]:
