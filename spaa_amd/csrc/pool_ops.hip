@@ -53,6 +53,73 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out
     argmax[idx] = am;
 }
 
+// kernel 3 / stride 2 / padding 1 (the ResNet stem pool), a thread per 2 x 2 block of input pixels: the block draws on four
+// windows, so four (arg-max byte, gradient) pairs serve four outputs (classifier_ops.hip: maxpool_bwd_quad_kernel); same order of
+// additions as the per-pixel form below
+template <typename T>
+__global__ void maxpool_bwd_quad_kernel(const T* __restrict__ g_out, const uchar4* __restrict__ argmax, const int relu_gate,
+                                        T* __restrict__ g_in, Geo g, int gout_c4stride, int gout_c4off, int Hq, int Wq) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.B * Hq * Wq * g.C4) return;
+    const int c = idx % g.C4;
+    int r = idx / g.C4;
+    const int bq = r % Wq;
+    r /= Wq;
+    const int a = r % Hq;
+    const int b = r / Hq;
+    const unsigned char need = relu_gate ? 0x80 : 0x00;
+    uchar4 am[2][2];
+    f4 gv[2][2];
+    bool wok[2][2];
+#pragma unroll
+    for (int p_ = 0; p_ < 2; ++p_)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            wok[p_][q] = a + p_ < g.Hout && bq + q < g.Wout;
+            const size_t opix = ((size_t)b * g.Hout + (wok[p_][q] ? a + p_ : 0)) * g.Wout + (wok[p_][q] ? bq + q : 0);
+            am[p_][q] = argmax[opix * g.C4 + c];
+            gv[p_][q] = io4<T>::ld(g_out, 4 * (opix * gout_c4stride + gout_c4off + c));
+        }
+    auto take = [&](f4& acc, const int p_, const int q, const unsigned char k) {
+        const uchar4 m = am[p_][q];
+        const f4 v = gv[p_][q];
+        if (wok[p_][q] && (m.x & 0x7f) == k && (m.x & need) == need) acc.x += v.x;
+        if (wok[p_][q] && (m.y & 0x7f) == k && (m.y & need) == need) acc.y += v.y;
+        if (wok[p_][q] && (m.z & 0x7f) == k && (m.z & need) == need) acc.z += v.z;
+        if (wok[p_][q] && (m.w & 0x7f) == k && (m.w & need) == need) acc.w += v.w;
+    };
+    const int iy = 2 * a, ix = 2 * bq;
+    const size_t base = 4 * ((((size_t)b * g.Hin + iy) * g.Win + ix) * g.C4 + c);
+    const size_t dx = 4 * (size_t)g.C4, dy = 4 * (size_t)g.Win * g.C4;
+    {
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        take(acc, 0, 0, 4);
+        io4<T>::st(g_in, base, acc);
+    }
+    if (ix + 1 < g.Win) {
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        take(acc, 0, 1, 3);
+        take(acc, 0, 0, 5);
+        io4<T>::st(g_in, base + dx, acc);
+    }
+    if (iy + 1 < g.Hin) {
+        {
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+            take(acc, 1, 0, 1);
+            take(acc, 0, 0, 7);
+            io4<T>::st(g_in, base + dy, acc);
+        }
+        if (ix + 1 < g.Win) {
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+            take(acc, 1, 1, 0);
+            take(acc, 1, 0, 2);
+            take(acc, 0, 1, 6);
+            take(acc, 0, 0, 8);
+            io4<T>::st(g_in, base + dy + dx, acc);
+        }
+    }
+}
+
 // CK/CS/CP > 0: kernel / stride / padding known at compile time (3 / 2 / 1: the ResNet stem pool in fp16 storage -- the runtime
 // divisions of the generic form cost more than the loads)
 template <typename T, int CK = 0, int CS = 0, int CP = 0>
@@ -293,11 +360,12 @@ int spaa_maxpool_bwd_f16(const void* g_out, const uint8_t* argmax, int relu_gate
         (gout_coff & 3) || gout_coff + C > gout_cstride)
         return hipErrorInvalidValue;
     Geo g{B, Hin, Win, C / 4, Hout, Wout, k, s, p};
-    if (k == 3 && s == 2 && p == 1)
-        hipLaunchKernelGGL((maxpool_bwd_kernel<_Float16, 3, 2, 1>), dim3(nb((int64_t)B * Hin * Win * g.C4)), dim3(256), 0,
-                           (hipStream_t)stream, (const _Float16*)g_out, (const uchar4*)argmax, relu_gate, (_Float16*)g_in, g,
-                           gout_cstride / 4, gout_coff / 4);
-    else
+    if (k == 3 && s == 2 && p == 1) {
+        const int Hq = (Hin + 1) / 2, Wq = (Win + 1) / 2;
+        hipLaunchKernelGGL(maxpool_bwd_quad_kernel<_Float16>, dim3(nb((int64_t)B * Hq * Wq * g.C4)), dim3(256), 0, (hipStream_t)stream,
+                           (const _Float16*)g_out, (const uchar4*)argmax, relu_gate, (_Float16*)g_in, g, gout_cstride / 4, gout_coff / 4,
+                           Hq, Wq);
+    } else
         hipLaunchKernelGGL(maxpool_bwd_kernel<_Float16>, dim3(nb((int64_t)B * Hin * Win * g.C4)), dim3(256), 0,
                            (hipStream_t)stream, (const _Float16*)g_out, (const uchar4*)argmax, relu_gate, (_Float16*)g_in, g,
                            gout_cstride / 4, gout_coff / 4);
