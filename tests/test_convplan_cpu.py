@@ -134,3 +134,39 @@ def test_thin_fold_layout(ci, co, k, s, p, h, w):
         out[:, cy::S, cx::S] = acc[:, :(h - cy + S - 1) // S, :(w - cx + S - 1) // S]
     assert torch.allclose(nchw(out)[:, :ci], x.grad, atol=1e-3), float((nchw(out)[:, :ci] - x.grad).abs().max())
     assert (out[..., ci:] == 0).all()
+
+
+@pytest.mark.parametrize('pad', [1, 0, 2])
+def test_winograd_form_all_paddings(pad):
+    """The Winograd F(2x2,3x3) form of a 3x3 / s1 plan (convplan.attach_winograd: U = G g G^T as a 16-'tap' matrix W[n][pos * Cin + c],
+    run by csrc/tapconv_wino.hip) restated on the CPU: V = B^T d B of the 4 x 4 input patch whose origin is (2 ty - pad, 2 tx - pad),
+    M[pos] = sum_c U[pos] V[pos], Y = A^T M A -- for the same-size layer (pad 1), the unpadded layer (pad 0: taps 0..2, output 2
+    smaller) and its input gradient (pad 2: taps -2..0, output 2 larger), against torch's conv2d / autograd."""
+    h, w = 9, 11
+    torch.manual_seed(pad)
+    if pad == 2:      # the unpadded layer 64 -> 32 read backwards: its output gradient [32, h, w] -> input gradient [64, h + 2, w + 2]
+        wt = torch.randn(32, 64, 3, 3, dtype=torch.float64)
+        src = torch.randn(2, 32, h, w, dtype=torch.float64)
+        xin = torch.randn(2, 64, h + 2, w + 2, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xin, wt, None, 1, 0).backward(src)
+        ref, plan = xin.grad, cp.conv_dgrad_plan(wt.float(), 1, 0, device='cpu')
+    else:
+        wt = torch.randn(64, 32, 3, 3, dtype=torch.float64)
+        src = torch.randn(2, 32, h, w, dtype=torch.float64)
+        ref, plan = F.conv2d(src, wt, None, 1, pad), cp.conv_fwd_plan(wt.float(), None, 1, pad, device='cpu')
+    assert plan.wino is not None and plan.wino_pad == pad
+    n_in, n_out = src.shape[1], ref.shape[1]
+    kp = plan.wino.cls[0]['Kpad']
+    U = plan.wino.weights[:plan.wino._npad * kp].view(plan.wino._npad, kp)[:n_out, :16 * n_in].double().view(n_out, 16, n_in)
+    BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
+    AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
+    ho, wo = ref.shape[2], ref.shape[3]
+    big = F.pad(src, (pad, pad + 3, pad, pad + 3))          # zeros around: patches past the border read zeros, as the DMA does
+    out = torch.zeros(2, n_out, ho + 1, wo + 1, dtype=torch.float64)
+    for ty in range((ho + 1) // 2):
+        for tx in range((wo + 1) // 2):
+            d = big[:, :, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4]                      # origin (2 ty - pad, 2 tx - pad) of the image
+            V = torch.einsum('ij,bcjk,lk->bcil', BT, d, BT).reshape(2, n_in, 16)
+            M = torch.einsum('npc,bcp->bnp', U, V).reshape(2, n_out, 4, 4)
+            out[:, :, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = torch.einsum('ij,bnjk,lk->bnil', AT, M, AT)
+    assert torch.allclose(out[:, :, :ho, :wo], ref.detach(), atol=1e-5)
