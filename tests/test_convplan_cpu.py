@@ -170,3 +170,19 @@ def test_winograd_form_all_paddings(pad):
             M = torch.einsum('npc,bcp->bnp', U, V).reshape(2, n_out, 4, 4)
             out[:, :, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = torch.einsum('ij,bnjk,lk->bnil', AT, M, AT)
     assert torch.allclose(out[:, :, :ho, :wo], ref.detach(), atol=1e-5)
+
+
+def test_small_linear_plan_dispatch():
+    """convplan.SmallLinearPlan (the classifiers' last layer at batch <= 64 on csrc/linear_small.hip): which calls take the dedicated
+    kernel and which the wrapped 1 x 1 convolution plan; the wrapped plan's attributes stay reachable (flops, tune keys)."""
+    w, b = torch.randn(12, 16), torch.randn(12)
+    plan = cp.linear_fwd_plan(w, b, device='cpu')
+    assert isinstance(plan, cp.SmallLinearPlan) and plan.n == 12 and plan.k == 16 and plan.cout == 12
+    x, y = torch.zeros(3, 1, 1, 16), torch.zeros(3, 1, 1, 12)
+    assert plan.applies(x, y, {})
+    assert not plan.applies(x, y, {'act': 1})                                    # fused epilogue: the convolution tiles
+    assert not plan.applies(x.half(), y, {})                                     # fp16 storage
+    assert not plan.applies(torch.zeros(65, 1, 1, 16), torch.zeros(65, 1, 1, 12), {})   # more rows than the kernel is meant for
+    assert not plan.applies(torch.zeros(3, 1, 1, 20), y, {})                     # a wider buffer (channel window)
+    assert plan.flops(3, 1, 1) == plan.conv.flops(3, 1, 1)
+    assert not isinstance(cp.linear_dgrad_plan(torch.randn(10, 16), device='cpu'), cp.SmallLinearPlan)   # 10 outputs: rows not 16-byte aligned
