@@ -598,6 +598,14 @@ def main():
         }
         if gather_ms is not None:
             out['gather_ms'] = round(gather_ms, 3)
+        try:   # kernel choices of the timed configuration that were not measured table entries (spaa_amd/tapconv_tune.json)
+            from spaa_amd import convplan as _cp
+            _tr = _cp.tune_report()
+            out['tune'] = {'borrowed_from_nearest_pixel_count': len(_tr['borrowed']), 'rule_chosen': len(_tr['untuned']),
+                           'shapes': (_tr['borrowed'] + _tr['untuned'])[:12],
+                           'note': 'layer-shape keys Cin_Cout_taps_sin_sout_M of this process, once-per-attack set-up launches included'}
+        except Exception:   # noqa: BLE001
+            pass
         if world == 1 and not args.no_cpu_baseline and args.classifier == 'resnet18' and args.dtype == 'f32' and args.attack == 'spaa':
             log(f'cpu baseline on {usable_cores()} cores')
             try:

@@ -101,6 +101,12 @@ def tuned_tile(key):
     return best
 
 
+def tune_report():
+    """Layer shapes of this process whose kernel was NOT a measured entry of the tune table: borrowed from the same layer at the
+    nearest pixel count, or left to the `_default_tile` rules (bench.py reports both counts next to the headline)."""
+    return {'borrowed': sorted(k for k, v in _NEAREST.items() if v >= 0), 'untuned': sorted(k for k, v in _NEAREST.items() if v < 0)}
+
+
 _STREAMK_WS = {}
 
 
