@@ -216,19 +216,23 @@ def reduce_times(dt, dist, world, dev):
 
 
 def gather_final(cam, prj, dist, world, sync):
-    """The path's only exchange: every rank's (cam_infer_best, prj_adv_best).  Receive buffers are allocated BEFORE the
-    timed gather."""
+    """The path's only exchange: every rank's (cam_infer_best, prj_adv_best), packed side by side into one send block and
+    gathered by ONE `all_gather_into_tensor` (spaa_amd/sharding.py: gather_results does the same).  Send and receive
+    buffers are allocated BEFORE the timed gather; the packing copy is inside it."""
     if dist is None:
         return None, (cam, prj)
-    outs = [torch.empty_like(prj) for _ in range(world)]
-    outs2 = [torch.empty_like(cam) for _ in range(world)]
+    n, fc, fp = cam.shape[0], cam[0].numel(), prj[0].numel()
+    send = torch.empty(n, fc + fp, dtype=cam.dtype, device=cam.device)
+    recv = torch.empty(world * n, fc + fp, dtype=cam.dtype, device=cam.device)
     sync()
     dist.barrier()
     g0 = time.perf_counter()
-    dist.all_gather(outs, prj)
-    dist.all_gather(outs2, cam)
+    send[:, :fc] = cam.reshape(n, fc)
+    send[:, fc:] = prj.reshape(n, fp)
+    dist.all_gather_into_tensor(recv, send)
     sync()
-    return (time.perf_counter() - g0) * 1e3, (torch.cat(outs2), torch.cat(outs))
+    ms = (time.perf_counter() - g0) * 1e3
+    return ms, (recv[:, :fc].reshape((world * n,) + tuple(cam.shape[1:])), recv[:, fc:].reshape((world * n,) + tuple(prj.shape[1:])))
 
 
 def rehearse_glue(args, world, rank, json_out):
@@ -376,11 +380,15 @@ def configs0_gpu(sd, csd, setup, scenes, dev):
         h1 = time.perf_counter()
         torch.cuda.synchronize()
         h2 = time.perf_counter()
-        out[name] = {'seconds': round(dt, 4), 'iterations_per_s': round(50 / dt, 2),
+        from spaa_amd import projector_based_attack as _pba
+        replayed = bool(_pba.LAST_RUN.get('graph'))
+        out[name] = {'seconds': round(dt, 4), 'iterations_per_s': round(50 / dt, 2), 'graph_replay': replayed,
                      'eager_host_enqueue_ms_per_iteration': round((h1 - h0) / 10 * 1e3, 3),
                      'eager_ms_per_iteration': round((h2 - h0) / 10 * 1e3, 3)}
         del st
-    out['note'] = 'spaa() end to end (50 iterations: 1 eager + 49 graph replays; the capture itself executes nothing); eager_* = the same loop body launched kernel by kernel'
+    graphs = [v['graph_replay'] for v in out.values()]
+    out['note'] = ('spaa() end to end (50 iterations: 1 eager + 49 graph replays; the capture itself executes nothing); eager_* = the same loop body launched kernel by kernel'
+                   if all(graphs) else 'spaa() end to end; GRAPH CAPTURE WAS REFUSED (graph_replay false): these runs launched every iteration kernel by kernel')
     return out
 
 
@@ -403,6 +411,33 @@ def time_mode(dev, args, classifier, storage, attack, steps=10, warmup=3):
     del st
     torch.cuda.empty_cache()
     return out
+
+
+def time_sustained(dev, args, classifier, storage, attack, steps):
+    """A configuration of BASELINE.json at ITS OWN iteration count (configs[1]: 200, configs[4]: 400) in one back-to-back run,
+    with the rate of every block of 20 steps (HIP events recorded on the launch stream, no host sync inside the run): shows
+    whether the 20-step headline rate holds once clocks and temperature have settled (MI355X_MICROARCH.md, DVFS give-back)."""
+    st, _sd, _csd, _setup, _scenes, _targets = build_attack(0, args.batch, args.size, 8, dev, classifier, storage, attack)
+    for _ in range(3):
+        st.step()
+    blocks = steps // 20
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(blocks + 1)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(blocks * 20):
+        if i % 20 == 0:
+            evs[i // 20].record()
+        st.step()
+    evs[blocks].record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per20 = [round(evs[i].elapsed_time(evs[i + 1]) / 20.0, 3) for i in range(blocks)]
+    del st
+    torch.cuda.empty_cache()
+    return {'steps': blocks * 20, 'attack_iterations_per_s': round(blocks * 20 / dt, 3), 'ms_per_step': round(dt / (blocks * 20) * 1e3, 3),
+            'ms_per_step_first_20': per20[0], 'ms_per_step_last_20': per20[-1], 'ms_per_step_slowest_20': max(per20),
+            'ms_per_step_per_20_steps': per20, 'batch': args.batch, 'classifier': classifier,
+            'dtype': 'f32' if storage == 'f32' else 'f16 storage', 'attack': attack}
 
 
 def main():
@@ -598,6 +633,10 @@ def main():
         }
         if gather_ms is not None:
             out['gather_ms'] = round(gather_ms, 3)
+        # what the process group and the runtime saw (the driver can check that RCCL really ran N ranks on N devices)
+        out['ranks_seen'] = {'world_size': dist.get_world_size() if dist is not None else 1,
+                             'backend': dist.get_backend() if dist is not None else None,
+                             'device_count': torch.cuda.device_count(), 'local_rank': local_rank}
         try:   # kernel choices of the timed configuration that were not measured table entries (spaa_amd/tapconv_tune.json)
             from spaa_amd import convplan as _cp
             _tr = _cp.tune_report()
@@ -635,6 +674,11 @@ def main():
                 'configs[2] (inception_v3 at 299x299, SPAA loop, f32)': guarded(time_mode, dev, args, 'inception_v3', 'f32', 'spaa'),
                 'configs[2] in f16 storage (inception_v3 at 299x299, SPAA loop)': guarded(time_mode, dev, args, 'inception_v3', 'f16', 'spaa'),
                 'configs[4] per GPU (vgg16, PerC-AL loop body, f16 storage)': guarded(time_mode, dev, args, 'vgg16', 'f16', 'perc_al'),
+            }
+            # the iteration counts BASELINE.json names, run back to back (the headline above is 20 steps = 0.16 s)
+            out['sustained'] = {
+                'configs[1]: 200 iterations (resnet18, SPAA loop, f32)': guarded(time_sustained, dev, args, 'resnet18', 'f32', 'spaa', 200),
+                'configs[4] per GPU: 400 iterations (vgg16, PerC-AL loop body, f16 storage)': guarded(time_sustained, dev, args, 'vgg16', 'f16', 'perc_al', 400),
             }
         json_out.write(json.dumps(out) + '\n')
         json_out.flush()

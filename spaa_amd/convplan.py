@@ -187,6 +187,7 @@ class ConvPlan:
         self.w_half = None  # fp16 plane for the fp16-storage kernels, packed on first use (half_plane())
         self.wino = None    # the same layer in Winograd F(2x2,3x3) form (attach_winograd), run as tile 70
         self.fixed_tile = 0
+        self._wino_plans = {}   # spaa_tapconv_wino_plan results per launch shape (run)
         self.alg_taps = self.ntaps_total
         self._thin = {}     # folded weight layouts of the thin-output matrix-core kernel (thin_fold), packed on first use
 
@@ -278,8 +279,9 @@ class ConvPlan:
 
     def run(self, inp, out, add=None, gate=None, gate_mode=_lib.GATE_POS, act=_lib.ACT_NONE, aux_out=None,
             gate2=None, in_coff=0, out_coff=0, add_coff=0, gate_coff=0, mask_out=None, gate_bits=None, gate2_bits=None,
-            inp2=None, in2_coff=0):
+            inp2=None, in2_coff=0, _wino=None):
         """inp: [B,Hin,Win,Cs_in], out: [B,Hout,Wout,Cs_out] NHWC float32 CUDA tensors.
+        `_wino` (internal): (tile, K ranges) of this launch when the plan is the Winograd form of another plan.
         `mask_out` / `gate_bits` / `gate2_bits`: uint8 [B,Hout,Wout,Cs/4] ReLU-gate masks (one byte per 4 channels,
         include/spaa_hip.h): written for this launch's output resp. read instead of a float `gate` / `gate2`."""
         _lib.check_dev(inp, out, add, gate, aux_out, gate2, inp2, half_ok=True)
@@ -368,9 +370,9 @@ class ConvPlan:
         if tile % 100 in (70, 71, 73):   # Winograd form of a 3x3 / stride-1 layer (csrc/tapconv_wino.hip): fp32 storage, same-size output
             # (tune values: 70 = the launcher's choice of N tile and K ranges, 71 = 64-wide N tile, 73 = 64-wide, four-wave workgroups; + 100 k = k K ranges, k = 1: none)
             if self.wino is not None and WINOGRAD and not (in_f16 or out_f16) and (hout, wout) == (hin + 2 * self.wino_pad - 2, win + 2 * self.wino_pad - 2):
-                self.wino.fixed_tile, self.wino.wino_ksplit = tile % 100, tile // 100
+                # (tile and K ranges travel as arguments: the shared Winograd plan keeps no per-call state)
                 return self.wino.run(inp, out, add, gate, gate_mode, act, aux_out, gate2, in_coff, out_coff, add_coff, gate_coff,
-                                     mask_out, gate_bits, gate2_bits, inp2, in2_coff)
+                                     mask_out, gate_bits, gate2_bits, inp2, in2_coff, _wino=(tile % 100, tile // 100))
             tile = 0 if forced else self._default_tile(b * d.Hm * d.Wm, winograd=False)
         if in_f16:    # fp16 activations: the h16 kernels, N tile by the GEMM's width
             ngemm = self.cout * self.nfold
@@ -449,7 +451,7 @@ class ConvPlan:
             if tile not in STORE4_TILES:
                 raise ValueError(f'{self.name}: gate masks need a layer shape served by the bf16x6 / smallcin kernels')
         if self.fixed_tile:
-            tile, d.ksplit, d.splitk_ws = self.fixed_tile, 0, None
+            tile, d.ksplit, d.splitk_ws = (_wino[0] if _wino else self.fixed_tile), 0, None
         if tile == 72:
             if in_f16:
                 d.w_half = self.thin_fold(True).data_ptr()
@@ -483,14 +485,20 @@ class ConvPlan:
         if tile in (70, 71, 73):
             # the launcher's plan (csrc/tapconv_wino.hip: N tile, canvas layout for small images, K ranges for few workgroups with
             # long K) -- asked for here because the K ranges need a workspace; its K-range count is then passed back explicitly
-            want = getattr(self, 'wino_ksplit', 0)
+            want = _wino[1] if _wino else getattr(self, 'wino_ksplit', 0)
             d.ksplit = want if WINO_SPLITK else 1
-            wp = (C.c_int32 * 8)()
-            rc = _lib.load().spaa_tapconv_wino_plan(C.byref(d), wp)
-            if rc != 0:
-                raise RuntimeError(f'{self.name}: spaa_tapconv_wino_plan failed with HIP error {rc}')
+            # (the plan depends on the shape, the tile, the K ranges asked for, a second source and the switches in reserved0 -- not
+            # on pointers: asked once per such key, the launcher's own canvas search is the only one left per launch)
+            pkey = (b, hin, win, hout, wout, cs_in, tile, d.ksplit, inp2 is not None, d.reserved0)
+            wp = self._wino_plans.get(pkey)
+            if wp is None:
+                wpc = (C.c_int32 * 8)()
+                rc = _lib.load().spaa_tapconv_wino_plan(C.byref(d), wpc)
+                if rc != 0:
+                    raise RuntimeError(f'{self.name}: spaa_tapconv_wino_plan failed with HIP error {rc}')
+                wp = self._wino_plans[pkey] = tuple(wpc)
             wino_bn, d.ksplit = wp[0], wp[1]
-            self.last_wino_plan = tuple(wp)
+            self.last_wino_plan = wp
             if d.ksplit > 1:
                 need = d.ksplit * b * hout * wout * ((self.cout + 127) // 128 * 128)
                 if self._ws is None or self._ws.numel() < need:
@@ -563,6 +571,11 @@ class ConvPlan:
     def refresh(self, weight, bias=None):
         """Re-pack a parameter that has changed (training): fp32 matrix and, for the bf16x6 kernels, its three bf16
         planes — on the device (needs the maps of `attach_maps`).  Exactly what the constructor does on the host."""
+        if getattr(self, 'w2_split', None) is not None or getattr(self, 'cin2_k', 0):
+            # a fused second source (attach_second_source / the two-source Winograd plans) keeps packed copies of ANOTHER layer's
+            # parameters and a summed bias: re-packing only this layer's would leave them stale -- build the plan again instead
+            raise RuntimeError(f'{self.name}: refresh() on a plan with a fused second source; rebuild it (PCNetTrainer builds its '
+                               'engine with fuse_skip2=False for this reason)')
         w = weight.detach().float().reshape(-1)
         self.weights[self.repack_pos] = w[self.repack_src]
         if self.w_split is not None:
@@ -849,8 +862,8 @@ class SmallLinearPlan:
     """nn.Linear on at most 64 rows as a wave-per-output kernel (csrc/linear_small.hip); more rows, fp16 tensors or a fused
     epilogue go to the 1 x 1 convolution plan it wraps.  `w_rows` [N, K]: row n holds the weights of output n."""
 
-    def __init__(self, conv_plan, w_rows, bias, device):
-        self.conv, self.name = conv_plan, conv_plan.name
+    def __init__(self, conv_plan, w_rows, bias, device, transposed=False):
+        self.conv, self.name, self.transposed = conv_plan, conv_plan.name, transposed
         self.w = w_rows.detach().float().contiguous().to(device)
         self.bias = bias.detach().float().contiguous().to(device) if bias is not None else None
         self.n, self.k = self.w.shape
@@ -873,7 +886,15 @@ class SmallLinearPlan:
         self.last_tile = 75
         return out
 
-    def __getattr__(self, item):      # (flops(), refresh(), tune keys ...: the wrapped plan's)
+    def refresh(self, weight, bias=None):
+        """A changed parameter (training): the wrapped plan's packed matrices AND this plan's own row-major copy."""
+        self.conv.refresh(weight, bias)
+        w = _w2(weight).to(self.w.device)
+        self.w.copy_(w.t() if self.transposed else w)
+        if bias is not None and self.bias is not None:
+            self.bias.copy_(bias.detach().float())
+
+    def __getattr__(self, item):      # (flops(), tune keys ...: the wrapped plan's)
         return getattr(self.conv, item)
 
 
@@ -891,7 +912,7 @@ def linear_dgrad_plan(weight, device='cuda', name=''):
     c = TapClassSpec(0, 0)
     c.add(0, 0, w.t().contiguous())
     plan = ConvPlan([c], w.shape[0], w.shape[1], 1, 1, None, device, name)
-    return SmallLinearPlan(plan, w.t().contiguous(), None, device) if w.numel() <= (1 << 22) and w.shape[0] % 4 == 0 else plan
+    return SmallLinearPlan(plan, w.t().contiguous(), None, device, transposed=True) if w.numel() <= (1 << 22) and w.shape[0] % 4 == 0 else plan
 
 
 def fold_bn(weight, bn_w, bn_b, bn_mean, bn_var, eps=1e-5):

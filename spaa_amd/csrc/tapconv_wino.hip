@@ -716,6 +716,7 @@ extern "C" int spaa_tapconv_wino_plan(const spaa_tapconv_t* desc, int32_t* plan)
     const bool nosplit = d.in2 != nullptr || wino_pad(d.reserved0) != 1;   // (two sources / unpadded layers: image-aligned regions, no K ranges)
     if (nosplit) d.reserved0 |= 1 << 30;
     const wino_plan_t pl = wino_make_plan(d, wino_ncu(), d.tile == 70 ? 0 : 64, nosplit ? 1 : d.ksplit, !nosplit, d.tile == 73 ? 4 : 8);
+    if (pl.bn == 0 || pl.ksplit < 1 || pl.n_tiles < 1) return hipErrorInvalidValue;   // (a forced K-range count with no admissible candidate)
     plan[0] = pl.bn, plan[1] = pl.ksplit, plan[2] = pl.canvas, plan[3] = pl.gy, plan[4] = pl.gx;
     plan[5] = (int32_t)(pl.nwg > 0x7fffffff ? 0x7fffffff : pl.nwg), plan[6] = pl.kb_per, plan[7] = pl.ncanvas;
     return 0;
@@ -735,7 +736,7 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     if (nosplit && d.ksplit > 1) return hipErrorInvalidValue;
     const wino_plan_t pl = wino_make_plan(dp, wino_ncu(), d.tile == 70 ? 0 : 64, (has_ws && !nosplit) ? d.ksplit : 1, has_ws && !nosplit,
                                           d.tile == 73 ? 4 : 8);   // (... and no K ranges)
-    if (pl.nwg > 0x7fffffff) return hipErrorInvalidValue;
+    if (pl.nwg > 0x7fffffff || pl.bn == 0 || pl.ksplit < 1 || pl.n_tiles < 1) return hipErrorInvalidValue;   // (no admissible plan: Cout % 4 with forced K ranges, > 2^24 pixels, sides > 4095)
     const int BN = pl.bn, n_tiles = pl.n_tiles, wg_y = pl.wg_y, wg_x = pl.wg_x;
     const int64_t nwg = pl.nwg;
     const bool two = d.in2 != nullptr;

@@ -12,6 +12,8 @@ with the reference values as defaults.  Differences in *mechanism*, not in resul
   * `cam_scene` may also be [B,3,H,W] (one scene per sample); the reference supports one scene x B targets (Q9),
     and its targeted mode needs B >= 8 because of a debug print (Q10) — not inherited.
 """
+import warnings
+
 import torch
 
 from . import _lib
@@ -185,8 +187,12 @@ def spaa(pcnet, classifier, imagenet_labels, target_idx, targeted, cam_scene, d_
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                     st.iteration(targeted, d_thr, adv_lr, col_lr, p_thresh)   # (recorded, not executed)
-            except RuntimeError:
-                graph = None     # the capture was refused: the remaining iterations run kernel by kernel, same results
+            except RuntimeError as e:
+                # the capture was refused or a launch inside it failed: the remaining iterations run kernel by kernel (same
+                # results; a real launch error shows again there, un-captured) -- said aloud, and recorded in LAST_RUN
+                warnings.warn(f'spaa(): HIP-graph capture of the iteration failed, running eagerly: {type(e).__name__}: {e}',
+                              RuntimeWarning, stacklevel=2)
+                graph = None
             while done < iters:
                 if graph is not None:
                     graph.replay()

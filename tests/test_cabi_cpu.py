@@ -178,3 +178,18 @@ def test_winograd_plan_keeps_the_measured_choices():
     assert p['bn'] == 64 and p['ksplit'] == 3 and p['kb_per'] == 3
     assert _wino_plan(64, 14, 14, 256, 256, ksplit=1)['ksplit'] == 1
     assert _wino_plan(64, 14, 14, 64, 64, ksplit=16)['ksplit'] == 2      # (two 32-channel blocks: at most two ranges)
+
+
+def test_winograd_plan_refuses_an_inadmissible_forced_split():
+    """A forced K-range count with no admissible candidate (Cout % 4 != 0: the second pass stores channel quads) is an error
+    from the plan query -- not an all-zero plan with rc 0 (the launcher then divided by zero on the host)."""
+    d = _lib.TapConv()
+    d.Hin = d.Hout = d.Hm = d.Win = d.Wout = d.Wm = 14
+    d.Cin, d.Cout, d.B, d.s_in, d.s_out, d.nclass = 256, 126, 8, 1, 1, 1
+    d.in_cstride, d.out_cstride = 256, 126
+    d.cls[0].ntaps, d.cls[0].K, d.cls[0].Kpad = 16, 16 * 256, 16 * 256 + 128
+    d.tile, d.ksplit = 70, 4
+    wp = (ctypes.c_int32 * 8)()
+    assert _lib.load().spaa_tapconv_wino_plan(ctypes.byref(d), wp) != 0
+    d.ksplit = 0                        # chosen by the plan: falls back to no split
+    assert _lib.load().spaa_tapconv_wino_plan(ctypes.byref(d), wp) == 0 and wp[1] == 1 and wp[0] in (64, 128)

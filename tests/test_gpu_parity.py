@@ -863,7 +863,9 @@ def _oracle_fp64(sd, csd, insz, targets, targeted, scene, d_thr, stealth, setup,
 # (golden whose configuration is used, iterations, scene seed -- None: the golden's own scene.  The three 64 x 64 goldens share
 # their scene, hence their first iterations: other scenes make the four trajectories independent samples)
 DRIFT_CASES = [('spaa_64_near', 12, None), ('spaa_64_prjl2', 12, 5), ('spaa_64_caml2_dthr', 12, 9), ('spaa_64_near/b', 12, 13),
-               ('spaa_64_near/c', 12, 17), ('spaa_64_prjl2/b', 12, 25), ('spaa_64_caml2_dthr/b', 12, 33), ('spaa_256_near', 8, None)]
+               ('spaa_64_near/c', 12, 17), ('spaa_64_prjl2/b', 12, 25), ('spaa_64_caml2_dthr/b', 12, 33),
+               ('spaa_64_near/d', 12, 61), ('spaa_64_prjl2/c', 12, 65), ('spaa_64_caml2_dthr/c', 12, 69), ('spaa_64_near/e', 12, 73),
+               ('spaa_256_near', 8, None)]
 
 
 def test_free_running_drift_vs_fp64_oracle(hip, golden_dir):
@@ -878,7 +880,7 @@ def test_free_running_drift_vs_fp64_oracle(hip, golden_dir):
     drift / fp32-oracle drift) is at most 1.5, none above 30, and the HIP path runs 10x ahead of the oracle's drift in at most
     two scenarios more than the oracle runs ahead of the HIP path's."""
     A, M = hip['attack'], hip['models']
-    rows, ratios = [], []
+    rows, ratios, left_out = [], [], []
     ahead_hip = ahead_f32 = 0
     for name, iters, scene_seed in DRIFT_CASES:
         z = load(golden_dir, name.split('/')[0])
@@ -907,8 +909,20 @@ def test_free_running_drift_vs_fp64_oracle(hip, golden_dir):
                 print(f'  {name}: scene {cand} not admitted (first iteration vs fp64: HIP {e_h:.1e}, fp32 oracle {e_o:.1e})')
             else:
                 # (at 256 x 256 a batch has ~1e8 gated units: most scenes put one of them within rounding of zero for one or the
-                # other implementation -- scene 22: the fp32 ORACLE flips and the HIP path does not)
-                print(f'  {name}: no candidate scene with a clean first iteration: left out of the statistic')
+                # other implementation -- scene 22: the fp32 ORACLE flips and the HIP path does not; the flip counts of both
+                # sides over twelve scenes: test_gate_flip_statistic_256_against_fp64.)  Not a silent skip: the golden scene's
+                # first iteration must then pass the GATE-AWARE bar -- 1e-4 on every sample whose gates agree with the oracle's
+                # and on every sample with the oracle's gates, each disagreeing unit within rounding of zero on both sides --
+                # and only full-size scenarios may be left out.
+                assert int(z['sz'][0]) > 64, f'{name}: no 64 x 64 candidate scene with a clean first iteration'
+                stg = _first_iteration_gate_aware(hip, 'resnet18', csd, insz, tuple(int(v) for v in z['sz']), tuple(int(v) for v in z['crop']),
+                                                  targets, int(z['seed']), mask=str(z['mask']), targeted=True, scene_seed=first,
+                                                  d_thr=d_thr, stealth=stealth)
+                assert int(stg.flips.sum()) >= 1, f'{name}: first iteration off by more than 1e-4 without a single differing gate'
+                left_out.append((name, int(stg.flips.sum())))
+                print(f'  {name}: no clean first iteration on the golden scene; gate-aware check passed '
+                      f'({int(stg.flips.sum())} gates within rounding of zero differ): left out of the drift statistic')
+                del stg
                 continue
         tr64 = _oracle_fp64(sd, csd, insz, targets, True, scene, d_thr, stealth, setup, iters)
         tr32 = []
@@ -944,11 +958,116 @@ def test_free_running_drift_vs_fp64_oracle(hip, golden_dir):
         print(f'  {name}: geometric-mean ratio HIP / fp32 oracle = {ratio:.2f}')
         print('     HIP          ', ' '.join(f'{v:.1e}' for v in d_hip))
         print('     fp32 oracle  ', ' '.join(f'{v:.1e}' for v in d_f32))
-    assert len(ratios) >= 5
+    assert len(ratios) >= 9 and len(left_out) <= 1
     med = float(np.median(ratios))
-    print(f'  median of the {len(ratios)} ratios = {med:.2f} (bound 1.5), min = {min(ratios):.2f}, max = {max(ratios):.2f} (bound 30)')
+    srt = sorted(ratios)
+    gm = float(np.exp(np.mean(np.log(ratios))))
+    print(f'  median of the {len(ratios)} ratios = {med:.2f} (bound 1.5), geometric mean = {gm:.2f} (bound 2), min = {srt[0]:.2f}, '
+          f'second largest = {srt[-2]:.2f} (bound 10), max = {srt[-1]:.2f} (bound 30)')
     print(f'  scenarios with one side more than 10x ahead of the other (two iterations of slack): HIP {ahead_hip}, fp32 oracle {ahead_f32}')
-    assert med <= 1.5 and max(ratios) < 30.0 and ahead_hip <= ahead_f32 + 2
+    # spread: measured over rounds 3-5 the per-scenario ratio ranges over 0.04 ... 7.8 (log-symmetric: one early gate flip of either
+    # side, held for the rest of the twelve iterations).  A fidelity loss moves the whole distribution: median and geometric mean;
+    # a single bad scenario shows in the second largest / largest ratio.
+    assert med <= 1.5 and gm <= 2.0 and srt[-2] < 10.0 and srt[-1] < 30.0 and ahead_hip <= ahead_f32 + 2
+
+
+def _three_way_layers(pairs64, pairs32):
+    """Per gate-carrying layer: forward error against the fp64 oracle of the HIP engine and of the fp32 oracle (relative to the
+    layer's largest fp64 activation), and the per-sample number of gates (ReLU / clamp signs, max-pool arg-maxes) on which each
+    differs from fp64.  `pairs64` / `pairs32`: tests/gates.py pair lists built from the fp64 resp. fp32 oracle activations."""
+    rows, fl_h, fl_o = [], None, None
+    for (name, kind, hbuf, o64), (_n, _k, _h, o32) in zip(pairs64, pairs32):
+        if kind == 'argmax':
+            h, c64, c32 = hbuf.detach().cpu(), o64.codes, o32.codes
+            mh, mo, eh, eo = (h != c64), (c32 != c64), 0.0, 0.0
+        else:
+            h = hbuf.detach().cpu().double()
+            a64, a32 = o64.double(), o32.double()
+            scale = float(a64.abs().max()) + 1e-300
+            eh, eo = float((h - a64).abs().max()) / scale, float((a32 - a64).abs().max()) / scale
+            if kind == 'relu':
+                mh, mo = (h > 0) != (a64 > 0), (a32 > 0) != (a64 > 0)
+            else:
+                g = lambda v: (v > 0) & (v <= 1)   # noqa: E731
+                mh, mo = g(h) != g(a64), g(a32) != g(a64)
+        nh, no = mh.flatten(1).sum(1), mo.flatten(1).sum(1)
+        fl_h = nh if fl_h is None else fl_h + nh
+        fl_o = no if fl_o is None else fl_o + no
+        rows.append((name, eh, eo, int(nh.sum()), int(no.sum())))
+    return rows, fl_h, fl_o
+
+
+def test_gate_flip_statistic_256_against_fp64(hip):
+    """Rounding parity at the benchmarked size, with float64 as the referee.  Twelve independent 256 x 256 scenes, B = 2, first
+    iteration of the benchmarked configuration (PCNet seed 0, ResNet-18, camdE_caml2): the oracle run in float64, the fp32
+    oracle (== the reference) and the HIP path.  With ~3e6 gated units per sample some sit within rounding of zero, and an
+    fp32 implementation puts a few on the other side -- the reference's own fp32 path included.  Asserted:
+      * forward: per gate-carrying layer, the HIP engine's error against float64 is at most 1.5 x the fp32 oracle's (+ 2e-7 of the
+        layer scale: single-rounding differences of layers the oracle computes in one pass);
+      * gates: the number of scenes whose produced projector image is more than 1e-4 from float64 (= a flipped gate reached the
+        gradient) is at most the fp32 oracle's + 2 for the HIP path, and the total number of differing gates at most 2 x + 8;
+      * every HIP image without a differing gate is within 1e-4 of float64."""
+    import gates
+    A, M = hip['attack'], hip['models']
+    sz, crop, insz = (256, 256), (240, 240), (224, 224)
+    sd = syn.pcnet_state_dict(0, cam_sz=sz, mask='ones')
+    csd = syn.resnet18_state_dict(2, logit_gain=20.0)
+    pc = make_pcnet(hip, sd, sz)
+    clf = hip['clf'].Classifier('resnet18', DEV, state_dict=csd, input_sz=insz)
+    oclf = so.OracleClassifier('resnet18', csd, input_sz=insz)
+    setup = dict(classifier_crop_sz=crop, prj_brightness=0.5, prj_im_sz=sz)
+    targets, B = [syn.IMAGENET10_TARGETS[0], syn.IMAGENET10_TARGETS[5]], 2
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    csd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in csd.items()}
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    x0 = torch.full((B, 3, *sz), 0.5)
+    bad_h = bad_o = tot_h = tot_o = 0
+    worst = {}
+    print('scene: image vs fp64 (HIP | fp32 oracle), gates differing from fp64 (HIP | fp32 oracle)')
+    for seed in range(101, 113):
+        scene = syn.scenes(seed, 1, sz)
+        scene_b = scene.expand(B, -1, -1, -1)
+        r64 = torch.from_numpy(_oracle_fp64(sd, csd, insz, targets, True, scene, 5, 'camdE_caml2', setup, 1)[0]['prj_adv'])
+        t32 = []
+        so.spaa(sd, oclf, targets, True, scene, 5, 'camdE_caml2', setup, iters=1, trace=t32)
+        r32 = torch.from_numpy(t32[0]['prj_adv']).double()
+        torch.set_default_dtype(torch.float64)
+        try:
+            acts64, cacts64 = _oracle_activations(sd64, csd64, x0.double(), scene_b.double(), sz, crop, insz)
+        finally:
+            torch.set_default_dtype(torch.float32)
+        acts32, cacts32 = _oracle_activations(sd, csd, x0, scene_b, sz, crop, insz)
+        st = A.AttackState(pc, clf, targets, scene, 'camdE_caml2', setup, DEV)
+        st.forward_decide(True, 5, 0.9)
+        p64 = gates.pcnet_pairs(st.eng, acts64) + gates.resnet18_pairs(st.clf.body, cacts64)
+        p32 = gates.pcnet_pairs(st.eng, acts32) + gates.resnet18_pairs(st.clf.body, cacts32)
+        rows, fl_h, fl_o = _three_way_layers(p64, p32)
+        st.backward_step(2, 1)
+        xh = M.to_nchw(st.x).cpu().double()
+        e_h = [rel_inf(xh[b], r64[b]) for b in range(B)]
+        e_o = [rel_inf(r32[b], r64[b]) for b in range(B)]
+        for name, eh, eo, _nh, _no in rows:
+            w = worst.setdefault(name, [0.0, 0.0])
+            w[0], w[1] = max(w[0], eh), max(w[1], eo)
+        for b in range(B):
+            if int(fl_h[b]) == 0:
+                assert e_h[b] < 1e-4, (seed, b, e_h[b])
+        bad_h += max(e_h) > 1e-4
+        bad_o += max(e_o) > 1e-4
+        tot_h += int(fl_h.sum())
+        tot_o += int(fl_o.sum())
+        lay = {n: (nh, no) for n, _a, _b, nh, no in rows if nh or no}
+        print(f'  {seed}: {max(e_h):.1e} | {max(e_o):.1e}   gates {int(fl_h.sum())} | {int(fl_o.sum())}  {lay}')
+        del st
+    print('forward error against fp64 per layer, relative to the layer scale, max over the scenes: HIP | fp32 oracle')
+    for name, (eh, eo) in worst.items():
+        print(f'  {name:24s} {eh:.2e} | {eo:.2e}')
+    ratio = max(eh / (eo + 1e-30) for eh, eo in worst.values() if eh > 0)
+    print(f'scenes (of 12) with an image more than 1e-4 from fp64: HIP {bad_h}, fp32 oracle {bad_o}; differing gates in all: HIP {tot_h}, '
+          f'fp32 oracle {tot_o}; worst layer error ratio HIP / fp32 oracle {ratio:.2f}')
+    assert bad_h <= bad_o + 2 and tot_h <= 2 * tot_o + 8
+    for name, (eh, eo) in worst.items():
+        assert eh <= 1.5 * eo + 2e-7, (name, eh, eo)
 
 
 FIFTY = ['spaa_64_untargeted', 'spaa_64_imagenet10', 'spaa_64_near', 'spaa_64_caml2_dthr', 'spaa_64_prjl2', 'spaa_64_camdE',
