@@ -86,6 +86,13 @@ __device__ __forceinline__ int swz_w16(int n) { return ((n >> 3) & 1) << 1; }
 // their two chunks in the opposite order (frag_addr below)
 __device__ __forceinline__ int swz_p(int q) { return ((q >> 1) & 3) << 1; }
 
+#ifdef SPAA_X6P_STAMP
+// timing-only diagnostic build (make stamp -> libspaa_hip_stamp.so, tools/lab/x6p_stamps.py): wave 0 of every workgroup records
+// s_memtime at its phase boundaries and the cycles it spends in the per-step wait + barrier; no output value depends on them
+__device__ unsigned long long* g_x6p_stamps = nullptr;
+#define X6P_T() __builtin_amdgcn_s_memtime()
+#endif
+
 template <int BN>
 __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p, const int wg_y, const int wg_x, const int n_tiles) {
     constexpr int TJ = BN / 16;
@@ -112,6 +119,10 @@ __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p,
         oy0 = (t % wg_y) * RY;
         img = t / wg_y;
     }
+#ifdef SPAA_X6P_STAMP
+    const unsigned long long ts0 = X6P_T(), tr0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long ts_wait = 0, ts_first = 0;
+#endif
     const int row_bytes = p.in_cstride * 4;
     const uint32_t in_bytes = (uint32_t)p.B * (uint32_t)(H * W) * (uint32_t)row_bytes;
     const uint64_t in_addr = reinterpret_cast<uint64_t>(p.in);
@@ -321,6 +332,9 @@ __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p,
             split8(lo, hi, pf[b][0], pf[b][1], pf[b][2]);
         }
     };
+#ifdef SPAA_X6P_STAMP
+    const unsigned long long ts1 = X6P_T();
+#endif
     int st = 0, step = 0;
     bf16x8 pfs[2][2][3];   // fragments of the current / the next window position
     f32x4 raw[2][2];
@@ -338,12 +352,25 @@ __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p,
                 // combos that follow a block's first, where the next block's patch was requested right after weights(n + 2) --
                 // that patch: combo 1 waits for weights issued before it, combo 2 for weights(2) issued just before it; from
                 // combo 3 on the patch is OLDER than the weights waited for
+#ifdef SPAA_X6P_STAMP
+                const unsigned long long tw0 = X6P_T();
+#endif
                 if (step + 1 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if ((n == 1 || n == 2) && kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + PPW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef SPAA_X6P_STAMP
+                const unsigned long long tw1 = X6P_T();
+#endif
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+#ifdef SPAA_X6P_STAMP
+                {
+                    const unsigned long long tw2 = X6P_T();
+                    ts_wait += tw2 - tw1;          // barrier
+                    ts_first += tw1 - tw0;         // vmcnt / lgkmcnt
+                }
+#endif
                 if (step == 0 && !w1_issued && nsteps > 1) dma_w(1, 1);   // (two blocks of second-source weights held its stage)
                 if (step + 2 < nsteps) dma_w(st >= 1 ? st - 1 : 2, step + 2);
                 if (n == 0 && kb + 1 < nkb) dma_patch((kb + 1) & 1, kb + 1);
@@ -376,6 +403,9 @@ __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p,
                      (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
     constexpr int ROWB = BN * 4 + 16;                  // (+16: the 16 pixels of a fragment write to distinct banks)
     constexpr int LPP = BN / 4, PPI = 64 / LPP;        // lanes per pixel, pixels per instruction
+#ifdef SPAA_X6P_STAMP
+    const unsigned long long ts2 = X6P_T();
+#endif
     __syncthreads();
     unsigned char* const eb = smem + wave * (32 * ROWB);
     const int ch = 4 * (lane % LPP);
@@ -425,9 +455,24 @@ __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p,
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
+#ifdef SPAA_X6P_STAMP
+    if (g_x6p_stamps != nullptr && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the stores have left: the epilogue's true end)
+        const unsigned long long ts3 = X6P_T(), tr3 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* o = g_x6p_stamps + ((size_t)blockIdx.x * NW + wave) * 8;
+        o[0] = ts0, o[1] = ts1, o[2] = ts2, o[3] = ts3, o[4] = tr0, o[5] = tr3, o[6] = ts_wait, o[7] = ts_first;
+    }
+#endif
 }
 
 }  // namespace
+
+#ifdef SPAA_X6P_STAMP
+// diagnostic build only: where the stamps of the NEXT launches go (device buffer of nwg * 4 * 8 uint64) or nullptr
+extern "C" int spaa_x6p_set_stamp_buffer(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_x6p_stamps), &buf, sizeof(buf));
+}
+#endif
 
 // called by spaa_tapconv_f32 (tapconv.hip) for tile 74 after the common shape checks: FOUR output-parity classes in row-major
 // order ((0,0), (0,1), (1,0), (1,1)), s_in = 1, s_out = 2, every tap inside one 2 x 2 window, fp32 storage, Cin % 32 == 0, the class
