@@ -26,7 +26,6 @@
 #include <hip/hip_runtime.h>
 #include "launch_util.hpp"
 #include <stdint.h>
-#include <stdlib.h>
 #include "../../include/spaa_hip.h"
 #include "epilogue.hpp"
 
@@ -104,8 +103,6 @@ struct wino_geo_t {
     unsigned int my, mx;       // v / py == (v * my) >> 20 for every canvas coordinate v (launcher: canvas sides <= 4095, periods <= 255)
     int nsp;                   // workgroup regions of all canvases together
     int order;                 // 1: regions fastest in the workgroup order, 0: N tiles fastest (as in the image-aligned form)
-    int stagger;               // > 0: every second first-round workgroup of an XCD starts this many 10-ns ticks late (phase stagger, below)
-    int first_round;           // workgroups that start together (one per compute unit)
 };
 
 // TWO: the layer's input channels come from TWO tensors of the same B x H x W (channel blocks [0, Cin - Cin2) from `in`, the rest from
@@ -169,16 +166,6 @@ __global__ __launch_bounds__(64 * NWT, NWT == 4 ? 2 : 1) void wino_x6_kernel(con
         t /= wg_x;
         oy0 = (t % wg_y) * (2 * TY);
         img = t / wg_y;
-    }
-    // PHASE STAGGER.  One workgroup per compute unit, equal tiles: every compute unit reaches its epilogue (512 KB of residual
-    // reads and stores per 128-wide tile) at the same moment, the memory system serves 256 epilogues at once and is idle during
-    // the main loops.  Every second workgroup of the first round starts `stagger` ticks late; the workgroups that follow on its
-    // compute unit inherit the shift, so at any time about half of the chip computes while the other half moves bytes.
-    if constexpr (NWT == 8 && !CV) {
-        if (geo.stagger > 0 && (int)blockIdx.x < geo.first_round && ((blockIdx.x >> 3) & 1)) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)geo.stagger) __builtin_amdgcn_s_sleep(64);
-        }
     }
     const int row_bytes = p.in_cstride * 4;
     const uint32_t in_bytes = (uint32_t)p.B * (uint32_t)(H * W) * (uint32_t)row_bytes;
@@ -767,13 +754,6 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     geo.nsp = (int)(nwg / ((int64_t)n_tiles * pl.ksplit));
     // workgroup order by what an XCD's L2 should keep: the weight planes (16 positions x three bf16) or the activations
     geo.order = (int64_t)((d.Cout + 127) & ~127) * d.cls[0].Kpad * 6 > (int64_t)d.B * d.Hin * d.Win * d.Cin * 4;
-    {
-        // phase stagger of the 8-wave image-aligned form (one workgroup per compute unit): SPAA_WINO_STAGGER_US, default off
-        const char* const env = getenv("SPAA_WINO_STAGGER_US");   // (read per launch: tools/lab/wino_stagger.py sweeps it in one process)
-        const int stagger_us = env ? atoi(env) : 0;
-        geo.first_round = wino_ncu();
-        geo.stagger = (stagger_us > 0 && nwg >= 2 * (int64_t)geo.first_round) ? stagger_us * 100 : 0;
-    }
     if (cv && !pl.canvas && (d.Hout > 4095 || d.Wout > 4095)) return hipErrorInvalidValue;
     if (cv && (int64_t)d.B * d.Hout * d.Wout >= ((int64_t)1 << 24)) return hipErrorInvalidValue;   // (the plan never asks for it: wino_make_plan)
     spaa_tapconv_t dd = d;

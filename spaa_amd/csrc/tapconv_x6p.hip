@@ -90,7 +90,10 @@ __device__ __forceinline__ int swz_p(int q) { return ((q >> 1) & 3) << 1; }
 // timing-only diagnostic build (make stamp -> libspaa_hip_stamp.so, tools/lab/x6p_stamps.py): wave 0 of every workgroup records
 // s_memtime at its phase boundaries and the cycles it spends in the per-step wait + barrier; no output value depends on them
 __device__ unsigned long long* g_x6p_stamps = nullptr;
-#define X6P_T() __builtin_amdgcn_s_memtime()
+#define X6P_T() (stamp_on ? __builtin_amdgcn_s_memtime() : 0ull)
+#define X6P_ABL(bit) ((abl >> (bit)) & 1)
+#else
+#define X6P_ABL(bit) 0
 #endif
 
 template <int BN>
@@ -120,6 +123,10 @@ __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p,
         img = t / wg_y;
     }
 #ifdef SPAA_X6P_STAMP
+    // reserved0 bits 8-15 (this build only): timing ablations -- wrong results -- 1 no DMA after the first stages, 2 no fragment split,
+    // 4 no barrier, 8 no MFMA, 16 no epilogue, 32 no fragment loads; 128: record the stamps
+    const int abl = (p.reserved0 >> 8) & 0xff;
+    const bool stamp_on = (abl & 128) != 0;
     const unsigned long long ts0 = X6P_T(), tr0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long ts_wait = 0, ts_first = 0;
 #endif
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p,
 #ifdef SPAA_X6P_STAMP
                 const unsigned long long tw1 = X6P_T();
 #endif
-                __builtin_amdgcn_s_barrier();
+                if (!X6P_ABL(2)) __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
 #ifdef SPAA_X6P_STAMP
                 {
@@ -372,17 +379,17 @@ __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p,
                 }
 #endif
                 if (step == 0 && !w1_issued && nsteps > 1) dma_w(1, 1);   // (two blocks of second-source weights held its stage)
-                if (step + 2 < nsteps) dma_w(st >= 1 ? st - 1 : 2, step + 2);
-                if (n == 0 && kb + 1 < nkb) dma_patch((kb + 1) & 1, kb + 1);
+                if (step + 2 < nsteps && !X6P_ABL(0)) dma_w(st >= 1 ? st - 1 : 2, step + 2);
+                if (n == 0 && kb + 1 < nkb && !X6P_ABL(0)) dma_patch((kb + 1) & 1, kb + 1);
                 if (step == 0) {   // the very first fragments: nothing to hide them under
                     frag_load(pb, 0, raw);
                     frag_split(raw, pfs[0]);
                 }
                 const bool fetch = c == 3 && (ps < 3 || kb + 1 < nkb);   // class 3: the position's last combo
-                if (fetch) frag_load(ps < 3 ? pb : pb_next, (ps + 1) & 3, raw);
+                if (fetch && !X6P_ABL(5)) frag_load(ps < 3 ? pb : pb_next, (ps + 1) & 3, raw);
                 const unsigned char* wc = wsm + st * WS_BYTES + w_addr_l;
-                if (fetch) frag_split(raw, pfs[(ps + 1) & 1]);   // (scheduled into the shadows of the MFMAs below)
-                {
+                if (fetch && !X6P_ABL(1)) frag_split(raw, pfs[(ps + 1) & 1]);   // (scheduled into the shadows of the MFMAs below)
+                if (!X6P_ABL(3)) {
                     bf16x8 (&pf)[2][3] = pfs[ps & 1];
                     X6P_MFMA(c, wc)
                 }
@@ -405,6 +412,15 @@ __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p,
     constexpr int LPP = BN / 4, PPI = 64 / LPP;        // lanes per pixel, pixels per instruction
 #ifdef SPAA_X6P_STAMP
     const unsigned long long ts2 = X6P_T();
+    if (X6P_ABL(4)) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) asm volatile("" ::"v"(acc[c][b][j]));
+        return;
+    }
 #endif
     __syncthreads();
     unsigned char* const eb = smem + wave * (32 * ROWB);
@@ -456,7 +472,7 @@ __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p,
         }
     }
 #ifdef SPAA_X6P_STAMP
-    if (g_x6p_stamps != nullptr && lane == 0) {
+    if (stamp_on && g_x6p_stamps != nullptr && lane == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the stores have left: the epilogue's true end)
         const unsigned long long ts3 = X6P_T(), tr3 = __builtin_amdgcn_s_memrealtime();
         unsigned long long* o = g_x6p_stamps + ((size_t)blockIdx.x * NW + wave) * 8;
