@@ -336,6 +336,11 @@ int spaa_maxpool_bwd_f16(const void* g_out, const uint8_t* argmax, int relu_gate
  * ReLU gate of `act` (fp16, may be NULL) */
 int spaa_avgpool_fwd_f16(const void* in, float* out, int B, int HW, int C, spaa_stream_t stream);
 int spaa_avgpool_bwd_f16(const float* g_out, const void* act, void* g_in, int B, int HW, int C, spaa_stream_t stream);
+/* ReLU-gate bytes (format of spaa_tapconv_t.mask_out) of channels [coff, coff + C) of an activation [M pixels][cstride] (fp32, or
+ * fp16 when f16 != 0) into mask [M][cstride / 4]: for activations that no convolution launch wrote -- the max-pool outputs that
+ * gate their consumers in torchvision's Inception-v3 (/root/reference/src/python/classifier.py:29-33; autograd's threshold_backward
+ * of the ReLU that produced the pooled values) */
+int spaa_gate_mask(const void* act, int f16, uint8_t* mask, int64_t M, int C, int cstride, int coff, spaa_stream_t stream);
 /* avg_pool2d(k, s, p), count_include_pad=True */
 int spaa_avgpool2d_fwd(const float* in, float* out, int B, int Hin, int Win, int C, int Hout, int Wout, int k, int s,
                        int p, int out_cstride, int out_coff, spaa_stream_t stream);

@@ -96,6 +96,7 @@ _SIGNATURES = {
     'spaa_maxpool_fwd': [_p, _p, _p] + [_i] * 11 + [_p],
     'spaa_maxpool_bwd': [_p, _p, _i, _p] + [_i] * 11 + [_p],
     'spaa_maxpool_fwd_f16': [_p, _p, _p] + [_i] * 11 + [_p],
+    'spaa_gate_mask': [_p, _i, _p, _l, _i, _i, _i, _p],
     'spaa_maxpool_bwd_f16': [_p, _p, _i, _p] + [_i] * 11 + [_p],
     'spaa_avgpool_fwd_f16': [_p, _p, _i, _i, _i, _p],
     'spaa_avgpool_bwd_f16': [_p, _p, _p, _i, _i, _i, _p],

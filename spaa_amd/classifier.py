@@ -10,6 +10,7 @@ them by URL, classifier.py:24-36): pass `state_dict=` (torchvision key names) or
 `ClassifierEngine` is what the fused attack loop drives: forward = crop + area-resize + normalise -> net -> logits;
 backward = input gradient only (all parameters frozen, classifier.py:41-44).
 """
+import os
 import weakref
 
 import numpy as np
@@ -18,6 +19,8 @@ import torch
 from . import _lib
 from . import convplan as cp
 from .models import to_nhwc4, to_nchw, USE_GATE_MASKS
+
+BODY_GATE_MASKS = os.environ.get('SPAA_BODY_MASKS', '1') != '0'   # 0: VGG-16 / Inception-v3 gate with the activation itself (A/B measurements)
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
@@ -118,6 +121,7 @@ class ResNet18Body:
         self.g_last = z(batch, hh, ww, 512)
         self.g_c1 = z(batch, h1, w1, 64)
         self.g_in = zf(batch, h, w, 4)
+        self.write_masks = True
 
     def forward(self, x4):
         R = _lib.ACT_RELU
@@ -132,7 +136,7 @@ class ResNet18Body:
         else:
             _lib.call('spaa_maxpool3s2_fwd', _lib.ptr(self.c1), _lib.ptr(self.mp), _lib.ptr(self.mp_arg), B, h1, w1, 64,
                       h2, w2)
-        masks = USE_GATE_MASKS or h16
+        masks = (USE_GATE_MASKS or h16) and getattr(self, 'write_masks', True)   # (write_masks False: a forward pass nobody differentiates)
         for blk in self.blocks:
             blk['f1'].run(blk['x'], blk['o1'], act=R, mask_out=blk['m_o1'] if masks else None)
             if 'fd' in blk:
@@ -241,6 +245,14 @@ class VGG16Body:
                 cin = v
                 idx += 2
         self.feat_hw = (h, w)
+        # ReLU gates of the conv -> conv transitions as byte masks (1 byte per 4 channels, written by the forward epilogue): the input
+        # gradient then reads 2 bits per element instead of the activation and stays on the branch-free epilogue
+        # (profiles/r05_vgg16_percal_f16s_tapconv_layers.json: features.2_dgrad 689 us against 477 forward with the activation as gate)
+        self.masks = BODY_GATE_MASKS and (USE_GATE_MASKS or storage == 'f16')
+        self.write_masks = True       # (ClassifierEngine.forward(need_grad=False): a forward pass nobody differentiates skips them)
+        for i, op in enumerate(self.ops[:-1]):
+            if op['kind'] == 'conv' and self.ops[i + 1]['kind'] == 'conv' and self.masks:
+                op['m'] = torch.zeros(*op['out'].shape[:3], op['out'].shape[3] // 4, dtype=torch.uint8, device=dev)
         self.pool7 = z(batch, 7, 7, 512)
         self.g_pool7 = z(batch, 7, 7, 512)
         self.g_feat = z(batch, h, w, 512)
@@ -263,7 +275,7 @@ class VGG16Body:
         t = x4
         for op in self.ops:
             if op['kind'] == 'conv':
-                op['f'].run(t, op['out'], act=R)
+                op['f'].run(t, op['out'], act=R, mask_out=op.get('m') if self.write_masks else None)
             else:
                 _lib.call('spaa_maxpool_fwd_f16' if self.storage == 'f16' else 'spaa_maxpool_fwd', _lib.hptr(t),
                           _lib.hptr(op['out']), _lib.ptr(op['arg']), B, op['hin'], op['win'], op['c'], op['hin'] // 2,
@@ -302,10 +314,19 @@ class VGG16Body:
                           op['win'] // 2, 2, 2, 0, op['c'], 0)
             else:
                 prev = self.ops[i - 1] if i > 0 else None
-                gate = op['inp'] if (prev is not None and prev['kind'] == 'conv') else None
-                op['d'].run(g, op['g'], gate=gate)
+                if prev is not None and prev['kind'] == 'conv' and 'm' in prev:
+                    op['d'].run(g, op['g'], gate_bits=prev['m'])
+                else:
+                    gate = op['inp'] if (prev is not None and prev['kind'] == 'conv') else None
+                    op['d'].run(g, op['g'], gate=gate)
             g = op['g']
         return g
+
+    def refresh_masks(self):
+        """Recompute the gate masks from the activation buffers (after a test has overwritten the activations)."""
+        for op in self.ops:
+            if 'm' in op:
+                op['m'].copy_(_lib.pack_gate_mask(op['out'].float()))
 
     def flops_fwd(self):
         t = 0
@@ -345,10 +366,14 @@ class ClassifierEngine:
         self.owner = None   # weakref to the attack state this engine is leased to (Classifier.engine)
         self.version = 0    # bumped whenever the activation workspaces are overwritten
 
-    def forward(self, y4):
+    def forward(self, y4, need_grad=True):
+        """`need_grad=False`: nobody will call backward() on this pass (PerC-AL's second, decision-only forward pass on the quantised
+        image, perc_al/__init__.py:220-238): the bodies that write ReLU-gate masks skip them."""
         _lib.check_dev(y4)
         assert y4.shape == (self.B, self.H, self.W, 4)
         self.version += 1
+        if hasattr(self.body, 'write_masks'):
+            self.body.write_masks = bool(need_grad)
         _lib.call('spaa_preproc_fwd', _lib.ptr(y4), _lib.ptr(self.pre), self.B, self.H, self.W, self.cy0, self.cx0,
                   self.ch, self.cw, self.oh, self.ow, self._mean, self._std)
         return self.body.forward(self.pre)

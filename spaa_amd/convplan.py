@@ -345,7 +345,7 @@ class ConvPlan:
             forced = 0
         if forced == 11 and (self.cout > 4 or self.cin_p > 256 or (self.cin_p & (self.cin_p - 1))):
             forced = 0
-        if forced == 38 and (len(self.cls) != 1 or self.cout > 32 or self.cin_p not in (4, 8) or self.ntaps_total > 9
+        if forced == 38 and (len(self.cls) != 1 or self.cout > 64 or self.cin_p not in (4, 8) or self.ntaps_total > 9
                              or self.s_in > 2):
             forced = 0
         if forced in (28, 29, 47) and (self.cout > 4 or self.s_in != 1 or self.cin_p % (32 if forced == 28 else 16)):
@@ -404,9 +404,12 @@ class ConvPlan:
                 # left -- strided and folded layers -- 128 x 128 is as good or better: tools/lab/f16_tiles.py)
         elif out_f16:  # fp32 image in, fp16 activation out: any kernel built on the shared epilogue, without split-K
             tile %= 100
+            # (the patch kernel's two-half form, Cout <= 64, is NOT preferred for VGG-16's first layer: measured on one box, VGG-16
+            # PerC-AL fp16 storage 88.9 it/s with the layer on the register-staged bf16x6 tile against 86.4 on tile 38 -- 72 fp32 MFMAs
+            # of 64 cycles per 64 pixels; tools/lab/body_masks_ab.sh, profiles/r05_body_masks_ab.txt)
+            sc_ok = len(self.cls) == 1 and self.cin_p in (4, 8) and self.cout <= 64 and self.ntaps_total <= 9 and self.s_in <= 2
             if tile not in F16OUT_TILES or tile in H16_TILES:   # (the fp16 implicit-GEMM tiles need an fp16 input as well)
-                tile = 38 if (len(self.cls) == 1 and self.cin_p in (4, 8) and self.cout <= 32 and self.ntaps_total <= 9
-                              and self.s_in <= 2) else (18 if self.cout > 32 else 16)
+                tile = 38 if (sc_ok and self.cout <= 32) else (18 if self.cout > 32 else 16)
         # tune values >= 100 encode split-K: tile + 100 * ksplit (x6d tiles, one class, enough K-steps per split)
         ksplit, tile = (tile // 100, tile % 100) if tile >= 100 else (1, tile)
         if self.nfold > 1:  # only the DMA-staged kernels know the folded epilogue

@@ -306,6 +306,22 @@ __global__ void adaptive_bwd_kernel(const float4* __restrict__ g_out, const floa
     g_in[idx] = acc;
 }
 
+// ReLU-gate bytes of a channel window of an activation (the `mask_out` format of spaa_tapconv_t: one byte per 4 channels, bit e =
+// channel 4 q + e > 0) for activations that no convolution launch wrote: the max-pool outputs of the Inception-v3 body, which
+// gate the layers that consume them like every other ReLU output (spaa_amd/inception.py).
+template <typename T>
+__global__ __launch_bounds__(256) void gate_mask_kernel(const T* __restrict__ act, uint8_t* __restrict__ mask, const int64_t M,
+                                                        const int C4, const int cstride, const int coff) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * C4) return;
+    const int64_t m = idx / C4;
+    const int q = (int)(idx - m * C4);
+    const T* a = act + m * cstride + coff + 4 * q;
+    const unsigned int b = ((float)a[0] > 0.f ? 1u : 0u) | ((float)a[1] > 0.f ? 2u : 0u) | ((float)a[2] > 0.f ? 4u : 0u) |
+                           ((float)a[3] > 0.f ? 8u : 0u);
+    mask[(m * cstride + coff) / 4 + q] = (uint8_t)b;
+}
+
 inline int nb(int64_t n) { return (int)((n + 255) / 256); }
 
 inline bool geo_ok(int B, int Hin, int Win, int C, int Hout, int Wout, int k, int s, int p) {
@@ -433,6 +449,19 @@ int spaa_adaptive_avgpool_bwd(const float* g_out, const float* gate_in, float* g
     Geo g{B, Hin, Win, C / 4, Hout, Wout, 0, 0, 0};
     hipLaunchKernelGGL(adaptive_bwd_kernel, dim3(nb((int64_t)B * Hin * Win * g.C4)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)g_out, (const float4*)gate_in, (float4*)g_in, g);
+    return (int)hipGetLastError();
+}
+
+int spaa_gate_mask(const void* act, int f16, uint8_t* mask, int64_t M, int C, int cstride, int coff, spaa_stream_t stream) {
+    if (!act || !mask || M < 1 || C < 4 || (C & 3) || (cstride & 3) || (coff & 3) || coff + C > cstride ||
+        M * (int64_t)(C / 4) >= ((int64_t)1 << 31) * 256)
+        return hipErrorInvalidValue;
+    if (f16)
+        hipLaunchKernelGGL(gate_mask_kernel<_Float16>, dim3(nb(M * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                           (const _Float16*)act, mask, M, C / 4, cstride, coff);
+    else
+        hipLaunchKernelGGL(gate_mask_kernel<float>, dim3(nb(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)act,
+                           mask, M, C / 4, cstride, coff);
     return (int)hipGetLastError();
 }
 

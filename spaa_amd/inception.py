@@ -11,10 +11,15 @@ and logits fp32): the fp16 matrix-core kernels take 32-channel slices, so the tw
 (`Conv2d_3b_1x1`: 80, `Mixed_5x.branch5x5_1`: 48) are built 96 / 64 wide with ZERO weights and biases in the extra channels
 (their activations and gradients are exactly 0; the consumer's weights for them are zero too).
 """
+import os
+
 import torch
 
 from . import _lib
 from . import convplan as cp
+from .models import USE_GATE_MASKS
+
+BODY_GATE_MASKS = os.environ.get('SPAA_BODY_MASKS', '1') != '0'   # 0: the activation itself as the ReLU gate (A/B measurements)
 
 # layer table: name -> builder spec.  conv spec = (name, cout, (kh, kw), stride, (ph, pw))
 A_ = lambda pf: dict(kind='A', pf=pf)  # noqa: E731
@@ -66,8 +71,9 @@ def block_spec(kind, arg):
 class Ten:
     """A channel window [coff, coff+C) of an NHWC buffer, plus its gradient buffer of identical layout."""
 
-    def __init__(self, buf, coff, c, gbuf=None, kind='act'):
-        self.buf, self.coff, self.c, self.gbuf, self.kind = buf, coff, c, gbuf, kind
+    def __init__(self, buf, coff, c, gbuf=None, kind='act', mbuf=None):
+        # mbuf: ReLU-gate bytes of the whole buffer (uint8 [B, H, W, C_buffer / 4], the `mask_out` format of include/spaa_hip.h) or None
+        self.buf, self.coff, self.c, self.gbuf, self.kind, self.mbuf = buf, coff, c, gbuf, kind, mbuf
         self.consumers = []
         self.g_written = False
 
@@ -101,6 +107,11 @@ class InceptionV3Body:
             return torch.zeros(*shape, device=dev, dtype=hd)
 
         self.z = z
+        # ReLU gates as byte masks written by the forward epilogues (and by spaa_gate_mask for the max-pool outputs): an input-gradient
+        # launch reads 2 bits per element instead of the activation and stays on the branch-free epilogue (epilogue.hpp fast_epi_*)
+        self.masks = BODY_GATE_MASKS and (USE_GATE_MASKS or self.h16)
+        self.write_masks = True       # (ClassifierEngine.forward(need_grad=False) clears it for a pass nobody differentiates)
+        self.zm = lambda *shape: torch.zeros(*shape, dtype=torch.uint8, device=dev) if self.masks else None
         # transform_input=True (torchvision): per-channel affine on the already-normalised image, folded into the
         # first convolution:  x' = a_c * x + b_c  =>  W' = W * a_c, bias' += sum_taps W * b_c  -- valid only where no
         # zero padding is involved: Conv2d_1a has padding 0, so the folding is exact.
@@ -153,7 +164,7 @@ class InceptionV3Body:
                 bp[:cout] = b
                 wgt, b, cout = wp, bp, cout_p
         if out is None:
-            out = Ten(self.z(self.B, ho, wo, cout), 0, cout, self.z(self.B, ho, wo, cout))
+            out = Ten(self.z(self.B, ho, wo, cout), 0, cout, self.z(self.B, ho, wo, cout), mbuf=self.zm(self.B, ho, wo, cout // 4))
         assert out.hw == (ho, wo) and out.c == cout
         op = dict(kind='conv', name=name, inp=inp, out=out,
                   f=cp.conv_fwd_plan(wgt, b, stride, pad, self.dev, name),
@@ -167,7 +178,9 @@ class InceptionV3Body:
         hin, win = inp.hw
         ho, wo = _osz(hin, k, s, p), _osz(win, k, s, p)
         if out is None:
-            out = Ten(self.z(self.B, ho, wo, inp.c), 0, inp.c, self.z(self.B, ho, wo, inp.c), kind='pool')
+            # (an average pool's output needs no gate of its own: where it is 0 every input of the window is 0 and gated itself)
+            out = Ten(self.z(self.B, ho, wo, inp.c), 0, inp.c, self.z(self.B, ho, wo, inp.c), kind='pool' if mode == 'max' or not self.masks else 'avgpool',
+                      mbuf=self.zm(self.B, ho, wo, inp.c // 4) if mode == 'max' else None)
         op = dict(kind=mode, inp=inp, out=out, k=k, s=s, p=p)
         if mode == 'max':
             op['arg'] = torch.zeros(self.B, ho, wo, inp.c, dtype=torch.uint8, device=self.dev)
@@ -201,18 +214,19 @@ class InceptionV3Body:
         ho, wo = spatial(spec[0], hin, win)
         cat = self.z(self.B, ho, wo, ctot)
         gcat = self.z(self.B, ho, wo, ctot)
+        mcat = self.zm(self.B, ho, wo, ctot // 4)
 
         def run_chain(ops, t, coff):
             """Builds ops; the LAST op of the chain writes into the concat window starting at coff."""
             for i, o in enumerate(ops):
                 is_last = i == len(ops) - 1
                 if o[0] == 'conv':
-                    dst = Ten(cat, coff, o[2], gcat) if is_last else None
+                    dst = Ten(cat, coff, o[2], gcat, mbuf=mcat) if is_last else None
                     t = self.add_conv(f'{name}.{o[1]}', t, o[2], o[3], o[4], o[5], out=dst)
                 elif o[0] == 'avg':
                     t = self.add_pool('avg', t, 3, 1, 1)
                 elif o[0] == 'max':
-                    dst = Ten(cat, coff, t.c, gcat, kind='pool') if is_last else None
+                    dst = Ten(cat, coff, t.c, gcat, kind='pool', mbuf=mcat) if is_last else None
                     t = self.add_pool('max', t, 3, 2, 0, out=dst)
                 elif o[0] == 'split':
                     assert is_last
@@ -225,23 +239,26 @@ class InceptionV3Body:
         for br in spec:
             run_chain(br, inp, coff)
             coff += out_channels(br)
-        return Ten(cat, 0, ctot, gcat)
+        return Ten(cat, 0, ctot, gcat, mbuf=mcat)
 
     # ---- execution ---------------------------------------------------------------------------------------------
     def forward(self, x4):
         B = self.B
         self.x_in.buf = x4
+        wm = self.masks and self.write_masks
         for op in self.ops:
             i, o = op['inp'], op['out']
             if op['kind'] == 'conv':
                 if i is self.x_in:
                     i.buf = x4
-                op['f'].run(i.buf, o.buf, act=_lib.ACT_RELU, in_coff=i.coff, out_coff=o.coff)
+                op['f'].run(i.buf, o.buf, act=_lib.ACT_RELU, in_coff=i.coff, out_coff=o.coff, mask_out=o.mbuf if wm else None)
             elif op['kind'] == 'max':
                 hin, win = i.hw
                 ho, wo = o.hw
                 _lib.call('spaa_maxpool_fwd_f16' if self.h16 else 'spaa_maxpool_fwd', _lib.hptr(i.buf), _lib.hptr(o.buf),
                           _lib.ptr(op['arg']), B, hin, win, i.c, ho, wo, op['k'], op['s'], op['p'], o.buf.shape[3], o.coff)
+                if wm:   # the pooled values gate the layers that consume them like every other ReLU output
+                    _lib.call('spaa_gate_mask', _lib.hptr(o.buf), int(self.h16), _lib.ptr(o.mbuf), B * ho * wo, i.c, o.buf.shape[3], o.coff)
             else:
                 hin, win = i.hw
                 ho, wo = o.hw
@@ -263,25 +280,35 @@ class InceptionV3Body:
             i, o = op['inp'], op['out']
             key = (id(i.gbuf), i.coff)
             last = i.consumers[0] is op          # processed last in reverse order -> applies the ReLU gate of `i`
-            gate = i.buf if (last and i.kind != 'input') else None
+            gated = last and i.kind not in ('input', 'avgpool')
+            gate = i.buf if (gated and not self.masks) else None
             if op['kind'] == 'conv':
                 add = i.gbuf if key in written else None
-                op['d'].run(o.gbuf, i.gbuf, add=add, gate=gate, in_coff=o.coff, out_coff=i.coff, add_coff=i.coff,
-                            gate_coff=i.coff)
+                op['d'].run(o.gbuf, i.gbuf, add=add, gate=gate, gate_bits=i.mbuf if (gated and self.masks) else None, in_coff=o.coff,
+                            out_coff=i.coff, add_coff=i.coff, gate_coff=i.coff)
             else:
                 assert key not in written, 'pool branches must be the first gradient contribution of their input'
                 hin, win = i.hw
                 ho, wo = o.hw
                 if op['kind'] == 'max':
                     _lib.call('spaa_maxpool_bwd_f16' if self.h16 else 'spaa_maxpool_bwd', _lib.hptr(o.gbuf), _lib.ptr(op['arg']),
-                              int(gate is not None), _lib.hptr(i.gbuf), B, hin, win, i.c, ho, wo,
+                              int(gated), _lib.hptr(i.gbuf), B, hin, win, i.c, ho, wo,
                               op['k'], op['s'], op['p'], o.gbuf.shape[3], o.coff)
                 else:
-                    assert gate is None, 'avg-pool is never the only consumer in Inception-v3'
+                    assert not gated, 'avg-pool is never the only consumer in Inception-v3'
                     _lib.call('spaa_avgpool2d_bwd_f16' if self.h16 else 'spaa_avgpool2d_bwd', _lib.hptr(o.gbuf), _lib.hptr(i.gbuf), B,
                               hin, win, i.c, ho, wo, op['k'], op['s'], op['p'], o.gbuf.shape[3], o.coff)
             written.add(key)
         return self.x_in.gbuf
+
+    def refresh_masks(self):
+        """Recompute the gate masks from the activation buffers (after a test has overwritten the activations)."""
+        if not self.masks:
+            return
+        for op in self.ops:
+            o = op['out']
+            if op['kind'] in ('conv', 'max') and o.mbuf is not None:
+                o.mbuf[..., o.coff // 4:(o.coff + o.c) // 4] = _lib.pack_gate_mask(o.buf[..., o.coff:o.coff + o.c].float())
 
     def flops_fwd(self):
         t = 0

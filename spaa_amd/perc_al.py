@@ -184,7 +184,7 @@ class PerCALState:
             _lib.call('spaa_grad_sumsq', p(self.g_col), p(x), 0.0, 0.0, p(state), p(part1), B, HW)
             _lib.call('spaa_masked_step', p(delta), p(self.g_col), p(part1), p(state), 1, 1, -float(alpha_c), B, HW)  # :204-209
             _lib.call('spaa_perc_clamp_quant', p(x_in), p(delta), p(self.x_round), p(part1), B, HW)  # :211-216
-            logits2 = clf.forward(self.x_round)                                            # :220/229/235
+            logits2 = clf.forward(self.x_round, need_grad=False)                           # :220/229/235 (decision only)
             # (untargeted with confidence != 0: the reference's margin is the literal 40 whatever `confidence` is, :223)
             _lib.call('spaa_perc_decide', p(logits2), clf.ncls, p(self.label), self.mode, 40.0 if att.confidence != 0 else 0.0, p(part1),
                       self.nblk, HW, p(self.color_dis), self.d_thr, 0.9, p(state), p(self.stats), B)  # :216-243

@@ -141,6 +141,33 @@ def test_directconv_thin_layers(hip, tile):
         cp.FORCE_TILE = 0
 
 
+def test_smallcin_two_output_halves(hip):
+    """csrc/smallcin.hip with 33..64 output channels (VGG-16's first layer, classifier.py:21-24): two 32-channel halves over one
+    staged patch; fp32 and fp16 output, residual + ReLU + gate bytes, ragged tiles, a channel count that is not a multiple of 32."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(38)
+    try:
+        for ci, co, k, s, p, h, w in [(3, 64, 3, 1, 1, 20, 37), (3, 48, 3, 1, 1, 9, 33), (6, 64, 3, 2, 1, 16, 22), (3, 64, 3, 1, 0, 12, 40)]:
+            x = torch.randn(2, ci, h, w)
+            wt = torch.randn(co, ci, k, k) / (ci * k * k) ** 0.5
+            bias = torch.randn(co)
+            y = F.conv2d(x, wt, bias, s, p)
+            add = torch.randn_like(y)
+            ref = F.relu(y + add)
+            plan = cp.conv_fwd_plan(wt, bias, s, p, DEV)
+            for dt, tol in ((torch.float32, 1e-5), (torch.float16, 2e-3)):
+                out = torch.zeros(2, y.shape[2], y.shape[3], co, device=DEV, dtype=dt)
+                mask = torch.zeros(2, y.shape[2], y.shape[3], co // 4, device=DEV, dtype=torch.uint8)
+                cp.FORCE_TILE = 38
+                plan.run(nhwc(x, plan.cin_p).to(DEV), out, add=nhwc(add, co).to(DEV).to(dt), act=lib.ACT_RELU, mask_out=mask)
+                cp.FORCE_TILE = 0
+                assert plan.last_tile == 38, plan.last_tile
+                assert rel_inf(nchw(out.float().cpu(), co), ref) < tol
+                assert torch.equal(mask.cpu(), hip['lib'].pack_gate_mask(out.float().cpu()))
+    finally:
+        cp.FORCE_TILE = 0
+
+
 @pytest.mark.parametrize('tile', [12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 30, 31, 32, 33, 34, 35, 36, 37, 225, 431, 234, 436, 39, 40, 41, 42, 43, 44, 45, 46, 242, 48, 49, 50, 51, 52, 53, 54, 248, 450, 948, 950, 952, 954])
 def test_tapconv_x6_is_fp32_accurate(hip, tile):
     """fp32 emulated on the bf16 matrix cores (exact 3-way operand split, 6 of 9 partial products, separate
@@ -2002,7 +2029,7 @@ def test_perc_al_with_vgg16_at_full_size(hip):
                 if mode == 'plain':
                     info['flips'], info['layers'] = gates.count_flips(pairs)
                 else:
-                    gates.inject(pairs)
+                    gates.inject(pairs, (eng.body,))
 
             st.iteration(0, after_forward=hook)
             d0 = hip['models'].to_nchw(st.delta).cpu()
