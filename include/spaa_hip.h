@@ -237,8 +237,12 @@ int spaa_shading_tail_fwd(const float* x6, const uint16_t* w2_split, const float
                           const float* res1, float* y, float* ypre, uint8_t* mask7, int B, int H2, int W2, spaa_stream_t stream);
 int spaa_shading_head_bwd(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7,
                           const uint8_t* mask6, float* p6, int B, int H2, int W2, spaa_stream_t stream);
-/* the same two kernels in fp16-storage mode (BASELINE.json configs[4]): x6 resp. p6 are fp16 [B,H2,W2,64]; images, res1, gp, the
- * activation kept in LDS and all arithmetic stay fp32 (the fp16 values are split exactly) */
+/* the same two kernels in fp16-storage mode (BASELINE.json configs[4]): x6 resp. p6 are fp16 [B,H2,W2,64]; the transposed
+ * convolution's weights are ROUNDED TO fp16 like every other layer's of this mode -- here `w2_split` is ONE fp16 matrix [128][64]
+ * (rows n = 32 (2 py + px) + c) and `w2t_split` ONE fp16 matrix [64][128] (same index order as the bf16 planes above) -- and its
+ * products run on v_mfma_f32_16x16x32_f16 with fp32 accumulation (backward: the conv6 gradient is rounded to fp16 as that MFMA's
+ * operand, the rounding the separate launches apply when they store it); images, res1, gp, the activation kept in LDS, conv6 and its
+ * transpose stay fp32 */
 int spaa_shading_tail_fwd_f16(const void* x6, const uint16_t* w2_split, const float* bias2, const float* w6, const float* bias6,
                               const float* res1, float* y, float* ypre, uint8_t* mask7, int B, int H2, int W2, spaa_stream_t stream);
 int spaa_shading_head_bwd_f16(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7,

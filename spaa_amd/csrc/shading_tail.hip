@@ -106,6 +106,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void shading_tail_fwd_kernel(
     const T6* __restrict__ x6, const uint16_t* __restrict__ w2s, const float* __restrict__ bias2, const float* __restrict__ w6,
     const float* __restrict__ bias6, const float* __restrict__ r1, float* __restrict__ y, float* __restrict__ ypre,
     uint8_t* __restrict__ mask7, const int B, const int H2, const int W2, const int tiles_y, const int tiles_x) {
+    // fp16 storage (configs[4]): X6's fp16 values and the weights ROUNDED TO fp16 -- `w2s` is then ONE [128][64] fp16 matrix, as the
+    // `w_half` of every other layer of this mode -- on v_mfma_f32_16x16x32_f16: one MFMA per product and no operand split (the
+    // bf16x6 form spent 48 MFMAs + 88 split instructions per wave and tile on operands that carry 11 bits)
+    constexpr bool H16 = sizeof(T6) == 2;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* wl = smem;                       // weight planes
     unsigned char* tl = smem + W_BYTES;             // X7 tile
@@ -118,7 +122,9 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void shading_tail_fwd_kernel(
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)addr);
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, W_BYTES, 0x00020000);
-        for (int piece = wave; piece < W_BYTES / 1024; piece += FWD_WAVES) {
+        // (fp16 storage: ONE plane of fp16 weights, same rows and swizzle; the descriptor still covers three planes' worth of bytes, of
+        // which the first third is read)
+        for (int piece = wave; piece < (H16 ? W_BYTES / 3 : W_BYTES) / 1024; piece += FWD_WAVES) {
             const int r = piece * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((r >> 1) & 7);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(wl + piece * 1024), 16, r * 128 + c * 16, 0, 0, 0);
@@ -150,12 +156,22 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void shading_tail_fwd_kernel(
     const int ntiles = B * tiles_y * tiles_x;
     // X6 operands of a tile (this wave's row; lane = (column, 8-channel chunk)), loaded one tile ahead
     f32x4 xin[4];
+    h8 xh[2];      // (fp16 storage: the two 8-channel operands as they are)
     auto load_x6 = [&](const int tile_) {
         const int tx_ = tile_ % tiles_x, ty_ = (tile_ / tiles_x) % tiles_y, img = tile_ / (tiles_x * tiles_y);
         const int ay = (OY / 2) * ty_ - 1 + row, ax = (OX / 2) * tx_ - 1 + rx;
         const bool in6 = tile_ < ntiles && (unsigned)ay < (unsigned)H2 && (unsigned)ax < (unsigned)W2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) xin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (H16) {
+            xh[0] = xh[1] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (in6) {
+                const T6* src = x6 + (((size_t)img * H2 + ay) * W2 + ax) * C6 + g * 8;
+                xh[0] = *reinterpret_cast<const h8*>(src);
+                xh[1] = *reinterpret_cast<const h8*>(src + 32);
+            }
+            return;
+        }
         if (in6) {
             const T6* src = x6 + (((size_t)img * H2 + ay) * W2 + ax) * C6 + g * 8;
             if constexpr (sizeof(T6) == 4) {
@@ -181,8 +197,14 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void shading_tail_fwd_kernel(
         // ---- phase 1: X7 tile = relu(transConv2(X6) + bias); lane = (X6 column, 8-channel chunk)
         {
             bf16x8 pf[2][3];
+            h8 ph[2];
+            if constexpr (H16) {
+                ph[0] = xh[0];
+                ph[1] = xh[1];
+            } else {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) split8(xin[2 * s], xin[2 * s + 1], pf[s][0], pf[s][1], pf[s][2]);
+                for (int s = 0; s < 2; ++s) split8(xin[2 * s], xin[2 * s + 1], pf[s][0], pf[s][1], pf[s][2]);
+            }
             load_x6(tile + gridDim.x);   // the next tile's operands fly during this tile's arithmetic
 #pragma unroll
             for (int nq = 0; nq < 4; ++nq) {
@@ -193,10 +215,14 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void shading_tail_fwd_kernel(
                     // A operand: row n = 16 nb + (lane & 15), k chunk 4 s + (lane >> 4)
                     const int r = 16 * nb + rx;
                     const unsigned char* wp = wl + r * 128 + (((4 * s + g) ^ ((r >> 1) & 7)) << 4);
-                    const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wp);
-                    const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wp + 128 * 128);
-                    const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wp + 2 * 128 * 128);
-                    acc = mfma6(w0, w1, w2, pf[s][0], pf[s][1], pf[s][2], acc);
+                    if constexpr (H16) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const h8*>(wp), ph[s], acc, 0, 0, 0);
+                    } else {
+                        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wp);
+                        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wp + 128 * 128);
+                        const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wp + 2 * 128 * 128);
+                        acc = mfma6(w0, w1, w2, pf[s][0], pf[s][1], pf[s][2], acc);
+                    }
                 }
                 // D: column = X6 pixel (lane & 15), rows n = 16 nb + 4 g + e: parity nb >> 1, channels 16 (nb & 1) + 4 g + e
                 f32x4 v;
@@ -288,6 +314,8 @@ __global__ __launch_bounds__(1024, 1) void shading_head_bwd_kernel(const float* 
                                                                    const uint8_t* __restrict__ mask6, T6* __restrict__ p6,
                                                                    const int B, const int H2, const int W2, const int tiles_y,
                                                                    const int tiles_x) {
+    constexpr bool H16 = sizeof(T6) == 2;   // fp16 storage: `w2ts` = ONE [64][128] fp16 matrix, P7 rounded to fp16 as the operand of
+                                            // v_mfma_f32_16x16x32_f16 (the separate launches store P7 as fp16 in HBM: the same rounding)
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* wl = smem;                       // weight planes
     unsigned char* pl = smem + WB_BYTES;            // P7 tile
@@ -300,7 +328,7 @@ __global__ __launch_bounds__(1024, 1) void shading_head_bwd_kernel(const float* 
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)addr);
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, WB_BYTES, 0x00020000);
-        for (int piece = wave; piece < WB_BYTES / 1024; piece += 16) {   // 4 rows per piece
+        for (int piece = wave; piece < (H16 ? WB_BYTES / 3 : WB_BYTES) / 1024; piece += 16) {   // 4 rows per piece
             const int r = piece * 4 + (lane >> 4);
             const int c = (lane & 15) ^ (r & 15);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(wl + piece * 1024), 16, r * 256 + c * 16, 0, 0, 0);
@@ -378,11 +406,15 @@ __global__ __launch_bounds__(1024, 1) void shading_head_bwd_kernel(const float* 
         {
             const int m = 16 * row + rx;
             bf16x8 pf[4][3];
+            h8 ph[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {   // k step s: columns 32 s + 8 g .. + 7 = chunks 8 s + 2 g, + 1
                 const f32x4 u0 = *reinterpret_cast<const f32x4*>(pl + m * 512 + (((8 * s + 2 * g) ^ (m & 31)) << 4));
                 const f32x4 u1 = *reinterpret_cast<const f32x4*>(pl + m * 512 + (((8 * s + 2 * g + 1) ^ (m & 31)) << 4));
-                split8(u0, u1, pf[s][0], pf[s][1], pf[s][2]);
+                if constexpr (H16)
+                    ph[s] = h8{(_Float16)u0[0], (_Float16)u0[1], (_Float16)u0[2], (_Float16)u0[3], (_Float16)u1[0], (_Float16)u1[1], (_Float16)u1[2], (_Float16)u1[3]};
+                else
+                    split8(u0, u1, pf[s][0], pf[s][1], pf[s][2]);
             }
             const int ay = a0 + row, ax = b0 + rx;
             const bool in6 = ay < H2 && ax < W2;
@@ -396,10 +428,14 @@ __global__ __launch_bounds__(1024, 1) void shading_head_bwd_kernel(const float* 
                 for (int s = 0; s < 4; ++s) {
                     const int r = 16 * nb + rx;   // weight row n
                     const unsigned char* wp = wl + r * 256 + (((4 * s + g) ^ (r & 15)) << 4);
-                    const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wp);
-                    const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wp + 64 * 256);
-                    const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wp + 2 * 64 * 256);
-                    acc = mfma6(w0, w1, w2, pf[s][0], pf[s][1], pf[s][2], acc);
+                    if constexpr (H16) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const h8*>(wp), ph[s], acc, 0, 0, 0);
+                    } else {
+                        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wp);
+                        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wp + 64 * 256);
+                        const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wp + 2 * 64 * 256);
+                        acc = mfma6(w0, w1, w2, pf[s][0], pf[s][1], pf[s][2], acc);
+                    }
                 }
                 // D: column = X6 pixel (lane & 15), rows n = 16 nb + 4 g + e: byte 4 nq + g of this half's gate bytes
                 const int n0 = 16 * nb + 4 * g;

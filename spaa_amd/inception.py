@@ -19,6 +19,7 @@ from . import _lib
 from . import convplan as cp
 from .models import USE_GATE_MASKS
 
+PAD32_F32 = int(os.environ.get('SPAA_INCEPTION_PAD32', '1'))
 BODY_GATE_MASKS = os.environ.get('SPAA_BODY_MASKS', '1') != '0'   # 0: the activation itself as the ReLU gate (A/B measurements)
 
 # layer table: name -> builder spec.  conv spec = (name, cout, (kh, kw), stride, (ph, pw))
@@ -154,8 +155,12 @@ class InceptionV3Body:
         hin, win = inp.hw
         ho, wo = _osz(hin, k[0], stride, pad[0]), _osz(win, k[1], stride, pad[1])
         wgt, b = self.folded(name, fold_input_affine)
-        if self.h16:   # 32-channel slices: zero-padded widths (see the module docstring)
-            cout_p = cout if out is not None else -(-cout // 32) * 32
+        # fp32 storage: Conv2d_3b_1x1's 80 channels are built 96 wide as well (SPAA_INCEPTION_PAD32: 0 never, 1 widths above 64 --
+        # the default --, 2 every width): Conv2d_4a_3x3 (80 -> 192, unpadded 3x3 on 73 x 73) then reads whole 32-channel blocks and
+        # runs on the Winograd kernel's pad-0 form instead of the register-staged tile
+        pad32 = self.h16 or (PAD32_F32 == 2 and out is None) or (PAD32_F32 == 1 and out is None and cout > 64)
+        if pad32 or (inp.kind != 'input' and inp.c != wgt.shape[1]):   # 32-channel slices: zero-padded widths (see the module docstring)
+            cout_p = cout if (out is not None or not pad32) else -(-cout // 32) * 32
             cin_p = inp.c if inp.kind != 'input' else wgt.shape[1]
             if cout_p != cout or cin_p != wgt.shape[1]:
                 wp = torch.zeros(cout_p, cin_p, *wgt.shape[2:], dtype=wgt.dtype)

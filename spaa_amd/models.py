@@ -476,6 +476,9 @@ class PCNetEngine:
         self.tail = dict(
             w2s=cp.split_planes(wt.permute(2, 3, 1, 0).reshape(128, 64)).to(dev),      # [3][32 (2 py + px) + c][k]
             w2ts=cp.split_planes(wt.permute(0, 2, 3, 1).reshape(64, 128)).to(dev),     # [3][n][32 (2 py + px) + c]
+            # fp16 storage: the same two matrices rounded to fp16 (one MFMA per product, as the `w_half` of every other layer of the mode)
+            w2h=wt.permute(2, 3, 1, 0).reshape(128, 64).half().contiguous().to(dev) if storage == 'f16' else None,
+            w2th=wt.permute(0, 2, 3, 1).reshape(64, 128).half().contiguous().to(dev) if storage == 'f16' else None,
             w6=w6.permute(0, 2, 3, 1).reshape(3, 9, 32).contiguous().to(dev),          # [o][3 ky + kx][c]
             w6t=w6.flip(2, 3).permute(2, 3, 0, 1).reshape(27, 32).contiguous().to(dev),  # [3 t + o][c], taps mirrored
             b2=sn.transConv2.bias.detach().float().contiguous().to(dev), b6=sn.conv6.bias.detach().float().contiguous().to(dev))
@@ -550,9 +553,9 @@ class PCNetEngine:
             f['transConv1'].run(a['X5'], a['X6'], add=a['R2'], act=R, mask_out=m['X6'])
         if self.fuse_tail:
             t = self.tail
-            f16 = self.storage == 'f16'   # (X6 fp16 in HBM; the activation kept in LDS and the arithmetic stay fp32)
+            f16 = self.storage == 'f16'   # (X6 and the transposed convolution's weights fp16, fp32 accumulation; the activation kept in LDS fp32)
             _lib.call('spaa_shading_tail_fwd_f16' if f16 else 'spaa_shading_tail_fwd', _lib.hptr(a['X6']) if f16 else _lib.ptr(a['X6']),
-                      _lib.ptr(t['w2s']), _lib.ptr(t['b2']), _lib.ptr(t['w6']), _lib.ptr(t['b6']), _lib.ptr(a['R1']), _lib.ptr(a['Y']),
+                      _lib.hptr(t['w2h']) if f16 else _lib.ptr(t['w2s']), _lib.ptr(t['b2']), _lib.ptr(t['w6']), _lib.ptr(t['b6']), _lib.ptr(a['R1']), _lib.ptr(a['Y']),
                       _lib.ptr(a['Ypre']), _lib.ptr(m['X7']), self.B, self.Hc // 2, self.Wc // 2)
             return a['Y']
         x7 = dict.__getitem__(a, 'X7')
@@ -577,6 +580,7 @@ class PCNetEngine:
         if self.fuse_tail:
             t = self.tail
             p6 = _lib.hptr(g['P6']) if self.storage == 'f16' else _lib.ptr(g['P6'])
+            w2t = _lib.hptr(t['w2th']) if self.storage == 'f16' else _lib.ptr(t['w2ts'])
             if select is not None:
                 assert gP is None and self.can_select()
                 ga, gc, state = select
@@ -584,13 +588,13 @@ class PCNetEngine:
                 assert ga.shape == gc.shape == (self.B, self.Hc, self.Wc, 4)
                 assert state.shape == (self.B, 4) and state.dtype == torch.int32 and state.is_contiguous() and state.device == ga.device
                 _lib.call('spaa_shading_head_bwd_select' if self.storage == 'f32' else 'spaa_shading_head_bwd_select_f16', _lib.ptr(ga),
-                          _lib.ptr(gc), _lib.ptr(state), _lib.ptr(self.a['Ypre']), _lib.ptr(t['w6t']), _lib.ptr(t['w2ts']),
+                          _lib.ptr(gc), _lib.ptr(state), _lib.ptr(self.a['Ypre']), _lib.ptr(t['w6t']), w2t,
                           _lib.ptr(m['X7']), _lib.ptr(m['X6']), p6, self.B, self.Hc // 2, self.Wc // 2)
             else:
                 _lib.check_dev(gP)
                 assert gP.shape == (self.B, self.Hc, self.Wc, 4) and gP.dtype == torch.float32
                 _lib.call('spaa_shading_head_bwd' if self.storage == 'f32' else 'spaa_shading_head_bwd_f16', _lib.ptr(gP), _lib.ptr(t['w6t']),
-                          _lib.ptr(t['w2ts']), _lib.ptr(m['X7']), _lib.ptr(m['X6']), p6, self.B, self.Hc // 2, self.Wc // 2)
+                          w2t, _lib.ptr(m['X7']), _lib.ptr(m['X6']), p6, self.B, self.Hc // 2, self.Wc // 2)
         else:
             d['conv6'].run(gP, g['P7'], gate_bits=m['X7'])
             d['transConv2'].run(g['P7'], g['P6'], gate_bits=m['X6'])

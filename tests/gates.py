@@ -143,7 +143,7 @@ def inception_pairs(body, relu_outs):
         for i, r in enumerate(relu_outs):
             if i in used or r.ndim != 4 or (r.shape[0], r.shape[2], r.shape[3]) != tuple(h.shape[:3]):
                 continue
-            if r.shape[1] != h.shape[3] and not (h16 and r.shape[1] < h.shape[3] and -(-r.shape[1] // 32) * 32 == h.shape[3]):
+            if r.shape[1] != h.shape[3] and not (r.shape[1] < h.shape[3] and -(-r.shape[1] // 32) * 32 == h.shape[3]):   # (zero pad channels)
                 continue
             e = float((r.permute(0, 2, 3, 1) - h[..., :r.shape[1]]).abs().max()) / (float(r.abs().max()) + 1e-30)
             if best is None or e < best[1]:
