@@ -121,7 +121,10 @@ typedef struct {
      * out[b, oy, ox, n] += sum_c in2[b, oy, ox, in2_coff + c] * W2[n][c] (weights `w2_split`, Cin2 = 32 or 64).
      * Tiles 70 / 71 (Winograd): the layer's LAST Cin2 input channels (Cin2 % 32 == 0, 0 < Cin2 < Cin) are read from `in2`
      * ([B, Hin, Win, in2_cstride]) instead of `in` -- conv(a, Wa) + conv(b, Wb) as one convolution over the concatenated channels,
-     * `conv5(x4) + skipConv3(x2)` (models.py:294,298); `w2_split` unused (the weights are the layer's own, K = 16 x Cin). */
+     * `conv5(x4) + skipConv3(x2)` (models.py:294,298); `w2_split` unused (the weights are the layer's own, K = 16 x Cin).
+     * Tile 68 (fp16 storage, FOLDED stride-2 transposed layer, nfold = 4, Cout % 16 == 0, fp16 output): the same 1 x 1 convolution
+     * of an fp16 tensor at output resolution; `in2` is fp16 and `w2_split` ONE fp16 matrix [Cout][Cin2] (the weights rounded to fp16
+     * like `w_half`). */
     const float* in2;         /* [B, Hout, Wout, in2_cstride] */
     int32_t in2_cstride, in2_coff, Cin2;   /* Cin2 = 32 or 64 */
     int32_t reserved2;

@@ -232,6 +232,20 @@ class ConvPlan:
         self.bias2 = b          # bias of the fused launch
         return self
 
+    def attach_second_source_h16(self, weight2, bias2=None):
+        """fp16 storage: the same fusion for a FOLDED stride-2 transposed layer on the patch-staged fp16 kernel (tile 68, nfold = 4):
+        `weight2` [Cout, Cin2] rounded to fp16 (as `w_half`).  `run(..., inp2=...)` (fp16 tensors) then adds the 1 x 1 convolution."""
+        assert self.nfold == 4 and len(self.cls) == 1 and self.cout % 16 == 0
+        w2 = weight2.detach().float().reshape(weight2.shape[0], -1).cpu()
+        assert w2.shape[0] == self.cout and w2.shape[1] in (32, 64)
+        self.w2_half = w2.half().contiguous().to(self._dev)
+        self.cin2 = w2.shape[1]
+        b = self.bias.clone() if self.bias is not None else torch.zeros(self.cout, device=self._dev)
+        if bias2 is not None:
+            b = b + bias2.detach().float().to(b.device)
+        self.bias2 = b
+        return self
+
     def thin_fold(self, half):
         """The weights in the folded layout of the thin-output matrix-core kernel: GEMM rows = class * 4 + channel (16 rows; rows of
         taps a class does not have, of absent channels and classes: zero), [channel block][tap column][plane][tap row][16][32
@@ -464,6 +478,15 @@ class ConvPlan:
             if tile not in (70, 71, 73):
                 raise ValueError(f'{self.name}: a two-source plan runs on the Winograd kernel only (fp32 storage, same-size output)')
             d.in2, d.in2_cstride, d.in2_coff, d.Cin2 = inp2.data_ptr(), inp2.shape[3], in2_coff, cin2k
+        elif inp2 is not None and in_f16:
+            # second source of a folded fp16 layer (attach_second_source_h16): the patch-staged fp16 kernel only
+            if getattr(self, 'w2_half', None) is None or not out_f16 or self.nfold != 4:
+                raise ValueError(f'{self.name}: an fp16 second source needs attach_second_source_h16() on a folded stride-2 layer')
+            assert inp2.dtype == torch.float16 and inp2.shape[:3] == out.shape[:3] and in2_coff + self.cin2 <= inp2.shape[3]
+            tile, d.ksplit, d.splitk_ws = 68, 0, None
+            d.in2, d.in2_cstride, d.in2_coff, d.Cin2 = inp2.data_ptr(), inp2.shape[3], in2_coff, self.cin2
+            d.w2_split = self.w2_half.data_ptr()
+            d.bias = self.bias2.data_ptr()
         elif inp2 is not None:
             # second source (attach_second_source): the patch-staged stride-2 kernel only, fp32 storage
             if getattr(self, 'w2_split', None) is None or in_f16 or out_f16 or not self.x6p_ok():
@@ -574,7 +597,7 @@ class ConvPlan:
     def refresh(self, weight, bias=None):
         """Re-pack a parameter that has changed (training): fp32 matrix and, for the bf16x6 kernels, its three bf16
         planes — on the device (needs the maps of `attach_maps`).  Exactly what the constructor does on the host."""
-        if getattr(self, 'w2_split', None) is not None or getattr(self, 'cin2_k', 0):
+        if getattr(self, 'w2_split', None) is not None or getattr(self, 'w2_half', None) is not None or getattr(self, 'cin2_k', 0):
             # a fused second source (attach_second_source / the two-source Winograd plans) keeps packed copies of ANOTHER layer's
             # parameters and a summed bias: re-packing only this layer's would leave them stale -- build the plan again instead
             raise RuntimeError(f'{self.name}: refresh() on a plan with a fused second source; rebuild it (PCNetTrainer builds its '

@@ -169,6 +169,42 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
         }
     }
 
+    // ---- optional SECOND SOURCE of a folded stride-2 transposed layer (nfold = 4): a 1 x 1 convolution of a tensor at OUTPUT
+    // resolution, `in2` [B, Hout, Wout, in2_cstride] fp16 (channels in2_coff .. + Cin2, Cin2 = 32 or 64) through `w2_split` = ONE fp16
+    // matrix [Cout][Cin2], added before bias / residual / activation: ShadingNetSPAA's `transConv1(x5) + skipConv2(x1)`
+    // (/root/reference/src/python/models.py:293,299) and, backward, `conv2^T(g2) + skipConv2^T(g6)` as one launch without the R2 / t1
+    // tensors.  Every element of `in2` is needed once: its fragments go from global memory to registers (as csrc/tapconv_x6p.hip);
+    // GEMM columns n_blk + 16 j .. + 15 lie in ONE parity class (launcher: Cout % 16 == 0), whose output pixel of class-grid pixel
+    // (y, x) is (2 y + cy, 2 x + cx).
+    if (p.in2 != nullptr) {
+        const int row2 = p.in2_cstride * 2;
+        const auto rsrc_in2 = rsrc_or_empty(p.in2, (int64_t)p.B * p.Hout * p.Wout * row2);
+        const auto rsrc_w2 = rsrc_or_empty(p.w2_split, (int64_t)p.Cout * p.Cin2 * 2);
+        const int nk2 = p.Cin2 >> 5;
+        for (int k2 = 0; k2 < nk2; ++k2) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int ng = n_blk + 16 * j;
+                const int fc = ng / p.Cout, n0 = ng - fc * p.Cout;   // (uniform) class and first channel of this 16-column block
+                if (fc >= nfold) break;
+                const int cy = fc >> 1, cx = fc & 1;
+                const h8 wf = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(
+                    rsrc_w2, ((n0 + (lane & 15)) * p.Cin2 + k2 * 32 + 8 * (lane >> 4)) * 2, 0, 0));
+                h8 xf[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int y = oy0 + 2 * wave + (b >> 1), x = ox0 + 16 * (b & 1) + (lane & 15);
+                    const int oy = 2 * y + cy, ox = 2 * x + cx;
+                    const bool ok = y < p.Hm && x < p.Wm && oy < p.Hout && ox < p.Wout;
+                    const int off = ok ? ((img * p.Hout + oy) * p.Wout + ox) * row2 + (p.in2_coff + k2 * 32 + 8 * (lane >> 4)) * 2 : (int)0x80000000;
+                    xf[b] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in2, off, 0, 0));
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[b], acc[b][j], 0, 0, 0);
+            }
+        }
+    }
+
     // ---- epilogue: D layout of a 16x16 block: column (lane & 15) = pixel, rows 4 (lane >> 4) + e = 4 consecutive channels
     const bool vec = !((p.Cout | p.out_cstride | p.out_coff) & 3) &&
                      (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
@@ -271,6 +307,12 @@ int spaa_launch_tapconv_h16p(const spaa_tapconv_t& d, hipStream_t stream) {
                    : (nfold != 4 || d.s_out != 2 || (d.Cout & 3) || d.Hm != (d.Hout + 1) / 2 || d.Wm != (d.Wout + 1) / 2))
         return hipErrorInvalidValue;
     if (d.tap_range[0] < -1 || d.tap_range[1] > 1 || d.tap_range[2] < -1 || d.tap_range[3] > 1) return hipErrorInvalidValue;
+    if (d.in2 != nullptr) {   // second source: folded layers, fp16 in and out, whole 16-column blocks per parity class
+        if (nfold != 4 || d.w2_split == nullptr || (d.Cin2 != 32 && d.Cin2 != 64) || (d.Cout & 15) || !(d.io_dtype & SPAA_IO_OUT_F16) ||
+            (d.in2_cstride & 7) || (d.in2_coff & 7) || d.in2_coff + d.Cin2 > d.in2_cstride ||
+            (int64_t)d.B * d.Hout * d.Wout * d.in2_cstride * 2 >= (int64_t)1 << 31)
+            return hipErrorInvalidValue;
+    }
     if ((int64_t)((d.Cout * nfold + 127) & ~127) * ((d.cls[0].K + 63) & ~63) * 2 >= (int64_t)1 << 31) return hipErrorInvalidValue;
     if ((int64_t)d.B * d.Hin * d.Win * d.in_cstride * 2 >= (int64_t)1 << 31) return hipErrorInvalidValue;
     const int wg_y = (d.Hm + OH - 1) / OH, wg_x = (d.Wm + OW - 1) / OW;

@@ -20,6 +20,7 @@ from . import convplan as cp
 from .models import USE_GATE_MASKS
 
 PAD32_F32 = int(os.environ.get('SPAA_INCEPTION_PAD32', '1'))
+FUSE_ENTRY = os.environ.get('SPAA_INCEPTION_FUSE_ENTRY', '1') != '0'
 BODY_GATE_MASKS = os.environ.get('SPAA_BODY_MASKS', '1') != '0'   # 0: the activation itself as the ReLU gate (A/B measurements)
 
 # layer table: name -> builder spec.  conv spec = (name, cout, (kh, kw), stride, (ph, pw))
@@ -240,9 +241,46 @@ class InceptionV3Body:
                     run_chain(o[2], t, coff + ca)
             return t
 
+        # The 1 x 1 convolutions that OPEN a multi-layer branch read the same block input (C blocks: branch7x7_1 and branch7x7dbl_1;
+        # A: branch5x5_1, branch3x3dbl_1; D: branch3x3_1, branch7x7x3_1; E: branch3x3_1, branch3x3dbl_1): built as ONE convolution whose
+        # output channels are the branches' intermediate tensors side by side in one buffer -- the input is read once instead of twice,
+        # and the backward pass has one accumulating input-gradient launch over the concatenated K instead of two read-modify-write
+        # passes over the block's input gradient (SPAA_INCEPTION_FUSE_ENTRY=0: separate launches, A/B measurements).
+        entries = [bi for bi, br in enumerate(spec) if len(br) > 1 and br[0][0] == 'conv' and br[0][3] == (1, 1) and br[0][4] == 1]
+        heads = {}
+        if FUSE_ENTRY and len(entries) >= 2:
+            ws, bs, widths = [], [], []
+            for bi in entries:
+                o = spec[bi][0]
+                wgt, b = self.folded(f'{name}.{o[1]}')
+                c = o[2]
+                cp_ = -(-c // 32) * 32 if (self.h16 or PAD32_F32 == 2) else c      # (zero pad channels, as add_conv)
+                if cp_ != c:
+                    wgt = torch.cat([wgt, torch.zeros(cp_ - c, *wgt.shape[1:], dtype=wgt.dtype)], 0)
+                    b = torch.cat([b, torch.zeros(cp_ - c, dtype=b.dtype)], 0)
+                ws.append(wgt), bs.append(b), widths.append(cp_)
+            ce = sum(widths)
+            ebuf, gebuf, mebuf = self.z(self.B, hin, win, ce), self.z(self.B, hin, win, ce), self.zm(self.B, hin, win, ce // 4)
+            eout = Ten(ebuf, 0, ce, gebuf, mbuf=mebuf)
+            wcat, bcat = torch.cat(ws, 0), torch.cat(bs, 0)
+            if inp.c != wcat.shape[1]:     # (an input with zero pad channels)
+                wcat = torch.cat([wcat, torch.zeros(ce, inp.c - wcat.shape[1], 1, 1, dtype=wcat.dtype)], 1)
+            op = dict(kind='conv', name=f'{name}.entry', inp=inp, out=eout, outs=[],
+                      f=cp.conv_fwd_plan(wcat, bcat, 1, (0, 0), self.dev, f'{name}.entry'),
+                      d=cp.conv_dgrad_plan(wcat, 1, (0, 0), self.dev, f'{name}.entry_dgrad'))
+            inp.consumers.append(op)
+            self.ops.append(op)
+            eoff = 0
+            for bi, wd in zip(entries, widths):
+                heads[bi] = Ten(ebuf, eoff, wd, gebuf, mbuf=mebuf)
+                op['outs'].append((f'{name}.{spec[bi][0][1]}', heads[bi]))
+                eoff += wd
         coff = 0
-        for br in spec:
-            run_chain(br, inp, coff)
+        for bi, br in enumerate(spec):
+            if bi in heads:
+                run_chain(br[1:], heads[bi], coff)
+            else:
+                run_chain(br, inp, coff)
             coff += out_channels(br)
         return Ten(cat, 0, ctot, gcat, mbuf=mcat)
 

@@ -407,6 +407,20 @@ class PCNetEngine:
                     d['conv2_s'] = cp.conv_dgrad_plan(sn.conv2_s.weight, 2, 1, dev, 'conv2_s_dgrad', fold=False)
                     d['conv2_s'].fixed_tile = 74
                 self.fuse_skip2 = True
+        # fp16 storage: the same two fusions on the patch-staged fp16 kernel's folded form (csrc/tapconv_h16p.hip, second source of a
+        # folded stride-2 transposed layer: skipConv2 101 us + skipConv2^T 64 us of separate launches and the R2 / t1 round trips)
+        if FUSE_SKIP2 and fuse_skip2 is not False and storage == 'f16' and batch * (self.Hc // 4) * (self.Wc // 4) >= FUSE_SKIP2_MIN_PIXELS:
+            tc = cp.deconv_fwd_plan(sn.transConv1.weight, sn.transConv1.bias, 2, 1, dev, 'transConv1+skipConv2', fold=True)
+            c2 = cp.conv_dgrad_plan(sn.conv2.weight, 2, 1, dev, 'conv2_dgrad+skipConv2_dgrad', fold=True)
+            if (tc.nfold == 4 and c2.nfold == 4 and tuple(sn.skipConv2.weight.shape) == (tc.cout, c2.cout, 1, 1) and c2.cout in (32, 64)
+                    and tc.cout in (32, 64)):
+                tc.attach_second_source_h16(sn.skipConv2.weight, sn.skipConv2.bias)
+                c2.attach_second_source_h16(sn.skipConv2.weight.detach()[:, :, 0, 0].t().contiguous(), None)
+                if FUSE_SKIP2 & 1:
+                    f['transConv1x'] = tc
+                if FUSE_SKIP2 & 2:
+                    d['conv2x'] = c2
+                self.fuse_skip2 = True
         # likewise `conv5(x4) + skipConv3(x2)` (models.py:294,298) and `conv3^T(g3) + skipConv3^T(g5)`: one Winograd launch each over
         # the concatenated input channels, read from two tensors (cp.conv_fwd_plan_2src)
         self.fuse_skip3 = False

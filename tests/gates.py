@@ -131,12 +131,14 @@ class record_relu:
 
 
 def inception_pairs(body, relu_outs):
-    """Inception-v3: the HIP body's 94 convolutions (every one followed by a ReLU) are matched with the oracle's recorded
+    """Inception-v3: the HIP body's 94 convolutions' outputs (every one followed by a ReLU) are matched with the oracle's recorded
     ReLU outputs by shape and value (call orders differ inside the mixed blocks)."""
     out, used = [], set()
     h16 = getattr(body, 'h16', False)     # fp16 storage: matching to fp16 accuracy; two layers carry zero pad channels
-    for n, op in enumerate(o for o in body.ops if o['kind'] == 'conv'):
-        t = op['out']
+    # (a fused branch-entry launch, spaa_amd/inception.py add_block, carries its logical outputs -- channel windows -- in 'outs')
+    logical = [(nm, t) for o in body.ops if o['kind'] == 'conv' for nm, t in (o.get('outs') or [(o.get('name'), o['out'])])]
+    for n, (lname, t) in enumerate(logical):
+        op = dict(name=lname)
         hip = t.buf[..., t.coff:t.coff + t.c]
         h = hip.detach().float().cpu()
         best = None

@@ -717,6 +717,45 @@ def test_maxpool3s2_adjoint_blocks(hip, b, c, h, w):
             assert torch.allclose(got, ref, atol=1e-6), gate
 
 
+@pytest.mark.parametrize('dt', [torch.float32, torch.float16])
+@pytest.mark.parametrize('b,c,h,w', [(2, 8, 12, 10), (3, 64, 28, 28), (1, 24, 6, 14)])
+def test_maxpool2x2_window_kernels(hip, b, c, h, w, dt):
+    """spaa_maxpool_fwd / _bwd (and the fp16-storage entries) with kernel 2 / stride 2 / padding 0 on even sides -- VGG-16's pools
+    (classifier.py:21-24 of the reference), a thread per window -- against max_pool2d(relu(x)) and its autograd: pooled values,
+    arg-max codes (first maximum in row-major order; bit 7 = maximum > 0), gated and ungated gradients; a concatenation window as
+    output (channel stride / offset) and ties (whole windows of zeros after the ReLU)."""
+    lib = hip['lib']
+    torch.manual_seed(h * w + c)
+    x = torch.randn(b, c, h, w)
+    x = x.to(dt).float()
+    ho, wo = h // 2, w // 2
+    g = torch.randn(b, c, ho, wo).to(dt).float()
+    xr = x.clone().requires_grad_(True)
+    F.max_pool2d(F.relu(xr), 2, 2).backward(g)
+    xp = F.relu(x).clone().requires_grad_(True)
+    pooled, idx = F.max_pool2d(xp, 2, 2, return_indices=True)
+    pooled.backward(g)
+    f16 = dt == torch.float16
+    sfx = '_f16' if f16 else ''
+    hp = lib.hptr
+    xin = nhwc(F.relu(x), c).to(DEV).to(dt)
+    cs, coff = c + 16, 8
+    out = torch.zeros(b, ho, wo, cs, device=DEV, dtype=dt)
+    arg = torch.zeros(b, ho, wo, c, dtype=torch.uint8, device=DEV)
+    lib.call('spaa_maxpool_fwd' + sfx, hp(xin), hp(out), lib.ptr(arg), b, h, w, c, ho, wo, 2, 2, 0, cs, coff)
+    assert torch.equal(nchw(out[..., coff:coff + c].float().cpu(), c), pooled.detach())
+    assert float(out[..., :coff].abs().max()) == 0 and float(out[..., coff + c:].abs().max()) == 0
+    code = ((idx // w) - 2 * torch.arange(ho).view(1, 1, ho, 1)) * 2 + ((idx % w) - 2 * torch.arange(wo).view(1, 1, 1, wo))
+    want = (code + 128 * (pooled.detach() > 0)).permute(0, 2, 3, 1).to(torch.uint8)
+    assert torch.equal(arg.cpu(), want)
+    gbuf = torch.zeros(b, ho, wo, cs, device=DEV, dtype=dt)
+    gbuf[..., coff:coff + c] = nhwc(g, c).to(DEV).to(dt)
+    for gate, ref in ((1, xr.grad), (0, xp.grad)):
+        gin = torch.full((b, h, w, c), float('nan'), device=DEV, dtype=dt)
+        lib.call('spaa_maxpool_bwd' + sfx, hp(gbuf), lib.ptr(arg), gate, hp(gin), b, h, w, c, ho, wo, 2, 2, 0, cs, coff)
+        assert torch.equal(nchw(gin.float().cpu(), c), ref), gate
+
+
 def test_resnet18_classifier_vs_oracle(hip):
     csd = syn.resnet18_state_dict(2, logit_gain=20.0)
     for (h, crop, insz, b) in [(64, (60, 60), (56, 56), 3), (256, (240, 240), (224, 224), 2)]:
@@ -2167,6 +2206,56 @@ def test_fused_skipconv2_forward_and_backward(hip, cam_sz, prj_sz, b):
         xw = so.warp(sd, x.clamp(0, 1), cam_sz) * sd['mask']
         ref = so.shading_net(sd, xw, (scene, xw * scene))
     assert rel_inf(M.to_nchw(y1), ref) < 1e-5
+
+
+@pytest.mark.parametrize('cam_sz,prj_sz,b', [((64, 64), (64, 64), 3), ((48, 80), (64, 64), 2), ((240, 320), (256, 256), 2)])
+def test_fused_skipconv2_fp16_storage(hip, cam_sz, prj_sz, b):
+    """fp16 storage: `transConv1(x5) + skipConv2(x1)` and `conv2^T(g2) + skipConv2^T(g6)` as single launches of the patch-staged fp16
+    kernel's folded form (csrc/tapconv_h16p.hip, second source) against the engine with the layers launched separately.  Both see
+    the same fp16 operands; the separate launches round the 1 x 1 convolution's result (R2, t1) to fp16 in HBM where the fused
+    launch keeps it in the fp32 accumulators: they differ by that rounding (2^-11 relative per element) and nothing else."""
+    M = hip['models']
+    sd = syn.pcnet_state_dict(5, cam_sz=cam_sz, mask='rect')
+    pc = make_pcnet(hip, sd, cam_sz)
+    old = M.FUSE_SKIP2_MIN_PIXELS
+    try:
+        M.FUSE_SKIP2_MIN_PIXELS = 0
+        e1 = M.PCNetEngine(pc, b, prj_sz, 'f16')
+        e0 = M.PCNetEngine(pc, b, prj_sz, 'f16', fuse_skip2=False)
+    finally:
+        M.FUSE_SKIP2_MIN_PIXELS = old
+    assert e1.fuse_skip2 and not e0.fuse_skip2 and 'transConv1x' in e1.f and 'conv2x' in e1.d
+    torch.manual_seed(b)
+    scene = syn.scenes(3, b, cam_sz)
+    x = torch.rand(b, 3, *prj_sz)
+    g = torch.randn(b, *cam_sz, 4, device=DEV)
+    g[..., 3] = 0
+    outs = []
+    for e in (e1, e0):
+        e.set_scene(M.to_nhwc4(scene.to(DEV)))
+        y = e.forward(M.to_nhwc4(x.to(DEV))).clone()
+        x5, x1 = e.a['X5'].clone(), e.a['X1'].clone()
+        gx = e.backward(g).clone()
+        outs.append((y, gx, e.a['X6'].float().clone(), e.g['P1'].float().clone(), x5, x1, e.g['P2'].clone(), e.g['P6'].clone()))
+    assert e1.f['transConv1x'].last_tile == 68 and e1.d['conv2x'].last_tile == 68
+    (y1, gx1, x61, p11, x51, x11, p21, p61), (y0, gx0, x60, p10, x50, x10, p20, p60) = outs
+    # (the engines differ in the conv1 pair as well -- `fuse_skip2=False` launches conv1_s / conv1 separately -- so X1 / X5 agree to fp16
+    # rounding, not bitwise; the fused layer's own operands are what the fp64 check below uses)
+    assert rel_inf(x51, x50) < 2e-2 and rel_inf(x11, x10) < 2e-3
+    print(f'fp16 fused vs separate at {cam_sz} B={b}: X6 {rel_inf(x61, x60):.1e}, Y {rel_inf(y1, y0):.1e}, P1 rel L2 {rel_l2(p11, p10):.1e}, '
+          f'input gradient rel L2 {rel_l2(gx1, gx0):.1e}')
+    assert rel_inf(x61, x60) < 2e-3 and rel_inf(y1, y0) < 2e-2
+    assert rel_l2(p11, p10) < 5e-2 and rel_l2(gx1, gx0) < 5e-2
+    # the fused forward layer against fp64 arithmetic on the SAME fp16 operands and fp16-rounded weights
+    sn = pc.shading_net
+    wt, w2 = sn.transConv1.weight.detach().half().double().cpu(), sn.skipConv2.weight.detach().half().double().cpu()
+    ref = F.conv_transpose2d(x51.double().cpu().permute(0, 3, 1, 2), wt, sn.transConv1.bias.detach().double().cpu(), 2, 1, 1) \
+        + F.conv2d(x11.double().cpu().permute(0, 3, 1, 2), w2, sn.skipConv2.bias.detach().double().cpu())
+    assert rel_inf(x61.cpu().permute(0, 3, 1, 2), F.relu(ref).float()) < 1.5e-3
+    with torch.no_grad():
+        xw = so.warp(sd, x.clamp(0, 1), cam_sz) * sd['mask']
+        ref = so.shading_net(sd, xw, (scene, xw * scene))
+    assert rel_inf(M.to_nchw(y1), ref) < 2e-2
 
 
 @pytest.mark.parametrize('storage', ['f32', 'f16'])
