@@ -247,7 +247,7 @@ class VGG16Body:
         self.feat_hw = (h, w)
         # ReLU gates of the conv -> conv transitions as byte masks (1 byte per 4 channels, written by the forward epilogue): the input
         # gradient then reads 2 bits per element instead of the activation and stays on the branch-free epilogue
-        # (profiles/r05_modes_vgg16_percal_f16s_tapconv_layers.json: features.2_dgrad 689 us against 477 forward with the activation as gate)
+        # (profiles/r05_configs4_f16s_tapconv_layers.json: features.2_dgrad 689 us against 477 forward with the activation as gate)
         self.masks = BODY_GATE_MASKS and (USE_GATE_MASKS or storage == 'f16')
         self.write_masks = True       # (ClassifierEngine.forward(need_grad=False): a forward pass nobody differentiates skips them)
         for i, op in enumerate(self.ops[:-1]):
