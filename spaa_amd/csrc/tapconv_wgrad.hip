@@ -60,11 +60,12 @@ __global__ __launch_bounds__(64) void wgrad_kernel(const spaa_tapconv_t p, const
     int b = (int)(m / HWm);
     int rr = (int)(m - (int64_t)b * HWm);
     int y = rr / p.Wm, x = rr - y * p.Wm;
-    for (; m < m_end + half; m += 2) {   // (both halves run the same number of iterations: the MFMA needs the whole wave)
-        float a = 0.f, bv[CT];
+    // operands of this lane's pixel m (zeros past the chunk, outside the image, for absent channels) ...
+    auto fetch = [&](const int64_t mm, float& a, float (&bv)[CT]) {
+        a = 0.f;
 #pragma unroll
         for (int j = 0; j < CT; ++j) bv[j] = 0.f;
-        if (m < m_end) {
+        if (mm < m_end) {
             const int oy = cl.oy0 + y * p.s_out, ox = cl.ox0 + x * p.s_out;
             const int iy = y * p.s_in + dy, ix = x * p.s_in + dx;
             if (oy < p.Hout && ox < p.Wout && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) {
@@ -75,8 +76,9 @@ __global__ __launch_bounds__(64) void wgrad_kernel(const spaa_tapconv_t p, const
                     if (c0 + 32 * j + l31 < p.Cin) bv[j] = ip[32 * j];
             }
         }
-#pragma unroll
-        for (int j = 0; j < CT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[j], acc[j], 0, 0, 0);
+    };
+    // ... and the step to the lane's next pixel (two further in row-major order)
+    auto advance = [&]() {
         x += 2;
         while (x >= p.Wm) {
             x -= p.Wm;
@@ -86,6 +88,21 @@ __global__ __launch_bounds__(64) void wgrad_kernel(const spaa_tapconv_t p, const
                 b += 1;
             }
         }
+    };
+    // the operands of pixel pair i + 1 are requested BEFORE the products of pair i are issued (a dependent round trip to L2 / HBM per
+    // pair otherwise: 13.8 ms of the 50 ms training step, profiles/r05_train_step_rocprofv3_kernel_stats.csv); same products in the
+    // same order
+    float a_cur, b_cur[CT];
+    fetch(m, a_cur, b_cur);
+    for (; m < m_end + half; m += 2) {   // (both halves run the same number of iterations: the MFMA needs the whole wave)
+        float a_nxt, b_nxt[CT];
+        advance();
+        fetch(m + 2, a_nxt, b_nxt);
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[j], acc[j], 0, 0, 0);
+        a_cur = a_nxt;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) b_cur[j] = b_nxt[j];
     }
     // D layout: column (lane & 31) = input channel, row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) = output channel
     float* dst = ws + (size_t)blockIdx.y * wtotal + cl.w_off;
@@ -110,7 +127,39 @@ __global__ void chunk_reduce_kernel(const float* __restrict__ ws, float* __restr
     out[i] = s;
 }
 
-// bias gradient partials: block = one pixel chunk, thread = one output channel (coalesced over n)
+// bias gradient partials of one pixel chunk per block, 16-byte loads: thread = (pixel row r of R = 256 / L, channel quad q of L); a
+// thread sums its pixels r, r + R, ... in order, the R rows are added in order through LDS (fixed order: deterministic).  The
+// per-channel form below kept 3 ... 256 threads per block busy with one dependent 4-byte load each (conv6, 3 channels: 560 us for
+// a 201 MB tensor; profiles/r05_train_step_rocprofv3_kernel_stats.csv: 5.05 ms per training step over the 21 layers)
+__global__ __launch_bounds__(256) void bias_partial4_kernel(const float* __restrict__ gout, float* __restrict__ ws, const int64_t npix,
+                                                            const int cstride, const int coff, const int C, const int nchunk) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    __shared__ f4v red[256];
+    const int C4 = (C + 3) >> 2;
+    const int L = C4 < 64 ? C4 : 64, R = 256 / L;
+    const int r = threadIdx.x / L, q0 = threadIdx.x - r * L;
+    const int64_t per = (npix + nchunk - 1) / nchunk;
+    const int64_t m0 = (int64_t)blockIdx.x * per, m1 = m0 + per < npix ? m0 + per : npix;
+    for (int qb = 0; qb < C4; qb += L) {
+        const int q = qb + q0;
+        f4v s = {0.f, 0.f, 0.f, 0.f};
+        if (r < R && q < C4)
+            for (int64_t m = m0 + r; m < m1; m += R) s += *reinterpret_cast<const f4v*>(gout + (size_t)m * cstride + coff + 4 * q);
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (r == 0 && q < C4) {
+            f4v t = red[q0];
+            for (int k = 1; k < R; ++k) t += red[k * L + q0];
+            float* dst = ws + (size_t)blockIdx.x * C + 4 * q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * q + e < C) dst[e] = t[e];
+        }
+        __syncthreads();
+    }
+}
+
+// (the per-channel form: layouts whose channel stride / offset is not a multiple of 4)
 __global__ void bias_partial_kernel(const float* __restrict__ gout, float* __restrict__ ws, const int64_t npix, const int cstride,
                                     const int coff, const int C, const int nchunk) {
     const int64_t per = (npix + nchunk - 1) / nchunk;
@@ -152,8 +201,13 @@ int spaa_tapconv_wgrad(const spaa_tapconv_t* desc, const float* gout, float* dw_
                        nchunk, wtotal);
     if (dbias != nullptr) {
         const int64_t npix = (int64_t)d.B * d.Hout * d.Wout;
-        hipLaunchKernelGGL(bias_partial_kernel, dim3(nchunk), dim3(d.Cout >= 256 ? 256 : ((d.Cout + 63) & ~63)), 0, stream, gout,
-                           workspace, npix, d.out_cstride, d.out_coff, d.Cout, nchunk);
+        // (a 4-channel load past Cout stays inside the pixel's row when the window ends on a multiple of 4 or the row does)
+        if (!(d.out_cstride & 3) && !(d.out_coff & 3) && ((d.out_coff + ((d.Cout + 3) & ~3)) <= d.out_cstride))
+            hipLaunchKernelGGL(bias_partial4_kernel, dim3(nchunk), dim3(256), 0, stream, gout, workspace, npix, d.out_cstride, d.out_coff,
+                               d.Cout, nchunk);
+        else
+            hipLaunchKernelGGL(bias_partial_kernel, dim3(nchunk), dim3(d.Cout >= 256 ? 256 : ((d.Cout + 63) & ~63)), 0, stream, gout,
+                               workspace, npix, d.out_cstride, d.out_coff, d.Cout, nchunk);
         hipLaunchKernelGGL(chunk_reduce_kernel, dim3((d.Cout + 255) / 256), dim3(256), 0, stream, workspace, dbias, nchunk,
                            (int64_t)d.Cout);
     }

@@ -583,11 +583,12 @@ class PCNetEngine:
         cotangents and the clamp gate itself (spaa_shading_head_bwd_select), no spaa_select_grad launch."""
         return bool(self.fuse_tail and (USE_GATE_MASKS or self.storage == 'f16') and FUSE_SELECT)
 
-    def backward(self, gP, select=None):
+    def backward(self, gP, select=None, input_grad=True):
         """gP: gradient w.r.t. conv6's pre-activation (already gated by 0 < Ypre <= 1), [B,Hc,Wc,4]; or None with
         `select` = (g_adv, g_col, state): the two candidate cotangents at the network output [B,Hc,Wc,4] and the loop's state
         int32 [B,4] (projector_based_attack.py:302-315), see `can_select`.
-        Returns the gradient w.r.t. the projector image x4 [B,Hp,Wp,4] (workspace)."""
+        Returns the gradient w.r.t. the projector image x4 [B,Hp,Wp,4] (workspace); `input_grad=False` (the training step: the
+        projector image is data, only the parameters' gradients are wanted) stops at the warped image and returns g['xw']."""
         if not USE_GATE_MASKS and self.storage == 'f32':
             return self._backward_float_gates(gP)
         g, d, m = self.g, self.d, self.m
@@ -630,7 +631,7 @@ class PCNetEngine:
             d['conv2'].run(g['P2'], g['P1'], add=g['t1'], gate_bits=m['X1'])
         if not self.rough:   # the surface branch is a constant: the gradient reaches the warped image through conv1 alone
             d['conv1'].run(g['P1'], g['xw'])
-            return self.warp_backward(g['xw'])
+            return self.warp_backward(g['xw']) if input_grad else g['xw']
         # surface branch (depends on x through the rough input x*s)
         d['conv4_s'].run(g['S4'], g['S3'], add=g['P3'], gate_bits=m['S3'])
         d['conv3_s'].run(g['S3'], g['S2'], add=g['P2'], gate_bits=m['S2'])
@@ -639,7 +640,7 @@ class PCNetEngine:
         # product and the sum are epilogues of the two thin convolutions instead of extra reads in the gather
         d['conv1_s'].run(g['S1'], g['xs'], gate=self.scene, gate_mode=_lib.GATE_MUL)
         d['conv1'].run(g['P1'], g['xw'], add=g['xs'])
-        return self.warp_backward(g['xw'])
+        return self.warp_backward(g['xw']) if input_grad else g['xw']
 
     def _backward_float_gates(self, gP):
         """The same backward pass reading the fp32 activations as gates (SPAA_GATE_MASKS=0: A/B measurements)."""

@@ -234,7 +234,7 @@ class PCNetTrainer:
         # clamp / ReLU gate of the output layer: gradient w.r.t. conv6's pre-activation
         _lib.call('spaa_select_grad', p(lw['gY']), p(lw['gY']), p(self.ones_state), p(eng.a['Ypre']), p(lw['gP']), B, H * W)
         # ---- backward: input gradients (fills every layer's pre-activation gradient), then weight gradients
-        eng.backward(lw['gP'])
+        eng.backward(lw['gP'], input_grad=False)   # (no gradient w.r.t. the projector image: it is data here)
         a, g = eng.a, eng.g
         gr = self.grads
         wplan = self.wg
