@@ -20,6 +20,10 @@ from . import _lib
 from . import convplan as cp
 from .models import to_nhwc4, to_nchw, USE_GATE_MASKS
 
+# 1: ResNet-18's max-pool adjoint as the prologue of the stem's input gradient.  Measured SLOWER (profiles/r05_frontend.txt: stem_dgrad
+# 190 -> 304 us for the 55 us launch it removes -- the patch formed by loads + VALU work in four dependent round trips per channel block
+# where the LDS-DMA of the separate form costs no issue slots): off by default, kept with its bitwise test.
+FUSE_POOL_ADJOINT = os.environ.get('SPAA_FUSE_POOL_ADJOINT', '0') == '1'
 BODY_GATE_MASKS = os.environ.get('SPAA_BODY_MASKS', '1') != '0'   # 0: VGG-16 / Inception-v3 gate with the activation itself (A/B measurements)
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -185,6 +189,11 @@ class ResNet18Body:
         if h16:
             _lib.call('spaa_maxpool_bwd_f16', _lib.hptr(gP), _lib.ptr(self.mp_arg), 1, _lib.hptr(self.g_c1), B, h1, w1, 64,
                       h2, w2, 3, 2, 1, 64, 0)
+        elif FUSE_POOL_ADJOINT and gP.is_contiguous() and gP.shape[3] == 64:
+            # the pool's adjoint as the prologue of the stem's input gradient (csrc/tapconv_thinmf.hip, POOL): g_c1 -- 205 MB at batch
+            # 64 -- is neither written nor read (measured slower, see FUSE_POOL_ADJOINT)
+            self.stem_d.run(gP, self.g_in, pool_adjoint=(self.mp_arg, (h1, w1), True))
+            return self.g_in
         else:
             _lib.call('spaa_maxpool3s2_bwd', _lib.ptr(gP), _lib.ptr(self.mp_arg), 1, _lib.ptr(self.g_c1),
                       B, h1, w1, 64, h2, w2)

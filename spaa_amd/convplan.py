@@ -293,11 +293,14 @@ class ConvPlan:
 
     def run(self, inp, out, add=None, gate=None, gate_mode=_lib.GATE_POS, act=_lib.ACT_NONE, aux_out=None,
             gate2=None, in_coff=0, out_coff=0, add_coff=0, gate_coff=0, mask_out=None, gate_bits=None, gate2_bits=None,
-            inp2=None, in2_coff=0, _wino=None):
+            inp2=None, in2_coff=0, _wino=None, pool_adjoint=None):
         """inp: [B,Hin,Win,Cs_in], out: [B,Hout,Wout,Cs_out] NHWC float32 CUDA tensors.
         `_wino` (internal): (tile, K ranges) of this launch when the plan is the Winograd form of another plan.
         `mask_out` / `gate_bits` / `gate2_bits`: uint8 [B,Hout,Wout,Cs/4] ReLU-gate masks (one byte per 4 channels,
-        include/spaa_hip.h): written for this launch's output resp. read instead of a float `gate` / `gate2`."""
+        include/spaa_hip.h): written for this launch's output resp. read instead of a float `gate` / `gate2`.
+        `pool_adjoint` = (arg-max bytes uint8 [B,Hp,Wp,C], (Hin, Win), relu_gate): `inp` is then the gradient w.r.t. the OUTPUT of a
+        3 x 3 / stride 2 / padding 1 max-pool [B,Hp,Wp,C] whose input (Hin x Win) is this layer's input: the pool's adjoint runs as the
+        prologue of the thin-output matrix-core kernel (tile 72, fp32) instead of as a launch of its own."""
         _lib.check_dev(inp, out, add, gate, aux_out, gate2, inp2, half_ok=True)
         _lib.check_mask(mask_out, gate_bits, gate2_bits)
         in_f16, out_f16 = inp.dtype == torch.float16, out.dtype == torch.float16
@@ -305,6 +308,11 @@ class ConvPlan:
             if t is not None and t.dtype != out.dtype:
                 raise ValueError(f'{self.name}: add / gate / aux_out / gate2 must have the storage type of `out` ({out.dtype})')
         b, hin, win, cs_in = inp.shape
+        if pool_adjoint is not None:
+            parg, (hin, win), pgate = pool_adjoint
+            if (in_f16 or out_f16 or inp2 is not None or parg.dtype != torch.uint8 or tuple(parg.shape) != tuple(inp.shape) or cs_in != self.cin_p
+                    or in_coff or inp.shape[1:3] != ((hin - 1) // 2 + 1, (win - 1) // 2 + 1)):
+                raise ValueError(f'{self.name}: pool_adjoint needs fp32 tensors, arg-max bytes of the pooled gradient\'s shape and a 3/2/1 pool geometry')
         b2, hout, wout, cs_out = out.shape
         cin2k = getattr(self, 'cin2_k', 0)   # (two-source Winograd plan: the last cin2_k input channels come from `inp2`)
         if cin2k and (inp2 is None or inp2.shape[:3] != inp.shape[:3] or inp2.dtype != torch.float32 or in2_coff + cin2k > inp2.shape[3]):
@@ -496,6 +504,10 @@ class ConvPlan:
             d.in2, d.in2_cstride, d.in2_coff, d.Cin2 = inp2.data_ptr(), inp2.shape[3], in2_coff, self.cin2
             d.w2_split = self.w2_split.data_ptr()
             d.bias = self.bias2.data_ptr()
+        if pool_adjoint is not None:
+            if tile != 72:
+                raise ValueError(f'{self.name}: pool_adjoint is served by the thin-output matrix-core kernel only (tile 72; got {tile})')
+            d.in2, d.in2_cstride, d.in2_coff, d.Cin2 = parg.data_ptr(), inp.shape[1], inp.shape[2], int(bool(pgate))
         if tile == 74 and not (self.x6p_ok() and not (in_f16 or out_f16)):
             tile = 0 if forced else self._default_tile(b * d.Hm * d.Wm, winograd=False) % 100
         d.tile = self.last_tile = tile     # (last_tile: for tests and reports)

@@ -584,7 +584,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
     for (int c = 0; c < d.nclass; ++c)
         if ((int64_t)((d.Cout + 127) & ~127) * d.cls[c].Kpad * 4 >= (int64_t)1 << 31) return hipErrorInvalidValue;
     int tile = d.tile;
-    if (d.in2 != nullptr && tile != 74 && tile != 68 && tile != 70 && tile != 71 && tile != 73) return hipErrorInvalidValue;   // (second source: the patch-staged stride-2 kernels and the Winograd kernel)
+    if (d.in2 != nullptr && tile != 74 && tile != 68 && tile != 72 && tile != 70 && tile != 71 && tile != 73) return hipErrorInvalidValue;   // (second source: the patch-staged stride-2 kernels and the Winograd kernel)
     // fp16-storage mode: fp16 inputs only through the h16 kernels; fp16 outputs only through the shared epilogue
     if ((d.io_dtype & SPAA_IO_IN_F16) && !((tile >= 60 && tile <= 65) || tile == 68 || ((tile == 29 || tile == 72) && !(d.io_dtype & SPAA_IO_OUT_F16)))) return hipErrorInvalidValue;
     if (!(d.io_dtype & SPAA_IO_IN_F16) && tile >= 60 && tile <= 63) return hipErrorInvalidValue;

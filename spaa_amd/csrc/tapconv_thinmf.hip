@@ -68,9 +68,16 @@ constexpr int NW = 8;
 // HIN: fp16 input (one weight plane, one MFMA per product); TBH: rows of the tap box (2..4); RW: class-grid rows per wave (the
 // workgroup covers 4 RW rows); PDB: the patch double-buffered over the channel blocks.  fp32 input runs RW = 2 with a SINGLE patch
 // buffer (49 + 24 KiB: two workgroups per CU cover each other's load phases; 3 / double-buffered needs 156 KiB = one per CU)
-template <bool HIN, int TBH, int RW, bool PDB>
+// POOL (fp32 input, single patch buffer): `in` is the gradient w.r.t. the OUTPUT of a 3 x 3 / stride 2 / padding 1 max-pool
+// ([B, Hp, Wp, Cin], Hp = ceil(Hin / 2)) and `in2` that pool's arg-max bytes (code | 0x80 = maximum positive, pool_ops.hip); the
+// patch of the pool's INPUT gradient (the Hin x Win tensor this layer's transposed taps read) is formed here from the up to four
+// windows that cover a pixel -- spaa_maxpool3s2_bwd's gather with the same order of additions -- instead of being read from a tensor
+// that a separate launch wrote: ResNet-18's `maxpool` adjoint as the prologue of the stem's input gradient
+// (/root/reference/src/python/classifier.py:26-28,59-60: 205 MB written and read again per batch-64 iteration otherwise).
+template <bool HIN, int TBH, int RW, bool PDB, bool POOL = false>
 __global__ __launch_bounds__(512, PDB ? 1 : 2) void thinmf_kernel(const spaa_tapconv_t p, const int tiles_y, const int tiles_x, const int TBW,
                                                         const int npieces) {
+    static_assert(!POOL || (!HIN && !PDB), "the pool-adjoint prologue serves the fp32 single-buffer form");
     constexpr int PB = HIN ? 64 : 128;     // bytes of a staged pixel (32 channels)
     constexpr int CPP = PB / 16;           // 16-byte chunks per pixel
     constexpr int PPP = 1024 / PB;         // pixels per 1-KiB piece
@@ -135,6 +142,65 @@ __global__ __launch_bounds__(512, PDB ? 1 : 2) void thinmf_kernel(const spaa_tap
             if (wave + NW * i < npieces && (nshare == 1 || i % nshare == share))
                 dma16(rsrc_in, smem + buf * pbuf + (wave + NW * i) * 1024, pvoff[i], kb * 32 * EB);
     };
+    // POOL: the patch of channel block kb computed from the pooled gradient (item = (patch pixel q, 4-channel group cq): the four
+    // candidate windows' (arg-max byte, gradient) pairs are loaded unconditionally, all of a thread's items in flight together)
+    auto pool_patch = [&](const int kb) {
+        if constexpr (POOL) {
+            const int Hp = p.in2_cstride, Wp = p.in2_coff, C4 = p.Cin >> 2;
+            const unsigned char need = p.Cin2 ? 0x80 : 0x00;    // (Cin2 != 0: only windows whose maximum is positive pass -- the ReLU gate)
+            const uchar4* am_p = reinterpret_cast<const uchar4*>(p.in2);
+            const float4* g_p = reinterpret_cast<const float4*>(p.in);
+            constexpr int NIT = 2;                               // items in flight per thread (2 x 4 windows x 20 bytes)
+            const int nitems = npieces * PPP * 8;
+#pragma unroll 1
+            for (int it0 = 0; it0 < nitems; it0 += 512 * NIT) {
+            uchar4 am[NIT][4];
+            float4 gv[NIT][4];
+            bool wok[NIT][4];
+            unsigned char kk[NIT][4];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int item = it0 + tid + 512 * it, q = item >> 3, cq = item & 7;
+                const int pr = q / PW, pc = q - pr * PW;
+                const int iy = y0 + dy0 + pr, ix = x0 + dx0 + pc;
+                const bool in_img = q < NPX && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                int oyc[2], kyc[2], oxc[2], kxc[2];
+                bool yok[2], xok[2];
+                if (iy & 1) { oyc[0] = (iy + 1) >> 1; kyc[0] = 0; oyc[1] = (iy - 1) >> 1; kyc[1] = 2; yok[0] = oyc[0] < Hp; yok[1] = true; }
+                else        { oyc[0] = iy >> 1; kyc[0] = 1; oyc[1] = 0; kyc[1] = 0; yok[0] = oyc[0] < Hp; yok[1] = false; }
+                if (ix & 1) { oxc[0] = (ix + 1) >> 1; kxc[0] = 0; oxc[1] = (ix - 1) >> 1; kxc[1] = 2; xok[0] = oxc[0] < Wp; xok[1] = true; }
+                else        { oxc[0] = ix >> 1; kxc[0] = 1; oxc[1] = 0; kxc[1] = 0; xok[0] = oxc[0] < Wp; xok[1] = false; }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const bool ok = in_img && yok[i] && xok[j];
+                        const size_t o = (((size_t)img * Hp + (ok ? oyc[i] : 0)) * Wp + (ok ? oxc[j] : 0)) * C4 + kb * 8 + cq;
+                        wok[it][2 * i + j] = ok;
+                        kk[it][2 * i + j] = (unsigned char)(kyc[i] * 3 + kxc[j]);
+                        am[it][2 * i + j] = am_p[o];
+                        gv[it][2 * i + j] = g_p[o];
+                    }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int item = it0 + tid + 512 * it, q = item >> 3, cq = item & 7;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const uchar4 a = am[it][w];
+                    const float4 g = gv[it][w];
+                    const unsigned char k = kk[it][w];
+                    if (wok[it][w] && (a.x & 0x7f) == k && (a.x & need) == need) acc[0] += g.x;
+                    if (wok[it][w] && (a.y & 0x7f) == k && (a.y & need) == need) acc[1] += g.y;
+                    if (wok[it][w] && (a.z & 0x7f) == k && (a.z & need) == need) acc[2] += g.z;
+                    if (wok[it][w] && (a.w & 0x7f) == k && (a.w & need) == need) acc[3] += g.w;
+                }
+                if (q < npieces * PPP) *reinterpret_cast<f32x4*>(smem + q * 128 + ((cq ^ ((q >> 1) & 7)) << 4)) = acc;
+            }
+            }
+        }
+    };
     auto dma_w = [&](const int stage, const int s) {
 #pragma unroll
         for (int i = 0; i < (WST + NW - 1) / NW; ++i)
@@ -147,7 +213,7 @@ __global__ __launch_bounds__(512, PDB ? 1 : 2) void thinmf_kernel(const spaa_tap
 #pragma unroll
     for (int r = 0; r < RW; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    dma_patch(0, 0, 0, 1);
+    if constexpr (POOL) pool_patch(0); else dma_patch(0, 0, 0, 1);
     dma_w(0, 0);
     for (int s = 0; s < nsteps; ++s) {
         const int kb = s / TBW, dxi = s - kb * TBW;
@@ -155,7 +221,7 @@ __global__ __launch_bounds__(512, PDB ? 1 : 2) void thinmf_kernel(const spaa_tap
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            dma_patch(0, kb, 0, 1);
+            if constexpr (POOL) pool_patch(kb); else dma_patch(0, kb, 0, 1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this step's weights, and the patch pieces requested so far, have landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -305,6 +371,22 @@ int spaa_launch_tapconv_thinmf(const spaa_tapconv_t& d, hipStream_t stream) {
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&thinmf_kernel<H, T, R, D>), 160 * 1024, attr_set[SLOT]); \
         if (e != hipSuccess) return (int)e;                                                                                \
         hipLaunchKernelGGL((thinmf_kernel<H, T, R, D>), dim3((unsigned)nwg), dim3(512), smem, stream, d, tiles_y, tiles_x, tbw, npieces); \
+    }
+    if (d.in2 != nullptr) {
+        // pool-adjoint prologue (see the kernel): fp32, `in` = the pooled gradient [B, Hp, Wp, Cin] contiguous, in2 = arg-max bytes,
+        // in2_cstride / in2_coff = Hp / Wp of a 3 x 3 / stride 2 / padding 1 pool over Hin x Win, Cin2 = ReLU gate on / off
+        if (hin || d.in_cstride != d.Cin || d.in_coff != 0 || d.in2_cstride != (d.Hin + 2 - 3) / 2 + 1 || d.in2_coff != (d.Win + 2 - 3) / 2 + 1)
+            return hipErrorInvalidValue;
+#define THINMF_LAUNCH_POOL(T, SLOT)                                                                                        \
+    {                                                                                                                      \
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&thinmf_kernel<false, T, 2, false, true>), 160 * 1024, attr_pool[SLOT]); \
+        if (e != hipSuccess) return (int)e;                                                                                \
+        hipLaunchKernelGGL((thinmf_kernel<false, T, 2, false, true>), dim3((unsigned)nwg), dim3(512), smem, stream, d, tiles_y, tiles_x, tbw, npieces); \
+    }
+        static bool attr_pool[3][SPAA_MAX_DEVICES] = {};
+        if (th == 2) THINMF_LAUNCH_POOL(2, 0) else if (th == 3) THINMF_LAUNCH_POOL(3, 1) else THINMF_LAUNCH_POOL(4, 2)
+#undef THINMF_LAUNCH_POOL
+        return (int)hipGetLastError();
     }
     if (hin) {
         if (th == 2) THINMF_LAUNCH(true, 2, 3, true, 0) else if (th == 3) THINMF_LAUNCH(true, 3, 3, true, 1) else THINMF_LAUNCH(true, 4, 3, true, 2)

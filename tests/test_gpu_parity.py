@@ -756,6 +756,40 @@ def test_maxpool2x2_window_kernels(hip, b, c, h, w, dt):
         assert torch.equal(nchw(gin.float().cpu(), c), ref), gate
 
 
+@pytest.mark.parametrize('b,h,w', [(2, 56, 56), (3, 29, 45), (1, 112, 112)])
+def test_pool_adjoint_as_stem_dgrad_prologue(hip, b, h, w):
+    """ResNet-18's max-pool adjoint as the prologue of the stem's input gradient (csrc/tapconv_thinmf.hip POOL, classifier.py
+    FUSE_POOL_ADJOINT; reference: torchvision maxpool + conv1 behind classifier.py:26-28,59-60): the fused launch against
+    spaa_maxpool3s2_bwd followed by the plain launch -- same windows in the same order of additions, the same matrix-core products:
+    BITWISE equal -- and against autograd of conv(7x7/s2) -> relu -> max_pool2d(3, 2, 1).  Odd sizes: partial windows, ragged tiles."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(h + w)
+    wt = torch.randn(64, 3, 7, 7) / 147 ** 0.5
+    x = torch.randn(b, 3, 2 * h, 2 * w, requires_grad=True)
+    c1 = F.relu(F.conv2d(x, wt, None, 2, 3))
+    assert c1.shape[2:] == (h, w)
+    mp = F.max_pool2d(c1, 3, 2, 1)
+    g = torch.randn_like(mp)
+    mp.backward(g)
+    hp_, wp_ = mp.shape[2:]
+    c1n = nhwc(c1.detach(), 64).to(DEV)
+    out = torch.zeros(b, hp_, wp_, 64, device=DEV)
+    arg = torch.zeros(b, hp_, wp_, 64, dtype=torch.uint8, device=DEV)
+    lib.call('spaa_maxpool3s2_fwd', lib.ptr(c1n), lib.ptr(out), lib.ptr(arg), b, h, w, 64, hp_, wp_)
+    gd = nhwc(g, 64).to(DEV)
+    dplan = cp.conv_dgrad_plan(wt, 2, 3, DEV, 'stem_dgrad_test')
+    g_c1 = torch.zeros(b, h, w, 64, device=DEV)
+    lib.call('spaa_maxpool3s2_bwd', lib.ptr(gd), lib.ptr(arg), 1, lib.ptr(g_c1), b, h, w, 64, hp_, wp_)
+    gin0 = torch.zeros(b, 2 * h, 2 * w, 4, device=DEV)
+    dplan.run(g_c1, gin0)
+    assert dplan.last_tile == 72
+    gin1 = torch.full((b, 2 * h, 2 * w, 4), float('nan'), device=DEV)
+    dplan.run(gd, gin1, pool_adjoint=(arg, (h, w), True))
+    assert dplan.last_tile == 72
+    assert torch.equal(gin1, gin0)
+    assert rel_inf(nchw(gin1.cpu(), 3), x.grad) < 1e-5
+
+
 def test_resnet18_classifier_vs_oracle(hip):
     csd = syn.resnet18_state_dict(2, logit_gain=20.0)
     for (h, crop, insz, b) in [(64, (60, 60), (56, 56), 3), (256, (240, 240), (224, 224), 2)]:
@@ -1955,6 +1989,22 @@ def test_benchmarked_configuration_first_iteration(hip):
     kinds = {tid % 100 for _n, tid in tiles}
     print('kernels of the benchmarked configuration:', sorted(kinds), 'split / canvas launches:', sorted({(n, t) for n, t in tiles if t >= 100})[:12])
     assert {70, 71} & kinds and any(t >= 100 and t % 100 in (70, 71) for _n, t in tiles)   # Winograd incl. its K-range (canvas) form
+
+
+@pytest.mark.parametrize('n_scenes', [4, 12])
+def test_untuned_batch_first_iteration(hip, n_scenes):
+    """Batch sizes the tune table was never measured at (B = 32 and B = 96 at 256 x 256: every layer's kernel is BORROWED from the
+    nearest measured pixel count, spaa_amd/convplan.py tuned_tile, or rule-chosen): one oracle-compared iteration, gate-aware, as
+    for the benchmarked batch -- a caller at such a batch runs on selections no other test exercises."""
+    from spaa_amd import convplan
+    csd = syn.resnet18_state_dict(2, logit_gain=20.0)
+    targets = (list(syn.IMAGENET10_TARGETS) * 8)[:8] * n_scenes
+    before = set(convplan.tune_report()['borrowed'])
+    st = _first_iteration_gate_aware(hip, 'resnet18', csd, (224, 224), (256, 256), (240, 240), targets, 0, scene_seed=2, n_scenes=n_scenes)
+    rep = convplan.tune_report()
+    borrowed = set(rep['borrowed']) - before
+    print(f'B = {8 * n_scenes}: {len(borrowed)} layer shapes borrowed their kernel from another pixel count, {len(rep["untuned"])} rule-chosen in this process')
+    assert st.B == 8 * n_scenes and len(borrowed) >= 10
 
 
 def test_inception_v3_full_input_size_first_iteration(hip):
