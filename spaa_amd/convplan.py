@@ -34,13 +34,13 @@ TILE_NAMES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '128x64a', 5: '128x32',
               48: 'x6d16p_128x128', 49: 'x6d16p_128x64', 50: 'x6d16a3p_128x64', 51: 'x6da3p_128x64', 52: 'x6d16p_256x128',
               53: 'x6d16p_128x32', 54: 'x6dp_128x128',
               60: 'h16_128x128', 61: 'h16_128x64', 62: 'h16_128x32', 63: 'h16_128x16', 64: 'h16_256x128', 65: 'h16_256x256', 68: 'h16p_16x32x128', 72: 'thinmf_12x32',
-              73: 'wino_x6_8x32x64', 74: 'x6p_4x32',
+              73: 'wino_x6_8x32x64', 74: 'x6p_4x32', 76: 'c3conv_16x32',
               70: 'wino_x6_16x32x128', 71: 'wino_x6_16x32x64'}   # (70: the launcher chooses the N tile -- reported as 71 when it took 64; 71: 64-wide forced)
 X6D_TILES = set(range(25, 28)) | set(range(30, 38)) | set(range(39, 47)) | set(range(48, 55))   # DMA-staged bf16x6 kernels (csrc/tapconv_x6d.hip)
 X6D_PERSISTENT = set(range(48, 55))      # ... of which the persistent ones (stream-K capable)
 H16_TILES = set(range(60, 66))           # fp16 implicit-GEMM kernels (csrc/tapconv_h16.hip); 68 = patch-staged 3x3 (tapconv_h16p.hip)
-STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 66)) | {68, 70, 71, 73, 74}  # shared epilogue (epilogue.hpp)
-F16OUT_TILES = set(range(15, 25)) | {38} | set(range(60, 66))  # ... of which these may write fp16 (fp32 image in, fp16 activation out)
+STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 66)) | {68, 70, 71, 73, 74, 76}  # shared epilogue (epilogue.hpp)
+F16OUT_TILES = set(range(15, 25)) | {38, 76} | set(range(60, 66))  # ... of which these may write fp16 (fp32 image in, fp16 activation out)
 DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
 DEBUG_TAPMAJOR = int(os.environ.get('SPAA_X6D_TAPMAJOR', '0'))      # 1: tap-major K order (A/B measurements only)
 DEBUG_PERSIST_CAP = int(os.environ.get('SPAA_X6D_PERSIST_CAP', '0'))  # > 0: persistent launches use this many workgroups
@@ -246,6 +246,28 @@ class ConvPlan:
         self.bias2 = b
         return self
 
+    def c3_ok(self):
+        """First layer of a network for csrc/tapconv_c3.hip (tile 76): a convolution over a 3-channel image (NHWC4, zero lane), one
+        class, stride 1 or 2, at most 64 output channels, 3 x taps products per output within one or five 32-deep steps."""
+        return (len(self.cls) == 1 and self.cin == 3 and self.cin_p == 4 and self.s_out == 1 and self.s_in in (1, 2) and self.cout <= 64
+                and self.nfold == 1 and 3 * self.ntaps_total <= 160)
+
+    def c3_pack(self):
+        """The weights as tile 76 stages them: K = (tap, channel of 3) products only, [NK][3 bf16 planes: w == h + m + l][BN rows][32],
+        16-byte chunk c of row n stored at chunk c ^ ((n >> 3 & 1) << 1) (conflict-free fragment reads); packed on first use."""
+        if getattr(self, '_c3', None) is None:
+            nt, c = self.ntaps_total, self.cls[0]
+            nk, bn = (1 if 3 * nt <= 32 else 5), (32 if self.cout <= 32 else 64)
+            w = self.weights[c['w_off']:c['w_off'] + self._npad * c['Kpad']].view(self._npad, c['Kpad'])[:bn, :4 * nt]
+            w = w.reshape(bn, nt, 4)[:, :, :3].reshape(bn, 3 * nt)
+            w = torch.nn.functional.pad(w, (0, 32 * nk - 3 * nt)).float().cpu()
+            pl = split_planes(w).view(3, bn, nk, 4, 8).permute(2, 0, 1, 3, 4).contiguous()        # [nk][plane][row][chunk][8]
+            n = torch.arange(bn)
+            idx = (torch.arange(4)[None, :] ^ (((n >> 3) & 1) << 1)[:, None])                       # logical chunk held by each slot
+            pl = torch.gather(pl, 3, idx[None, None, :, :, None].expand(nk, 3, bn, 4, 8))
+            self._c3 = pl.contiguous().reshape(-1).to(self._dev)
+        return self._c3
+
     def thin_fold(self, half):
         """The weights in the folded layout of the thin-output matrix-core kernel: GEMM rows = class * 4 + channel (16 rows; rows of
         taps a class does not have, of absent channels and classes: zero), [channel block][tap column][plane][tap row][16][32
@@ -370,6 +392,8 @@ class ConvPlan:
         if forced == 38 and (len(self.cls) != 1 or self.cout > 64 or self.cin_p not in (4, 8) or self.ntaps_total > 9
                              or self.s_in > 2):
             forced = 0
+        if forced == 76 and not self.c3_ok():
+            forced = 0
         if forced in (28, 29, 47) and (self.cout > 4 or self.s_in != 1 or self.cin_p % (32 if forced == 28 else 16)):
             forced = 0
         if forced in X6D_TILES and (self.cin_p % 32 or any(c['Kpad'] != c['K'] for c in self.cls)):
@@ -377,6 +401,8 @@ class ConvPlan:
         if (forced in H16_TILES or forced == 68) and not in_f16:   # fp16 kernels forced (A/B runs) on a layer with fp32 input
             forced = 0
         tile = forced if forced else tuned_tile(key)
+        if tile == 76 and not forced and (not self.c3_ok() or in_f16 or 'c3' in DEFAULT_DISABLE):   # (the key of a first layer, but not a 3-channel image: the rules decide)
+            tile = -1
         if tile < 0:
             tile = self._default_tile(b * d.Hm * d.Wm)
         if cin2k and self.wino is not None and tile % 100 not in (70, 71, 73):
@@ -477,6 +503,10 @@ class ConvPlan:
                 raise ValueError(f'{self.name}: gate masks need a layer shape served by the bf16x6 / smallcin kernels')
         if self.fixed_tile:
             tile, d.ksplit, d.splitk_ws = (_wino[0] if _wino else self.fixed_tile), 0, None
+        if tile == 76:
+            if not self.c3_ok() or in_f16:
+                raise ValueError(f'{self.name}: tile 76 serves 3-channel-image convolutions only')
+            d.w_split = self.c3_pack().data_ptr()
         if tile == 72:
             if in_f16:
                 d.w_half = self.thin_fold(True).data_ptr()
@@ -628,6 +658,7 @@ class ConvPlan:
             self.w_split.copy_(torch.cat(parts))
         self.w_half = None
         self._thin = {}
+        self._c3 = None
         if self.wino is not None:
             _winograd_weights(self, self.wino)
         if bias is not None:

@@ -25,6 +25,7 @@ int spaa_launch_tapconv_h16p(const spaa_tapconv_t& d, hipStream_t stream);      
 int spaa_launch_tapconv_thinmf(const spaa_tapconv_t& d, hipStream_t stream);         // tapconv_thinmf.hip
 int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream);          // tapconv_wino.hip
 int spaa_launch_tapconv_x6p(const spaa_tapconv_t& d, hipStream_t stream);           // tapconv_x6p.hip
+int spaa_launch_tapconv_c3(const spaa_tapconv_t& d, hipStream_t stream);            // tapconv_c3.hip
 int spaa_launch_thinpatch(const spaa_tapconv_t& d, hipStream_t stream);               // thinpatch.hip
 int spaa_launch_smallcin(const spaa_tapconv_t& d, hipStream_t stream);                // smallcin.hip
 
@@ -562,7 +563,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         // byte masks (1 byte per 4 channels): only the epilogues built on epilogue.hpp's store4 know them, and only in its
         // 4-channel-vector form
         const int t = d.tile;
-        if (!((t >= 15 && t <= 27) || (t >= 30 && t <= 46) || (t >= 48 && t <= 54) || (t >= 60 && t <= 65) || t == 68 || t == 70 || t == 71 || t == 73 || t == 74)) return hipErrorInvalidValue;
+        if (!((t >= 15 && t <= 27) || (t >= 30 && t <= 46) || (t >= 48 && t <= 54) || (t >= 60 && t <= 65) || t == 68 || t == 70 || t == 71 || t == 73 || t == 74 || t == 76)) return hipErrorInvalidValue;
         if ((d.Cout | d.out_cstride | d.out_coff) & 3) return hipErrorInvalidValue;
         if (d.add != nullptr && ((d.add_cstride | d.add_coff) & 3)) return hipErrorInvalidValue;
         if (d.gate_bits != nullptr && (d.gate != nullptr || ((d.gate_cstride | d.gate_coff) & 3))) return hipErrorInvalidValue;
@@ -588,7 +589,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
     // fp16-storage mode: fp16 inputs only through the h16 kernels; fp16 outputs only through the shared epilogue
     if ((d.io_dtype & SPAA_IO_IN_F16) && !((tile >= 60 && tile <= 65) || tile == 68 || ((tile == 29 || tile == 72) && !(d.io_dtype & SPAA_IO_OUT_F16)))) return hipErrorInvalidValue;
     if (!(d.io_dtype & SPAA_IO_IN_F16) && tile >= 60 && tile <= 63) return hipErrorInvalidValue;
-    if ((d.io_dtype & SPAA_IO_OUT_F16) && !((tile >= 15 && tile <= 24) || tile == 38 || (tile >= 60 && tile <= 65) || tile == 68))
+    if ((d.io_dtype & SPAA_IO_OUT_F16) && !((tile >= 15 && tile <= 24) || tile == 38 || (tile >= 60 && tile <= 65) || tile == 68 || tile == 76))
         return hipErrorInvalidValue;
     if ((d.io_dtype & SPAA_IO_OUT_F16) && (d.ksplit < 0 || (d.ksplit > 1 && !(tile >= 60 && tile <= 63)))) return hipErrorInvalidValue;  // (fp32 partial sums: only the fp16 kernel's own second pass writes fp16)
     if (d.gate != nullptr && d.gate_mode == SPAA_GATE_MUL && tile < 25) return hipErrorInvalidValue;
@@ -667,6 +668,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
         case 73: return spaa_launch_tapconv_wino(d, stream);
         case 72: return spaa_launch_tapconv_thinmf(d, stream);
         case 74: return spaa_launch_tapconv_x6p(d, stream);
+        case 76: return spaa_launch_tapconv_c3(d, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -268,6 +268,24 @@ __global__ __launch_bounds__(256) void warp_bwd_tiled_kernel(const float4* __res
     const bool direct = ch < 0;
     const int npx = direct ? 0 : ch * cw;
     const size_t HWc = (size_t)Hc * Wc, HWp = (size_t)Hp * Wp;
+    // Every load that does not depend on the staged box is requested BEFORE the box is staged: the list bounds, the first four
+    // list entries and the clamp gate's operand -- four dependent round trips per workgroup (box, bounds, entries, gate) become two
+    // (bounds, then box + entries + gate together).  Same arithmetic in the same order.
+    const int sy = ty * TS + (threadIdx.x >> 4), sx = tx * TS + (threadIdx.x & 15);
+    const bool live = sy < Hp && sx < Wp;
+    const int sp = live ? sy * Wp + sx : 0;
+    const int e0 = live ? off[sp] : 0, e1 = live ? off[sp + 1] : 0;
+    float4 xv[WB];
+#pragma unroll
+    for (int k = 0; k < WB; ++k) xv[k] = (clamp && live) ? x[(size_t)(b0 + k < B ? b0 + k : B - 1) * HWp + sp] : make_float4(0.f, 0.f, 0.f, 0.f);
+    int li0[4];
+    float w0[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ee = e0 + q < e1 ? e0 + q : (e1 > e0 ? e1 - 1 : 0);
+        li0[q] = e1 > e0 ? lidx[ee] : 0;
+        w0[q] = e1 > e0 ? w_e[ee] : 0.f;
+    }
     for (int i = threadIdx.x; i < npx; i += 256) {
         const int r = i / cw, c = i - r * cw;
         const size_t cp = (size_t)(cy0 + r) * Wc + (cx0 + c);
@@ -276,23 +294,26 @@ __global__ __launch_bounds__(256) void warp_bwd_tiled_kernel(const float4* __res
             box[k * box_cap + i] = g_xw[(size_t)(b0 + k < B ? b0 + k : B - 1) * HWc + cp];   // (images past B: a copy of the last, never stored)
     }
     __syncthreads();
-    const int sy = ty * TS + (threadIdx.x >> 4), sx = tx * TS + (threadIdx.x & 15);
-    if (sy >= Hp || sx >= Wp) return;
-    const int sp = sy * Wp + sx;
-    const int e0 = off[sp], e1 = off[sp + 1];
+    if (!live) return;
     float a0[WB], a1[WB], a2[WB];
 #pragma unroll
     for (int k = 0; k < WB; ++k) a0[k] = a1[k] = a2[k] = 0.f;
     // four list entries per round, their (index, weight) pairs loaded together (entries past the list: the last one again with
-    // weight 0 -- a dependent global round trip per entry otherwise; 3.2 entries per pixel on average)
+    // weight 0 -- a dependent global round trip per entry otherwise; 3.2 entries per pixel on average); the first round's were
+    // requested above
     for (int e = e0; e < e1; e += 4) {
         int li[4];
         float w[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int ee = e + q < e1 ? e + q : e1 - 1;
-            li[q] = lidx[ee];
-            w[q] = w_e[ee];
+            if (e == e0) {
+                li[q] = li0[q];
+                w[q] = w0[q];
+            } else {
+                const int ee = e + q < e1 ? e + q : e1 - 1;
+                li[q] = lidx[ee];
+                w[q] = w_e[ee];
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -314,7 +335,7 @@ __global__ __launch_bounds__(256) void warp_bwd_tiled_kernel(const float4* __res
         const size_t o = (size_t)(b0 + k) * HWp + sp;
         float r0 = a0[k], r1 = a1[k], r2 = a2[k];
         if (clamp) {
-            const float4 v = x[o];
+            const float4 v = xv[k];
             r0 = (v.x >= 0.f && v.x <= 1.f) ? r0 : 0.f;
             r1 = (v.y >= 0.f && v.y <= 1.f) ? r1 : 0.f;
             r2 = (v.z >= 0.f && v.z <= 1.f) ? r2 : 0.f;

@@ -141,6 +141,35 @@ def test_directconv_thin_layers(hip, tile):
         cp.FORCE_TILE = 0
 
 
+def test_c3conv_first_layers(hip):
+    """csrc/tapconv_c3.hip (tile 76): the first convolution of the classifier bodies (classifier.py:21-33 of the reference: ResNet-18
+    7 x 7 / stride 2, VGG-16 3 x 3, Inception-v3 3 x 3 / stride 2 without padding) from a 3-channel NHWC4 image -- K = 3 x taps
+    products only, patch and weights staged once -- against conv2d in float64: fp32-accurate (bf16x6, exact operands), fp32 and fp16
+    output, bias + ReLU + gate bytes, ragged tiles, 32 / 48 / 64 output channels."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(76)
+    try:
+        for co, k, s, p, h, w in [(64, 3, 1, 1, 20, 37), (64, 7, 2, 3, 40, 70), (32, 3, 2, 0, 35, 41), (48, 3, 1, 1, 9, 33), (64, 7, 2, 3, 64, 64),
+                                  (64, 5, 1, 2, 17, 19)]:
+            x = torch.randn(2, 3, h, w)
+            wt = torch.randn(co, 3, k, k) / (3 * k * k) ** 0.5
+            bias = torch.randn(co)
+            ref = F.relu(F.conv2d(x.double(), wt.double(), bias.double(), s, p)).float()
+            plan = cp.conv_fwd_plan(wt, bias, s, p, DEV)
+            assert plan.c3_ok()
+            for dt, tol in ((torch.float32, 2e-6), (torch.float16, 1e-3)):
+                out = torch.zeros(2, ref.shape[2], ref.shape[3], co, device=DEV, dtype=dt)
+                mask = torch.zeros(2, ref.shape[2], ref.shape[3], co // 4, device=DEV, dtype=torch.uint8)
+                cp.FORCE_TILE = 76
+                plan.run(nhwc(x, 4).to(DEV), out, act=lib.ACT_RELU, mask_out=mask)
+                cp.FORCE_TILE = 0
+                assert plan.last_tile == 76, plan.last_tile
+                assert rel_inf(nchw(out.float().cpu(), co), ref) < tol, (co, k, s, dt, rel_inf(nchw(out.float().cpu(), co), ref))
+                assert torch.equal(mask.cpu(), lib.pack_gate_mask(out.float().cpu()))
+    finally:
+        cp.FORCE_TILE = 0
+
+
 def test_smallcin_two_output_halves(hip):
     """csrc/smallcin.hip with 33..64 output channels (VGG-16's first layer, classifier.py:21-24): two 32-channel halves over one
     staged patch; fp32 and fp16 output, residual + ReLU + gate bytes, ragged tiles, a channel count that is not a multiple of 32."""
