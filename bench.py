@@ -143,8 +143,9 @@ def cpu_baseline(sd, csd, setup, scenes, budget_b=16, iters=8):
 def pmc_traffic(tile):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py), or None."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
-    path = next((os.path.join(prof, f) for f in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
-                 if os.path.exists(os.path.join(prof, f))), None)
+    # (the latest round's file: rNN_pmc_traffic.json)
+    cands = sorted((f for f in (os.listdir(prof) if os.path.isdir(prof) else []) if re.fullmatch(r'r\d+_pmc_traffic\.json', f)), reverse=True)
+    path = os.path.join(prof, cands[0]) if cands else None
     if path is None:
         return None, None
     m = re.match(r'(x6d(?:16)?(?:co)?(?:a3)?|x6v\d|x6)_(\d+)x(\d+)(?:g(\d))?', tile)
