@@ -337,8 +337,8 @@ class ConvPlan:
                 raise ValueError(f'{self.name}: pool_adjoint needs fp32 tensors, arg-max bytes of the pooled gradient\'s shape and a 3/2/1 pool geometry')
         b2, hout, wout, cs_out = out.shape
         cin2k = getattr(self, 'cin2_k', 0)   # (two-source Winograd plan: the last cin2_k input channels come from `inp2`)
-        if cin2k and (inp2 is None or inp2.shape[:3] != inp.shape[:3] or inp2.dtype != torch.float32 or in2_coff + cin2k > inp2.shape[3]):
-            raise ValueError(f'{self.name}: a two-source plan needs `inp2` [B, H, W, >= {cin2k} channels] (fp32)')
+        if cin2k and (inp2 is None or inp2.shape[:3] != inp.shape[:3] or inp2.dtype != inp.dtype or in2_coff + cin2k > inp2.shape[3]):
+            raise ValueError(f'{self.name}: a two-source plan needs `inp2` [B, H, W, >= {cin2k} channels] of the storage type of `inp`')
         assert b == b2 and cs_in % 4 == 0 and in_coff % 4 == 0 and in_coff + self.cin_p - cin2k <= cs_in
         assert out_coff + self.cout <= cs_out
         d = _lib.TapConv()
@@ -405,8 +405,8 @@ class ConvPlan:
             tile = -1
         if tile < 0:
             tile = self._default_tile(b * d.Hm * d.Wm)
-        if cin2k and self.wino is not None and tile % 100 not in (70, 71, 73):
-            tile = 70      # (two sources: only the Winograd kernel reads them)
+        if cin2k and self.wino is not None and tile % 100 not in (70, 71, 73) and not in_f16:
+            tile = 70      # (two sources: only the Winograd kernel reads them -- and, in fp16 storage, the patch-staged fp16 kernel below)
         thin_mf = (forced in (0, 72) and 'thinmf' not in DEFAULT_DISABLE and not out_f16 and not masked and self.thin_ok())
         if thin_mf and not in_f16:
             # fp32 input (bf16x6: the 3-way operand split costs as much as the products): the stride-2 layers, whose four classes fill
@@ -513,8 +513,10 @@ class ConvPlan:
             else:
                 d.w_split = self.thin_fold(False).data_ptr()
         if cin2k:
-            if tile not in (70, 71, 73):
-                raise ValueError(f'{self.name}: a two-source plan runs on the Winograd kernel only (fp32 storage, same-size output)')
+            if in_f16 and self.nfold == 1:
+                tile, d.ksplit, d.splitk_ws = 68, 0, None      # (fp16 storage: the patch-staged fp16 kernel's two-source form)
+            elif tile not in (70, 71, 73):
+                raise ValueError(f'{self.name}: a two-source plan runs on the Winograd kernel (fp32 storage, same-size output) or the patch-staged fp16 kernel')
             d.in2, d.in2_cstride, d.in2_coff, d.Cin2 = inp2.data_ptr(), inp2.shape[3], in2_coff, cin2k
         elif inp2 is not None and in_f16:
             # second source of a folded fp16 layer (attach_second_source_h16): the patch-staged fp16 kernel only

@@ -554,7 +554,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
     // host-side shape checks: a faulting kernel can take the whole node down
     if (d.in == nullptr || d.out == nullptr || d.weights == nullptr || d.taps == nullptr) return hipErrorInvalidValue;
     // (Winograd with two sources: the last Cin2 of the Cin input channels are read from `in2`)
-    const int cin_main = (d.in2 != nullptr && (d.tile == 70 || d.tile == 71 || d.tile == 73)) ? d.Cin - d.Cin2 : d.Cin;
+    const int cin_main = (d.in2 != nullptr && (d.tile == 70 || d.tile == 71 || d.tile == 73 || (d.tile == 68 && d.nfold <= 1))) ? d.Cin - d.Cin2 : d.Cin;
     if (d.Cin <= 0 || (d.Cin & 3) || (d.in_cstride & 3) || (d.in_coff & 3) || cin_main <= 0 || d.in_coff + cin_main > d.in_cstride)
         return hipErrorInvalidValue;
     if (d.Cout <= 0 || d.out_coff + d.Cout > d.out_cstride) return hipErrorInvalidValue;

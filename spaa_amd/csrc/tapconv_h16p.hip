@@ -89,10 +89,19 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
     typedef const __attribute__((address_space(4))) int* cint_ptr;
     cint_ptr ctaps = (cint_ptr)(uintptr_t)(p.taps + 2 * cl.tap_off);
 
+    // TWO SOURCES (unfolded layers, `in2` set): the layer's LAST Cin2 input channels come from a second tensor of the same B x H x W
+    // -- conv(a, Wa) + conv(b, Wb) as one convolution over the concatenated channels, as the Winograd kernel's two-source form:
+    // `conv5(x4) + skipConv3(x2)` (/root/reference/src/python/models.py:294,298) and `conv3^T(g3) + skipConv3^T(g5)` in fp16 storage
+    const bool two = p.in2 != nullptr && nfold == 1;
+    const int kb1 = two ? (Cin - p.Cin2) >> 5 : 0x7fffffff;      // first channel block of the second source
+    const int row_bytes2 = two ? p.in2_cstride * 2 : 0;
+    const auto rsrc_in2 = two ? rsrc_or_empty(p.in2, (int64_t)p.B * (H * W) * row_bytes2) : rsrc_in;
     // ---- patch staging: piece i (16 consecutive patch pixels) -> wave i % 8; lane -> (pixel lane >> 2, physical chunk lane & 3)
     auto dma_patch = [&](const int buf, const int kb) {
         int ln = lane;
         asm volatile("" : "+v"(ln));   // (per-lane constants recomputed here, not kept in registers across the K loop)
+        const bool s2 = kb >= kb1;     // (uniform)
+        const int rb = s2 ? row_bytes2 : row_bytes, cb = s2 ? (p.in2_coff + (kb - kb1) * 32) * 2 : (p.in_coff + kb * 32) * 2;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int q = (wave + NW * i) * 16 + (ln >> 2);          // patch pixel
@@ -100,8 +109,9 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
             const int iy = oy0 - 1 + pr, ix = ox0 - 1 + pc;
             const bool ok = q < NPX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
             const int c = (ln & 3) ^ swz64(q);
-            const int off = ok ? ((img * H + iy) * W + ix) * row_bytes + (p.in_coff + kb * 32) * 2 + c * 16 : (int)0x80000000;
-            dma16(rsrc_in, smem + buf * PATCH_BYTES + (wave + NW * i) * 1024, off, 0);
+            const int off = ok ? ((img * H + iy) * W + ix) * rb + cb + c * 16 : (int)0x80000000;
+            if (s2) dma16(rsrc_in2, smem + buf * PATCH_BYTES + (wave + NW * i) * 1024, off, 0);
+            else dma16(rsrc_in, smem + buf * PATCH_BYTES + (wave + NW * i) * 1024, off, 0);
         }
     };
     // ---- weights of step (kb, s): taps 3 s .. 3 s + 2; piece q = wave + 8 i -> (tap q / (BN / 16), 16-row block q % (BN / 16))
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
     // tensors.  Every element of `in2` is needed once: its fragments go from global memory to registers (as csrc/tapconv_x6p.hip);
     // GEMM columns n_blk + 16 j .. + 15 lie in ONE parity class (launcher: Cout % 16 == 0), whose output pixel of class-grid pixel
     // (y, x) is (2 y + cy, 2 x + cx).
-    if (p.in2 != nullptr) {
+    if (p.in2 != nullptr && nfold > 1) {
         const int row2 = p.in2_cstride * 2;
         const auto rsrc_in2 = rsrc_or_empty(p.in2, (int64_t)p.B * p.Hout * p.Wout * row2);
         const auto rsrc_w2 = rsrc_or_empty(p.w2_split, (int64_t)p.Cout * p.Cin2 * 2);
@@ -307,7 +317,11 @@ int spaa_launch_tapconv_h16p(const spaa_tapconv_t& d, hipStream_t stream) {
                    : (nfold != 4 || d.s_out != 2 || (d.Cout & 3) || d.Hm != (d.Hout + 1) / 2 || d.Wm != (d.Wout + 1) / 2))
         return hipErrorInvalidValue;
     if (d.tap_range[0] < -1 || d.tap_range[1] > 1 || d.tap_range[2] < -1 || d.tap_range[3] > 1) return hipErrorInvalidValue;
-    if (d.in2 != nullptr) {   // second source: folded layers, fp16 in and out, whole 16-column blocks per parity class
+    if (d.in2 != nullptr && nfold == 1) {   // two sources of an unfolded layer: the last Cin2 channels (whole 32-channel blocks) from `in2`
+        if ((d.Cin2 & 31) || d.Cin2 <= 0 || d.Cin2 >= d.Cin || (d.in2_cstride & 7) || (d.in2_coff & 7) || d.in2_coff + d.Cin2 > d.in2_cstride ||
+            (int64_t)d.B * d.Hin * d.Win * d.in2_cstride * 2 >= (int64_t)1 << 31)
+            return hipErrorInvalidValue;
+    } else if (d.in2 != nullptr) {   // second source: folded layers, fp16 in and out, whole 16-column blocks per parity class
         if (nfold != 4 || d.w2_split == nullptr || (d.Cin2 != 32 && d.Cin2 != 64) || (d.Cout & 15) || !(d.io_dtype & SPAA_IO_OUT_F16) ||
             (d.in2_cstride & 7) || (d.in2_coff & 7) || d.in2_coff + d.Cin2 > d.in2_cstride ||
             (int64_t)d.B * d.Hout * d.Wout * d.in2_cstride * 2 >= (int64_t)1 << 31)

@@ -424,7 +424,7 @@ class PCNetEngine:
         # likewise `conv5(x4) + skipConv3(x2)` (models.py:294,298) and `conv3^T(g3) + skipConv3^T(g5)`: one Winograd launch each over
         # the concatenated input channels, read from two tensors (cp.conv_fwd_plan_2src)
         self.fuse_skip3 = False
-        if FUSE_SKIP2 & 8 and fuse_skip2 is not False and storage == 'f32' and USE_GATE_MASKS and cp.WINOGRAD and self.fuse_skip2:
+        if FUSE_SKIP2 & 8 and fuse_skip2 is not False and (USE_GATE_MASKS or storage == 'f16') and cp.WINOGRAD and self.fuse_skip2:
             c5 = cp.conv_fwd_plan_2src(sn.conv5.weight, sn.skipConv3.weight, sn.conv5.bias.detach() + sn.skipConv3.bias.detach(), dev, 'conv5+skipConv3')
             c3 = cp.conv_dgrad_plan_2src(sn.conv3.weight, sn.skipConv3.weight, dev, 'conv3_dgrad+skipConv3_dgrad')
             if c5 is not None and c3 is not None:

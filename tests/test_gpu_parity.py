@@ -2317,6 +2317,8 @@ def test_fused_skipconv2_fp16_storage(hip, cam_sz, prj_sz, b):
         gx = e.backward(g).clone()
         outs.append((y, gx, e.a['X6'].float().clone(), e.g['P1'].float().clone(), x5, x1, e.g['P2'].clone(), e.g['P6'].clone()))
     assert e1.f['transConv1x'].last_tile == 68 and e1.d['conv2x'].last_tile == 68
+    # (and `conv5(x4) + skipConv3(x2)` / `conv3^T + skipConv3^T` as two-source launches of the same kernel: K-concatenated channels)
+    assert e1.fuse_skip3 and not e0.fuse_skip3 and e1.f['conv5x'].last_tile == 68 and e1.d['conv3x'].last_tile == 68
     (y1, gx1, x61, p11, x51, x11, p21, p61), (y0, gx0, x60, p10, x50, x10, p20, p60) = outs
     # (the engines differ in the conv1 pair as well -- `fuse_skip2=False` launches conv1_s / conv1 separately -- so X1 / X5 agree to fp16
     # rounding, not bitwise; the fused layer's own operands are what the fp64 check below uses)
