@@ -427,7 +427,10 @@ class ConvPlan:
             patch_ok = (len(self.cls) == 1 and 4 <= self.ntaps_total <= 9 and self.s_in == 1 and (hin, win) == (d.Hm, d.Wm)
                         and self.tap_range[0] >= -1 and self.tap_range[1] <= 1 and self.tap_range[2] >= -1 and self.tap_range[3] <= 1
                         and ((self.nfold == 1 and self.s_out == 1) or (self.nfold == 4 and self.s_out == 2)))
-            if forced in H16_TILES or (forced == 68 and patch_ok):
+            # the forward form of a 3 x 3 / stride-2 convolution on the same kernel (S = 2: 8 x 32-pixel tiles, one patch buffer)
+            patch2_ok = (len(self.cls) == 1 and 4 <= self.ntaps_total <= 9 and self.s_in == 2 and self.s_out == 1 and self.nfold == 1
+                         and not cin2k and inp2 is None and self.tap_range[1] - self.tap_range[0] <= 2 and self.tap_range[3] - self.tap_range[2] <= 2)
+            if forced in H16_TILES or (forced == 68 and (patch_ok or patch2_ok)):
                 tile = forced
             elif thin_mf:
                 tile = 72
@@ -441,6 +444,10 @@ class ConvPlan:
                         and b * ((d.Hm + 15) // 16) * ((d.Wm + 31) // 32) * ((ngemm + 127) // 128) >= 256
                         and d.Hm * d.Wm >= 0.6 * ((d.Hm + 15) // 16 * 16) * ((d.Wm + 31) // 32 * 32)):   # (16 x 32-pixel tiles)
                     tile = 68   # 3x3 / stride 1 (or a folded stride-2 transposed layer): the input patch staged once for all taps (csrc/tapconv_h16p.hip)
+                elif (patch2_ok and ngemm >= 64 and 'h16p2' not in DEFAULT_DISABLE and forced == 0
+                      and b * ((d.Hm + 7) // 8) * ((d.Wm + 31) // 32) * ((ngemm + 127) // 128) >= 192
+                      and d.Hm * d.Wm >= 0.6 * ((d.Hm + 7) // 8 * 8) * ((d.Wm + 31) // 32 * 32)):
+                    tile = 68   # 3x3 / stride 2 forward: conv2 / conv2_s, transConv1's input gradient, the classifiers' stride-2 layers
                 elif tile == 60 and 'h16n64' not in DEFAULT_DISABLE and (
                         (m_all + 127) // 128 * ((ngemm + 127) // 128) < 256 or
                         (0 < ngemm % 128 <= 64 and (m_all + 127) // 128 * ((ngemm + 127) // 128) < 1024 and 'h16waste' not in DEFAULT_DISABLE)):

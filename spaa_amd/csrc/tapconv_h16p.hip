@@ -34,15 +34,27 @@ __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rsrc, unsigne
 // chunk swizzle of a 64-byte row (four 16-byte chunks): rows 8 apart swap chunk pairs (tapconv_h16.hip swz64)
 __device__ __forceinline__ int swz64(int r) { return ((r >> 3) & 1) << 1; }
 
-constexpr int OH = 16, OW = 32;                // output pixels of a workgroup
-constexpr int PH = OH + 2, PW = OW + 2;        // input patch 18 x 34
-constexpr int NPX = PH * PW;                   // 612
-constexpr int P_PIECES = (NPX + 15) / 16;      // 1-KiB pieces of 16 pixels x 32 channels (fp16): 39
-constexpr int PPW = (P_PIECES + 7) / 8;        // per wave: 5
-constexpr int PATCH_BYTES = PPW * 8 * 1024;    // 40960 (pieces 39: pad)
+constexpr int OW = 32;                         // output pixel columns of a workgroup
+// S = 1: 16 x 32 output pixels (a wave: two rows = four 16-pixel blocks), patch 18 x 34 pixels = 39 KiB, double-buffered.
+// S = 2 (round 5): the FORWARD form of a 3 x 3 / stride-2 convolution (ShadingNetSPAA.conv2 / conv2_s, models.py:224,230, the input
+// gradient of transConv1, the classifiers' stride-2 3 x 3 layers): 8 x 32 output pixels (a wave: one row = two blocks), patch
+// 17 x 65 pixels = 70 KiB in ONE buffer (reloaded per 32-channel block behind a barrier); the implicit-GEMM kernel gathered every
+// input pixel once per tap that reads it (2.25 times) and ran these byte-bound layers at 140-320 TFLOP/s.
+template <int S> struct h16p_geo {
+    static constexpr int OH = S == 1 ? 16 : 8;
+    static constexpr int NB = S == 1 ? 4 : 2;                        // 16-pixel blocks per wave
+    static constexpr int PH = (OH - 1) * S + 3, PW = (OW - 1) * S + 3;
+    static constexpr int NPX = PH * PW;
+    static constexpr int P_PIECES = (NPX + 15) / 16;                 // 1-KiB pieces of 16 pixels x 32 channels (fp16)
+    static constexpr int PPW = (P_PIECES + 7) / 8;                   // per wave
+    static constexpr int PATCH_BYTES = PPW * 8 * 1024;
+    static constexpr int NBUF = S == 1 ? 2 : 1;
+};
 
-template <int BN>
+template <int BN, int S = 1>
 __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, const int wg_y, const int wg_x, const int n_tiles) {
+    typedef h16p_geo<S> G;
+    constexpr int OH = G::OH, NB = G::NB, PW = G::PW, NPX = G::NPX, PPW = G::PPW, PATCH_BYTES = G::PATCH_BYTES;
     constexpr int TJ = BN / 16;
     constexpr int NW = 8;
     constexpr int W_TAP = BN * 64;                     // one tap's weight rows (32 fp16 each)
@@ -50,7 +62,7 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
     constexpr int WPW = (W_PIECES + NW - 1) / NW;      // 3 (BN = 128) or 2 (BN = 64: 12 pieces, the last four DMA slots are pad)
     constexpr int WS_BYTES = WPW * NW * 1024;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    unsigned char* const wsm = smem + 2 * PATCH_BYTES;
+    unsigned char* const wsm = smem + G::NBUF * PATCH_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -92,6 +104,11 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
     // TWO SOURCES (unfolded layers, `in2` set): the layer's LAST Cin2 input channels come from a second tensor of the same B x H x W
     // -- conv(a, Wa) + conv(b, Wb) as one convolution over the concatenated channels, as the Winograd kernel's two-source form:
     // `conv5(x4) + skipConv3(x2)` (/root/reference/src/python/models.py:294,298) and `conv3^T(g3) + skipConv3^T(g5)` in fp16 storage
+    // patch origin relative to the first sampled pixel of the tile: the layer's first tap (S = 1: always -1: taps within [-1, 1])
+    const int py0 = S == 1 ? -1 : p.tap_range[0], px0 = S == 1 ? -1 : p.tap_range[2];
+    // chunk swizzle of a patch pixel's 64-byte row: S = 1 as the weights' (16 consecutive pixels: conflict-free); S = 2: a fragment
+    // reads every second pixel (128 bytes apart): lane pairs rotate through the four chunks (two-way conflicts at worst)
+    auto pswz = [](const int q) { return S == 1 ? swz64(q) : ((q >> 2) & 3); };
     const bool two = p.in2 != nullptr && nfold == 1;
     const int kb1 = two ? (Cin - p.Cin2) >> 5 : 0x7fffffff;      // first channel block of the second source
     const int row_bytes2 = two ? p.in2_cstride * 2 : 0;
@@ -106,9 +123,9 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
         for (int i = 0; i < PPW; ++i) {
             const int q = (wave + NW * i) * 16 + (ln >> 2);          // patch pixel
             const int pr = q / PW, pc = q - pr * PW;
-            const int iy = oy0 - 1 + pr, ix = ox0 - 1 + pc;
+            const int iy = oy0 * S + py0 + pr, ix = ox0 * S + px0 + pc;
             const bool ok = q < NPX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const int c = (ln & 3) ^ swz64(q);
+            const int c = (ln & 3) ^ pswz(q);
             const int off = ok ? ((img * H + iy) * W + ix) * rb + cb + c * 16 : (int)0x80000000;
             if (s2) dma16(rsrc_in2, smem + buf * PATCH_BYTES + (wave + NW * i) * 1024, off, 0);
             else dma16(rsrc_in, smem + buf * PATCH_BYTES + (wave + NW * i) * 1024, off, 0);
@@ -127,9 +144,9 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
     };
     const int w_addr_l = (lane & 15) * 64 + (((lane >> 4) ^ swz64(lane & 15)) * 16);
 
-    f32x4 acc[4][TJ];
+    f32x4 acc[NB][TJ];
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -140,12 +157,19 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
     if (nsteps > 1) dma_w(1, 0, 1);
     int st = 0;
     for (int kb = 0; kb < nkb; ++kb) {
-        const unsigned char* pb = smem + (kb & 1) * PATCH_BYTES;
+        const unsigned char* pb = smem + (G::NBUF == 2 ? (kb & 1) : 0) * PATCH_BYTES;
         for (int s = 0; s < spk; ++s) {
             const int step = spk * kb + s;
+            if (G::NBUF == 1 && s == 0 && kb > 0) {   // one patch buffer: everybody is done with the previous block's patch
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                dma_patch(0, kb);
+            }
             // this wave's pieces of the step's weights (and, at s == 0, of the block's patch) have landed
-            if (step + 1 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (s != 0 && kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + PPW) : "memory");   // (the next block's patch, requested at s == 0)
+            // (one patch buffer: the block's patch was requested just above, AFTER the next step's weights: everything must have landed)
+            if (step + 1 >= nsteps || (G::NBUF == 1 && s == 0 && kb > 0)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (G::NBUF == 2 && s != 0 && kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + PPW) : "memory");   // (the next block's patch, requested at s == 0)
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -155,24 +179,25 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
                 const int kb2 = (step + 2) / spk, s2 = step + 2 - kb2 * spk;
                 dma_w(st2, kb2, s2);
             }
-            if (s == 0 && kb + 1 < nkb) dma_patch((kb + 1) & 1, kb + 1);
+            if (G::NBUF == 2 && s == 0 && kb + 1 < nkb) dma_patch((kb + 1) & 1, kb + 1);
 #pragma unroll
             for (int tl = 0; tl < 3; ++tl) {
                 if (3 * s + tl >= ntaps) break;   // (uniform: a tap list that is not a multiple of three ends inside a step)
                 const int dy = ctaps[2 * (3 * s + tl)], dx = ctaps[2 * (3 * s + tl) + 1];
-                h8 bf[4];
+                h8 bf[NB];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    // pixel block b = (row 2 wave + (b >> 1), columns 16 (b & 1) ..): patch pixel of this lane's column
-                    const int q = (2 * wave + (b >> 1) + dy + 1) * PW + 16 * (b & 1) + dx + 1 + (lane & 15);
-                    bf[b] = *reinterpret_cast<const h8*>(pb + q * 64 + (((lane >> 4) ^ swz64(q)) << 4));
+                for (int b = 0; b < NB; ++b) {
+                    // pixel block b = (row (NB / 2) wave + (b >> 1), columns 16 (b & 1) ..): patch pixel of this lane's column
+                    const int orow = S == 1 ? 2 * wave + (b >> 1) : wave, ocol = 16 * (b & 1) + (lane & 15);
+                    const int q = (orow * S + dy - py0) * PW + ocol * S + dx - px0;
+                    bf[b] = *reinterpret_cast<const h8*>(pb + q * 64 + (((lane >> 4) ^ pswz(q)) << 4));
                 }
                 const unsigned char* wc = wsm + st * WS_BYTES + tl * W_TAP + w_addr_l;
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
                     const h8 wf = *reinterpret_cast<const h8*>(wc + j * 1024);
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, bf[b], acc[b][j], 0, 0, 0);
+                    for (int b = 0; b < NB; ++b) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, bf[b], acc[b][j], 0, 0, 0);
                 }
             }
             st = st == 2 ? 0 : st + 1;
@@ -186,7 +211,7 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
     // tensors.  Every element of `in2` is needed once: its fragments go from global memory to registers (as csrc/tapconv_x6p.hip);
     // GEMM columns n_blk + 16 j .. + 15 lie in ONE parity class (launcher: Cout % 16 == 0), whose output pixel of class-grid pixel
     // (y, x) is (2 y + cy, 2 x + cx).
-    if (p.in2 != nullptr && nfold > 1) {
+    if constexpr (S == 1) if (p.in2 != nullptr && nfold > 1) {
         const int row2 = p.in2_cstride * 2;
         const auto rsrc_in2 = rsrc_or_empty(p.in2, (int64_t)p.B * p.Hout * p.Wout * row2);
         const auto rsrc_w2 = rsrc_or_empty(p.w2_split, (int64_t)p.Cout * p.Cin2 * 2);
@@ -240,7 +265,7 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
 #define H16P_EPI(T, hb)                                                                                            \
     {                                                                                                              \
         H16P_TO_LDS(hb)                                                                                            \
-        const int oy = oy0 + 2 * wave + (hb);                                                                      \
+        const int oy = oy0 + (NB / 2) * wave + (hb);                                                               \
         if (oy < p.Hm) {                                                                                           \
             const size_t orow = ((size_t)img * p.Hm + oy) * p.Wm + ox0;                                            \
             for (int i = 0; i < 32 / PPI; ++i) {                                                                   \
@@ -258,7 +283,7 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
 #define H16P_EPI_FAST(T, hb)                                                                                       \
     {                                                                                                              \
         H16P_TO_LDS(hb)                                                                                            \
-        const int oy = oy0 + 2 * wave + (hb);                                                                      \
+        const int oy = oy0 + (NB / 2) * wave + (hb);                                                               \
         if (oy < p.Hm) {                                                                                           \
             /* output pixel of class-grid pixel (oy, ox0 + pr): itself, or (2 oy + cy, 2 x + cx) of a folded transposed layer */ \
             const int orow = (img * p.Hout + fs * oy + cy) * p.Wout + fs * ox0 + cx;                               \
@@ -287,14 +312,18 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
         const int fs = nfold > 1 ? 2 : 1, cy = fc >> 1, cx = fc & 1;
         const fast_epi_t fe = make_fast_epi(p, n_ok ? n : 0);
         if (p.io_dtype & SPAA_IO_OUT_F16) {
-            H16P_EPI_FAST(_Float16, 0) H16P_EPI_FAST(_Float16, 1)
+            H16P_EPI_FAST(_Float16, 0)
+            if constexpr (NB == 4) H16P_EPI_FAST(_Float16, 1)
         } else {
-            H16P_EPI_FAST(float, 0) H16P_EPI_FAST(float, 1)
+            H16P_EPI_FAST(float, 0)
+            if constexpr (NB == 4) H16P_EPI_FAST(float, 1)
         }
     } else if (p.io_dtype & SPAA_IO_OUT_F16) {
-        H16P_EPI(_Float16, 0) H16P_EPI(_Float16, 1)
+        H16P_EPI(_Float16, 0)
+        if constexpr (NB == 4) H16P_EPI(_Float16, 1)
     } else {
-        H16P_EPI(float, 0) H16P_EPI(float, 1)
+        H16P_EPI(float, 0)
+        if constexpr (NB == 4) H16P_EPI(float, 1)
     }
 #undef H16P_EPI
 #undef H16P_EPI_FAST
@@ -309,14 +338,22 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
 // taps, GEMM columns = parity class * Cout + channel, output twice the input size); fp16 input, Cin % 32 == 0
 int spaa_launch_tapconv_h16p(const spaa_tapconv_t& d, hipStream_t stream) {
     const int nfold = d.nfold > 1 ? d.nfold : 1;
+    const int S = d.s_in;
     if (!(d.io_dtype & SPAA_IO_IN_F16) || d.w_half == nullptr || (d.Cin % 32) != 0 || d.nclass != 1 || d.cls[0].ntaps < 4 ||
-        d.cls[0].ntaps > 9 || d.cls[0].K != d.cls[0].ntaps * d.Cin || d.s_in != 1 || d.Hm != d.Hin || d.Wm != d.Win ||
-        d.ksplit > 1 || d.ksplit < 0)
+        d.cls[0].ntaps > 9 || d.cls[0].K != d.cls[0].ntaps * d.Cin || (S != 1 && S != 2) || d.ksplit > 1 || d.ksplit < 0)
         return hipErrorInvalidValue;
-    if (nfold == 1 ? (d.s_out != 1 || d.Hm != d.Hout || d.Wm != d.Wout)
-                   : (nfold != 4 || d.s_out != 2 || (d.Cout & 3) || d.Hm != (d.Hout + 1) / 2 || d.Wm != (d.Wout + 1) / 2))
-        return hipErrorInvalidValue;
-    if (d.tap_range[0] < -1 || d.tap_range[1] > 1 || d.tap_range[2] < -1 || d.tap_range[3] > 1) return hipErrorInvalidValue;
+    if (S == 1) {
+        if (d.Hm != d.Hin || d.Wm != d.Win) return hipErrorInvalidValue;
+        if (nfold == 1 ? (d.s_out != 1 || d.Hm != d.Hout || d.Wm != d.Wout)
+                       : (nfold != 4 || d.s_out != 2 || (d.Cout & 3) || d.Hm != (d.Hout + 1) / 2 || d.Wm != (d.Wout + 1) / 2))
+            return hipErrorInvalidValue;
+        if (d.tap_range[0] < -1 || d.tap_range[1] > 1 || d.tap_range[2] < -1 || d.tap_range[3] > 1) return hipErrorInvalidValue;
+    } else {
+        // the forward form of a 3 x 3 / stride-2 convolution: unfolded, one source, taps inside a 3 x 3 box starting at the first tap
+        if (nfold != 1 || d.s_out != 1 || d.Hm != d.Hout || d.Wm != d.Wout || d.in2 != nullptr || d.tap_range[1] - d.tap_range[0] > 2 ||
+            d.tap_range[3] - d.tap_range[2] > 2)
+            return hipErrorInvalidValue;
+    }
     if (d.in2 != nullptr && nfold == 1) {   // two sources of an unfolded layer: the last Cin2 channels (whole 32-channel blocks) from `in2`
         if ((d.Cin2 & 31) || d.Cin2 <= 0 || d.Cin2 >= d.Cin || (d.in2_cstride & 7) || (d.in2_coff & 7) || d.in2_coff + d.Cin2 > d.in2_cstride ||
             (int64_t)d.B * d.Hin * d.Win * d.in2_cstride * 2 >= (int64_t)1 << 31)
@@ -329,20 +366,28 @@ int spaa_launch_tapconv_h16p(const spaa_tapconv_t& d, hipStream_t stream) {
     }
     if ((int64_t)((d.Cout * nfold + 127) & ~127) * ((d.cls[0].K + 63) & ~63) * 2 >= (int64_t)1 << 31) return hipErrorInvalidValue;
     if ((int64_t)d.B * d.Hin * d.Win * d.in_cstride * 2 >= (int64_t)1 << 31) return hipErrorInvalidValue;
+    const int OH = S == 1 ? h16p_geo<1>::OH : h16p_geo<2>::OH;
     const int wg_y = (d.Hm + OH - 1) / OH, wg_x = (d.Wm + OW - 1) / OW;
     const int BN = d.Cout * nfold <= 64 ? 64 : 128;
     const int n_tiles = (d.Cout * nfold + BN - 1) / BN;
     const int64_t nwg = (int64_t)d.B * wg_y * wg_x * n_tiles;
     if (nwg > 0x7fffffff) return hipErrorInvalidValue;
-    static bool attr_set[2][SPAA_MAX_DEVICES] = {};
-#define H16P_LAUNCH(N, SLOT)                                                                                               \
+    static bool attr_set[4][SPAA_MAX_DEVICES] = {};
+#define H16P_LAUNCH(N, SS, SLOT)                                                                                           \
     {                                                                                                                      \
-        const size_t smem = 2 * (size_t)PATCH_BYTES + 3 * (size_t)(((3 * N / 16 + 7) / 8) * 8 * 1024);                     \
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&h16p_kernel<N>), (int)smem, attr_set[SLOT]);      \
+        typedef h16p_geo<SS> G;                                                                                            \
+        const size_t wbytes = 3 * (size_t)(((3 * N / 16 + 7) / 8) * 8 * 1024);                                             \
+        const size_t mainb = G::NBUF * (size_t)G::PATCH_BYTES + wbytes, epib = 8 * 32 * (size_t)(N * 4 + 16);              \
+        const size_t smem = mainb > epib ? mainb : epib;                                                                   \
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&h16p_kernel<N, SS>), (int)smem, attr_set[SLOT]);  \
         if (e != hipSuccess) return (int)e;                                                                                \
-        hipLaunchKernelGGL((h16p_kernel<N>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles);        \
+        hipLaunchKernelGGL((h16p_kernel<N, SS>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles);    \
     }
-    if (BN == 64) H16P_LAUNCH(64, 0) else H16P_LAUNCH(128, 1)
+    if (S == 1) {
+        if (BN == 64) H16P_LAUNCH(64, 1, 0) else H16P_LAUNCH(128, 1, 1)
+    } else {
+        if (BN == 64) H16P_LAUNCH(64, 2, 2) else H16P_LAUNCH(128, 2, 3)
+    }
 #undef H16P_LAUNCH
     return (int)hipGetLastError();
 }

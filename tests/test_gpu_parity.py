@@ -2442,6 +2442,39 @@ def _h(x):
     return x.half().float()
 
 
+def test_h16p_stride2_forward(hip):
+    """The patch-staged fp16 kernel's stride-2 FORWARD form (csrc/tapconv_h16p.hip S = 2: ShadingNetSPAA.conv2 / conv2_s,
+    models.py:224,230 of the reference, the input gradient of transConv1, the classifiers' 3 x 3 / stride-2 layers) against float64
+    on the same fp16 operands: one and several 32-channel blocks (the single patch buffer reloaded), 64- and 128-wide N tiles,
+    padded and unpadded, ragged 8 x 32-pixel tiles, residual + ReLU + gate bytes, fp16 and fp32 output."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(682)
+    try:
+        for ci, co, p, h, w, b in [(32, 64, 1, 44, 70, 2), (64, 128, 1, 37, 41, 2), (96, 192, 0, 35, 35, 1), (32, 64, 1, 128, 128, 1), (128, 96, 1, 20, 66, 2)]:
+            x = _h(torch.randn(b, ci, h, w))
+            wt = _h(torch.randn(co, ci, 3, 3) / (ci * 9) ** 0.5)
+            bias = torch.randn(co)
+            y = F.conv2d(x.double(), wt.double(), bias.double(), 2, p).float()
+            add = _h(torch.randn_like(y))
+            plan = cp.conv_fwd_plan(wt, bias, 2, p, DEV)
+            ho, wo = y.shape[2:]
+            out = torch.zeros(b, ho, wo, co, device=DEV, dtype=torch.float16)
+            mask = torch.zeros(b, ho, wo, co // 4, dtype=torch.uint8, device=DEV)
+            cp.FORCE_TILE = 68
+            plan.run(nhwc(x).half().to(DEV), out, add=nhwc(add, co).half().to(DEV), act=lib.ACT_RELU, mask_out=mask)
+            assert plan.last_tile == 68, (plan.last_tile, ci, co)
+            want = F.relu(y + add)
+            got = nchw(out.float().cpu(), co)
+            assert rel_inf(got, want) < 1.5e-3, (ci, co, p, rel_inf(got, want))
+            assert torch.equal(mask, lib.pack_gate_mask(out.float()))
+            out32 = torch.zeros(b, ho, wo, co, device=DEV)
+            plan.run(nhwc(x).half().to(DEV), out32)
+            cp.FORCE_TILE = 0
+            assert plan.last_tile == 68 and rel_inf(nchw(out32.cpu(), co), y) < 2e-5, (ci, co, p, rel_inf(nchw(out32.cpu(), co), y))
+    finally:
+        cp.FORCE_TILE = 0
+
+
 @pytest.mark.parametrize('tile', [0, 60, 61, 62, 63, 64, 65, 68])
 def test_tapconv_fp16_storage(hip, tile):
     cp, lib = hip['cp'], hip['lib']
