@@ -127,7 +127,8 @@ typedef struct {
      * like `w_half`). */
     const float* in2;         /* [B, Hout, Wout, in2_cstride] */
     int32_t in2_cstride, in2_coff, Cin2;   /* Cin2 = 32 or 64 */
-    int32_t reserved2;
+    int32_t reserved2;        /* tile 74: bit 0 = the classes' tap lists have the canonical k3 / s2 order (csrc/tapconv_x6p.hip STD: the caller
+                                 has compared them; the launcher re-checks what the descriptor shows: tap counts 1 / 2 / 2 / 4, window (0..1)^2) */
     const uint16_t* w2_split; /* W2 as three bf16 planes [3][Npad][Cin2] with w == h + m + l exactly */
 } spaa_tapconv_t;
 

@@ -42,6 +42,7 @@ H16_TILES = set(range(60, 66))           # fp16 implicit-GEMM kernels (csrc/tapc
 STORE4_TILES = set(range(15, 28)) | set(range(30, 47)) | set(range(48, 55)) | set(range(60, 66)) | {68, 70, 71, 73, 74, 76}  # shared epilogue (epilogue.hpp)
 F16OUT_TILES = set(range(15, 25)) | {38, 76} | set(range(60, 66))  # ... of which these may write fp16 (fp32 image in, fp16 activation out)
 DEFAULT_DISABLE = set(os.environ.get('SPAA_DEFAULT_DISABLE', '').split(','))
+X6P_STD = os.environ.get('SPAA_X6P_STD', '1') != '0'   # 0: the stride-2 patch kernel's run-time schedule (A/B measurements)
 DEBUG_TAPMAJOR = int(os.environ.get('SPAA_X6D_TAPMAJOR', '0'))      # 1: tap-major K order (A/B measurements only)
 DEBUG_PERSIST_CAP = int(os.environ.get('SPAA_X6D_PERSIST_CAP', '0'))  # > 0: persistent launches use this many workgroups
 FORCE_KSPLIT = int(os.environ.get('SPAA_FORCE_KSPLIT', '0'))        # split-K factor of the fp16 implicit-GEMM kernel (A/B runs, tests)
@@ -215,6 +216,14 @@ class ConvPlan:
             return False
         # (the kernel fetches the next window position's pixels under the products of class (1, 1): it must have a tap at each)
         return sorted((dy, dx) for dy, dx, _ in self.classes_host[3].taps) == [(dy0, dx0), (dy0, dx1), (dy1, dx0), (dy1, dx1)]
+
+    def x6p_canonical(self):
+        """The (class, tap) structure csrc/tapconv_x6p.hip has compiled in (its STD instantiation): tap window (0..1) x (0..1), class
+        (0,0) = [(0,0)], (0,1) = [(0,1), (0,0)], (1,0) = [(1,0), (0,0)], (1,1) = [(1,1), (1,0), (0,1), (0,0)] -- what a k3 / s2 / p1
+        transposed convolution and the input gradient of a k3 / s2 / p1 convolution give."""
+        want = [[(0, 0)], [(0, 1), (0, 0)], [(1, 0), (0, 0)], [(1, 1), (1, 0), (0, 1), (0, 0)]]
+        return (self.x6p_ok() and tuple(self.tap_range) == (0, 1, 0, 1)
+                and [[(dy, dx) for dy, dx, _ in c.taps] for c in self.classes_host] == want)
 
     def attach_second_source(self, weight2, bias2=None):
         """Fuse a 1 x 1 convolution of a tensor at OUTPUT resolution into this stride-2 layer (tile 74): `weight2` [Cout, Cin2] (Cin2 =
@@ -549,6 +558,8 @@ class ConvPlan:
             d.in2, d.in2_cstride, d.in2_coff, d.Cin2 = parg.data_ptr(), inp.shape[1], inp.shape[2], int(bool(pgate))
         if tile == 74 and not (self.x6p_ok() and not (in_f16 or out_f16)):
             tile = 0 if forced else self._default_tile(b * d.Hm * d.Wm, winograd=False) % 100
+        if tile == 74 and X6P_STD and self.x6p_canonical():
+            d.reserved2 = 1      # (the kernel's compile-time schedule: x6p_canonical)
         d.tile = self.last_tile = tile     # (last_tile: for tests and reports)
         d.reserved0 = (DEBUG_TAPMAJOR | (DEBUG_PERSIST_CAP << 8) | (DEBUG_WINO << 16) | (DEBUG_H16_2STAGE << 25) | (DEBUG_SMALLCIN_NOSLAB << 26)
                        | (((DEBUG_THINMF & 7) << 27) if tile == 72 else 0)

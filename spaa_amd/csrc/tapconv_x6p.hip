@@ -96,7 +96,19 @@ __device__ unsigned long long* g_x6p_stamps = nullptr;
 #define X6P_ABL(bit) 0
 #endif
 
-template <int BN>
+// STD (`reserved2` bit 0, vouched for by spaa_amd/convplan.py which sees the tap lists): the CANONICAL structure of a 3 x 3 / stride-2
+// fractional layer -- tap window (0..1) x (0..1); class 0 = [(0,0)], class 1 = [(0,1), (0,0)], class 2 = [(1,0), (0,0)], class 3 =
+// [(1,1), (1,0), (0,1), (0,0)], which is what ConvTranspose2d(k3, s2, p1, op1) and the input gradient of Conv2d(k3, s2, p1) give.
+// The nine combos' (class, tap, window position) are then compile-time constants: no schedule words, no divisions by the combo
+// count, no per-step scalar loads of the classes' Kpad / w_off from the argument buffer, weight-row offsets by shifts (Kpad =
+// Cin x 1 / 2 / 2 / 4), and the 16-entry tap table with its 68-83 spilled scalar registers is gone.
+constexpr int STD_CLS[9] = {0, 1, 2, 3, 1, 3, 2, 3, 3};     // combo n -> class
+constexpr int STD_TAP[9] = {0, 1, 1, 3, 0, 2, 0, 1, 0};     //         -> tap index inside the class
+constexpr int STD_TIX[4][4] = {{0, -1, -1, -1}, {1, 0, -1, -1}, {1, -1, 0, -1}, {3, 2, 1, 0}};   // [class][window position] -> tap or -1
+constexpr int STD_LG[4] = {0, 1, 1, 2};                     // log2(taps of the class)
+constexpr int STD_WOFF[4] = {0, 1, 3, 5};                   // w_off of the class in units of Npad x Cin
+
+template <int BN, bool STD = false>
 __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p, const int wg_y, const int wg_x, const int n_tiles) {
     constexpr int TJ = BN / 16;
     constexpr int W_PLANE = BN * 64;                  // one plane of a combo: BN rows of 32 bf16
@@ -156,7 +168,9 @@ __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p,
     int tix[4][4];
     unsigned long long sched = 0;
     int ncombo = 0;
-    {
+    if constexpr (STD) {
+        ncombo = 9;
+    } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -216,6 +230,23 @@ __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p,
             dma16(rsrc_w, wsm + stage * WS_BYTES + q * 1024, voff, soff);
         }
     };
+    // STD: per-lane row offsets of this wave's weight pieces for a class with ONE tap (Kpad = Cin); a class with 2 / 4 taps: << 1 / 2
+    int wrow2[WPW], wch16[WPW];
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        const int q = wave + NW * i;
+        const int pl = q / (BN / 16), rb = q - pl * (BN / 16);
+        const int nrow = 16 * rb + (lane >> 2);
+        wrow2[i] = (pl * npad + n_blk + nrow) * Cin * 2;
+        wch16[i] = (((lane & 3) ^ swz_w16(nrow)) << 4) | (q < W_PIECES ? 0 : (int)0x80000000);
+    }
+    const int wcls_bytes = 6 * npad * Cin;     // bytes of the three planes of a one-tap class
+    auto dma_w_std = [&](const int stage, const int kb2, const int n2) {   // (n2: a compile-time constant wherever this is expanded)
+        const int c = STD_CLS[n2], t = STD_TAP[n2];
+        const int soff = STD_WOFF[c] * wcls_bytes + (t * Cin + kb2 * 32) * 2;
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) dma16(rsrc_w, wsm + stage * WS_BYTES + (wave + NW * i) * 1024, (wrow2[i] << STD_LG[c]) + wch16[i], soff);
+    };
     const int w_addr_l = (lane & 15) * 64 + (((lane >> 4) ^ swz_w16(lane & 15)) * 16);
     const int q8 = lane >> 4;
 
@@ -262,10 +293,10 @@ __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p,
     // ---- prologue: second source (if any), then the pipeline's first patch and weight stages
     const int nkb2 = p.in2 != nullptr ? p.Cin2 >> 5 : 0;     // (launcher: 0, 1 or 2 channel blocks)
     dma_patch(0, 0);
-    dma_w(0, 0);
+    if constexpr (STD) dma_w_std(0, 0, 0); else dma_w(0, 0);
     bool w1_issued = false;
     if (nkb2 < 2 && nsteps > 1) {
-        dma_w(1, 1);
+        if constexpr (STD) dma_w_std(1, 0, 1); else dma_w(1, 1);
         w1_issued = true;
     }
     if (nkb2 > 0) {
@@ -348,12 +379,14 @@ __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p,
     for (int kb = 0; kb < nkb; ++kb) {
         const unsigned char* pb = smem + (kb & 1) * PATCH_BYTES;
         const unsigned char* pb_next = smem + ((kb + 1) & 1) * PATCH_BYTES;
+        int nn = 0;   // (STD: the combo index, a compile-time constant in every expanded body)
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if (tix[c][ps] < 0) continue;   // (uniform)
-                const int n = step - kb * ncombo;
+                if ((STD ? STD_TIX[c][ps] : tix[c][ps]) < 0) continue;   // (uniform; STD: resolved at compile time)
+                const int n = STD ? nn : step - kb * ncombo;
+                ++nn;
                 // this wave's pieces of the step's weights (and, at a block's first combo, of its patch) have landed.  Loads
                 // complete in order; issued AFTER this step's weights (two steps ago) are the next combo's pieces and -- on the two
                 // combos that follow a block's first, where the next block's patch was requested right after weights(n + 2) --
@@ -362,7 +395,13 @@ __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p,
 #ifdef SPAA_X6P_STAMP
                 const unsigned long long tw0 = X6P_T();
 #endif
-                if (step + 1 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // (STD: nine combos and three weight stages: the stage of combo n is n % 3, and every condition on `step` is one on
+                // the channel block and the compile-time n)
+                const bool last_step = STD ? (kb + 1 == nkb && n == 8) : step + 1 >= nsteps;
+                const bool two_ahead = STD ? (kb + 1 < nkb || n < 7) : step + 2 < nsteps;
+                const bool first_step = STD ? (kb == 0 && n == 0) : step == 0;
+                if (STD) st = n % 3;
+                if (last_step) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if ((n == 1 || n == 2) && kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + PPW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -378,10 +417,15 @@ __global__ __launch_bounds__(64 * NW, 2) void x6p_kernel(const spaa_tapconv_t p,
                     ts_first += tw1 - tw0;         // vmcnt / lgkmcnt
                 }
 #endif
-                if (step == 0 && !w1_issued && nsteps > 1) dma_w(1, 1);   // (two blocks of second-source weights held its stage)
-                if (step + 2 < nsteps && !X6P_ABL(0)) dma_w(st >= 1 ? st - 1 : 2, step + 2);
+                if constexpr (STD) {
+                    if (first_step && !w1_issued && nsteps > 1) dma_w_std(1, 0, 1);   // (two blocks of second-source weights held its stage)
+                    if (two_ahead && !X6P_ABL(0)) dma_w_std((n + 2) % 3, n + 2 >= 9 ? kb + 1 : kb, (n + 2) % 9);
+                } else {
+                    if (step == 0 && !w1_issued && nsteps > 1) dma_w(1, 1);   // (two blocks of second-source weights held its stage)
+                    if (step + 2 < nsteps && !X6P_ABL(0)) dma_w(st >= 1 ? st - 1 : 2, step + 2);
+                }
                 if (n == 0 && kb + 1 < nkb && !X6P_ABL(0)) dma_patch((kb + 1) & 1, kb + 1);
-                if (step == 0) {   // the very first fragments: nothing to hide them under
+                if (first_step) {   // the very first fragments: nothing to hide them under
                     frag_load(pb, 0, raw);
                     frag_split(raw, pfs[0]);
                 }
@@ -521,16 +565,23 @@ int spaa_launch_tapconv_x6p(const spaa_tapconv_t& d, hipStream_t stream) {
     const int n_tiles = (d.Cout + BN - 1) / BN;
     const int64_t nwg = (int64_t)d.B * wg_y * wg_x * n_tiles;
     if (nwg > 0x7fffffff) return hipErrorInvalidValue;
-    static bool attr_set[2][SPAA_MAX_DEVICES] = {};
-#define X6P_LAUNCH(N, SLOT)                                                                                                \
+    static bool attr_set[4][SPAA_MAX_DEVICES] = {};
+#define X6P_LAUNCH_T(N, T, SLOT)                                                                                           \
     {                                                                                                                      \
         /* (main loop: two patch buffers + three weight stages; epilogue: NW x 32 rows of N * 4 + 16 bytes) */              \
         const size_t smem = (size_t)W_OFF + 3 * (size_t)(((3 * N / 16 + NW - 1) / NW) * NW * 1024);                        \
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&x6p_kernel<N>), (int)smem, attr_set[SLOT]);       \
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&x6p_kernel<N, T>), (int)smem, attr_set[SLOT]);    \
         if (e != hipSuccess) return (int)e;                                                                                \
-        hipLaunchKernelGGL((x6p_kernel<N>), dim3((unsigned)nwg), dim3(64 * NW), smem, stream, d, wg_y, wg_x, n_tiles);         \
+        hipLaunchKernelGGL((x6p_kernel<N, T>), dim3((unsigned)nwg), dim3(64 * NW), smem, stream, d, wg_y, wg_x, n_tiles);      \
     }
-    if (BN == 32) X6P_LAUNCH(32, 0) else X6P_LAUNCH(64, 1)
-#undef X6P_LAUNCH
+    // canonical (class, tap) structure (reserved2 bit 0: the caller has checked the tap lists; here: what the descriptor shows of it)
+    const bool std_ok = (d.reserved2 & 1) && d.cls[0].ntaps == 1 && d.cls[1].ntaps == 2 && d.cls[2].ntaps == 2 && d.cls[3].ntaps == 4 &&
+                        d.tap_range[0] == 0 && d.tap_range[1] == 1 && d.tap_range[2] == 0 && d.tap_range[3] == 1;
+    if (std_ok) {
+        if (BN == 32) X6P_LAUNCH_T(32, true, 2) else X6P_LAUNCH_T(64, true, 3)
+    } else {
+        if (BN == 32) X6P_LAUNCH_T(32, false, 0) else X6P_LAUNCH_T(64, false, 1)
+    }
+#undef X6P_LAUNCH_T
     return (int)hipGetLastError();
 }

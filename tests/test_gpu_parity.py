@@ -406,6 +406,16 @@ def test_patch_staged_stride2_kernel(hip, kind, ci, co, h, w, b, ci2):
         out2 = torch.zeros_like(out)
         plan.run(xin, out2, **kw)
         assert torch.equal(out, out2)
+        # the compile-time schedule (STD: these layers have the canonical tap order) against the run-time one: the same products in
+        # the same order, bit for bit
+        assert plan.x6p_canonical() and cp.X6P_STD
+        cp.X6P_STD = False
+        try:
+            out3 = torch.zeros_like(out)
+            plan.run(xin, out3, **kw)
+        finally:
+            cp.X6P_STD = True
+        assert torch.equal(out, out3)
         add, gate = torch.randn(b, co, ho, wo), torch.randn(b, co, ho, wo)
         mask = torch.zeros(b, ho, wo, co // 4, dtype=torch.uint8, device=DEV)
         plan.run(xin, out, add=nhwc(add).to(DEV), act=lib.ACT_RELU, mask_out=mask, **kw)
