@@ -114,21 +114,27 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
     const int row_bytes2 = two ? p.in2_cstride * 2 : 0;
     const auto rsrc_in2 = two ? rsrc_or_empty(p.in2, (int64_t)p.B * (H * W) * row_bytes2) : rsrc_in;
     // ---- patch staging: piece i (16 consecutive patch pixels) -> wave i % 8; lane -> (pixel lane >> 2, physical chunk lane & 3)
+    // (round 5: the pixel index and chunk of a lane's PPW pieces are computed ONCE -- the per-block recomputation, a division by the
+    // patch width per piece, and the per-tap fragment addresses below were 168 VALU instructions per 96-MFMA step: as many issue
+    // cycles as the MFMAs themselves)
+    int ppix[PPW], pch16[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int q = (wave + NW * i) * 16 + (lane >> 2);          // patch pixel
+        const int pr = q / PW, pc = q - pr * PW;
+        const int iy = oy0 * S + py0 + pr, ix = ox0 * S + px0 + pc;
+        const bool ok = q < NPX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        ppix[i] = ok ? (img * H + iy) * W + ix : -1;
+        pch16[i] = ((lane & 3) ^ pswz(q)) << 4;
+    }
     auto dma_patch = [&](const int buf, const int kb) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));   // (per-lane constants recomputed here, not kept in registers across the K loop)
         const bool s2 = kb >= kb1;     // (uniform)
         const int rb = s2 ? row_bytes2 : row_bytes, cb = s2 ? (p.in2_coff + (kb - kb1) * 32) * 2 : (p.in_coff + kb * 32) * 2;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            const int q = (wave + NW * i) * 16 + (ln >> 2);          // patch pixel
-            const int pr = q / PW, pc = q - pr * PW;
-            const int iy = oy0 * S + py0 + pr, ix = ox0 * S + px0 + pc;
-            const bool ok = q < NPX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const int c = (ln & 3) ^ pswz(q);
-            const int off = ok ? ((img * H + iy) * W + ix) * rb + cb + c * 16 : (int)0x80000000;
-            if (s2) dma16(rsrc_in2, smem + buf * PATCH_BYTES + (wave + NW * i) * 1024, off, 0);
-            else dma16(rsrc_in, smem + buf * PATCH_BYTES + (wave + NW * i) * 1024, off, 0);
+            const int off = ppix[i] >= 0 ? ppix[i] * rb + pch16[i] : (int)0x80000000;
+            if (s2) dma16(rsrc_in2, smem + buf * PATCH_BYTES + (wave + NW * i) * 1024, off, cb);
+            else dma16(rsrc_in, smem + buf * PATCH_BYTES + (wave + NW * i) * 1024, off, cb);
         }
     };
     // ---- weights of step (kb, s): taps 3 s .. 3 s + 2; piece q = wave + 8 i -> (tap q / (BN / 16), 16-row block q % (BN / 16))
@@ -143,6 +149,23 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
         }
     };
     const int w_addr_l = (lane & 15) * 64 + (((lane >> 4) ^ swz64(lane & 15)) * 16);
+    // fragment address (inside a patch buffer) of every (tap, pixel block) of this lane: the taps are read once here
+    // (pixel block b = (row (NB / 2) wave + (b >> 1), columns 16 (b & 1) ..).  The second column block is 16 S patch pixels further:
+    // the same chunk swizzle (bits 3 resp. 2-3 of q unchanged by + 16 / + 32), so its address is the first's + 1024 S bytes -- an
+    // immediate offset; one register per (tap, row))
+    constexpr int NR = NB / 2;
+    int faddr[9][NR];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const bool has = t < ntaps;
+        const int dy = has ? ctaps[2 * t] : py0, dx = has ? ctaps[2 * t + 1] : px0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int orow = S == 1 ? 2 * wave + r : wave, ocol = lane & 15;
+            const int q = (orow * S + dy - py0) * PW + ocol * S + dx - px0;
+            faddr[t][r] = q * 64 + (((lane >> 4) ^ pswz(q)) << 4);
+        }
+    }
 
     f32x4 acc[NB][TJ];
 #pragma unroll
@@ -158,7 +181,9 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
     int st = 0;
     for (int kb = 0; kb < nkb; ++kb) {
         const unsigned char* pb = smem + (G::NBUF == 2 ? (kb & 1) : 0) * PATCH_BYTES;
-        for (int s = 0; s < spk; ++s) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {   // (expanded: the tap index 3 s + tl below is a constant, `faddr` stays in registers)
+            if (s >= spk) break;
             const int step = spk * kb + s;
             if (G::NBUF == 1 && s == 0 && kb > 0) {   // one patch buffer: everybody is done with the previous block's patch
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -180,24 +205,33 @@ __global__ __launch_bounds__(512, 1) void h16p_kernel(const spaa_tapconv_t p, co
                 dma_w(st2, kb2, s2);
             }
             if (G::NBUF == 2 && s == 0 && kb + 1 < nkb) dma_patch((kb + 1) & 1, kb + 1);
+            // software pipeline over the step's (tap, 16-channel block) units: the weight fragment of unit u + 1 and, at a tap's first
+            // unit, the pixel fragments of the NEXT tap are requested before unit u's MFMAs are issued (the compiler's own order was
+            // read -> wait for all of LDS -> four MFMAs -> read ...: a full LDS round trip per four MFMAs, the matrix cores at a third)
+            h8 bfs[2][NB], wfs[2];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) bfs[0][b] = *reinterpret_cast<const h8*>(pb + faddr[3 * s][b >> 1] + (b & 1) * (1024 * S));
+            wfs[0] = *reinterpret_cast<const h8*>(wsm + st * WS_BYTES + w_addr_l);
 #pragma unroll
             for (int tl = 0; tl < 3; ++tl) {
                 if (3 * s + tl >= ntaps) break;   // (uniform: a tap list that is not a multiple of three ends inside a step)
-                const int dy = ctaps[2 * (3 * s + tl)], dx = ctaps[2 * (3 * s + tl) + 1];
-                h8 bf[NB];
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    // pixel block b = (row (NB / 2) wave + (b >> 1), columns 16 (b & 1) ..): patch pixel of this lane's column
-                    const int orow = S == 1 ? 2 * wave + (b >> 1) : wave, ocol = 16 * (b & 1) + (lane & 15);
-                    const int q = (orow * S + dy - py0) * PW + ocol * S + dx - px0;
-                    bf[b] = *reinterpret_cast<const h8*>(pb + q * 64 + (((lane >> 4) ^ pswz(q)) << 4));
-                }
+                const bool more = tl + 1 < 3 && 3 * s + tl + 1 < ntaps;   // (uniform) another tap in this step
                 const unsigned char* wc = wsm + st * WS_BYTES + tl * W_TAP + w_addr_l;
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
-                    const h8 wf = *reinterpret_cast<const h8*>(wc + j * 1024);
+                    const int u = tl * TJ + j;
+                    if (j + 1 < TJ) wfs[(u + 1) & 1] = *reinterpret_cast<const h8*>(wc + (j + 1) * 1024);
+                    else if (more) wfs[(u + 1) & 1] = *reinterpret_cast<const h8*>(wc + W_TAP);
+                    if (j == 0 && more) {
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, bf[b], acc[b][j], 0, 0, 0);
+                        for (int b = 0; b < NB; ++b)
+                            bfs[(tl + 1) & 1][b] = *reinterpret_cast<const h8*>(pb + faddr[3 * s + tl + 1][b >> 1] + (b & 1) * (1024 * S));
+                    }
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfs[u & 1], bfs[tl & 1][b], acc[b][j], 0, 0, 0);
+                    // order: this unit's LDS reads (for the units to come) first, then its MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x100, NB + 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NB, 0);
                 }
             }
             st = st == 2 ? 0 : st + 1;
