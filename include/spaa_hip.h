@@ -112,7 +112,9 @@ typedef struct {
                              SPAA_IO_OUT_F16 (tiles 60..65, 68, and the kernels that read fp32 IMAGES: 15..24, 38):
                                              `out`, `add`, `gate`, `aux_out`, `gate2` are fp16.
                              0 = everything fp32 (the default path; dtype "f32" in bench.py). */
-    int32_t reserved1;
+    int32_t reserved1;    /* tile 68: bit 2 = the canvas / K-range form (small images with long K: spaa_tapconv_h16p_plan below; `ksplit` > 1 with
+                             `splitk_ws` = that many K ranges), bits 0-1 = its N tile (0 chosen, 1 = 64, 2 = 128), bit 3 (tests) = canvases wherever they
+                             have fewer regions, bit 4 (A/B runs) = 64-wide stride-1 layers as ONE workgroup per compute unit.  0 otherwise. */
     int32_t nclass;
     spaa_tapclass_t cls[SPAA_MAX_CLASSES];
     /* optional SECOND SOURCE (NULL = none).
@@ -151,6 +153,12 @@ int spaa_tapconv_wgrad(const spaa_tapconv_t* desc, const float* gout, float* dw_
  * (plan[1] * B * H * W * Npad floats) from the plan and passes plan[1] back as `ksplit` (ksplit = 1: never split; 0 with a
  * workspace: the launcher's own choice, which this function reports). */
 int spaa_tapconv_wino_plan(const spaa_tapconv_t* desc, int32_t* plan);
+/* The same query for the canvas / K-range form of the patch-staged fp16 kernel (tile 68 with `reserved1` bit 2: 3 x 3 / stride-1 layers of
+ * the fp16-storage classifiers on 14 x 14 and 7 x 7 maps -- ResNet-18 layer3 / layer4, VGG-16's last block; classifier.py:26-28,
+ * perc_al/__init__.py:181-238): plan[0..7] as above.  `desc->ksplit` > 1 asks for that many K ranges, 1 for none, 0 leaves the choice to
+ * the plan; `reserved1` bits 0-1 likewise for the N tile.  The caller passes plan[1] back as `ksplit` (with `splitk_ws` of plan[1] * B * H *
+ * W * Npad floats when > 1) and plan[0] in `reserved1`. */
+int spaa_tapconv_h16p_plan(const spaa_tapconv_t* desc, int32_t* plan);
 /* layout probes for language bindings: sizeof(spaa_tapconv_t) and the byte offset of field # `field`
  * (0 out, 1 weights, 2 taps, 3 gate2, 4 mask_out, 5 tap_range, 6 splitk_ws, 7 io_dtype, 8 nclass, 9 cls, 10 in2, 11 w2_split; else -1) */
 int spaa_tapconv_sizeof(void);

@@ -116,7 +116,7 @@ _SIGNATURES = {
     'spaa_zero': [_p, _l, _p],
 }
 
-EXPORTS = sorted(list(_SIGNATURES) + ['spaa_version', 'spaa_tapconv_sizeof', 'spaa_tapconv_offsetof', 'spaa_tapconv_wino_plan'])
+EXPORTS = sorted(list(_SIGNATURES) + ['spaa_version', 'spaa_tapconv_sizeof', 'spaa_tapconv_offsetof', 'spaa_tapconv_wino_plan', 'spaa_tapconv_h16p_plan'])
 
 _lib = None
 
@@ -140,6 +140,8 @@ def load():
     lib.spaa_tapconv_offsetof.restype = C.c_int
     lib.spaa_tapconv_wino_plan.argtypes = [C.POINTER(TapConv), C.POINTER(C.c_int32)]   # (host-side query: no stream)
     lib.spaa_tapconv_wino_plan.restype = C.c_int
+    lib.spaa_tapconv_h16p_plan.argtypes = [C.POINTER(TapConv), C.POINTER(C.c_int32)]   # (host-side query: no stream)
+    lib.spaa_tapconv_h16p_plan.restype = C.c_int
     _lib = lib
     return lib
 

@@ -51,6 +51,7 @@ DEBUG_WINO_NOCANVAS = int(os.environ.get('SPAA_WINO_NOCANVAS', '0'))  # 1: small
 WINO_SPLITK = os.environ.get('SPAA_WINO_SPLITK', '1') != '0'        # Winograd layers with few workgroups and long K: K ranges + ordered second pass
 DEBUG_THINMF = int(os.environ.get('SPAA_THINMF_DBG', '0'))           # timing experiments of csrc/tapconv_thinmf.hip (builds with -DSPAA_THINMF_ABLATE)
 DEBUG_SMALLCIN_NOSLAB = int(os.environ.get('SPAA_SMALLCIN_NOSLAB', '0'))  # 1: stride-2 smallcin layers store from the MFMA layout (A/B)
+H16P_CV = tuple(int(v) for v in os.environ.get('SPAA_H16P_CV', '0,0,0').split(','))   # (N tile 0 = chosen / 64 / 128, K ranges 0 = chosen, 1 = canvases wherever they have fewer regions: tests) of the patch-staged fp16 kernel's canvas / K-range form (A/B runs)
 DEBUG_H16_2STAGE = int(os.environ.get('SPAA_H16_2STAGE', '0'))      # 1: the fp16 implicit-GEMM kernel never takes its four-stage form (A/B measurements)
 FOLD_K3S2 = os.environ.get('SPAA_FOLD_K3S2', '1') != '0'   # 3x3 / s2 input gradients with few output channels: classes folded
 FOLD_K3S2_MAX_COUT = 32
@@ -431,10 +432,15 @@ class ConvPlan:
                 return self.wino.run(inp, out, add, gate, gate_mode, act, aux_out, gate2, in_coff, out_coff, add_coff, gate_coff,
                                      mask_out, gate_bits, gate2_bits, inp2, in2_coff, _wino=(tile % 100, tile // 100))
             tile = 0 if forced else self._default_tile(b * d.Hm * d.Wm, winograd=False)
+        h16p_cv = False
         if in_f16:    # fp16 activations: the h16 kernels, N tile by the GEMM's width
             ngemm = self.cout * self.nfold
-            patch_ok = (len(self.cls) == 1 and 4 <= self.ntaps_total <= 9 and self.s_in == 1 and (hin, win) == (d.Hm, d.Wm)
-                        and self.tap_range[0] >= -1 and self.tap_range[1] <= 1 and self.tap_range[2] >= -1 and self.tap_range[3] <= 1
+            same_ok = ((hin, win) == (d.Hm, d.Wm) and self.tap_range[0] >= -1 and self.tap_range[1] <= 1 and self.tap_range[2] >= -1
+                       and self.tap_range[3] <= 1)
+            # (unfolded stride-1 layers: any 3 x 3 tap window -- the unpadded 3 x 3 layers of Inception-v3's stem and their input gradients)
+            span_ok = (self.nfold == 1 and self.s_out == 1 and self.tap_range[1] - self.tap_range[0] <= 2 and self.tap_range[3] - self.tap_range[2] <= 2
+                       and 'h16pvalid' not in DEFAULT_DISABLE)
+            patch_ok = (len(self.cls) == 1 and 4 <= self.ntaps_total <= 9 and self.s_in == 1 and (same_ok or span_ok)
                         and ((self.nfold == 1 and self.s_out == 1) or (self.nfold == 4 and self.s_out == 2)))
             # the forward form of a 3 x 3 / stride-2 convolution on the same kernel (S = 2: 8 x 32-pixel tiles, one patch buffer)
             patch2_ok = (len(self.cls) == 1 and 4 <= self.ntaps_total <= 9 and self.s_in == 2 and self.s_out == 1 and self.nfold == 1
@@ -457,6 +463,11 @@ class ConvPlan:
                       and b * ((d.Hm + 7) // 8) * ((d.Wm + 31) // 32) * ((ngemm + 127) // 128) >= 192
                       and d.Hm * d.Wm >= 0.6 * ((d.Hm + 7) // 8 * 8) * ((d.Wm + 31) // 32 * 32)):
                     tile = 68   # 3x3 / stride 2 forward: conv2 / conv2_s, transConv1's input gradient, the classifiers' stride-2 layers
+                elif (patch_ok and same_ok and self.nfold == 1 and not cin2k and inp2 is None and ngemm >= 64 and self.cin_p >= 64 and forced == 0
+                      and 'h16pcv' not in DEFAULT_DISABLE and m_all < (1 << 24) and max(d.Hm, d.Wm) <= 254):
+                    # small images / few regions with long K (ResNet-18 layer3 / layer4, VGG-16's 14 x 14 block at batch 64): the
+                    # patch-staged kernel's canvas / K-range form (the launcher's plan, asked for below: it needs the workspace)
+                    tile, h16p_cv = 68, True
                 elif tile == 60 and 'h16n64' not in DEFAULT_DISABLE and (
                         (m_all + 127) // 128 * ((ngemm + 127) // 128) < 256 or
                         (0 < ngemm % 128 <= 64 and (m_all + 127) // 128 * ((ngemm + 127) // 128) < 1024 and 'h16waste' not in DEFAULT_DISABLE)):
@@ -592,9 +603,33 @@ class ConvPlan:
                 if self._ws is None or self._ws.numel() < need:
                     self._ws = torch.empty(need, device=inp.device, dtype=torch.float32)
                 d.splitk_ws = self._ws.data_ptr()
+        if tile == 68 and h16p_cv:
+            # the launcher's plan of the canvas / K-range form (csrc/tapconv_h16p.hip), cached per launch shape like the Winograd plans
+            d.reserved1 = 4 | {0: 0, 64: 1, 128: 2}[H16P_CV[0]] | (8 if len(H16P_CV) > 2 and H16P_CV[2] else 0)
+            d.ksplit, d.splitk_ws = H16P_CV[1], None
+            pkey = ('h16p', b, hin, win, cs_in, d.reserved1, d.ksplit)
+            wp = self._wino_plans.get(pkey)
+            if wp is None:
+                wpc = (C.c_int32 * 8)()
+                rc = _lib.load().spaa_tapconv_h16p_plan(C.byref(d), wpc)
+                if rc != 0:
+                    raise RuntimeError(f'{self.name}: spaa_tapconv_h16p_plan failed with HIP error {rc}')
+                wp = self._wino_plans[pkey] = tuple(wpc)
+            d.ksplit = wp[1]
+            d.reserved1 = (d.reserved1 & 8) | 4 | {64: 1, 128: 2}[wp[0]]
+            self.last_h16p_plan = wp
+            if d.ksplit > 1:
+                need = d.ksplit * b * hout * wout * ((self.cout + 127) // 128 * 128)
+                if self._ws is None or self._ws.numel() < need:
+                    self._ws = torch.empty(need, device=inp.device, dtype=torch.float32)
+                d.splitk_ws = self._ws.data_ptr()
+        if tile == 68 and 'h16plean' in DEFAULT_DISABLE:
+            d.reserved1 |= 16    # (A/B runs: the 64-wide stride-1 form as one workgroup per compute unit)
         tid = 0
         if PROFILE is not None:
             tid = d.tile + 100 * (d.ksplit if d.ksplit > 1 else (9 if d.ksplit == -1 else 0))
+            if d.tile == 68 and h16p_cv:
+                tid += 1000
             if d.tile == 70 and wino_bn == 64:   # the launcher's choice of the N tile: a kernel of its own for rocprofv3
                 tid += 1
             if d.tile in (70, 71, 73):           # ... and so are the canvas / K-range form (+ 1000) and the two-source form (+ 2000)

@@ -591,7 +591,7 @@ extern "C" int spaa_tapconv_f32(const spaa_tapconv_t* desc, spaa_stream_t stream
     if (!(d.io_dtype & SPAA_IO_IN_F16) && tile >= 60 && tile <= 63) return hipErrorInvalidValue;
     if ((d.io_dtype & SPAA_IO_OUT_F16) && !((tile >= 15 && tile <= 24) || tile == 38 || (tile >= 60 && tile <= 65) || tile == 68 || tile == 76))
         return hipErrorInvalidValue;
-    if ((d.io_dtype & SPAA_IO_OUT_F16) && (d.ksplit < 0 || (d.ksplit > 1 && !(tile >= 60 && tile <= 63)))) return hipErrorInvalidValue;  // (fp32 partial sums: only the fp16 kernel's own second pass writes fp16)
+    if ((d.io_dtype & SPAA_IO_OUT_F16) && (d.ksplit < 0 || (d.ksplit > 1 && !((tile >= 60 && tile <= 63) || tile == 68)))) return hipErrorInvalidValue;  // (fp32 partial sums: only the fp16 kernels' own second passes write fp16)
     if (d.gate != nullptr && d.gate_mode == SPAA_GATE_MUL && tile < 25) return hipErrorInvalidValue;
     if (d.nfold > 1 && !((tile >= 25 && tile <= 27) || (tile >= 30 && tile <= 37) || (tile >= 39 && tile <= 46) || (tile >= 48 && tile <= 54) || (tile >= 60 && tile <= 65) || tile == 68))
         return hipErrorInvalidValue;

@@ -167,6 +167,83 @@ def test_winograd_canvas_plan_covers_every_pixel_once(b, h, w, cin, cout, tile):
     assert (count == 1).all()
 
 
+def _h16p_plan(b, h, w, cin, cout, ksplit=0, bn=0, force_canvas=False):
+    d = _lib.TapConv()
+    d.Hin = d.Hout = d.Hm = h
+    d.Win = d.Wout = d.Wm = w
+    d.Cin, d.Cout, d.B, d.s_in, d.s_out, d.nclass = cin, cout, b, 1, 1, 1
+    d.in_cstride, d.out_cstride = cin, cout
+    d.cls[0].ntaps, d.cls[0].K, d.cls[0].Kpad = 9, 9 * cin, 9 * cin
+    d.tile, d.ksplit, d.reserved1 = 68, ksplit, 4 | {0: 0, 64: 1, 128: 2}[bn] | (8 if force_canvas else 0)
+    wp = (ctypes.c_int32 * 8)()
+    rc = _lib.load().spaa_tapconv_h16p_plan(ctypes.byref(d), wp)
+    return rc, dict(zip(('bn', 'ksplit', 'canvas', 'gy', 'gx', 'nwg', 'kb_per', 'ncanvas'), wp))
+
+
+@pytest.mark.parametrize('b,h,w,cin,cout', [(64, 14, 14, 256, 256), (64, 7, 7, 512, 512), (5, 14, 14, 64, 64), (64, 17, 17, 128, 128),
+                                             (3, 7, 9, 512, 512), (64, 14, 14, 512, 512), (9, 20, 33, 96, 192)])
+def test_h16p_canvas_plan_covers_every_pixel_once(b, h, w, cin, cout):
+    """csrc/tapconv_h16p.hip, canvas / K-range form of the patch-staged fp16 kernel (host-side plan through spaa_tapconv_h16p_plan): the
+    kernel's index arithmetic restated here maps the 16 x 32-pixel regions onto every output pixel exactly once, the 3 x 3
+    neighbourhood of every output pixel onto the same image's pixels or onto the zero padding, and the K ranges onto every
+    32-channel block exactly once."""
+    import numpy as np
+    rc, pl = _h16p_plan(b, h, w, cin, cout, force_canvas=True)
+    assert rc == 0 and pl['bn'] in (64, 128) and pl['ksplit'] >= 1
+    nkb = cin // 32
+    assert pl['ksplit'] * pl['kb_per'] >= nkb > (pl['ksplit'] - 1) * pl['kb_per']
+    gy, gx, nc = pl['gy'], pl['gx'], pl['ncanvas']
+    n_tiles = (cout + pl['bn'] - 1) // pl['bn']
+    if not pl['canvas']:
+        assert pl['nwg'] == b * ((h + 15) // 16) * ((w + 31) // 32) * n_tiles * pl['ksplit']
+        return
+    py, px = h + 1, w + 1
+    assert gy * gx * nc >= b and gy * py - 1 <= 4095 and gx * px - 1 <= 4095 and py <= 255 and px <= 255
+    my, mx = ((1 << 20) + py - 1) // py, ((1 << 20) + px - 1) // px
+    wg_y, wg_x = (gy * py - 1 + 15) // 16, (gx * px - 1 + 31) // 32
+    assert pl['nwg'] == nc * wg_y * wg_x * n_tiles * pl['ksplit']
+    assert pl['nwg'] // (n_tiles * pl['ksplit']) < b * ((h + 15) // 16) * ((w + 31) // 32)     # fewer regions than the image-aligned form
+
+    def canvas_pixel(cv, vy, vx):
+        sy = ((vy.astype(np.int64) & 0xffffffff) * my & 0xffffffff) >> 20
+        sx = ((vx.astype(np.int64) & 0xffffffff) * mx & 0xffffffff) >> 20
+        iy, ix = vy - sy * py, vx - sx * px
+        im = cv * gy * gx + sy * gx + sx
+        ok = (vy >= 0) & (vx >= 0) & (iy < h) & (ix < w) & (sy < gy) & (sx < gx) & (im < b)
+        return ok, im, iy, ix
+
+    count = np.zeros((b, h, w), dtype=np.int64)
+    for cv in range(nc):
+        vy, vx = np.meshgrid(np.arange(16 * wg_y), np.arange(32 * wg_x), indexing='ij')
+        ok, im, iy, ix = canvas_pixel(cv, vy, vx)
+        assert (iy[ok] >= 0).all() and (ix[ok] >= 0).all()
+        np.add.at(count, (im[ok], iy[ok], ix[ok]), 1)
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                ok2, im2, iy2, ix2 = canvas_pixel(cv, vy + dy, vx + dx)
+                inside = ok & (iy + dy >= 0) & (iy + dy < h) & (ix + dx >= 0) & (ix + dx < w)
+                assert (ok2[ok] == inside[ok]).all()                      # a tap is read iff it lies inside the SAME image
+                sel = ok & inside
+                assert (im2[sel] == im[sel]).all() and (iy2[sel] == iy[sel] + dy).all() and (ix2[sel] == ix[sel] + dx).all()
+    assert (count == 1).all()
+
+
+def test_h16p_plan_honours_forced_choices():
+    """Explicit K ranges / N tiles of the patch-staged fp16 kernel's plan are honoured and clamped; a K split needs whole channel quads."""
+    rc, p = _h16p_plan(64, 14, 14, 256, 256, ksplit=3, bn=64)
+    assert rc == 0 and p['bn'] == 64 and p['ksplit'] == 3 and p['kb_per'] == 3
+    assert _h16p_plan(64, 14, 14, 256, 256, ksplit=1)[1]['ksplit'] == 1
+    assert _h16p_plan(64, 14, 14, 64, 64, ksplit=16)[1]['ksplit'] == 2
+    assert _h16p_plan(64, 7, 7, 512, 512, bn=128)[1]['bn'] == 128
+    assert _h16p_plan(8, 14, 14, 256, 126, ksplit=4)[0] != 0
+    rc, p = _h16p_plan(8, 14, 14, 256, 126)
+    assert rc == 0 and p['ksplit'] == 1
+    # the shapes this form was built for fill the chip: ResNet-18 layer3 / layer4 and VGG-16's last block at batch 64
+    for shp in [(64, 14, 14, 256, 256), (64, 7, 7, 512, 512), (64, 14, 14, 512, 512)]:
+        rc, p = _h16p_plan(*shp)
+        assert rc == 0 and p['canvas'] == 1 and 100 <= p['nwg'] <= 512, (shp, p)
+
+
 def test_winograd_plan_keeps_the_measured_choices():
     """Layer shapes whose Winograd launches were tuned in rounds 2 / 3 keep their image-aligned regions and N tiles; explicit K
     ranges are honoured and clamped."""
