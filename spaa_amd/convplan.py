@@ -52,6 +52,7 @@ WINO_SPLITK = os.environ.get('SPAA_WINO_SPLITK', '1') != '0'        # Winograd l
 DEBUG_THINMF = int(os.environ.get('SPAA_THINMF_DBG', '0'))           # timing experiments of csrc/tapconv_thinmf.hip (builds with -DSPAA_THINMF_ABLATE)
 DEBUG_SMALLCIN_NOSLAB = int(os.environ.get('SPAA_SMALLCIN_NOSLAB', '0'))  # 1: stride-2 smallcin layers store from the MFMA layout (A/B)
 H16P_CV = tuple(int(v) for v in os.environ.get('SPAA_H16P_CV', '0,0,0').split(','))   # (N tile 0 = chosen / 64 / 128, K ranges 0 = chosen, 1 = canvases wherever they have fewer regions: tests) of the patch-staged fp16 kernel's canvas / K-range form (A/B runs)
+H16P_LEAN_WIDE = int(os.environ.get('SPAA_H16P_LEAN_WIDE', '2'))   # 64-wide two-workgroup form of the patch-staged fp16 kernel for wider layers: 0 never, 1 always, 2 by shape
 DEBUG_H16_2STAGE = int(os.environ.get('SPAA_H16_2STAGE', '0'))      # 1: the fp16 implicit-GEMM kernel never takes its four-stage form (A/B measurements)
 FOLD_K3S2 = os.environ.get('SPAA_FOLD_K3S2', '1') != '0'   # 3x3 / s2 input gradients with few output channels: classes folded
 FOLD_K3S2_MAX_COUT = 32
@@ -625,6 +626,8 @@ class ConvPlan:
                 d.splitk_ws = self._ws.data_ptr()
         if tile == 68 and 'h16plean' in DEFAULT_DISABLE:
             d.reserved1 |= 16    # (A/B runs: the 64-wide stride-1 form as one workgroup per compute unit)
+        if tile == 68 and not h16p_cv and self.s_in == 1 and self.cout * self.nfold > 64 and self.h16p_lean_wide(b, d.Hm, d.Wm):
+            d.reserved1 |= 32    # (wider layers as 64-wide N tiles, two workgroups per compute unit)
         tid = 0
         if PROFILE is not None:
             tid = d.tile + 100 * (d.ksplit if d.ksplit > 1 else (9 if d.ksplit == -1 else 0))
@@ -654,6 +657,17 @@ class ConvPlan:
                 fl += 2 * npx * self.cin2 * self.cout
             PROFILE.append((self.name, key, fl, e0, e1, tid, nbytes))
         return out
+
+    def h16p_lean_wide(self, b, hm, wm):
+        """Patch-staged fp16 kernel, stride-1 form, more than 64 GEMM columns: 64-wide N tiles with two workgroups per compute unit
+        (csrc/tapconv_h16p.hip LEAN) instead of one 128-wide workgroup?  SPAA_H16P_LEAN_WIDE: 0 never, 1 always (A/B runs), 2 (default) by
+        the layer's shape."""
+        if H16P_LEAN_WIDE != 2:
+            return H16P_LEAN_WIDE == 1
+        # measured per layer in both loops (profiles/r05_h16p_lean_wide.txt): up to eight 32-channel blocks the overlap of one
+        # workgroup's patch loads / epilogue with the other's products wins (conv4 195 -> 174 us, transConv1 + skipConv2 166 -> 148, VGG-16
+        # features.5 217 -> 184); with sixteen blocks the 128-wide tile's halved patch traffic does (features.19 / 21: + 4-6 us)
+        return self.cin_p <= 256
 
     def wgrad(self, inp, gout, dbias=True, nchunk=None, out_coff=0, in_coff=0):
         """Weight (and bias) gradient of this layer in its forward form (csrc/tapconv_wgrad.hip): `inp` = the layer's input

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void h16p_kernel(const spaa_tapc
     // tensors.  Every element of `in2` is needed once: its fragments go from global memory to registers (as csrc/tapconv_x6p.hip);
     // GEMM columns n_blk + 16 j .. + 15 lie in ONE parity class (launcher: Cout % 16 == 0), whose output pixel of class-grid pixel
     // (y, x) is (2 y + cy, 2 x + cx).
-    if constexpr (S == 1 && !CV && !LEAN) if (p.in2 != nullptr && nfold > 1) {
+    if constexpr (S == 1 && !CV) if (p.in2 != nullptr && nfold > 1) {
         const int row2 = p.in2_cstride * 2;
         const auto rsrc_in2 = rsrc_or_empty(p.in2, (int64_t)p.B * p.Hout * p.Wout * row2);
         const auto rsrc_w2 = rsrc_or_empty(p.w2_split, (int64_t)p.Cout * p.Cin2 * 2);
@@ -659,7 +659,9 @@ int spaa_launch_tapconv_h16p(const spaa_tapconv_t& d, hipStream_t stream) {
     if (d.ksplit > 1) return hipErrorInvalidValue;
     const int OH = S == 1 ? h16p_geo<1>::OH : h16p_geo<2>::OH;
     const int wg_y = (d.Hm + OH - 1) / OH, wg_x = (d.Wm + OW - 1) / OW;
-    const int BN = d.Cout * nfold <= 64 ? 64 : 128;
+    // (`reserved1` bit 5: the 64-wide two-workgroups-per-CU form for wider layers too -- short K, where prologue and epilogue outweigh the
+    // products: chosen per layer shape by spaa_amd/convplan.py)
+    const int BN = (d.Cout * nfold <= 64 || (S == 1 && (d.reserved1 & 32) && !(d.reserved1 & 16))) ? 64 : 128;
     const int n_tiles = (d.Cout * nfold + BN - 1) / BN;
     const int64_t nwg = (int64_t)d.B * wg_y * wg_x * n_tiles;
     if (nwg > 0x7fffffff) return hipErrorInvalidValue;
@@ -673,7 +675,7 @@ int spaa_launch_tapconv_h16p(const spaa_tapconv_t& d, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;                                                                                \
         hipLaunchKernelGGL((h16p_kernel<N, SS>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles, nogeo); \
     }
-    if (S == 1 && BN == 64 && !(d.reserved1 & 16) && !(d.in2 != nullptr && nfold > 1)) {
+    if (S == 1 && BN == 64 && !(d.reserved1 & 16)) {
         // two workgroups per compute unit (LEAN): one 40 KiB patch buffer + three 12 KiB weight stages; epilogue 8 x 32 rows of 272 bytes
         typedef h16p_geo<1> G;
         const size_t mainb = (size_t)G::PATCH_BYTES + 3 * (size_t)(12 * 1024), epib = 8 * 32 * (size_t)(64 * 4 + 16);
