@@ -253,8 +253,10 @@ int spaa_shading_head_bwd(const float* gp, const float* w6t, const uint16_t* w2t
  * convolution's weights are ROUNDED TO fp16 like every other layer's of this mode -- here `w2_split` is ONE fp16 matrix [128][64]
  * (rows n = 32 (2 py + px) + c) and `w2t_split` ONE fp16 matrix [64][128] (same index order as the bf16 planes above) -- and its
  * products run on v_mfma_f32_16x16x32_f16 with fp32 accumulation (backward: the conv6 gradient is rounded to fp16 as that MFMA's
- * operand, the rounding the separate launches apply when they store it); images, res1, gp, the activation kept in LDS, conv6 and its
- * transpose stay fp32 */
+ * operand, the rounding the separate launches apply when they store it).  Round 5: the forward kernel keeps X7 in LDS as fp16 (the value a
+ * separate transConv2 launch of this mode would store) and takes conv6's weights rounded to fp16 as well: `w6` of
+ * spaa_shading_tail_fwd_f16 points at [3][9][32] fp16 ([o][3 ky + kx][c]), its taps accumulate in fp32 (v_dot2_f32_f16).  Images, res1,
+ * gp and conv6's transpose (`w6t`) stay fp32 */
 int spaa_shading_tail_fwd_f16(const void* x6, const uint16_t* w2_split, const float* bias2, const float* w6, const float* bias6,
                               const float* res1, float* y, float* ypre, uint8_t* mask7, int B, int H2, int W2, spaa_stream_t stream);
 int spaa_shading_head_bwd_f16(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7,

@@ -26,6 +26,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16v __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) h16v* ch16_ptr;
 
 namespace {
 
@@ -101,8 +104,12 @@ constexpr int FWD_WAVES = 16;
 constexpr int PW2 = (OY * TX + 63) / 64;            // waves per channel half in phase 2 (7: 14 rows of 32 lanes, 30 of them pixels)
 constexpr int RED_BYTES = PW2 * 64 * 16;            // partial sums of the second half
 
-template <typename T6>   // storage type of X6: float, or _Float16 in fp16-storage mode (the arithmetic is the same: exact operands)
-__global__ __launch_bounds__(64 * FWD_WAVES, 1) void shading_tail_fwd_kernel(
+// fp16 storage (round 5): the X7 tile lives in LDS as fp16 -- the value a separate transConv2 launch of this mode would store -- in
+// chunks of 8 channels (32 KB instead of 64), conv6's weights come rounded to fp16 like every other layer's of the mode (`w6` then
+// points at [3][9][32] fp16) and its taps run on v_dot2_f32_f16 (two channels per instruction, fp32 accumulation: as many
+// instructions as the packed fp32 FMAs, half the LDS reads): 55 KB and 64 VGPRs -- TWO workgroups per compute unit.
+template <typename T6>   // storage type of X6: float, or _Float16 in fp16-storage mode
+__global__ __launch_bounds__(64 * FWD_WAVES, sizeof(T6) == 2 ? 8 : 1) void shading_tail_fwd_kernel(
     const T6* __restrict__ x6, const uint16_t* __restrict__ w2s, const float* __restrict__ bias2, const float* __restrict__ w6,
     const float* __restrict__ bias6, const float* __restrict__ r1, float* __restrict__ y, float* __restrict__ ypre,
     uint8_t* __restrict__ mask7, const int B, const int H2, const int W2, const int tiles_y, const int tiles_x) {
@@ -112,8 +119,8 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void shading_tail_fwd_kernel(
     constexpr bool H16 = sizeof(T6) == 2;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* wl = smem;                       // weight planes
-    unsigned char* tl = smem + W_BYTES;             // X7 tile
-    unsigned char* rl = smem + W_BYTES + T_BYTES;   // phase-2 partial sums
+    unsigned char* tl = smem + (H16 ? W_BYTES / 3 : W_BYTES);             // X7 tile (fp16 storage: four planes of 8 channels)
+    unsigned char* rl = tl + (H16 ? T_BYTES / 2 : T_BYTES);               // phase-2 partial sums
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = 2 * H2, W = 2 * W2;
@@ -143,14 +150,16 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void shading_tail_fwd_kernel(
     const int oy_r = pix / TX, ox_r = pix - oy_r * TX;
     const bool p2 = wave < 2 * PW2 && oy_r < OY && ox_r < OX;
     const int oy_l = p2 ? oy_r : 0, ox_l = p2 ? ox_r : 0;
-    const unsigned char* p2base = tl + 4 * ph * PLANE + (oy_l * TX + ox_l) * 16;
+    const unsigned char* p2base = tl + (H16 ? 2 : 4) * ph * PLANE + (oy_l * TX + ox_l) * 16;
     // per-lane constants of the phase-1 epilogue: LDS address and bias of its four 16-channel blocks
     int wofs[4];
     f32x4 bq[4];
 #pragma unroll
     for (int nq = 0; nq < 4; ++nq) {
         const int nb = 4 * nh + nq, par = nb >> 1, c0 = 16 * (nb & 1) + 4 * g;
-        wofs[nq] = (c0 >> 2) * PLANE + ((2 * row + (par >> 1)) * TX + 2 * rx + (par & 1)) * 16;
+        // (fp16 tile: the quad c0 .. c0 + 3 is half (c0 >> 2) & 1 of the 8-channel chunk c0 >> 3)
+        wofs[nq] = H16 ? (c0 >> 3) * PLANE + ((2 * row + (par >> 1)) * TX + 2 * rx + (par & 1)) * 16 + 8 * ((c0 >> 2) & 1)
+                       : (c0 >> 2) * PLANE + ((2 * row + (par >> 1)) * TX + 2 * rx + (par & 1)) * 16;
         bq[nq] = *reinterpret_cast<const f32x4*>(bias2 + c0);
     }
     const int ntiles = B * tiles_y * tiles_x;
@@ -233,7 +242,8 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void shading_tail_fwd_kernel(
                     const int gy = 2 * a0 + 2 * row + (par >> 1), gx = 2 * b0 + 2 * rx + (par & 1);
                     if (!((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                *reinterpret_cast<f32x4*>(tl + wofs[nq]) = v;
+                if constexpr (H16) *reinterpret_cast<h4*>(tl + wofs[nq]) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                else *reinterpret_cast<f32x4*>(tl + wofs[nq]) = v;
             }
         }
         __syncthreads();
@@ -244,6 +254,40 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void shading_tail_fwd_kernel(
         const size_t o = ((size_t)img * H + (ok ? gy : 0)) * W + (ok ? gx : 0);
         f32x4 rv = {0.f, 0.f, 0.f, 0.f};
         if (ok && ph == 0) rv = *reinterpret_cast<const f32x4*>(r1 + o * 4);   // (requested early: used after the taps)
+        if constexpr (H16) {
+          if (p2) {
+            unsigned int bits = 0;
+            float a3[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int t = 0; t < 9; ++t) {
+                const unsigned char* pp = p2base + ((t / 3) * TX + t % 3) * 16;
+                h16v w[3];                  // 16 fp16 channels x 3 outputs of this tap: one s_load_dwordx8 per output channel
+#pragma unroll
+                for (int n = 0; n < 3; ++n) w[n] = *(ch16_ptr)(uintptr_t)(reinterpret_cast<const _Float16*>(w6) + (n * 9 + t) * C7 + 16 * ph);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const h8 a = *reinterpret_cast<const h8*>(pp + u * PLANE);
+#pragma unroll
+                    for (int n = 0; n < 3; ++n) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const h2 av = {a[2 * e], a[2 * e + 1]}, wv = {w[n][8 * u + 2 * e], w[n][8 * u + 2 * e + 1]};
+                            a3[n] = __builtin_amdgcn_fdot2(av, wv, a3[n], false);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {   // X7's gate bytes of this pixel: 16 channels = two chunks of 8
+                const h8 a = *reinterpret_cast<const h8*>(p2base + (TX + 1) * 16 + u * PLANE);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bits |= (a[e] > (_Float16)0 ? 1u : 0u) << (16 * u + 8 * (e >> 2) + (e & 3));
+            }
+            if (ok) *reinterpret_cast<uint32_t*>(mask7 + o * (C7 / 4) + 4 * ph) = bits;
+            acc[0] = f2{a3[0], 0.f}, acc[1] = f2{a3[1], 0.f}, acc[2] = f2{a3[2], 0.f};
+            if (ph == 1) *reinterpret_cast<f32x4*>(rl + pix * 16) = f32x4{a3[0], a3[1], a3[2], 0.f};
+          }
+        } else
         if (p2) {
             unsigned int bits = 0;
 #pragma unroll 1
@@ -305,8 +349,11 @@ constexpr int GP_BYTES = GP_W * GP_H * 16;    // 9792 B
 // 16 waves per workgroup: phase 1 gives a thread one X7 pixel of the tile and ONE half of P7's 32 channels (waves 0-7: channels
 // 0-15, waves 8-15: 16-31; per tap 3 inputs x 16 weights = three scalar loads feeding 24 packed FMAs); phase 2 gives wave w the X6
 // row w & 7 and the N half w >> 3 (two of the four 16-channel blocks of P6).
+// fp16 storage (round 5): P7 lives in LDS as the fp16 it is multiplied as (the rounding used to happen when a fragment was read: the same
+// values, 32 KB instead of 64), the weights are one 16 KB plane: 58 KB and 64 VGPRs -- TWO workgroups per compute unit, one's VALU phase
+// and barriers under the other's matrix-core phase (the fp32 form needs 122 KB: one).
 template <typename T6>   // storage type of P6 (float / _Float16)
-__global__ __launch_bounds__(1024, 1) void shading_head_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ gcol,
+__global__ __launch_bounds__(1024, sizeof(T6) == 2 ? 8 : 1) void shading_head_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ gcol,
                                                                    const int32_t* __restrict__ state, const float* __restrict__ ypre,
                                                                    const float* __restrict__ w6t,
                                                                    const uint16_t* __restrict__ w2ts,
@@ -318,8 +365,8 @@ __global__ __launch_bounds__(1024, 1) void shading_head_bwd_kernel(const float* 
                                             // v_mfma_f32_16x16x32_f16 (the separate launches store P7 as fp16 in HBM: the same rounding)
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* wl = smem;                       // weight planes
-    unsigned char* pl = smem + WB_BYTES;            // P7 tile
-    unsigned char* gl = smem + WB_BYTES + P7_BYTES;  // gP tile
+    unsigned char* pl = smem + (H16 ? WB_BYTES / 3 : WB_BYTES);            // P7 tile (fp16 storage: 128 rows of 256 B)
+    unsigned char* gl = pl + (H16 ? P7_BYTES / 2 : P7_BYTES);               // gP tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = 2 * H2, W = 2 * W2;
@@ -397,8 +444,14 @@ __global__ __launch_bounds__(1024, 1) void shading_head_bwd_kernel(const float* 
                 f32x4 v = acc[c4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = ((nib >> e) & 1u) ? v[e] : 0.f;
-                // 16-byte chunk ch1 + c4 of row m1 at chunk ^ (m1 & 31)
-                *reinterpret_cast<f32x4*>(pl + m1 * 512 + (((ch1 + c4) ^ (m1 & 31)) << 4)) = v;
+                if constexpr (H16) {
+                    // fp16 row of 16 chunks of 8 values: this quad is half (c4 & 1) of chunk (ch1 + c4) >> 1, at chunk ^ (m1 & 15)
+                    *reinterpret_cast<h4*>(pl + m1 * 256 + ((((ch1 + c4) >> 1) ^ (m1 & 15)) << 4) + 8 * ((ch1 + c4) & 1)) =
+                        h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                } else {
+                    // 16-byte chunk ch1 + c4 of row m1 at chunk ^ (m1 & 31)
+                    *reinterpret_cast<f32x4*>(pl + m1 * 512 + (((ch1 + c4) ^ (m1 & 31)) << 4)) = v;
+                }
             }
         }
         __syncthreads();
@@ -408,13 +461,14 @@ __global__ __launch_bounds__(1024, 1) void shading_head_bwd_kernel(const float* 
             bf16x8 pf[4][3];
             h8 ph[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {   // k step s: columns 32 s + 8 g .. + 7 = chunks 8 s + 2 g, + 1
-                const f32x4 u0 = *reinterpret_cast<const f32x4*>(pl + m * 512 + (((8 * s + 2 * g) ^ (m & 31)) << 4));
-                const f32x4 u1 = *reinterpret_cast<const f32x4*>(pl + m * 512 + (((8 * s + 2 * g + 1) ^ (m & 31)) << 4));
-                if constexpr (H16)
-                    ph[s] = h8{(_Float16)u0[0], (_Float16)u0[1], (_Float16)u0[2], (_Float16)u0[3], (_Float16)u1[0], (_Float16)u1[1], (_Float16)u1[2], (_Float16)u1[3]};
-                else
+            for (int s = 0; s < 4; ++s) {   // k step s: columns 32 s + 8 g .. + 7 = chunks 8 s + 2 g, + 1 (fp16 rows: chunk 4 s + g)
+                if constexpr (H16) {
+                    ph[s] = *reinterpret_cast<const h8*>(pl + m * 256 + (((4 * s + g) ^ (m & 15)) << 4));
+                } else {
+                    const f32x4 u0 = *reinterpret_cast<const f32x4*>(pl + m * 512 + (((8 * s + 2 * g) ^ (m & 31)) << 4));
+                    const f32x4 u1 = *reinterpret_cast<const f32x4*>(pl + m * 512 + (((8 * s + 2 * g + 1) ^ (m & 31)) << 4));
                     split8(u0, u1, pf[s][0], pf[s][1], pf[s][2]);
+                }
             }
             const int ay = a0 + row, ax = b0 + rx;
             const bool in6 = ay < H2 && ax < W2;
@@ -466,13 +520,15 @@ static int launch_tail_fwd(const T6* x6, const uint16_t* w2_split, const float* 
     const int tiles_y = (H + 1 + OY - 1) / OY, tiles_x = (W + 1 + OX - 1) / OX;   // owned rows start at -1
     const int64_t ntiles = (int64_t)B * tiles_y * tiles_x;
     if (ntiles > 0x7fffffff) return hipErrorInvalidValue;
-    const size_t smem = (size_t)W_BYTES + T_BYTES + RED_BYTES;
+    constexpr bool H16 = sizeof(T6) == 2;
+    const size_t smem = H16 ? (size_t)W_BYTES / 3 + T_BYTES / 2 + RED_BYTES : (size_t)W_BYTES + T_BYTES + RED_BYTES;
     static bool attr_set[SPAA_MAX_DEVICES] = {};
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&shading_tail_fwd_kernel<T6>), (int)smem, attr_set);
     if (e != hipSuccess) return (int)e;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
-    const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);
+    const int64_t slots = (int64_t)(H16 ? 2 : 1) * ncu;      // (fp16 storage: two resident workgroups per compute unit)
+    const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
     hipLaunchKernelGGL(shading_tail_fwd_kernel<T6>, dim3(grid), dim3(64 * FWD_WAVES), smem, stream, x6, w2_split, bias2, w6, bias6, res1,
                        y, ypre, mask7, B, H2, W2, tiles_y, tiles_x);
     return (int)hipGetLastError();
@@ -488,13 +544,15 @@ static int launch_head_bwd(const float* gp, const float* gcol, const int32_t* st
     const int tiles_y = (H2 + RY - 1) / RY, tiles_x = (W2 + RX - 1) / RX;
     const int64_t ntiles = (int64_t)B * tiles_y * tiles_x;
     if (ntiles > 0x7fffffff) return hipErrorInvalidValue;
-    const size_t smem = (size_t)WB_BYTES + P7_BYTES + GP_BYTES;
+    constexpr bool H16 = sizeof(T6) == 2;
+    const size_t smem = H16 ? (size_t)WB_BYTES / 3 + P7_BYTES / 2 + GP_BYTES : (size_t)WB_BYTES + P7_BYTES + GP_BYTES;
     static bool attr_set[SPAA_MAX_DEVICES] = {};
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&shading_head_bwd_kernel<T6>), (int)smem, attr_set);
     if (e != hipSuccess) return (int)e;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
-    const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);
+    const int64_t slots = (int64_t)(H16 ? 2 : 1) * ncu;      // (fp16 storage: two resident workgroups per compute unit)
+    const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
     hipLaunchKernelGGL(shading_head_bwd_kernel<T6>, dim3(grid), dim3(1024), smem, stream, gp, gcol, state, ypre, w6t, w2t_split, mask7, mask6, p6,
                        B, H2, W2, tiles_y, tiles_x);
     return (int)hipGetLastError();

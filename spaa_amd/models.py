@@ -494,6 +494,7 @@ class PCNetEngine:
             w2h=wt.permute(2, 3, 1, 0).reshape(128, 64).half().contiguous().to(dev) if storage == 'f16' else None,
             w2th=wt.permute(0, 2, 3, 1).reshape(64, 128).half().contiguous().to(dev) if storage == 'f16' else None,
             w6=w6.permute(0, 2, 3, 1).reshape(3, 9, 32).contiguous().to(dev),          # [o][3 ky + kx][c]
+            w6h=w6.permute(0, 2, 3, 1).reshape(3, 9, 32).half().contiguous().to(dev) if storage == 'f16' else None,   # (fp16 storage: rounded like every weight of the mode)
             w6t=w6.flip(2, 3).permute(2, 3, 0, 1).reshape(27, 32).contiguous().to(dev),  # [3 t + o][c], taps mirrored
             b2=sn.transConv2.bias.detach().float().contiguous().to(dev), b6=sn.conv6.bias.detach().float().contiguous().to(dev))
         self.owner = None    # weakref to the AttackState this engine is leased to (PCNet.engine)
@@ -567,9 +568,9 @@ class PCNetEngine:
             f['transConv1'].run(a['X5'], a['X6'], add=a['R2'], act=R, mask_out=m['X6'])
         if self.fuse_tail:
             t = self.tail
-            f16 = self.storage == 'f16'   # (X6 and the transposed convolution's weights fp16, fp32 accumulation; the activation kept in LDS fp32)
+            f16 = self.storage == 'f16'   # (X6 and both layers' weights fp16, fp32 accumulation; X7 in LDS as the fp16 a separate launch would store)
             _lib.call('spaa_shading_tail_fwd_f16' if f16 else 'spaa_shading_tail_fwd', _lib.hptr(a['X6']) if f16 else _lib.ptr(a['X6']),
-                      _lib.hptr(t['w2h']) if f16 else _lib.ptr(t['w2s']), _lib.ptr(t['b2']), _lib.ptr(t['w6']), _lib.ptr(t['b6']), _lib.ptr(a['R1']), _lib.ptr(a['Y']),
+                      _lib.hptr(t['w2h']) if f16 else _lib.ptr(t['w2s']), _lib.ptr(t['b2']), _lib.hptr(t['w6h']) if f16 else _lib.ptr(t['w6']), _lib.ptr(t['b6']), _lib.ptr(a['R1']), _lib.ptr(a['Y']),
                       _lib.ptr(a['Ypre']), _lib.ptr(m['X7']), self.B, self.Hc // 2, self.Wc // 2)
             return a['Y']
         x7 = dict.__getitem__(a, 'X7')

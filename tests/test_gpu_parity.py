@@ -2401,9 +2401,9 @@ def test_fused_shading_tail_and_head(hip, cam_sz, b, storage):
     """csrc/shading_tail.hip: transConv2 + conv6 forward and their input gradients as one kernel each (X7 and its gradient stay
     in LDS) against the separate launches on the same engine: outputs, gate bytes and the gradient handed to transConv1.
     fp32 storage: equal to rounding.  fp16 storage (the <_Float16> instantiations: X6 / P6 fp16 in HBM, read 8 / written 4
-    halves per lane): both paths see the SAME fp16 X6 and the same gate bytes; the separate launches round X7 and its gradient
-    to fp16 in HBM where the fused kernels keep them fp32 in LDS, so the two differ by that rounding (2^-11 relative per
-    element of X7 / P7) and nothing else."""
+    halves per lane): both paths see the SAME fp16 X6 and the same gate bytes and round X7 and its gradient to fp16 (the separate
+    launches in HBM, the fused kernels in LDS -- round 5: 32 KB tiles, two workgroups per compute unit) and conv6's weights to fp16
+    (forward); what is left is the accumulation order (conv6's taps on v_dot2_f32_f16 against the MFMA of the separate launch)."""
     lib, m_ = hip['lib'], hip['models']
     torch.manual_seed(cam_sz[0] + b)
     sd = syn.pcnet_state_dict(4, cam_sz=cam_sz, mask='ones')
