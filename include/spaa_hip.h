@@ -112,7 +112,9 @@ typedef struct {
                              SPAA_IO_OUT_F16 (tiles 60..65, 68, and the kernels that read fp32 IMAGES: 15..24, 38):
                                              `out`, `add`, `gate`, `aux_out`, `gate2` are fp16.
                              0 = everything fp32 (the default path; dtype "f32" in bench.py). */
-    int32_t reserved1;    /* tile 68: bit 2 = the canvas / K-range form (small images with long K: spaa_tapconv_h16p_plan below; `ksplit` > 1 with
+    int32_t reserved1;    /* tile 76: bit 0 = fp16 operands (fp16-storage mode, fp16 output only): the image rounded to fp16 in registers, `w_split` = ONE
+                             plane of fp16 weights in the layout of ConvPlan.c3_pack(half=True), products on v_mfma_f32_16x16x32_f16.
+                             tile 68: bit 2 = the canvas / K-range form (small images with long K: spaa_tapconv_h16p_plan below; `ksplit` > 1 with
                              `splitk_ws` = that many K ranges), bits 0-1 = its N tile (0 chosen, 1 = 64, 2 = 128), bit 3 (tests) = canvases wherever they
                              have fewer regions, bit 4 (A/B runs) = 64-wide stride-1 layers as ONE workgroup per compute unit.  0 otherwise. */
     int32_t nclass;

@@ -263,9 +263,23 @@ class ConvPlan:
         return (len(self.cls) == 1 and self.cin == 3 and self.cin_p == 4 and self.s_out == 1 and self.s_in in (1, 2) and self.cout <= 64
                 and self.nfold == 1 and 3 * self.ntaps_total <= 160)
 
-    def c3_pack(self):
+    def c3_pack(self, half=False):
         """The weights as tile 76 stages them: K = (tap, channel of 3) products only, [NK][3 bf16 planes: w == h + m + l][BN rows][32],
-        16-byte chunk c of row n stored at chunk c ^ ((n >> 3 & 1) << 1) (conflict-free fragment reads); packed on first use."""
+        16-byte chunk c of row n stored at chunk c ^ ((n >> 3 & 1) << 1) (conflict-free fragment reads); packed on first use.
+        `half` (fp16-storage mode): ONE plane of the weights rounded to fp16, same rows and swizzle."""
+        if half:
+            if getattr(self, '_c3h', None) is None:
+                nt, c = self.ntaps_total, self.cls[0]
+                nk, bn = (1 if 3 * nt <= 32 else 5), (32 if self.cout <= 32 else 64)
+                w = self.weights[c['w_off']:c['w_off'] + self._npad * c['Kpad']].view(self._npad, c['Kpad'])[:bn, :4 * nt]
+                w = w.reshape(bn, nt, 4)[:, :, :3].reshape(bn, 3 * nt)
+                w = torch.nn.functional.pad(w, (0, 32 * nk - 3 * nt)).float().cpu().half().view(torch.int16)
+                pl = w.view(bn, nk, 4, 8).permute(1, 0, 2, 3).contiguous()                              # [nk][row][chunk][8]
+                n = torch.arange(bn)
+                idx = (torch.arange(4)[None, :] ^ (((n >> 3) & 1) << 1)[:, None])
+                pl = torch.gather(pl, 2, idx[None, :, :, None].expand(nk, bn, 4, 8))
+                self._c3h = pl.contiguous().reshape(-1).to(self._dev)
+            return self._c3h
         if getattr(self, '_c3', None) is None:
             nt, c = self.ntaps_total, self.cls[0]
             nk, bn = (1 if 3 * nt <= 32 else 5), (32 if self.cout <= 32 else 64)
@@ -534,7 +548,12 @@ class ConvPlan:
         if tile == 76:
             if not self.c3_ok() or in_f16:
                 raise ValueError(f'{self.name}: tile 76 serves 3-channel-image convolutions only')
-            d.w_split = self.c3_pack().data_ptr()
+            if out_f16 and 'c3h' not in DEFAULT_DISABLE:
+                # fp16-storage mode: fp16 operands like every other layer of the mode (the image rounded in registers, one fp16 weight plane)
+                d.w_split = self.c3_pack(True).data_ptr()
+                d.reserved1 |= 1
+            else:
+                d.w_split = self.c3_pack().data_ptr()
         if tile == 72:
             if in_f16:
                 d.w_half = self.thin_fold(True).data_ptr()
@@ -727,7 +746,7 @@ class ConvPlan:
             self.w_split.copy_(torch.cat(parts))
         self.w_half = None
         self._thin = {}
-        self._c3 = None
+        self._c3 = self._c3h = None
         if self.wino is not None:
             _winograd_weights(self, self.wino)
         if bias is not None:

@@ -25,6 +25,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -62,11 +63,14 @@ __device__ __forceinline__ int swz_w16(int n) { return ((n >> 3) & 1) << 1; }
 // ONE TILE PER WORKGROUP (the 3 x 3 layers: 12 KB of weights, two workgroups per compute unit cover each other's prologue and epilogue;
 // the persistent form below measured slower there -- VGG-16 features.0 217 -> 276 us: its tile loop costs registers the two-per-CU
 // occupancy does not have)
-template <int NK, int BN>
+// HO (round 5, fp16-STORAGE mode: `reserved1` bit 0): the image operand rounded to fp16 in registers and ONE plane of fp16 weights on
+// v_mfma_f32_16x16x32_f16 -- what every other layer of the mode multiplies (fp16 operands, fp32 accumulation); the bf16x6 form spent six MFMAs
+// and a 44-instruction split per fragment on an output that is rounded to fp16.
+template <int NK, int BN, bool HO = false>
 __global__ __launch_bounds__(512, 4) void c3conv_tile_kernel(const spaa_tapconv_t p, const int tiles_y, const int tiles_x, const int PH, const int PW,
                                                              const int w_bytes, const int patch_off) {
     constexpr int TJ = BN / 16;
-    constexpr int KS_BYTES = 3 * BN * 64;   // one K-step of weights: three planes of BN rows x 32 bf16
+    constexpr int KS_BYTES = (HO ? 1 : 3) * BN * 64;   // one K-step of weights: three planes (HO: one) of BN rows x 32 bf16 / fp16
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* const wl = smem;
     unsigned char* const pl = smem + patch_off;
@@ -135,16 +139,24 @@ __global__ __launch_bounds__(512, 4) void c3conv_tile_kernel(const spaa_tapconv_
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
         bf16x8 pf[4][3];
+        h8 pfh[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(pl + pbase[b] + koff[ks][e]);
-            split8(v, pf[b][0], pf[b][1], pf[b][2]);
+            if constexpr (HO) pfh[b] = h8{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3], (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+            else split8(v, pf[b][0], pf[b][1], pf[b][2]);
         }
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const unsigned char* wc = wl + ks * KS_BYTES + j * 1024 + w_addr_l;
+            if constexpr (HO) {
+                const h8 wh = *reinterpret_cast<const h8*>(wc);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, pfh[b], acc[b][j], 0, 0, 0);
+                continue;
+            }
             const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wc);
             const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wc + BN * 64);
             const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wc + 2 * BN * 64);
@@ -217,11 +229,11 @@ __global__ __launch_bounds__(512, 4) void c3conv_tile_kernel(const spaa_tapconv_
 // PERSISTENT: a workgroup walks tiles  blockIdx.x, + gridDim.x, ...  -- the weights are staged once per workgroup, the patch of
 // tile i + 1 is requested (second patch buffer: DB) before the arithmetic of tile i, or (7 x 7: one buffer fits) right after it, under
 // tile i's epilogue; the epilogue's stores are still in flight when the next tile's fragments are read.
-template <int NK, int BN, bool DB>
+template <int NK, int BN, bool DB, bool HO = false>
 __global__ __launch_bounds__(512, 2) void c3conv_kernel(const spaa_tapconv_t p, const int tiles_y, const int tiles_x, const int PH, const int PW,
                                                         const int w_bytes, const int patch_bytes, const int ntiles) {
     constexpr int TJ = BN / 16;
-    constexpr int KS_BYTES = 3 * BN * 64;   // one K-step of weights: three planes of BN rows x 32 bf16
+    constexpr int KS_BYTES = (HO ? 1 : 3) * BN * 64;   // one K-step of weights: three planes (HO: one) of BN rows x 32 bf16 / fp16
     constexpr int ROWB = BN * 4 + 16;       // epilogue: 16 pixels x (BN channels + pad) per wave
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* const wl = smem;
@@ -309,16 +321,24 @@ __global__ __launch_bounds__(512, 2) void c3conv_kernel(const spaa_tapconv_t p, 
 #pragma unroll
             for (int bp = 0; bp < 2; ++bp) {   // (two pixel blocks at a time: 24 fragment registers live instead of 48)
                 bf16x8 pf[2][3];
+                h8 pfh[2];
 #pragma unroll
                 for (int bb = 0; bb < 2; ++bb) {
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(pl + pbase[2 * bp + bb] + koff[ks][e]);
-                    split8(v, pf[bb][0], pf[bb][1], pf[bb][2]);
+                    if constexpr (HO) pfh[bb] = h8{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3], (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+                    else split8(v, pf[bb][0], pf[bb][1], pf[bb][2]);
                 }
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
                     const unsigned char* wc = wl + ks * KS_BYTES + j * 1024 + w_addr_l;
+                    if constexpr (HO) {
+                        const h8 wh = *reinterpret_cast<const h8*>(wc);
+#pragma unroll
+                        for (int bb = 0; bb < 2; ++bb) acc[2 * bp + bb][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, pfh[bb], acc[2 * bp + bb][j], 0, 0, 0);
+                        continue;
+                    }
                     const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wc);
                     const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wc + BN * 64);
                     const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wc + 2 * BN * 64);
@@ -400,24 +420,28 @@ int spaa_launch_tapconv_c3(const spaa_tapconv_t& d, hipStream_t stream) {
     if ((int64_t)d.B * d.Hin * d.Win * d.in_cstride * 4 >= (int64_t)1 << 31) return hipErrorInvalidValue;
     const int PH = (OH - 1) * d.s_in + kh, PW = (OW - 1) * d.s_in + kw;
     const int BN = d.Cout <= 32 ? 32 : 64;
-    const int w_bytes = nk * 3 * BN * 64;
+    const bool ho = (d.reserved1 & 1) != 0;      // fp16 operands (fp16-storage mode): one fp16 weight plane
+    if (ho && !(d.io_dtype & SPAA_IO_OUT_F16)) return hipErrorInvalidValue;
+    const int w_bytes = nk * (ho ? 1 : 3) * BN * 64;
     const int patch_bytes = (PH * PW * 16 + 1023) & ~1023;
     const int tiles_y = (d.Hout + OH - 1) / OH, tiles_x = (d.Wout + OW - 1) / OW;
     const int64_t ntiles = (int64_t)d.B * tiles_y * tiles_x;
     if (ntiles > 0x7fffffff) return hipErrorInvalidValue;
-    static bool attr_set[4][SPAA_MAX_DEVICES] = {};
+    static bool attr_set[8][SPAA_MAX_DEVICES] = {};
     if (nk == 1) {
         // one tile per workgroup: weights + patch, then (aliased) 32 pixels x (BN + 4) floats per wave for the epilogue
         const int epi_bytes = NW * 32 * (BN * 4 + 16), main_bytes = w_bytes + patch_bytes;
         const size_t smem = (size_t)(main_bytes > epi_bytes ? main_bytes : epi_bytes);
         if (smem > 80 * 1024) return hipErrorInvalidValue;
-#define C3_LAUNCH_TILE(N, SLOT)                                                                                            \
+#define C3_LAUNCH_TILE(N, HO_, SLOT)                                                                                       \
     {                                                                                                                      \
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&c3conv_tile_kernel<1, N>), 80 * 1024, attr_set[SLOT]); \
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&c3conv_tile_kernel<1, N, HO_>), 80 * 1024, attr_set[SLOT]); \
         if (e != hipSuccess) return (int)e;                                                                                \
-        hipLaunchKernelGGL((c3conv_tile_kernel<1, N>), dim3((unsigned)ntiles), dim3(512), smem, stream, d, tiles_y, tiles_x, PH, PW, w_bytes, w_bytes); \
+        hipLaunchKernelGGL((c3conv_tile_kernel<1, N, HO_>), dim3((unsigned)ntiles), dim3(512), smem, stream, d, tiles_y, tiles_x, PH, PW, w_bytes, w_bytes); \
     }
-        if (BN == 32) C3_LAUNCH_TILE(32, 0) else C3_LAUNCH_TILE(64, 1)
+        if (ho) {
+            if (BN == 32) C3_LAUNCH_TILE(32, true, 4) else C3_LAUNCH_TILE(64, true, 5)
+        } else if (BN == 32) C3_LAUNCH_TILE(32, false, 0) else C3_LAUNCH_TILE(64, false, 1)
 #undef C3_LAUNCH_TILE
         return (int)hipGetLastError();
     }
@@ -429,14 +453,16 @@ int spaa_launch_tapconv_c3(const spaa_tapconv_t& d, hipStream_t stream) {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
     const int slots = (smem <= 80 * 1024 ? 2 : 1) * ncu;
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
-#define C3_LAUNCH(N, SLOT)                                                                                                 \
+#define C3_LAUNCH(N, HO_, SLOT)                                                                                            \
     {                                                                                                                      \
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&c3conv_kernel<5, N, false>), 160 * 1024, attr_set[SLOT]); \
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&c3conv_kernel<5, N, false, HO_>), 160 * 1024, attr_set[SLOT]); \
         if (e != hipSuccess) return (int)e;                                                                                \
-        hipLaunchKernelGGL((c3conv_kernel<5, N, false>), dim3(grid), dim3(512), smem, stream, d, tiles_y, tiles_x, PH, PW, w_bytes, patch_bytes, \
+        hipLaunchKernelGGL((c3conv_kernel<5, N, false, HO_>), dim3(grid), dim3(512), smem, stream, d, tiles_y, tiles_x, PH, PW, w_bytes, patch_bytes, \
                            (int)ntiles);                                                                                   \
     }
-    if (BN == 32) C3_LAUNCH(32, 2) else C3_LAUNCH(64, 3)
+    if (ho) {
+        if (BN == 32) C3_LAUNCH(32, true, 6) else C3_LAUNCH(64, true, 7)
+    } else if (BN == 32) C3_LAUNCH(32, false, 2) else C3_LAUNCH(64, false, 3)
 #undef C3_LAUNCH
     return (int)hipGetLastError();
 }
