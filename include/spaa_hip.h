@@ -116,7 +116,11 @@ typedef struct {
                              plane of fp16 weights in the layout of ConvPlan.c3_pack(half=True), products on v_mfma_f32_16x16x32_f16.
                              tile 68: bit 2 = the canvas / K-range form (small images with long K: spaa_tapconv_h16p_plan below; `ksplit` > 1 with
                              `splitk_ws` = that many K ranges), bits 0-1 = its N tile (0 chosen, 1 = 64, 2 = 128), bit 3 (tests) = canvases wherever they
-                             have fewer regions, bit 4 (A/B runs) = 64-wide stride-1 layers as ONE workgroup per compute unit.  0 otherwise. */
+                             have fewer regions, bit 4 (A/B runs) = 64-wide stride-1 layers as ONE workgroup per compute unit, bit 5 = 64-wide N tiles (two
+                             workgroups per compute unit) for a wider layer, bit 6 = the layer's ReLU and the 2 x 2 / stride-2 max-pool that follows it in the epilogue
+                             (stride 1, unfolded, image-aligned regions, act = ReLU, no residual / gates, even Hout / Wout): `out` is then the POOLED tensor
+                             [B, Hout / 2, Wout / 2, out_cstride] and `mask_out` the pool's arg-max bytes [B, Hout / 2, Wout / 2, Cout] in spaa_maxpool_fwd's format
+                             (or NULL) -- torchvision VGG-16's conv -> ReLU -> MaxPool2d(2, 2), classifier.py:21-24.  0 otherwise. */
     int32_t nclass;
     spaa_tapclass_t cls[SPAA_MAX_CLASSES];
     /* optional SECOND SOURCE (NULL = none).

@@ -23,6 +23,7 @@ from .models import to_nhwc4, to_nchw, USE_GATE_MASKS
 # 1: ResNet-18's max-pool adjoint as the prologue of the stem's input gradient.  Measured SLOWER (profiles/r05_frontend.txt: stem_dgrad
 # 190 -> 304 us for the 55 us launch it removes -- the patch formed by loads + VALU work in four dependent round trips per channel block
 # where the LDS-DMA of the separate form costs no issue slots): off by default, kept with its bitwise test.
+FUSE_POOL = os.environ.get('SPAA_FUSE_POOL', '1') != '0'   # VGG-16, fp16 storage: the 2 x 2 max-pools in the epilogue of the convolution before them
 FUSE_POOL_ADJOINT = os.environ.get('SPAA_FUSE_POOL_ADJOINT', '0') == '1'
 BODY_GATE_MASKS = os.environ.get('SPAA_BODY_MASKS', '1') != '0'   # 0: VGG-16 / Inception-v3 gate with the activation itself (A/B measurements)
 
@@ -259,6 +260,9 @@ class VGG16Body:
         # (profiles/r05_configs4_f16s_tapconv_layers.json: features.2_dgrad 689 us against 477 forward with the activation as gate)
         self.masks = BODY_GATE_MASKS and (USE_GATE_MASKS or storage == 'f16')
         self.write_masks = True       # (ClassifierEngine.forward(need_grad=False): a forward pass nobody differentiates skips them)
+        # fp16 storage: conv -> ReLU -> 2 x 2 max-pool in ONE launch (csrc/tapconv_h16p.hip POOL); tests that read the convolution's own
+        # activation switch it off
+        self.fuse_pool = FUSE_POOL and storage == 'f16'
         for i, op in enumerate(self.ops[:-1]):
             if op['kind'] == 'conv' and self.ops[i + 1]['kind'] == 'conv' and self.masks:
                 op['m'] = torch.zeros(*op['out'].shape[:3], op['out'].shape[3] // 4, dtype=torch.uint8, device=dev)
@@ -282,9 +286,19 @@ class VGG16Body:
     def forward(self, x4):
         B, R = self.B, _lib.ACT_RELU
         t = x4
-        for op in self.ops:
+        fused_pool = False
+        for i, op in enumerate(self.ops):
             if op['kind'] == 'conv':
-                op['f'].run(t, op['out'], act=R, mask_out=op.get('m') if self.write_masks else None)
+                nxt = self.ops[i + 1] if i + 1 < len(self.ops) else None
+                if self.fuse_pool and nxt is not None and nxt['kind'] == 'pool' and 'm' not in op:
+                    # conv -> ReLU -> MaxPool2d(2, 2) as one launch where the patch-staged fp16 kernel serves the layer (its epilogue pools: the
+                    # full-size activation is not written; ConvPlan.run falls back to conv + spaa_maxpool_fwd anywhere else)
+                    op['f'].run(t, op['out'], act=R, pool=(nxt['out'], nxt['arg'], self.write_masks))
+                    fused_pool = True
+                else:
+                    op['f'].run(t, op['out'], act=R, mask_out=op.get('m') if self.write_masks else None)
+            elif fused_pool:
+                fused_pool = False       # (pooled by the convolution's launch)
             else:
                 _lib.call('spaa_maxpool_fwd_f16' if self.storage == 'f16' else 'spaa_maxpool_fwd', _lib.hptr(t),
                           _lib.hptr(op['out']), _lib.ptr(op['arg']), B, op['hin'], op['win'], op['c'], op['hin'] // 2,

@@ -340,14 +340,18 @@ class ConvPlan:
 
     def run(self, inp, out, add=None, gate=None, gate_mode=_lib.GATE_POS, act=_lib.ACT_NONE, aux_out=None,
             gate2=None, in_coff=0, out_coff=0, add_coff=0, gate_coff=0, mask_out=None, gate_bits=None, gate2_bits=None,
-            inp2=None, in2_coff=0, _wino=None, pool_adjoint=None):
+            inp2=None, in2_coff=0, _wino=None, pool_adjoint=None, pool=None):
         """inp: [B,Hin,Win,Cs_in], out: [B,Hout,Wout,Cs_out] NHWC float32 CUDA tensors.
         `_wino` (internal): (tile, K ranges) of this launch when the plan is the Winograd form of another plan.
         `mask_out` / `gate_bits` / `gate2_bits`: uint8 [B,Hout,Wout,Cs/4] ReLU-gate masks (one byte per 4 channels,
         include/spaa_hip.h): written for this launch's output resp. read instead of a float `gate` / `gate2`.
         `pool_adjoint` = (arg-max bytes uint8 [B,Hp,Wp,C], (Hin, Win), relu_gate): `inp` is then the gradient w.r.t. the OUTPUT of a
         3 x 3 / stride 2 / padding 1 max-pool [B,Hp,Wp,C] whose input (Hin x Win) is this layer's input: the pool's adjoint runs as the
-        prologue of the thin-output matrix-core kernel (tile 72, fp32) instead of as a launch of its own."""
+        prologue of the thin-output matrix-core kernel (tile 72, fp32) instead of as a launch of its own.
+        `pool` = (pooled [B,Hout/2,Wout/2,C], arg-max bytes uint8 [B,Hout/2,Wout/2,C], want_arg): this layer's ReLU is followed by a 2 x 2 /
+        stride-2 max-pool (torchvision VGG-16): where the patch-staged fp16 kernel serves the layer (tile 68, image-aligned regions) the pool
+        runs in its epilogue and `out` is NOT written; anywhere else the layer runs as usual and spaa_maxpool_fwd follows -- the same pooled
+        values and arg-max bytes either way."""
         _lib.check_dev(inp, out, add, gate, aux_out, gate2, inp2, half_ok=True)
         _lib.check_mask(mask_out, gate_bits, gate2_bits)
         in_f16, out_f16 = inp.dtype == torch.float16, out.dtype == torch.float16
@@ -647,6 +651,18 @@ class ConvPlan:
             d.reserved1 |= 16    # (A/B runs: the 64-wide stride-1 form as one workgroup per compute unit)
         if tile == 68 and not h16p_cv and self.s_in == 1 and self.cout * self.nfold > 64 and self.h16p_lean_wide(b, d.Hm, d.Wm):
             d.reserved1 |= 32    # (wider layers as 64-wide N tiles, two workgroups per compute unit)
+        pool_fused = False
+        if pool is not None:
+            assert (act == _lib.ACT_RELU and add is None and gate is None and gate2 is None and aux_out is None and mask_out is None
+                    and gate_bits is None and gate2_bits is None and out_coff == 0)
+            pooled, parg, want_arg = pool
+            assert pooled.shape == (b, hout // 2, wout // 2, cs_out) and pooled.dtype == out.dtype and parg.shape == (b, hout // 2, wout // 2, self.cout)
+            if (tile == 68 and not h16p_cv and self.s_in == 1 and self.nfold == 1 and hout % 2 == 0 and wout % 2 == 0 and self.cout % 4 == 0
+                    and cs_out == self.cout and 'h16ppool' not in DEFAULT_DISABLE):
+                d.out, d.mask_out = pooled.data_ptr(), (parg.data_ptr() if want_arg else None)
+                d.reserved1 |= 64
+                pool_fused = True
+        self.last_pool_fused = pool_fused
         tid = 0
         if PROFILE is not None:
             tid = d.tile + 100 * (d.ksplit if d.ksplit > 1 else (9 if d.ksplit == -1 else 0))
@@ -674,7 +690,13 @@ class ConvPlan:
             if inp2 is not None and not cin2k:   # (second source of the stride-2 kernel; a two-source plan's channels are in cin_p)
                 nbytes += 4 * npx * self.cin2
                 fl += 2 * npx * self.cin2 * self.cout
+            if pool_fused:   # (the pooled tensor and its arg-max bytes instead of the full-size activation)
+                nbytes -= bo * npx * self.cout - (bo + 1) * (npx // 4) * self.cout
             PROFILE.append((self.name, key, fl, e0, e1, tid, nbytes))
+        if pool is not None and not pool_fused:
+            pooled, parg, _want = pool
+            _lib.call('spaa_maxpool_fwd_f16' if out_f16 else 'spaa_maxpool_fwd', _lib.hptr(out), _lib.hptr(pooled), _lib.ptr(parg), b, hout, wout,
+                      self.cout, hout // 2, wout // 2, 2, 2, 0, pooled.shape[3], 0)
         return out
 
     def h16p_lean_wide(self, b, hm, wm):

@@ -378,6 +378,75 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void h16p_kernel(const spaa_tapc
     // output) without a branch: absent tensors are zero-record buffer descriptors (loads give 0, stores are dropped), so that
     // the operand loads of four pixels per lane are in flight together; anything else: the shared store4_t
     const bool fast = fast_epi_ok(e, vec);
+    // ---- POOL (round 5; `reserved1` bit 6; S = 1, unfolded, image-aligned regions): the layer's ReLU and the 2 x 2 / stride-2 max-pool that
+    // follows it (torchvision VGG-16 `features`: conv -> ReLU -> MaxPool2d(2, 2), /root/reference/src/python/classifier.py:21-24) in this
+    // epilogue: `out` is the POOLED tensor [B, Hout / 2, Wout / 2, out_cstride], `mask_out` the pool's arg-max bytes [B, Hout / 2, Wout / 2,
+    // Cout] (code 2 ky + kx of the first maximum | 0x80 if it is positive: spaa_maxpool_fwd's format; NULL = not needed) -- the full-size
+    // activation (VGG-16 conv1_2 at 224 x 224: 411 MB written and read again per forward pass) never reaches HBM.  A wave owns output rows
+    // 2 w, 2 w + 1: the vertical pair of a window is in ONE lane (accumulators b and b + 2), the horizontal pair in neighbouring lanes
+    // (a quad-permute DPP move); values are rounded to the storage type BEFORE they are compared, in the window order of
+    // maxpool2x2_fwd_kernel: bitwise the pooled values and arg-max bytes of the separate launches (finite values).
+    if constexpr (S == 1 && !CV) {
+        if (p.reserved1 & 64) {
+            const bool o16 = (p.io_dtype & SPAA_IO_OUT_F16) != 0;
+            const int Hp = p.Hout >> 1, Wp = p.Wout >> 1;
+            const int64_t npool = (int64_t)p.B * Hp * Wp;
+            const auto r_out = rsrc_or_empty(p.out, npool * p.out_cstride * (o16 ? 2 : 4));
+            const auto r_arg = rsrc_or_empty(p.mask_out, npool * p.Cout);
+            const auto r_bias = rsrc_or_empty(p.bias, (int64_t)p.Cout * 4);
+            const int c = lane & 15, q = lane >> 4;
+            unsigned char* const ab = eb + 16 * ROWB;      // arg-max bytes of the wave's 16 pooled pixels: [16][BN]
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const int n = n_blk + 16 * j + 4 * q;
+                    const u32x4 bv = __builtin_amdgcn_raw_buffer_load_b128(r_bias, n < p.Cout ? n * 4 : (int)0x80000000, 0, 0);
+                    f32x4 best;
+                    unsigned int am = 0;
+#pragma unroll
+                    for (int e_ = 0; e_ < 4; ++e_) {
+                        const float b_ = __uint_as_float(bv[e_]);
+                        float r0 = fmaxf(acc[bb][j][e_] + b_, 0.f), r1 = fmaxf(acc[2 + bb][j][e_] + b_, 0.f);
+                        if (o16) r0 = (float)(_Float16)r0, r1 = (float)(_Float16)r1;
+                        // the neighbouring column's pair (lanes 2 i <-> 2 i + 1 swapped: quad_perm [1, 0, 3, 2])
+                        const float n0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(r0), 0xB1, 0xF, 0xF, true));
+                        const float n1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(r1), 0xB1, 0xF, 0xF, true));
+                        float m_ = r0;
+                        unsigned int k = 0;
+                        if (n0 > m_) m_ = n0, k = 1;
+                        if (r1 > m_) m_ = r1, k = 2;
+                        if (n1 > m_) m_ = n1, k = 3;
+                        best[e_] = m_;
+                        am |= (k | (m_ > 0.f ? 0x80u : 0u)) << (8 * e_);
+                    }
+                    if (!(c & 1)) {     // (even columns hold the windows)
+                        const int pp = 8 * bb + (c >> 1);
+                        *reinterpret_cast<f32x4*>(eb + pp * ROWB + (16 * j + 4 * q) * 4) = best;
+                        *reinterpret_cast<uint32_t*>(ab + pp * BN + 16 * j + 4 * q) = am;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int py = (oy0 >> 1) + wave;
+            const int n = n_blk + ch;
+            if (py < Hp) {
+#pragma unroll
+                for (int i = 0; i < 16 / PPI; ++i) {
+                    const int pr = i * PPI + lane / LPP, px = (ox0 >> 1) + pr;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(eb + pr * ROWB + ch * 4);
+                    const uint32_t am = *reinterpret_cast<const uint32_t*>(ab + pr * BN + ch);
+                    const bool ok = n < p.Cout && px < Wp;
+                    const int o = (img * Hp + py) * Wp + px;
+                    const float v[4] = {a[0], a[1], a[2], a[3]};
+                    if (o16) fast_io<_Float16>::st(r_out, ok ? (o * p.out_cstride + p.out_coff + n) * 2 : (int)0x80000000, v);
+                    else fast_io<float>::st(r_out, ok ? (o * p.out_cstride + p.out_coff + n) * 4 : (int)0x80000000, v);
+                    __builtin_amdgcn_raw_buffer_store_b32(am, r_arg, ok ? o * p.Cout + n : (int)0x80000000, 0, 0);
+                }
+            }
+            return;
+        }
+    }
 #define H16P_TO_LDS(hb)                                                                                            \
     _Pragma("unroll") for (int bb = 0; bb < 2; ++bb)                                                               \
     _Pragma("unroll") for (int j = 0; j < TJ; ++j)                                                                 \
@@ -608,6 +677,14 @@ int spaa_launch_tapconv_h16p(const spaa_tapconv_t& d, hipStream_t stream) {
         if (nfold != 4 || d.w2_split == nullptr || (d.Cin2 != 32 && d.Cin2 != 64) || (d.Cout & 15) || !(d.io_dtype & SPAA_IO_OUT_F16) ||
             (d.in2_cstride & 7) || (d.in2_coff & 7) || d.in2_coff + d.Cin2 > d.in2_cstride ||
             (int64_t)d.B * d.Hout * d.Wout * d.in2_cstride * 2 >= (int64_t)1 << 31)
+            return hipErrorInvalidValue;
+    }
+    if (d.reserved1 & 64) {
+        // fused ReLU + 2 x 2 / stride-2 max-pool: `out` / `mask_out` are the POOLED tensor and its arg-max bytes
+        if (S != 1 || nfold != 1 || (d.reserved1 & 4) || d.act != SPAA_ACT_RELU || d.add != nullptr || d.gate != nullptr || d.gate2 != nullptr ||
+            d.gate_bits != nullptr || d.gate2_bits != nullptr || d.aux_out != nullptr || (d.Hout & 1) || (d.Wout & 1) || (d.Cout & 3) ||
+            (d.out_cstride & 3) || (d.out_coff & 3) || d.out_coff + d.Cout > d.out_cstride ||
+            (int64_t)d.B * (d.Hout / 2) * (d.Wout / 2) * d.out_cstride * 4 >= (int64_t)1 << 31)
             return hipErrorInvalidValue;
     }
     if ((int64_t)((d.Cout * nfold + 127) & ~127) * ((d.cls[0].K + 63) & ~63) * 2 >= (int64_t)1 << 31) return hipErrorInvalidValue;

@@ -1897,6 +1897,10 @@ def _first_iteration_gate_aware(hip, body, csd, insz, im_sz, crop, targets, seed
         print(f'oracle on this host vs reference fixture, first iteration: max abs diff {d:.2e}')
         assert d < 5e-3
     st = A.AttackState(pc, clf, targets, scene, stealth, setup, DEV, storage=storage)
+    if getattr(st.clf.body, 'fuse_pool', False):
+        # (this decomposition reads every convolution's own activation; VGG-16's fp16 pool fusion does not write the ones in front of a pool --
+        # fused and separate launches are bitwise equal: test_vgg16_fp16_pool_fusion_is_bitwise)
+        st.clf.body.fuse_pool = False
     x0 = torch.full((B, 3, *prj_sz), 0.5)
     acts, cacts = _oracle_activations(sd, csd, x0, scene.expand(B, -1, -1, -1) if n_scenes == 1 else scene, im_sz, crop, insz, body)
     errs = {}
@@ -2608,6 +2612,71 @@ def test_h16p_unpadded_3x3_and_its_input_gradient(hip):
             assert rel_inf(nchw(gin.float().cpu(), ci), wantg) < 1.5e-3, (ci, co)
     finally:
         cp.FORCE_TILE = 0
+
+
+def test_h16p_fused_relu_maxpool(hip):
+    """conv -> ReLU -> MaxPool2d(2, 2) (torchvision VGG-16 `features`, classifier.py:21-24) as ONE launch of the patch-staged fp16 kernel
+    (csrc/tapconv_h16p.hip POOL: the pool in the epilogue, the full-size activation never written) against the same plan run as
+    convolution + spaa_maxpool_fwd: bitwise the pooled values and the arg-max bytes (code of the FIRST maximum | 0x80 if positive);
+    64- and 128-wide layers (two workgroups per CU and one), ragged 16 x 32-pixel tiles, the decision-only form without arg-max bytes,
+    and the fall-back inside ConvPlan.run where another kernel serves the layer (14 x 14 maps: canvas form)."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(686)
+    try:
+        for ci, co, h, w, b, fused in [(64, 64, 32, 64, 2, True), (64, 128, 28, 28, 3, True), (128, 256, 20, 70, 2, True), (256, 256, 56, 56, 2, True),
+                                       (128, 128, 14, 14, 4, False)]:
+            x = _h(torch.randn(b, ci, h, w))
+            wt = _h(torch.randn(co, ci, 3, 3) / (ci * 9) ** 0.5)
+            bias = torch.randn(co)
+            plan = cp.conv_fwd_plan(wt, bias, 1, 1, DEV)
+            xin = nhwc(x).half().to(DEV)
+            full = torch.zeros(b, h, w, co, device=DEV, dtype=torch.float16)
+            res = []
+            for fuse in (True, False):
+                (cp.DEFAULT_DISABLE.discard if fuse else cp.DEFAULT_DISABLE.add)('h16ppool')
+                pooled = torch.full((b, h // 2, w // 2, co), -1.0, device=DEV, dtype=torch.float16)
+                arg = torch.full((b, h // 2, w // 2, co), 77, device=DEV, dtype=torch.uint8)
+                if fused:
+                    cp.FORCE_TILE = 68
+                plan.run(xin, full, act=lib.ACT_RELU, pool=(pooled, arg, True))
+                cp.FORCE_TILE = 0
+                assert plan.last_pool_fused == (fuse and fused), (ci, co, h, w, plan.last_tile)
+                res.append((pooled, arg))
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), (ci, co, h, w)
+            y = F.max_pool2d(F.relu(F.conv2d(x.double(), wt.double(), bias.double(), 1, 1)), 2, 2).float()
+            assert rel_inf(nchw(res[0][0].float().cpu(), co), y) < 1.5e-3
+            cp.DEFAULT_DISABLE.discard('h16ppool')
+            pooled2 = torch.zeros_like(res[0][0])
+            arg2 = torch.full_like(res[0][1], 5)
+            if fused:
+                cp.FORCE_TILE = 68
+            plan.run(xin, full, act=lib.ACT_RELU, pool=(pooled2, arg2, False))     # a forward pass nobody differentiates
+            cp.FORCE_TILE = 0
+            assert torch.equal(pooled2, res[0][0]) and (not fused or bool((arg2 == 5).all()))
+    finally:
+        cp.FORCE_TILE = 0
+        cp.DEFAULT_DISABLE.discard('h16ppool')
+
+
+def test_vgg16_fp16_pool_fusion_is_bitwise(hip):
+    """VGG-16 in fp16 storage with the 2 x 2 max-pools fused into the convolutions before them (VGG16Body.fuse_pool) against the same
+    engine with separate pool launches: logits and input gradient bitwise equal."""
+    M = hip['models']
+    csd = syn.vgg16_state_dict(2, logit_gain=20.0)
+    clf = hip['clf'].Classifier('vgg16', DEV, state_dict=csd)
+    ce = clf.engine(2, (256, 256), (240, 240), storage='f16')
+    assert ce.body.fuse_pool
+    im = M.to_nhwc4(syn.scenes(9, 2, (256, 256)).to(DEV))
+    q = torch.zeros(2, 1000, device=DEV)
+    q[0, 3] = -64.0
+    q[1, 17] = -64.0
+    l1 = ce.forward(im).clone()
+    g1 = ce.backward(q).clone()
+    ce.body.fuse_pool = False
+    l0 = ce.forward(im).clone()
+    g0 = ce.backward(q).clone()
+    ce.body.fuse_pool = True
+    assert torch.equal(l1, l0) and torch.equal(g1, g0) and torch.isfinite(g1).all() and float(g1.abs().max()) > 0
 
 
 def test_h16p_stride2_forward(hip):
