@@ -120,7 +120,10 @@ typedef struct {
                              workgroups per compute unit) for a wider layer, bit 6 = the layer's ReLU and the 2 x 2 / stride-2 max-pool that follows it in the epilogue
                              (stride 1, unfolded, image-aligned regions, act = ReLU, no residual / gates, even Hout / Wout): `out` is then the POOLED tensor
                              [B, Hout / 2, Wout / 2, out_cstride] and `mask_out` the pool's arg-max bytes [B, Hout / 2, Wout / 2, Cout] in spaa_maxpool_fwd's format
-                             (or NULL) -- torchvision VGG-16's conv -> ReLU -> MaxPool2d(2, 2), classifier.py:21-24.  0 otherwise. */
+                             (or NULL) -- torchvision VGG-16's conv -> ReLU -> MaxPool2d(2, 2), classifier.py:21-24; bit 7 = the
+                             pool-adjoint PROLOGUE of that layer's input gradient (two-workgroup form only): `in` = the gradient w.r.t. the pool's output [B, Hin / 2,
+                             Win / 2, in_cstride] fp16, `in2` = the pool's arg-max bytes [B, Hin / 2, Win / 2, in2_cstride] -- spaa_maxpool_bwd with its ReLU gate applied
+                             while the patch is staged.  0 otherwise. */
     int32_t nclass;
     spaa_tapclass_t cls[SPAA_MAX_CLASSES];
     /* optional SECOND SOURCE (NULL = none).

@@ -328,20 +328,28 @@ class VGG16Body:
             _lib.call('spaa_adaptive_avgpool_bwd', _lib.ptr(g), None, _lib.ptr(self.g_feat), B, fh, fw, 512, 7, 7)
             g = self.g_feat
         # g is the gradient w.r.t. the last pool's output
+        pending = None     # (fp16 storage: a pool whose adjoint runs as the prologue of the convolution's input gradient below it)
         for i in range(len(self.ops) - 1, -1, -1):
             op = self.ops[i]
             if op['kind'] == 'pool':
+                if self.fuse_pool and i > 0 and self.ops[i - 1]['kind'] == 'conv':
+                    pending = (g, op)       # (ConvPlan.run(unpool=...) falls back to spaa_maxpool_bwd where the fused form does not apply)
+                    continue
                 # input of a pool is a conv+ReLU output: gather + ReLU gate -> gradient w.r.t. that conv's pre-activation
                 _lib.call('spaa_maxpool_bwd_f16' if self.storage == 'f16' else 'spaa_maxpool_bwd', _lib.hptr(g),
                           _lib.ptr(op['arg']), 1, _lib.hptr(op['g']), B, op['hin'], op['win'], op['c'], op['hin'] // 2,
                           op['win'] // 2, 2, 2, 0, op['c'], 0)
             else:
                 prev = self.ops[i - 1] if i > 0 else None
+                kw = {}
+                if pending is not None:
+                    g, pop = pending
+                    kw, pending = dict(unpool=(pop['arg'], pop['g'])), None
                 if prev is not None and prev['kind'] == 'conv' and 'm' in prev:
-                    op['d'].run(g, op['g'], gate_bits=prev['m'])
+                    op['d'].run(g, op['g'], gate_bits=prev['m'], **kw)
                 else:
                     gate = op['inp'] if (prev is not None and prev['kind'] == 'conv') else None
-                    op['d'].run(g, op['g'], gate=gate)
+                    op['d'].run(g, op['g'], gate=gate, **kw)
             g = op['g']
         return g
 

@@ -340,7 +340,7 @@ class ConvPlan:
 
     def run(self, inp, out, add=None, gate=None, gate_mode=_lib.GATE_POS, act=_lib.ACT_NONE, aux_out=None,
             gate2=None, in_coff=0, out_coff=0, add_coff=0, gate_coff=0, mask_out=None, gate_bits=None, gate2_bits=None,
-            inp2=None, in2_coff=0, _wino=None, pool_adjoint=None, pool=None):
+            inp2=None, in2_coff=0, _wino=None, pool_adjoint=None, pool=None, unpool=None):
         """inp: [B,Hin,Win,Cs_in], out: [B,Hout,Wout,Cs_out] NHWC float32 CUDA tensors.
         `_wino` (internal): (tile, K ranges) of this launch when the plan is the Winograd form of another plan.
         `mask_out` / `gate_bits` / `gate2_bits`: uint8 [B,Hout,Wout,Cs/4] ReLU-gate masks (one byte per 4 channels,
@@ -351,7 +351,11 @@ class ConvPlan:
         `pool` = (pooled [B,Hout/2,Wout/2,C], arg-max bytes uint8 [B,Hout/2,Wout/2,C], want_arg): this layer's ReLU is followed by a 2 x 2 /
         stride-2 max-pool (torchvision VGG-16): where the patch-staged fp16 kernel serves the layer (tile 68, image-aligned regions) the pool
         runs in its epilogue and `out` is NOT written; anywhere else the layer runs as usual and spaa_maxpool_fwd follows -- the same pooled
-        values and arg-max bytes either way."""
+        values and arg-max bytes either way.
+        `unpool` = (arg-max bytes uint8 [B,Hin/2,Win/2,C], full-size gradient buffer [B,Hin,Win,Cs]): `inp` is the gradient w.r.t. the OUTPUT of
+        the 2 x 2 / stride-2 max-pool that followed this layer's input (an input-gradient plan of torchvision VGG-16): where the
+        two-workgroup form of the patch-staged fp16 kernel serves the layer the pool's adjoint (with its ReLU gate) runs as the patch
+        prologue and the full-size gradient is never written; anywhere else spaa_maxpool_bwd fills the buffer first."""
         _lib.check_dev(inp, out, add, gate, aux_out, gate2, inp2, half_ok=True)
         _lib.check_mask(mask_out, gate_bits, gate2_bits)
         in_f16, out_f16 = inp.dtype == torch.float16, out.dtype == torch.float16
@@ -359,6 +363,10 @@ class ConvPlan:
             if t is not None and t.dtype != out.dtype:
                 raise ValueError(f'{self.name}: add / gate / aux_out / gate2 must have the storage type of `out` ({out.dtype})')
         b, hin, win, cs_in = inp.shape
+        if unpool is not None:
+            assert in_f16 and inp2 is None and in_coff == 0 and unpool[0].shape[:3] == inp.shape[:3] and unpool[0].shape[3] == self.cin_p == cs_in
+            assert unpool[1].shape == (b, 2 * hin, 2 * win, cs_in) and unpool[1].dtype == inp.dtype
+            hin, win = 2 * hin, 2 * win       # (the layer's input grid; `inp` is at the pooled resolution)
         if pool_adjoint is not None:
             parg, (hin, win), pgate = pool_adjoint
             if (in_f16 or out_f16 or inp2 is not None or parg.dtype != torch.uint8 or tuple(parg.shape) != tuple(inp.shape) or cs_in != self.cin_p
@@ -651,6 +659,20 @@ class ConvPlan:
             d.reserved1 |= 16    # (A/B runs: the 64-wide stride-1 form as one workgroup per compute unit)
         if tile == 68 and not h16p_cv and self.s_in == 1 and self.cout * self.nfold > 64 and self.h16p_lean_wide(b, d.Hm, d.Wm):
             d.reserved1 |= 32    # (wider layers as 64-wide N tiles, two workgroups per compute unit)
+        unpool_fused = False
+        if unpool is not None:
+            parg, gfull = unpool
+            if (tile == 68 and not h16p_cv and self.s_in == 1 and self.nfold == 1 and (self.cout <= 64 or (d.reserved1 & 32)) and not (d.reserved1 & 16)
+                    and self.tap_range[0] >= -1 and self.tap_range[1] <= 1 and self.tap_range[2] >= -1 and self.tap_range[3] <= 1
+                    and self.cin_p % 8 == 0 and 'h16punp' not in DEFAULT_DISABLE):
+                d.in2, d.in2_cstride, d.in2_coff, d.Cin2 = parg.data_ptr(), parg.shape[3], 0, 0
+                d.reserved1 |= 128
+                unpool_fused = True
+            else:
+                _lib.call('spaa_maxpool_bwd_f16', _lib.hptr(inp), _lib.ptr(parg), 1, _lib.hptr(gfull), b, hin, win, self.cin_p, hin // 2, win // 2,
+                          2, 2, 0, cs_in, 0)
+                d.inp, d.in_cstride = gfull.data_ptr(), gfull.shape[3]
+        self.last_unpool_fused = unpool_fused
         pool_fused = False
         if pool is not None:
             assert (act == _lib.ACT_RELU and add is None and gate is None and gate2 is None and aux_out is None and mask_out is None
@@ -690,6 +712,8 @@ class ConvPlan:
             if inp2 is not None and not cin2k:   # (second source of the stride-2 kernel; a two-source plan's channels are in cin_p)
                 nbytes += 4 * npx * self.cin2
                 fl += 2 * npx * self.cin2 * self.cout
+            if unpool_fused:   # (the pooled gradient and the arg-max bytes instead of the full-size gradient)
+                nbytes -= bi * b * hin * win * self.cin_p - (bi + 1) * b * (hin // 2) * (win // 2) * self.cin_p
             if pool_fused:   # (the pooled tensor and its arg-max bytes instead of the full-size activation)
                 nbytes -= bo * npx * self.cout - (bo + 1) * (npx // 4) * self.cout
             PROFILE.append((self.name, key, fl, e0, e1, tid, nbytes))

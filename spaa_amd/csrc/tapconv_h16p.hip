@@ -70,7 +70,13 @@ struct h16p_cv_t {
 // KiB of LDS, at most 128 VGPRs.  The 64 -> 64-channel layers (VGG-16 features.2 at 224 x 224, ResNet-18 layer1) have two channel blocks:
 // with one workgroup per CU the patch load, six steps and a 64 KiB epilogue ran strictly one after the other (490 TFLOP/s); now one
 // workgroup's memory phases lie under the other's products.
-template <int BN, int S = 1, bool CV = false, bool LEAN = false>
+// UNP (round 5; LEAN only; `reserved1` bit 7): the layer is the input gradient of a convolution whose ReLU output fed a 2 x 2 / stride-2
+// max-pool (torchvision VGG-16): `in` is the gradient w.r.t. the POOL's output [B, Hin / 2, Win / 2, in_cstride] and `in2` that pool's arg-max
+// bytes [B, Hin / 2, Win / 2, in2_cstride] (spaa_maxpool_fwd's format); the patch of the pool's INPUT gradient -- g if the pixel is the
+// window's first maximum and that maximum is positive, else 0: spaa_maxpool_bwd with its ReLU gate -- is formed in registers on its way
+// to LDS (two loads, eight byte compares and one 16-byte LDS write per piece) instead of being read from a tensor that a separate
+// launch wrote: 154 MB read instead of 411 MB written and read at VGG-16's first pool.
+template <int BN, int S = 1, bool CV = false, bool LEAN = false, bool UNP = false>
 __global__ __launch_bounds__(512, LEAN ? 4 : 1) void h16p_kernel(const spaa_tapconv_t p, const int wg_y, const int wg_x, const int n_tiles, const h16p_cv_t geo) {
     static_assert(!CV || S == 1, "canvas / K-range form: stride-1 layers");
     typedef h16p_geo<S> G;
@@ -81,6 +87,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void h16p_kernel(const spaa_tapc
     constexpr int W_PIECES = 3 * BN / 16;              // per step (three taps)
     constexpr int WPW = (W_PIECES + NW - 1) / NW;      // 3 (BN = 128) or 2 (BN = 64: 12 pieces, the last four DMA slots are pad)
     static_assert(!LEAN || (S == 1 && BN == 64 && !CV), "lean form: stride 1, 64-wide N tile");
+    static_assert(!UNP || LEAN, "pool-adjoint prologue: the two-workgroup form (one patch buffer)");
     constexpr int NBUF = LEAN ? 1 : G::NBUF;
     constexpr int WS_BYTES = LEAN ? W_PIECES * 1024 : WPW * NW * 1024;
     static_assert(!LEAN || G::P_PIECES < PPW * 8, "lean form: the patch buffer ends in a pad piece");
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void h16p_kernel(const spaa_tapc
         img = t / wg_y;
     }
     const int row_bytes = p.in_cstride * 2;
-    const uint32_t in_bytes = (uint32_t)p.B * (uint32_t)(H * W) * (uint32_t)row_bytes;
+    const uint32_t in_bytes = (uint32_t)p.B * (uint32_t)(UNP ? (H >> 1) * (W >> 1) : H * W) * (uint32_t)row_bytes;
     const uint64_t in_addr = reinterpret_cast<uint64_t>(p.in);
     const uint32_t in_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)in_addr);
     const uint32_t in_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(in_addr >> 32));
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void h16p_kernel(const spaa_tapc
     // chunk swizzle of a patch pixel's 64-byte row: S = 1 as the weights' (16 consecutive pixels: conflict-free); S = 2: a fragment
     // reads every second pixel (128 bytes apart): lane pairs rotate through the four chunks (two-way conflicts at worst)
     auto pswz = [](const int q) { return S == 1 ? swz64(q) : ((q >> 2) & 3); };
-    const bool two = p.in2 != nullptr && nfold == 1;
+    const bool two = !UNP && p.in2 != nullptr && nfold == 1;
     const int kb1 = two ? (Cin - p.Cin2) >> 5 : 0x7fffffff;      // first channel block of the second source
     const int row_bytes2 = two ? p.in2_cstride * 2 : 0;
     const auto rsrc_in2 = two ? rsrc_or_empty(p.in2, (int64_t)p.B * (H * W) * row_bytes2) : rsrc_in;
@@ -177,12 +184,47 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void h16p_kernel(const spaa_tapc
         bool ok = q < NPX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
         int pxi = (img * H + iy) * W + ix;
         if constexpr (CV) ok = canvas_pixel(iy, ix, pxi) && q < NPX;
+        // (UNP: the pooled pixel and the position 2 ky + kx of this pixel in its window)
+        if constexpr (UNP) pxi = (((img * (H >> 1) + (iy >> 1)) * (W >> 1) + (ix >> 1)) << 2) | ((iy & 1) << 1) | (ix & 1);
         ppix[i] = ok ? pxi : -1;
     }
+    const auto rsrc_arg = UNP ? rsrc_or_empty(p.in2, (int64_t)p.B * (H >> 1) * (W >> 1) * p.in2_cstride) : rsrc_in;
     // 32-channel blocks of this workgroup: all of them, or (CV) the K range [kb0, kb0 + nkb)
     const int kb0 = CV ? ks * geo.kb_per : 0;
     auto dma_patch = [&](const int buf, const int kbl) {
         const int kb = kb0 + kbl;
+        if constexpr (UNP) {
+            // two batches (three and two pieces): at most 18 registers of loaded data live at a time
+            constexpr int HB = (PPW + 1) / 2;
+#pragma unroll
+            for (int i0 = 0; i0 < PPW; i0 += HB) {
+                u32x4 gv[HB];
+                u32x2 av[HB];
+#pragma unroll
+                for (int i = i0; i < i0 + HB && i < PPW; ++i) {
+                    int pp = ppix[i];
+                    asm volatile("" : "+v"(pp));     // (the two offsets are recomputed per block: not ten more registers across the K loop)
+                    const bool ok = pp >= 0;
+                    gv[i - i0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, ok ? (pp >> 2) * row_bytes + pch16 : (int)0x80000000,
+                                                                       (p.in_coff + kb * 32) * 2, 0);
+                    av[i - i0] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_arg, ok ? (pp >> 2) * p.in2_cstride + (pch16 >> 1) : (int)0x80000000,
+                                                                      p.in2_coff + kb * 32, 0);
+                }
+#pragma unroll
+                for (int i = i0; i < i0 + HB && i < PPW; ++i) {
+                    const unsigned int code = 0x80u | (unsigned int)(ppix[i] & 3);
+                    u32x4 o;
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) {     // two fp16 values (channels 2 e2, 2 e2 + 1 of the chunk) per register
+                        const unsigned int a0 = (av[i - i0][e2 >> 1] >> (16 * (e2 & 1))) & 0xffu, a1 = (av[i - i0][e2 >> 1] >> (16 * (e2 & 1) + 8)) & 0xffu;
+                        const unsigned int g = gv[i - i0][e2];
+                        o[e2] = (a0 == code ? (g & 0xffffu) : 0u) | (a1 == code ? (g & 0xffff0000u) : 0u);
+                    }
+                    *reinterpret_cast<u32x4*>(smem + buf * PATCH_BYTES + (wave + NW * i) * 1024 + lane * 16) = o;
+                }
+            }
+            return;
+        }
         const bool s2 = kb >= kb1;     // (uniform)
         const int rb = s2 ? row_bytes2 : row_bytes, cb = s2 ? (p.in2_coff + (kb - kb1) * 32) * 2 : (p.in_coff + kb * 32) * 2;
 #pragma unroll
@@ -209,18 +251,34 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void h16p_kernel(const spaa_tapc
     // the same chunk swizzle (bits 3 resp. 2-3 of q unchanged by + 16 / + 32), so its address is the first's + 1024 S bytes -- an
     // immediate offset; one register per (tap, row))
     constexpr int NR = NB / 2;
-    int faddr[9][NR];
+    // (UNP: the two rows' addresses -- below 64 KiB -- share a register: nine registers less where 128 are all there is; one shift / mask
+    // per fragment read)
+    constexpr bool FPK = UNP && NR == 2;
+    int faddr_[9][FPK ? 1 : NR];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const bool has = t < ntaps;
         const int dy = has ? ctaps[2 * t] : py0, dx = has ? ctaps[2 * t + 1] : px0;
+        int fa[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int orow = S == 1 ? 2 * wave + r : wave, ocol = lane & 15;
             const int q = (orow * S + dy - py0) * PW + ocol * S + dx - px0;
-            faddr[t][r] = q * 64 + (((lane >> 4) ^ pswz(q)) << 4);
+            fa[r] = q * 64 + (((lane >> 4) ^ pswz(q)) << 4);
+        }
+        if constexpr (FPK) faddr_[t][0] = fa[0] | (fa[NR - 1] << 16);
+        else {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) faddr_[t][r] = fa[r];
         }
     }
+    auto faddr = [&](const int t, const int r) -> int {
+        if constexpr (FPK) {
+            int v = faddr_[t][0];
+            asm volatile("" : "+v"(v));     // (unpacked where it is used: the optimiser would hoist both halves out of the K loop again)
+            return r ? (int)((unsigned int)v >> 16) : (v & 0xffff);
+        } else return faddr_[t][r];
+    };
 
     f32x4 acc[NB][TJ];
 #pragma unroll
@@ -268,7 +326,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void h16p_kernel(const spaa_tapc
             h8 bfs[NBF][NB], wfs[2];
             if constexpr (NBF == 2) {
 #pragma unroll
-                for (int b = 0; b < NB; ++b) bfs[0][b] = *reinterpret_cast<const h8*>(pb + faddr[3 * s][b >> 1] + (b & 1) * (1024 * S));
+                for (int b = 0; b < NB; ++b) bfs[0][b] = *reinterpret_cast<const h8*>(pb + faddr(3 * s, b >> 1) + (b & 1) * (1024 * S));
             }
             wfs[0] = *reinterpret_cast<const h8*>(wsm + st * WS_BYTES + w_addr_l);
 #pragma unroll
@@ -278,7 +336,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void h16p_kernel(const spaa_tapc
                 const unsigned char* wc = wsm + st * WS_BYTES + tl * W_TAP + w_addr_l;
                 if constexpr (NBF == 1) {
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) bfs[0][b] = *reinterpret_cast<const h8*>(pb + faddr[3 * s + tl][b >> 1] + (b & 1) * (1024 * S));
+                    for (int b = 0; b < NB; ++b) bfs[0][b] = *reinterpret_cast<const h8*>(pb + faddr(3 * s + tl, b >> 1) + (b & 1) * (1024 * S));
                 }
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
@@ -289,7 +347,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void h16p_kernel(const spaa_tapc
                     if (NBF == 2 && j == 0 && more) {
 #pragma unroll
                         for (int b = 0; b < NB; ++b)
-                            bfs[(tl + 1) & (NBF - 1)][b] = *reinterpret_cast<const h8*>(pb + faddr[3 * s + tl + 1][b >> 1] + (b & 1) * (1024 * S));
+                            bfs[(tl + 1) & (NBF - 1)][b] = *reinterpret_cast<const h8*>(pb + faddr(3 * s + tl + 1, b >> 1) + (b & 1) * (1024 * S));
                     }
 #pragma unroll
                     for (int b = 0; b < NB; ++b) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfs[u & 1], bfs[tl & (NBF - 1)][b], acc[b][j], 0, 0, 0);
@@ -669,7 +727,9 @@ int spaa_launch_tapconv_h16p(const spaa_tapconv_t& d, hipStream_t stream) {
             d.tap_range[3] - d.tap_range[2] > 2)
             return hipErrorInvalidValue;
     }
-    if (d.in2 != nullptr && nfold == 1) {   // two sources of an unfolded layer: the last Cin2 channels (whole 32-channel blocks) from `in2`
+    if (d.reserved1 & 128) {
+        // (`in2` = arg-max bytes of the pool-adjoint prologue: checked with the launch below)
+    } else if (d.in2 != nullptr && nfold == 1) {   // two sources of an unfolded layer: the last Cin2 channels (whole 32-channel blocks) from `in2`
         if ((d.Cin2 & 31) || d.Cin2 <= 0 || d.Cin2 >= d.Cin || (d.in2_cstride & 7) || (d.in2_coff & 7) || d.in2_coff + d.Cin2 > d.in2_cstride ||
             (int64_t)d.B * d.Hin * d.Win * d.in2_cstride * 2 >= (int64_t)1 << 31)
             return hipErrorInvalidValue;
@@ -752,15 +812,28 @@ int spaa_launch_tapconv_h16p(const spaa_tapconv_t& d, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;                                                                                \
         hipLaunchKernelGGL((h16p_kernel<N, SS>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles, nogeo); \
     }
+    const bool unp = (d.reserved1 & 128) != 0;
+    if (unp) {
+        // pool-adjoint prologue: `in` = the pooled gradient, `in2` = the pool's arg-max bytes; the two-workgroup form only
+        if (S != 1 || BN != 64 || (d.reserved1 & 16) || nfold != 1 || d.in2 == nullptr || (d.Hin & 1) || (d.Win & 1) || (d.in2_cstride & 7) || (d.in2_coff & 7) ||
+            d.in2_coff + d.Cin > d.in2_cstride || d.tap_range[0] < -1 || d.tap_range[1] > 1 || d.tap_range[2] < -1 || d.tap_range[3] > 1)
+            return hipErrorInvalidValue;
+    }
     if (S == 1 && BN == 64 && !(d.reserved1 & 16)) {
         // two workgroups per compute unit (LEAN): one 40 KiB patch buffer + three 12 KiB weight stages; epilogue 8 x 32 rows of 272 bytes
         typedef h16p_geo<1> G;
         const size_t mainb = (size_t)G::PATCH_BYTES + 3 * (size_t)(12 * 1024), epib = 8 * 32 * (size_t)(64 * 4 + 16);
         const size_t smem = mainb > epib ? mainb : epib;
-        static bool lean_set[SPAA_MAX_DEVICES] = {};
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&h16p_kernel<64, 1, false, true>), (int)smem, lean_set);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((h16p_kernel<64, 1, false, true>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles, nogeo);
+        static bool lean_set[2][SPAA_MAX_DEVICES] = {};
+        if (unp) {
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&h16p_kernel<64, 1, false, true, true>), (int)smem, lean_set[1]);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((h16p_kernel<64, 1, false, true, true>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles, nogeo);
+        } else {
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&h16p_kernel<64, 1, false, true>), (int)smem, lean_set[0]);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((h16p_kernel<64, 1, false, true>), dim3((unsigned)nwg), dim3(512), smem, stream, d, wg_y, wg_x, n_tiles, nogeo);
+        }
     } else if (S == 1) {
         if (BN == 64) H16P_LAUNCH(64, 1, 0) else H16P_LAUNCH(128, 1, 1)
     } else {

@@ -2679,6 +2679,40 @@ def test_vgg16_fp16_pool_fusion_is_bitwise(hip):
     assert torch.equal(l1, l0) and torch.equal(g1, g0) and torch.isfinite(g1).all() and float(g1.abs().max()) > 0
 
 
+def test_h16p_pool_adjoint_prologue(hip):
+    """The input gradient of a convolution whose ReLU output fed a 2 x 2 / stride-2 max-pool (torchvision VGG-16, classifier.py:21-24) with
+    the pool's adjoint as the patch prologue of the patch-staged fp16 kernel (csrc/tapconv_h16p.hip UNP: the pooled gradient and the arg-max
+    bytes in, the full-size gradient never written) against spaa_maxpool_bwd + the plain launch: bitwise equal; 64-wide layers and wider ones
+    with short K (two workgroups per CU), byte-mask gate of the layer below, ragged tiles, and the fall-back inside ConvPlan.run (long K)."""
+    cp, lib = hip['cp'], hip['lib']
+    torch.manual_seed(687)
+    try:
+        for ci, co, h, w, b, fused in [(64, 64, 32, 64, 2, True), (64, 128, 28, 36, 3, True), (128, 256, 20, 70, 2, True), (64, 512, 16, 32, 2, True), (128, 512, 16, 32, 2, False)]:
+            # (forward layer ci -> co at h x w, then ReLU and the pool; the input gradient maps co -> ci channels)
+            wt = _h(torch.randn(co, ci, 3, 3) / (ci * 9) ** 0.5)
+            dplan = cp.conv_dgrad_plan(wt, 1, 1, DEV)
+            act = _h(torch.randn(b, h, w, co, device=DEV)).half()                           # the layer's ReLU output is max(act, 0)
+            pooled = torch.zeros(b, h // 2, w // 2, co, device=DEV, dtype=torch.float16)
+            arg = torch.zeros(b, h // 2, w // 2, co, device=DEV, dtype=torch.uint8)
+            lib.call('spaa_maxpool_fwd_f16', lib.hptr(torch.relu(act)), lib.hptr(pooled), lib.ptr(arg), b, h, w, co, h // 2, w // 2, 2, 2, 0, co, 0)
+            gp = _h(torch.randn(b, h // 2, w // 2, co, device=DEV)).half()
+            gbits = lib.pack_gate_mask(torch.randn(b, h, w, ci, device=DEV))
+            res = []
+            for fuse in (True, False):
+                (cp.DEFAULT_DISABLE.discard if fuse else cp.DEFAULT_DISABLE.add)('h16punp')
+                gfull = torch.full((b, h, w, co), 3.0, device=DEV, dtype=torch.float16)
+                gin = torch.zeros(b, h, w, ci, device=DEV, dtype=torch.float16)
+                cp.FORCE_TILE = 68
+                dplan.run(gp, gin, gate_bits=gbits, unpool=(arg, gfull))
+                cp.FORCE_TILE = 0
+                assert dplan.last_tile == 68 and dplan.last_unpool_fused == (fuse and fused), (ci, co, dplan.last_unpool_fused)
+                res.append(gin)
+            assert torch.equal(res[0], res[1]) and float(res[0].float().abs().max()) > 0, (ci, co, h, w)
+    finally:
+        cp.FORCE_TILE = 0
+        cp.DEFAULT_DISABLE.discard('h16punp')
+
+
 def test_h16p_stride2_forward(hip):
     """The patch-staged fp16 kernel's stride-2 FORWARD form (csrc/tapconv_h16p.hip S = 2: ShadingNetSPAA.conv2 / conv2_s,
     models.py:224,230 of the reference, the input gradient of transConv1, the classifiers' 3 x 3 / stride-2 layers) against float64
