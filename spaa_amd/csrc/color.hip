@@ -22,16 +22,33 @@ constexpr float kRad = (float)(3.14159265358979323846 / 180.0);   // radians(n) 
 constexpr float kXn = 95.0489f, kYn = 100.f, kZn = 108.8840f;
 constexpr float k25_7 = 6103515625.f;  // 25^7
 
+// Round 5: the remaining libm sequences of the per-pixel colour map on the hardware transcendentals as well -- t^1.4 = exp2(1.4 log2 t)
+// (v_log_f32 + v_exp_f32: 3 instructions for powf's ~60), the cube root likewise, v_sqrt_f32 (1 ulp) for sqrtf's 12-instruction
+// correctly-rounded form, divisions by the colour constants as multiplications by their reciprocals: a few ulp on Lab (the fixtures of
+// the reference are met at 1e-5 relative, dE at 2e-4 absolute, as before), the SAME functions in spaa_rgb2lab and inside the fused loss
+// (identical pixels still give dE == 0 exactly).  SPAA_COLOR_LIBM: the libm forms, for A/B accuracy runs.
+#ifdef SPAA_COLOR_LIBM
+__device__ __forceinline__ float fpow14(float t) { return powf(t, 1.4f); }
+__device__ __forceinline__ float fcbrt(float t) { return cbrtf(t); }
+__device__ __forceinline__ float fsqrt(float t) { return sqrtf(t); }
+__device__ __forceinline__ float fdivc(float x, float c) { return x / c; }
+#else
+__device__ __forceinline__ float fpow14(float t) { return __builtin_amdgcn_exp2f(1.4f * __builtin_amdgcn_logf(t)); }
+__device__ __forceinline__ float fcbrt(float t) { return __builtin_amdgcn_exp2f((1.f / 3.f) * __builtin_amdgcn_logf(t)); }
+__device__ __forceinline__ float fsqrt(float t) { return __builtin_amdgcn_sqrtf(t); }
+__device__ __forceinline__ float fdivc(float x, float c) { return x * (1.f / c); }      // (c: a compile-time constant)
+#endif
+
 __device__ __forceinline__ float srgb_lin(float v, float& dv) {
     // rgb2xyz :16-20
     if (v > 0.0405f) {
-        const float t = (v + 0.055f) / 1.055f;
-        const float p14 = powf(t, 1.4f);
+        const float t = fdivc(v + 0.055f, 1.055f);
+        const float p14 = fpow14(t);
         dv = 100.f * (2.4f / 1.055f) * p14;
         return 100.f * (p14 * t);  // t^2.4 = t^1.4 * t  (within an ulp of powf(t, 2.4f))
     }
     dv = 100.f / 12.92f;
-    return 100.f * (v / 12.92f);
+    return 100.f * fdivc(v, 12.92f);
 }
 
 // forward-only variant: the SAME arithmetic as srgb_lin, so that Lab(scene) cached by spaa_rgb2lab and Lab(y)
@@ -48,7 +65,7 @@ __device__ __forceinline__ float lab_f(float t, float& dt) {
         return 0.f;
     }
     if (t > 0.008856f) {
-        const float c = cbrtf(t);
+        const float c = fcbrt(t);
         dt = (1.f / 3.f) / (c * c);
         return c;
     }
@@ -62,7 +79,7 @@ __device__ __forceinline__ void rgb_to_lab(float r, float g, float b, float& L, 
     const float X = 0.4124f * lr + 0.3576f * lg + 0.1805f * lb;
     const float Y = 0.2126f * lr + 0.7152f * lg + 0.0722f * lb;
     const float Z = 0.0193f * lr + 0.1192f * lg + 0.9504f * lb;
-    const float fx = lab_f(X / kXn, d), fy = lab_f(Y / kYn, d), fz = lab_f(Z / kZn, d);
+    const float fx = lab_f(fdivc(X, kXn), d), fy = lab_f(fdivc(Y, kYn), d), fz = lab_f(fdivc(Z, kZn), d);
     L = 116.f * fy - 16.f;
     A = 500.f * (fx - fy);
     Bv = 200.f * (fy - fz);
@@ -116,17 +133,17 @@ __device__ __forceinline__ DE ciede2000(float L1, float A1, float B1, float L2, 
     const bool m02 = (A2 == 0.f) && (B2 == 0.f);
     if (m01) B1 += 0.0001f;
     if (m02) B2 += 0.0001f;
-    const float C1 = sqrtf(A1 * A1 + B1 * B1);
-    const float C2 = sqrtf(A2 * A2 + B2 * B2);
+    const float C1 = fsqrt(A1 * A1 + B1 * B1);
+    const float C2 = fsqrt(A2 * A2 + B2 * B2);
     const float aC = ((C1 + C2) * 0.5f);
     const float aC7 = pow7(aC);
     const float fG = fdiv(aC7, (aC7 + k25_7));
-    const float sfG = sqrtf(fG);
+    const float sfG = sqrtf(fG);   // (fG = aC^7 / (aC^7 + 25^7) is DENORMAL for near-grey pairs: v_sqrt_f32 would flush it to 0)
     const float G = 0.5f * (1.f - sfG);
     const float a1P = (1.f + G) * A1;
     const float a2P = (1.f + G) * A2;
-    const float c1P = sqrtf(a1P * a1P + B1 * B1);
-    const float c2P = sqrtf(a2P * a2P + B2 * B2);
+    const float c1P = fsqrt(a1P * a1P + B1 * B1);
+    const float c2P = fsqrt(a2P * a2P + B2 * B2);
     const float h1P = m01 ? 0.f : hue_deg(B1, a1P);
     const float h2P = m02 ? 0.f : hue_deg(B2, a2P);
     const float dLP = L2 - L1;
@@ -135,7 +152,7 @@ __device__ __forceinline__ DE ciede2000(float L1, float A1, float B1, float L2, 
     const float dh = h2P - h1P;
     float dhP = 0.f;
     if (!mc0) dhP = (fabsf(dh) <= 180.f) ? dh : (dh > 180.f ? dh - 360.f : dh + 360.f);
-    const float sq = sqrtf(c1P * c2P);
+    const float sq = fsqrt(c1P * c2P);
     const float half = ((dhP * kRad) * 0.5f);
     const float sn = fsin(half), cs = fcos(half);
     const float m_no = (m01 || m02) ? 0.f : 1.f;
@@ -155,9 +172,9 @@ __device__ __forceinline__ DE ciede2000(float L1, float A1, float B1, float L2, 
     const float dRO = 30.f * fexp(-1.f * (e * e));
     const float aCP7 = pow7(aCP);
     const float fR = fdiv(aCP7, (aCP7 + k25_7));
-    const float rC = sqrtf(fR);
+    const float rC = sqrtf(fR);    // (likewise)
     const float q = (aL - 50.f) * (aL - 50.f);
-    const float sq20 = sqrtf(20.f + q);
+    const float sq20 = fsqrt(20.f + q);
     const float sL = 1.f + fdiv((0.015f * q), sq20);
     const float sC = 1.f + 0.045f * aCP;
     const float sH = 1.f + 0.015f * aCP * T;
@@ -167,7 +184,7 @@ __device__ __forceinline__ DE ciede2000(float L1, float A1, float B1, float L2, 
     const float u = fdiv(dLP, sL), v = fdiv(dCP, sC), w = fdiv(dHP, sH);
     const float rs = u * u + (v * v) * m_no + (w * w) * m_no + rT * v * w * m_no;
     const bool m0 = rs <= 0.f;
-    out.de = m0 ? 0.f : sqrtf(rs);
+    out.de = m0 ? 0.f : fsqrt(rs);
     out.gL = out.gA = out.gB = 0.f;
     if (!GRAD || m0) return out;
 
@@ -273,13 +290,13 @@ __global__ void rgb2lab_bwd_kernel(const float4* __restrict__ rgb, const float4*
     const float Y = 0.2126f * lr + 0.7152f * lg + 0.0722f * lb;
     const float Z = 0.0193f * lr + 0.1192f * lg + 0.9504f * lb;
     float dfx, dfy, dfz;
-    lab_f(X / kXn, dfx);
-    lab_f(Y / kYn, dfy);
-    lab_f(Z / kZn, dfz);
+    lab_f(fdivc(X, kXn), dfx);
+    lab_f(fdivc(Y, kYn), dfy);
+    lab_f(fdivc(Z, kZn), dfz);
     const float fy_b = 116.f * gl.x - 500.f * gl.y + 200.f * gl.z;
     const float fx_b = 500.f * gl.y;
     const float fz_b = -200.f * gl.z;
-    const float X_b = fx_b * dfx / kXn, Y_b = fy_b * dfy / kYn, Z_b = fz_b * dfz / kZn;
+    const float X_b = fdivc(fx_b * dfx, kXn), Y_b = fdivc(fy_b * dfy, kYn), Z_b = fdivc(fz_b * dfz, kZn);
     g_rgb[idx] = make_float4((0.4124f * X_b + 0.2126f * Y_b + 0.0193f * Z_b) * dr,
                              (0.3576f * X_b + 0.7152f * Y_b + 0.1192f * Z_b) * dg,
                              (0.1805f * X_b + 0.0722f * Y_b + 0.9504f * Z_b) * db, 0.f);
@@ -317,13 +334,13 @@ __device__ __forceinline__ float de_rgb_grad(float r, float g, float b, float L2
     const float Y = 0.2126f * lr + 0.7152f * lg + 0.0722f * lb;
     const float Z = 0.0193f * lr + 0.1192f * lg + 0.9504f * lb;
     float dfx, dfy, dfz;
-    const float fx = lab_f(X / kXn, dfx), fy = lab_f(Y / kYn, dfy), fz = lab_f(Z / kZn, dfz);
+    const float fx = lab_f(fdivc(X, kXn), dfx), fy = lab_f(fdivc(Y, kYn), dfy), fz = lab_f(fdivc(Z, kZn), dfz);
     const float L = 116.f * fy - 16.f, A = 500.f * (fx - fy), Bv = 200.f * (fy - fz);
     const DE d = ciede2000<true>(L, A, Bv, L2, A2, B2);
     const float fy_b = 116.f * d.gL - 500.f * d.gA + 200.f * d.gB;
     const float fx_b = 500.f * d.gA;
     const float fz_b = -200.f * d.gB;
-    const float X_b = fx_b * dfx / kXn, Y_b = fy_b * dfy / kYn, Z_b = fz_b * dfz / kZn;
+    const float X_b = fdivc(fx_b * dfx, kXn), Y_b = fdivc(fy_b * dfy, kYn), Z_b = fdivc(fz_b * dfz, kZn);
     gr = (0.4124f * X_b + 0.2126f * Y_b + 0.0193f * Z_b) * dr;
     gg = (0.3576f * X_b + 0.7152f * Y_b + 0.1192f * Z_b) * dg;
     gb = (0.1805f * X_b + 0.0722f * Y_b + 0.9504f * Z_b) * db;
