@@ -24,7 +24,7 @@ from .models import to_nhwc4, to_nchw, USE_GATE_MASKS
 # 190 -> 304 us for the 55 us launch it removes -- the patch formed by loads + VALU work in four dependent round trips per channel block
 # where the LDS-DMA of the separate form costs no issue slots): off by default, kept with its bitwise test.
 FUSE_POOL = os.environ.get('SPAA_FUSE_POOL', '1') != '0'   # VGG-16, fp16 storage: the 2 x 2 max-pools in the epilogue of the convolution before them
-FOLD_S2_F16 = os.environ.get('SPAA_FOLD_S2_F16', '0') == '1'   # fp16 storage: ResNet's stride-2 input gradients with the four parity classes folded into N (A/B)
+FOLD_S2_F16 = int(os.environ.get('SPAA_FOLD_S2_F16', '0'))   # fp16 storage: ResNet's stride-2 input gradients with the four parity classes folded into N: 0 never (default: neutral in the loop, 238.7-239.3 it/s either way), 1 layer2.0 (49.5 -> 38 us per launch), 2 all three
 FUSE_POOL_ADJOINT = os.environ.get('SPAA_FUSE_POOL_ADJOINT', '0') == '1'
 BODY_GATE_MASKS = os.environ.get('SPAA_BODY_MASKS', '1') != '0'   # 0: VGG-16 / Inception-v3 gate with the activation itself (A/B measurements)
 
@@ -92,7 +92,7 @@ class ResNet18Body:
                 w2_, b2_ = folded(p + '.conv2', p + '.bn2')
                 blk['f1'] = cp.conv_fwd_plan(w1_, b1_, stride, 1, dev, p + '.conv1')
                 blk['d1'] = cp.conv_dgrad_plan(w1_, stride, 1, dev, p + '.conv1_dgrad',
-                                               fold=True if (FOLD_S2_F16 and storage == 'f16' and stride == 2) else None)
+                                               fold=True if (FOLD_S2_F16 and storage == 'f16' and stride == 2 and (cin <= 64 or FOLD_S2_F16 > 1)) else None)
                 if stride == 2 and cin in (32, 64) and storage == 'f32' and batch * hh * ww >= 100000:
                     # layer2.0.conv1's input gradient (128 -> 64 channels, 28^2 -> 56^2) at benchmark batches: the patch-staged
                     # stride-2 kernel with its four parity classes in one launch (tools/lab/x6p_resnet.py: 79 -> 71 us)
