@@ -482,7 +482,9 @@ class ConvPlan:
             else:
                 tile = 60 if ngemm > 64 else 61 if ngemm > 32 else 62 if ngemm > 16 else 63
                 m_all = b * d.Hm * d.Wm
-                if (patch_ok and ngemm >= 64 and 'h16p' not in DEFAULT_DISABLE and forced == 0
+                # (32 GEMM columns leave half of the 64-wide tile empty and still win: Inception-v3 Conv2d_2a 138 -> 125 us, its input gradient 148 -> 128,
+                # Conv2d_2b's 203 -> 170; `h16p64` in SPAA_DEFAULT_DISABLE: the round-4 threshold)
+                if (patch_ok and ngemm >= (64 if 'h16p64' in DEFAULT_DISABLE else 32) and 'h16p' not in DEFAULT_DISABLE and forced == 0
                         and b * ((d.Hm + 15) // 16) * ((d.Wm + 31) // 32) * ((ngemm + 127) // 128) >= 256
                         and d.Hm * d.Wm >= 0.6 * ((d.Hm + 15) // 16 * 16) * ((d.Wm + 31) // 32 * 32)):   # (16 x 32-pixel tiles)
                     tile = 68   # 3x3 / stride 1 (or a folded stride-2 transposed layer): the input patch staged once for all taps (csrc/tapconv_h16p.hip)
