@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2516.0  # dense bf16 MFMA (16x the fp32 rate; "~2.5 PF dense" in MI355X_MICROARCH.md)
+WINO_ALGORITHMIC_GAIN = 36.0 / 16.0  # Winograd F(2x2,3x3): 16 products per 2x2 output tile instead of 36
 PEAK_HBM_TBS = 8.0  # HBM3E spec (MI355X_MICROARCH.md; 6.3 TB/s is what a float4 copy achieves)
 
 # algorithmic bytes per scene-iteration at 256x256 (3-channel fp32 images, per-batch constants
@@ -305,7 +306,10 @@ def instrumented_pass(st, args, n_prof=3):
         b[2] += 1
         b[4] += nbytes
         t_hbm = nbytes / (PEAK_HBM_TBS * 1e12)
-        t_roof_x6 += max(t_hbm, flops / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12)) / n_prof
+        # (a Winograd launch executes 16 of the 36 products of a 3 x 3 tap set: its ceiling for ALGORITHMIC FLOPs is 36/16 of the
+        # direct bf16x6 kernels' -- each layer is priced against the ceiling of the kernel that runs it, the saving is credited once)
+        peak_x6 = PEAK_BF16_MFMA_TFLOPS / 6.0 * (WINO_ALGORITHMIC_GAIN if base.startswith('wino') else 1.0)
+        t_roof_x6 += max(t_hbm, flops / (peak_x6 * 1e12)) / n_prof
         t_roof_f32 += max(t_hbm, flops / (PEAK_F32_MFMA_TFLOPS * 1e12)) / n_prof
     # second pass: the non-convolution entry points
     _lib.PROFILE = []
@@ -550,8 +554,11 @@ def main():
             # Winograd F(2x2,3x3) on the bf16x6 arithmetic: `achieved` counts the ALGORITHMIC FLOPs of the 3x3 convolution
             # (2 x 9 x Cin x Cout per pixel) against the same matrix-core ceiling as the direct bf16x6 kernels; the
             # kernel itself issues 16/36 of those products (+ the transforms on the VALU), reported as `executed_tflops`
-            peak, kname = PEAK_BF16_MFMA_TFLOPS / 6.0, (f'tapconv_{dom} (Winograd F(2x2,3x3), bf16x6-split MFMA, fp32-exact '
-                                                         'operands)')
+            # `frac` prices them against the kernel's OWN ceiling: the dense bf16 peak / 6 partial products x 36/16 (what the
+            # matrix cores would deliver in algorithmic FLOPs if the 16 executed products ran at peak) = executed bf16 MFMA FLOPs
+            # over the dense bf16 peak.  The ratio to the DIRECT bf16x6 ceiling is kept as `algorithmic_vs_direct_x6_ceiling`
+            peak, kname = PEAK_BF16_MFMA_TFLOPS / 6.0 * WINO_ALGORITHMIC_GAIN, (f'tapconv_{dom} (Winograd F(2x2,3x3), bf16x6-split MFMA, fp32-exact '
+                                                                                'operands)')
         elif dom.startswith('x6'):
             # fp32 emulated with six bf16 MFMAs per product group: the matrix-core ceiling for algorithmic fp32 FLOPs
             # is the dense bf16 peak / 6
@@ -583,16 +590,18 @@ def main():
                 'traffic_source': f'{traffic_src} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes over this '
                                   'same command; bench.py cannot collect PMC itself)',
                 'algorithmic_bytes_per_launch': round(nb / n),
-                'peak_note': 'algorithmic fp32 FLOP/s; dense bf16 MFMA peak 2516 TF / 6 partial products for the x6 kernels, '
+                'peak_note': 'algorithmic fp32 FLOP/s; dense bf16 MFMA peak 2516 TF / 6 partial products for the x6 kernels (x 36/16 for '
+                             'the Winograd form, which executes 16 of the 36 products: frac = executed bf16 MFMA FLOPs / 2516 TF), '
                              '157.3 TF for the fp32-MFMA kernels',
                 'avg_launch_us': round(ms * 1e3 / n, 2), 'launches_per_step': n_instr // n_prof,
                 'avg_launch_us_source': 'HIP events around this kernel\'s launches inside the timed region (launch stream)' if timed_events else 'HIP events, instrumented passes after the timed region',
                 'avg_launch_us_instrumented_pass': round(ms_instr * 1e3 / n_instr, 2),
                 'flop_per_launch': f / n, 'share_of_conv_time': round(ms_instr / tot_ms, 3),
-                **({'executed_tflops': round(ach * 16 / 36, 2),
-                    'executed_mfma_frac': round(ach * 16 / 36 * 6 / PEAK_BF16_MFMA_TFLOPS, 4),
+                **({'executed_tflops': round(ach / WINO_ALGORITHMIC_GAIN, 2),
+                    'executed_mfma_frac': round(ach / WINO_ALGORITHMIC_GAIN * 6 / PEAK_BF16_MFMA_TFLOPS, 4),
                     'executed_mfma_note': 'bf16 MFMA FLOPs the kernel issues (16 of the 36 products of a 3x3 tap set, six bf16 '
-                                          'MFMAs each) over the dense bf16 peak: the headroom `frac` does not show'}
+                                          'MFMAs each) over the dense bf16 peak: equal to `frac` by construction',
+                    'algorithmic_vs_direct_x6_ceiling': round(ach / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4)}
                    if dom.startswith('wino') else {}),
                 'all_tapconv_tflops': round(sum(v[0] for v in per_tile.values()) / (tot_ms * 1e-3) / 1e12, 2),
                 'conv_ms_per_step': round(tot_ms / n_prof, 3),
@@ -604,7 +613,8 @@ def main():
                          'ms_per_step': round(ms_step, 3),
                          'frac': round((t_roof_x6 * 1e3 + other_roof) / ms_step, 4),
                          'note': 'T_roof = sum over launches of max(algorithmic bytes / 8 TB/s, FLOP / peak) (SURVEY 8d); '
-                                 'conv peak 419.3 TF (bf16x6) resp. 157.3 TF (fp32 MFMA)'}}
+                                 'conv peak 419.3 TF (direct bf16x6 launches), 943.5 TF (Winograd bf16x6 launches: 36/16 of it) '
+                                 'resp. 157.3 TF (fp32 MFMA)'}}
         table = {k: {'tile': v[3], 'gflop_per_launch': v[0] / v[2] / 1e9, 'us_per_launch': v[1] * 1e3 / v[2],
                      'tflops': v[0] / (v[1] * 1e-3) / 1e12, 'algorithmic_tb_s': v[4] / (v[1] * 1e-3) / 1e12}
                  for k, v in per_layer.items()}

@@ -347,7 +347,12 @@ int spaa_avgpool_bwd(const float* g_out, const float* act, float* g_in, int B, i
                      spaa_stream_t stream);
 
 /* Generic NHWC pooling of the VGG-16 / Inception-v3 bodies (C % 4 == 0); `*_cstride/_coff` address a channel window
- * of a concatenated buffer; backward passes are deterministic gathers with an optional ReLU gate of the input. */
+ * of a concatenated buffer; backward passes are deterministic gathers with an optional ReLU gate of the input.
+ * NaN contract: the stand-alone pool propagates a NaN of its input ("NaN wins", like ATen's max_pool2d).  Every ReLU epilogue of this
+ * library is fmaxf(v, 0), which maps a NaN pre-activation to 0 -- in the separate conv + ReLU launch exactly as in the fused
+ * conv + ReLU + 2 x 2 pool epilogue (spaa_tapconv_h16p, bit 6) -- so the two forms of a conv -> ReLU -> pool chain agree on every input,
+ * NaN included: a NaN produced by a convolution never reaches a pool.  The library's contract is FINITE VALUES ONLY (inputs in range and
+ * finite weights give finite activations); torch's relu would propagate a NaN where these epilogues clear it. */
 int spaa_maxpool_fwd(const float* in, float* out, uint8_t* argmax, int B, int Hin, int Win, int C, int Hout, int Wout,
                      int k, int s, int p, int out_cstride, int out_coff, spaa_stream_t stream);
 int spaa_maxpool_bwd(const float* g_out, const uint8_t* argmax, int relu_gate, float* g_in, int B, int Hin,

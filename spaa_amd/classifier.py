@@ -20,11 +20,11 @@ from . import _lib
 from . import convplan as cp
 from .models import to_nhwc4, to_nchw, USE_GATE_MASKS
 
+FUSE_POOL = os.environ.get('SPAA_FUSE_POOL', '1') != '0'   # VGG-16, fp16 storage: the 2 x 2 max-pools in the epilogue of the convolution before them
+FOLD_S2_F16 = int(os.environ.get('SPAA_FOLD_S2_F16', '0'))   # fp16 storage: ResNet's stride-2 input gradients with the four parity classes folded into N: 0 never (default: neutral in the loop, 238.7-239.3 it/s either way), 1 layer2.0 (49.5 -> 38 us per launch), 2 all three
 # 1: ResNet-18's max-pool adjoint as the prologue of the stem's input gradient.  Measured SLOWER (profiles/r05_frontend.txt: stem_dgrad
 # 190 -> 304 us for the 55 us launch it removes -- the patch formed by loads + VALU work in four dependent round trips per channel block
 # where the LDS-DMA of the separate form costs no issue slots): off by default, kept with its bitwise test.
-FUSE_POOL = os.environ.get('SPAA_FUSE_POOL', '1') != '0'   # VGG-16, fp16 storage: the 2 x 2 max-pools in the epilogue of the convolution before them
-FOLD_S2_F16 = int(os.environ.get('SPAA_FOLD_S2_F16', '0'))   # fp16 storage: ResNet's stride-2 input gradients with the four parity classes folded into N: 0 never (default: neutral in the loop, 238.7-239.3 it/s either way), 1 layer2.0 (49.5 -> 38 us per launch), 2 all three
 FUSE_POOL_ADJOINT = os.environ.get('SPAA_FUSE_POOL_ADJOINT', '0') == '1'
 BODY_GATE_MASKS = os.environ.get('SPAA_BODY_MASKS', '1') != '0'   # 0: VGG-16 / Inception-v3 gate with the activation itself (A/B measurements)
 
@@ -405,6 +405,7 @@ class ClassifierEngine:
         _lib.check_dev(y4)
         assert y4.shape == (self.B, self.H, self.W, 4)
         self.version += 1
+        self._grad_ready = bool(need_grad)
         if hasattr(self.body, 'write_masks'):
             self.body.write_masks = bool(need_grad)
         _lib.call('spaa_preproc_fwd', _lib.ptr(y4), _lib.ptr(self.pre), self.B, self.H, self.W, self.cy0, self.cx0,
@@ -412,6 +413,10 @@ class ClassifierEngine:
         return self.body.forward(self.pre)
 
     def backward(self, g_logits):
+        if not getattr(self, '_grad_ready', False):
+            # (a need_grad=False pass overwrote the activations but left the ReLU-gate masks / pool arg-max bytes of the pass before it)
+            raise RuntimeError('ClassifierEngine.backward(): the last forward() ran with need_grad=False (its gate masks were not '
+                               'written); run forward(..., need_grad=True) first')
         g_pre = self.body.backward(g_logits)
         _lib.call('spaa_preproc_bwd', _lib.ptr(g_pre), _lib.ptr(self.g_y), self.B, self.H, self.W, self.cy0, self.cx0,
                   self.ch, self.cw, self.oh, self.ow, self._std)

@@ -442,6 +442,12 @@ class ConvPlan:
             tile = -1
         if tile < 0:
             tile = self._default_tile(b * d.Hm * d.Wm)
+        if out_f16 and not in_f16 and not forced and self.c3_ok() and not ({'c3', 'c3h'} & DEFAULT_DISABLE):
+            # fp16-storage mode: a first layer over the 3-channel image multiplies fp16 operands (image rounded in registers, one fp16
+            # weight plane) "like every other layer of the mode" -- at EVERY batch size: until round 6 only the pixel counts with a tune
+            # entry (batch 64) took tile 76, a batch of 8 ran the same layer on fp32-exact operands, and a sub-batch did not reproduce its
+            # rows of the full batch to the mode's own noise (profiles/r06_vgg_f16_bisect.txt)
+            tile = 76
         if cin2k and self.wino is not None and tile % 100 not in (70, 71, 73) and not in_f16:
             tile = 70      # (two sources: only the Winograd kernel reads them -- and, in fp16 storage, the patch-staged fp16 kernel below)
         thin_mf = (forced in (0, 72) and 'thinmf' not in DEFAULT_DISABLE and not out_f16 and not masked and self.thin_ok())

@@ -7,10 +7,6 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/body_masks_ab
 mkdir -p $O
 cd $R
-run() {  # tag, env..., -- bench args
-    local tag=$1; shift
-    env "$@" > /dev/null 2>&1 || true
-}
 line() { python3 -c "
 import sys, json
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
