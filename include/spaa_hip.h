@@ -24,6 +24,7 @@ typedef void* spaa_stream_t; /* hipStream_t */
 
 #define SPAA_MAX_CLASSES 4
 #define SPAA_MAX_TAPS 64
+#define SPAA_SPLITK_HDR_FLOATS 4096 /* arrival counters at the head of a K-range workspace (spaa_tapconv_t.reserved1 bit 8) */
 
 /* activation applied after bias + residual add */
 enum { SPAA_ACT_NONE = 0, SPAA_ACT_RELU = 1, SPAA_ACT_RELU_CLAMP1 = 2, SPAA_ACT_LEAKY01 = 3 };
@@ -112,7 +113,12 @@ typedef struct {
                              SPAA_IO_OUT_F16 (tiles 60..65, 68, and the kernels that read fp32 IMAGES: 15..24, 38):
                                              `out`, `add`, `gate`, `aux_out`, `gate2` are fp16.
                              0 = everything fp32 (the default path; dtype "f32" in bench.py). */
-    int32_t reserved1;    /* tile 76: bit 0 = fp16 operands (fp16-storage mode, fp16 output only): the image rounded to fp16 in registers, `w_split` = ONE
+    int32_t reserved1;    /* tiles 70 / 71 / 73 (and tile 68's K-range form): bit 8 = `splitk_ws` BEGINS with SPAA_SPLITK_HDR_FLOATS floats of arrival
+                             counters (int32, all zero on first use; the kernels leave them zero), the K ranges' partial sums follow: the
+                             last-arriving workgroup of a (region, N tile) adds the K ranges in fixed order and applies the epilogue inside the
+                             kernel -- the same bits as the separate second pass, one launch less.  The workspace is then SPAA_SPLITK_HDR_FLOATS +
+                             K ranges x B x H x W x Npad floats.  Bit 8 clear: the two-pass form on a workspace without header.
+                             tile 76: bit 0 = fp16 operands (fp16-storage mode, fp16 output only): the image rounded to fp16 in registers, `w_split` = ONE
                              plane of fp16 weights in the layout of ConvPlan.c3_pack(half=True), products on v_mfma_f32_16x16x32_f16.
                              tile 68: bit 2 = the canvas / K-range form (small images with long K: spaa_tapconv_h16p_plan below; `ksplit` > 1 with
                              `splitk_ws` = that many K ranges), bits 0-1 = its N tile (0 chosen, 1 = 64, 2 = 128), bit 3 (tests) = canvases wherever they
@@ -229,6 +235,19 @@ int spaa_warp_bwd_gather(const float* g_xw, const float* g_xs, const float* x, c
 int spaa_warp_bwd_tiled(const float* g_xw, const float* x, const int32_t* off, const int32_t* lidx, const float* w_e,
                         const int32_t* tbox, int box_cap, float* g_x, int B, int Hp, int Wp, int Hc, int Wc, int clamp01,
                         spaa_stream_t stream);
+/* ... with spaa_grad_sumsq folded into its epilogue (round 6: one launch and one pass over g_x less per iteration): g_x additionally takes
+ * the prjl2 term's gradient for colour-step samples (prjl2_scale != 0: `state`, `gray` as spaa_grad_sumsq), and partial_ss
+ * [B][ceil(Wp/16) * ceil(Hp/16)] receives the per-(image, 16 x 16 tile) sums of ||g_x||^2 in a fixed order -- consumed by
+ * spaa_step_and_track_n with npartial = that tile count */
+int spaa_warp_bwd_tiled_sumsq(const float* g_xw, const float* x, const int32_t* off, const int32_t* lidx, const float* w_e,
+                              const int32_t* tbox, int box_cap, float* g_x, int B, int Hp, int Wp, int Hc, int Wc, int clamp01,
+                              float gray, float prjl2_scale, const int32_t* state, float* partial_ss, spaa_stream_t stream);
+/* F.grid_sample forward (models.py:184,340) from the per-attack TAP TABLE of spaa_warp_taps instead of the grid: tap_src [Hc*Wc][4]
+ * projector pixel of every bilinear tap (0x7fffffff: outside, weight 0), tap_wgt [Hc*Wc][4] its weight x mask -- the table the
+ * deterministic backward pass is built from, so the pair is an exact adjoint.  A workgroup owns a 32 x 8 tile of camera pixels and four
+ * images; xw [B,Hc,Wc,4].  (spaa_warp_fwd stays for the 8-channel concatenation output and for callers without a table.) */
+int spaa_warp_fwd_taps(const float* x, const int32_t* tap_src, const float* tap_wgt, float* xw, int B, int Hp, int Wp, int Hc, int Wc,
+                       int clamp01, spaa_stream_t stream);
 
 /* ---- PCNet training step: WarpingNet parameter gradients and the optimiser (train_network.py:235-363) ------- */
 /* d loss / d fine_grid summed over the batch: grid_sampler_2d_backward w.r.t. the GRID (models.py:184 under autograd).
@@ -415,6 +434,10 @@ int spaa_grad_sumsq(float* g, const float* x, float gray, float prjl2_scale, con
 int spaa_step_and_track(float* x, const float* g, const float* partial, const int32_t* state, float adv_lr,
                         float col_lr, float* x_best, const float* cam, float* cam_best, int B, int HWp, int HWc,
                         spaa_stream_t stream);
+/* the same with the number of partial sums per sample stated (partial [B][npartial]: spaa_warp_bwd_tiled_sumsq's tile sums) */
+int spaa_step_and_track_n(float* x, const float* g, const float* partial, int npartial, const int32_t* state, float adv_lr,
+                          float col_lr, float* x_best, const float* cam, float* cam_best, int B, int HWp, int HWc,
+                          spaa_stream_t stream);
 
 /* ---- PerC_AL.adversary_projector (perc_al/__init__.py:133-256) ------------------------------------------ */
 /* x = a + b (inputs + delta), NHWC4 */

@@ -49,6 +49,13 @@ FORCE_KSPLIT = int(os.environ.get('SPAA_FORCE_KSPLIT', '0'))        # split-K fa
 DEBUG_WINO = int(os.environ.get('SPAA_WINO_DBG', '0'))              # timing experiments of the Winograd kernel
 DEBUG_WINO_NOCANVAS = int(os.environ.get('SPAA_WINO_NOCANVAS', '0'))  # 1: small images keep the image-aligned workgroup regions (A/B); 2: canvas wherever it has fewer regions (tests)
 WINO_SPLITK = os.environ.get('SPAA_WINO_SPLITK', '1') != '0'        # Winograd layers with few workgroups and long K: K ranges + ordered second pass
+# ... with the second pass INSIDE the kernel (the last-arriving workgroup of a tile adds the K ranges; asked for in round 5's review).  Built,
+# bitwise the two-pass form -- and SLOWER (profiles/r06_splitk_fixup.txt: 8.94 ms per step against 8.26 with agent-scope stores / loads,
+# 9.61 with __threadfence's L2 write-back; fp16 storage 4.34 against 4.13): a layer with few tiles and many K ranges (ResNet layer4: 32 tiles
+# x 8 ranges) leaves its whole reduction to 32 workgroups, 2 MB of uncached reads each, where the separate launch spreads it over the chip in
+# ~8 us.  Off by default; the tests run both forms
+WINO_SPLITK_FIXUP = os.environ.get('SPAA_SPLITK_FIXUP', '0') == '1'
+SPLITK_HDR = 4096   # include/spaa_hip.h: SPAA_SPLITK_HDR_FLOATS
 DEBUG_THINMF = int(os.environ.get('SPAA_THINMF_DBG', '0'))           # timing experiments of csrc/tapconv_thinmf.hip (builds with -DSPAA_THINMF_ABLATE)
 DEBUG_SMALLCIN_NOSLAB = int(os.environ.get('SPAA_SMALLCIN_NOSLAB', '0'))  # 1: stride-2 smallcin layers store from the MFMA layout (A/B)
 H16P_CV = tuple(int(v) for v in os.environ.get('SPAA_H16P_CV', '0,0,0').split(','))   # (N tile 0 = chosen / 64 / 128, K ranges 0 = chosen, 1 = canvases wherever they have fewer regions: tests) of the patch-staged fp16 kernel's canvas / K-range form (A/B runs)
@@ -186,6 +193,7 @@ class ConvPlan:
         self.flops_per_pixel = 2 * sum(c['ntaps'] for c in self.cls) * cin * ngemm
         self.ntaps_total = sum(c['ntaps'] for c in self.cls)
         self._ws = None  # split-K workspace, allocated on first use
+        self._ws_fix = None  # ... with the arrival-counter header (K ranges combined inside the kernel)
         self._npad, self._dev = npad, device
         self.w_half = None  # fp16 plane for the fp16-storage kernels, packed on first use (half_plane())
         self.wino = None    # the same layer in Winograd F(2x2,3x3) form (attach_winograd), run as tile 70
@@ -640,9 +648,17 @@ class ConvPlan:
             self.last_wino_plan = wp
             if d.ksplit > 1:
                 need = d.ksplit * b * hout * wout * ((self.cout + 127) // 128 * 128)
-                if self._ws is None or self._ws.numel() < need:
-                    self._ws = torch.empty(need, device=inp.device, dtype=torch.float32)
-                d.splitk_ws = self._ws.data_ptr()
+                if WINO_SPLITK_FIXUP:
+                    # round 6: the K ranges meet inside the kernel (the last-arriving workgroup of a tile adds them in fixed order): the
+                    # workspace starts with a header of arrival counters, zero before and after every launch (include/spaa_hip.h)
+                    if self._ws_fix is None or self._ws_fix.numel() < need + SPLITK_HDR:
+                        self._ws_fix = torch.zeros(need + SPLITK_HDR, device=inp.device, dtype=torch.float32)
+                    d.splitk_ws = self._ws_fix.data_ptr()
+                    d.reserved1 |= 256
+                else:
+                    if self._ws is None or self._ws.numel() < need:
+                        self._ws = torch.empty(need, device=inp.device, dtype=torch.float32)
+                    d.splitk_ws = self._ws.data_ptr()
         if tile == 68 and h16p_cv:
             # the launcher's plan of the canvas / K-range form (csrc/tapconv_h16p.hip), cached per launch shape like the Winograd plans
             d.reserved1 = 4 | {0: 0, 64: 1, 128: 2}[H16P_CV[0]] | (8 if len(H16P_CV) > 2 and H16P_CV[2] else 0)
@@ -660,9 +676,15 @@ class ConvPlan:
             self.last_h16p_plan = wp
             if d.ksplit > 1:
                 need = d.ksplit * b * hout * wout * ((self.cout + 127) // 128 * 128)
-                if self._ws is None or self._ws.numel() < need:
-                    self._ws = torch.empty(need, device=inp.device, dtype=torch.float32)
-                d.splitk_ws = self._ws.data_ptr()
+                if WINO_SPLITK_FIXUP:   # (the K ranges meet inside the kernel: workspace with the arrival-counter header, as the Winograd form)
+                    if self._ws_fix is None or self._ws_fix.numel() < need + SPLITK_HDR:
+                        self._ws_fix = torch.zeros(need + SPLITK_HDR, device=inp.device, dtype=torch.float32)
+                    d.splitk_ws = self._ws_fix.data_ptr()
+                    d.reserved1 |= 256
+                else:
+                    if self._ws is None or self._ws.numel() < need:
+                        self._ws = torch.empty(need, device=inp.device, dtype=torch.float32)
+                    d.splitk_ws = self._ws.data_ptr()
         if tile == 68 and 'h16plean' in DEFAULT_DISABLE:
             d.reserved1 |= 16    # (A/B runs: the 64-wide stride-1 form as one workgroup per compute unit)
         if tile == 68 and not h16p_cv and self.s_in == 1 and self.cout * self.nfold > 64 and self.h16p_lean_wide(b, d.Hm, d.Wm):

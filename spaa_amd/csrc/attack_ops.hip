@@ -266,12 +266,18 @@ int spaa_grad_sumsq(float* g, const float* x, float gray, float prjl2_scale, con
 int spaa_step_and_track(float* x, const float* g, const float* partial, const int32_t* state, float adv_lr,
                         float col_lr, float* x_best, const float* cam, float* cam_best, int B, int HWp, int HWc,
                         spaa_stream_t stream) {
-    if (!x || !g || !partial || !state || !x_best || !cam || !cam_best || B < 1 || HWp < 1 || HWc < 1)
+    return spaa_step_and_track_n(x, g, partial, (HWp + 255) / 256, state, adv_lr, col_lr, x_best, cam, cam_best, B, HWp, HWc, stream);
+}
+
+int spaa_step_and_track_n(float* x, const float* g, const float* partial, int npartial, const int32_t* state, float adv_lr,
+                          float col_lr, float* x_best, const float* cam, float* cam_best, int B, int HWp, int HWc,
+                          spaa_stream_t stream) {
+    if (!x || !g || !partial || !state || !x_best || !cam || !cam_best || B < 1 || HWp < 1 || HWc < 1 || npartial < 1)
         return hipErrorInvalidValue;
     const int nblk = (HWp + 255) / 256;
     dim3 grid(nblk, B);
     hipLaunchKernelGGL(step_kernel, grid, dim3(256), 0, (hipStream_t)stream, (float4*)x, (const float4*)g, partial,
-                       nblk, state, adv_lr, col_lr, (float4*)x_best, HWp);
+                       npartial, state, adv_lr, col_lr, (float4*)x_best, HWp);
     hipLaunchKernelGGL(track_cam_kernel, dim3((int)(((int64_t)B * HWc + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)cam, (float4*)cam_best, state, B, HWc);
     return (int)hipGetLastError();

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include "launch_util.hpp"
 #include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
 #include "../../include/spaa_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -193,6 +195,198 @@ __global__ __launch_bounds__(256, 2) void conv1pair_kernel(const c1p_args p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the same pair on the 16 x 16 x 32 matrix instructions.  The 27 products (9 taps x 3 channels) of an output pixel are ONE
+// K = 32 step: k = 8 g + j holds tap 2 g (j < 3) and tap 2 g + 1 (4 <= j < 7); the pad lanes of the 4-float pixels (k = 3, 7, 11) carry
+// tap 8's three channels.  Per 16 pixels: conv1 = 2 products (two blocks of 16 output channels), conv1_s = 4 (s step, xw * s step).
+//   F16 (fp16-STORAGE mode): "fp16 operands like every other layer of the mode" -- xw, s and xw * s (formed in fp32) rounded to fp16 in
+//       registers, the weights once per workgroup, one v_mfma_f32_16x16x32_f16 per product: 6 MFMAs per 16 pixels;
+//   fp32: both operands split exactly into three bf16 planes, six of the nine partial products (the arithmetic of every bf16x6 kernel
+//       of this library): 36 v_mfma_f32_16x16x32_bf16 per 16 pixels
+// instead of 54 v_mfma_f32_32x32x2_f32 of four times the length (46 us of matrix time on 5.4 GFLOP in the kernel above).  The epilogue
+// writes a lane's four channels of a pixel as one 8- / 16-byte store and one gate byte.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned int cvt2(float a, float b) {
+    f2 v = {a, b};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float lo_f(unsigned int p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float hi_f(unsigned int p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+// 8 fp32 -> three bf16x8 with x == h + m + l exactly
+__device__ __forceinline__ void split8(const f4 a, const f4 b, bf16x8& h, bf16x8& m, bf16x8& l) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    u4 hh, mm, ll;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned int ph = cvt2(x[2 * i], x[2 * i + 1]);
+        const float r0 = x[2 * i] - lo_f(ph), r1 = x[2 * i + 1] - hi_f(ph);
+        const unsigned int pm = cvt2(r0, r1);
+        const float s0 = r0 - lo_f(pm), s1 = r1 - hi_f(pm);
+        hh[i] = ph;
+        mm[i] = pm;
+        ll[i] = cvt2(s0, s1);
+    }
+    h = __builtin_bit_cast(bf16x8, hh);
+    m = __builtin_bit_cast(bf16x8, mm);
+    l = __builtin_bit_cast(bf16x8, ll);
+}
+// six of the nine partial products of (w0 + w1 + w2) . (p0 + p1 + p2), small terms first
+__device__ __forceinline__ f32x4 mfma6(const bf16x8 (&w)[3], const bf16x8 (&q)[3], f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], q[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], q[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], q[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], q[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], q[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], q[0], acc, 0, 0, 0);
+    return acc;
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void conv1pair_mfma_kernel(const c1p_args p) {
+    typedef typename std::conditional<F16, _Float16, float>::type T;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int tx = tile % p.tiles_x;
+    const int ty = (tile / p.tiles_x) % p.tiles_y;
+    const int b = tile / (p.tiles_x * p.tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW;
+    {   // the two input patches, as the kernel above stages them
+        const uint32_t bytes = (uint32_t)p.B * (uint32_t)(p.H * p.W) * 16u;
+        const auto rx = make_rsrc(p.xw, bytes), rs = make_rsrc(p.s, bytes);
+        for (int i = wave; i < NPIECE; i += 4) {
+            const int q = i * 64 + lane;
+            const int py = q / PW, px = q - py * PW;
+            const int iy = 2 * y0 - 1 + py, ix = 2 * x0 - 1 + px;
+            const bool v = q < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const int off = v ? ((b * p.H + iy) * p.W + ix) * 16 : (int)0x80000000;
+            dma16(rx, smem + i * 1024, off);
+            dma16(rs, smem + SRC_BYTES + i * 1024, off);
+        }
+    }
+    // weights as A operands: row = output channel 16 nb + (lane & 15), k = 8 (lane >> 4) + j as above; group 0 conv1, 1 conv1_s on s,
+    // 2 conv1_s on xw * s  (p.w: [3][32 n][9 taps][4 channels] fp32)
+    const int r16 = lane & 15, g = lane >> 4;
+    h8 A[3][2];
+    bf16x8 Ab[3][2][3];
+#pragma unroll
+    for (int grp = 0; grp < 3; ++grp)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const float* wr = p.w + (size_t)grp * (32 * 36) + (size_t)(16 * nb + r16) * 36;
+            float wv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int tap = 2 * g + (j >> 2), c = j & 3;
+                if (c == 3) {
+                    const int k = 8 * g + j;
+                    tap = 8;
+                    c = k == 3 ? 0 : (k == 7 ? 1 : (k == 11 ? 2 : 3));
+                }
+                wv[j] = (c < 3 && tap < 9) ? wr[tap * 4 + c] : 0.f;
+            }
+            if constexpr (F16) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) A[grp][nb][j] = (_Float16)wv[j];
+            } else {
+                split8(f4{wv[0], wv[1], wv[2], wv[3]}, f4{wv[4], wv[5], wv[6], wv[7]}, Ab[grp][nb][0], Ab[grp][nb][1], Ab[grp][nb][2]);
+            }
+        }
+    f32x4 b1q[2], bsq[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        b1q[nb] = *reinterpret_cast<const f32x4*>(p.b1 + 16 * nb + 4 * g);
+        bsq[nb] = *reinterpret_cast<const f32x4*>(p.bs + 16 * nb + 4 * g);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int t0 = 2 * g, t1 = 2 * g + 1;
+    const int o0 = ((t0 / 3) * PW + t0 % 3) * 16, o1 = ((t1 / 3) * PW + t1 % 3) * 16, o8 = (2 * PW + 2) * 16;
+#pragma unroll 1
+    for (int grp = 0; grp < 4; ++grp) {       // 2 rows x 2 groups of 16 output pixels per wave
+        const int ly = wave * 2 + (grp >> 1), lx = 16 * (grp & 1) + r16;
+        const unsigned char* pp = smem + ((2 * ly) * PW + 2 * lx) * 16;
+        f4 x0v = *reinterpret_cast<const f4*>(pp + o0), x1v = *reinterpret_cast<const f4*>(pp + o1);
+        const f4 x8v = *reinterpret_cast<const f4*>(pp + o8);
+        f4 s0v = *reinterpret_cast<const f4*>(pp + SRC_BYTES + o0), s1v = *reinterpret_cast<const f4*>(pp + SRC_BYTES + o1);
+        const f4 s8v = *reinterpret_cast<const f4*>(pp + SRC_BYTES + o8);
+        x0v[3] = g == 0 ? x8v[0] : (g == 1 ? x8v[2] : 0.f);
+        x1v[3] = g == 0 ? x8v[1] : 0.f;
+        s0v[3] = g == 0 ? s8v[0] : (g == 1 ? s8v[2] : 0.f);
+        s1v[3] = g == 0 ? s8v[1] : 0.f;
+        const f4 p0v = x0v * s0v, p1v = x1v * s1v;      // xw * s in fp32 (models.py:342)
+        h8 X, S, XS;
+        bf16x8 Xb[3], Sb[3], XSb[3];
+        if constexpr (F16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                X[e] = (_Float16)x0v[e], X[4 + e] = (_Float16)x1v[e];
+                S[e] = (_Float16)s0v[e], S[4 + e] = (_Float16)s1v[e];
+                XS[e] = (_Float16)p0v[e], XS[4 + e] = (_Float16)p1v[e];
+            }
+        } else {
+            split8(x0v, x1v, Xb[0], Xb[1], Xb[2]);
+            split8(s0v, s1v, Sb[0], Sb[1], Sb[2]);
+            split8(p0v, p1v, XSb[0], XSb[1], XSb[2]);
+        }
+        const int y = y0 + ly, x = x0 + lx;
+        const bool ok = y < p.Hm && x < p.Wm;
+        const size_t o = ((size_t)b * p.Hm + (ok ? y : 0)) * p.Wm + (ok ? x : 0);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (F16) {
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0][nb], X, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[1][nb], S, a2, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2][nb], XS, a2, 0, 0, 0);
+            } else {
+                a1 = mfma6(Ab[0][nb], Xb, a1);
+                a2 = mfma6(Ab[1][nb], Sb, a2);
+                a2 = mfma6(Ab[2][nb], XSb, a2);
+            }
+            // D: column = pixel, rows = channels 16 nb + 4 g + e
+            float sv[4], xv[4];
+            unsigned int ms = 0, mx = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = fmaxf(a2[e] + bsq[nb][e], 0.f);
+                if constexpr (F16) a = (float)(_Float16)a;      // (the residual added is the ROUNDED S1, as when conv1 reads it back)
+                float v = fmaxf(a1[e] + b1q[nb][e] + a, 0.f);
+                if constexpr (F16) v = (float)(_Float16)v;
+                sv[e] = a, xv[e] = v;
+                ms |= (a > 0.f ? 1u : 0u) << e;
+                mx |= (v > 0.f ? 1u : 0u) << e;
+            }
+            if (ok) {
+                const size_t oc = o * 32 + 16 * nb + 4 * g;
+                if constexpr (F16) {
+                    *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(p.S1) + oc) = h4{(_Float16)sv[0], (_Float16)sv[1], (_Float16)sv[2], (_Float16)sv[3]};
+                    *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(p.X1) + oc) = h4{(_Float16)xv[0], (_Float16)xv[1], (_Float16)xv[2], (_Float16)xv[3]};
+                } else {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.S1) + oc) = f32x4{sv[0], sv[1], sv[2], sv[3]};
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.X1) + oc) = f32x4{xv[0], xv[1], xv[2], xv[3]};
+                }
+                if (p.mS1 != nullptr) p.mS1[o * 8 + 4 * nb + g] = (uint8_t)ms;
+                if (p.mX1 != nullptr) p.mX1[o * 8 + 4 * nb + g] = (uint8_t)mx;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int spaa_conv1_pair_fwd(const float* xw, const float* s, const float* w_pair, const float* bias1, const float* bias_s,
@@ -207,7 +401,13 @@ extern "C" int spaa_conv1_pair_fwd(const float* xw, const float* s, const float*
     a.tiles_x = (a.Wm + TW - 1) / TW, a.tiles_y = (a.Hm + TH - 1) / TH;
     const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * B), 1, 1);
     hipStream_t st = (hipStream_t)stream;
-    if (out_f16)
+    // SPAA_C1P_MFMA: 1 (default) the 16 x 16 x 32 forms of round 6 (fp16 operands in fp16 storage, bf16x6 in fp32); 0: the fp32-MFMA form (A/B runs)
+    static const bool mfma = []() { const char* e = getenv("SPAA_C1P_MFMA"); return !(e && e[0] == '0'); }();
+    if (out_f16 && mfma)
+        hipLaunchKernelGGL(conv1pair_mfma_kernel<true>, grid, dim3(256), LDS_BYTES, st, a);
+    else if (mfma)
+        hipLaunchKernelGGL(conv1pair_mfma_kernel<false>, grid, dim3(256), LDS_BYTES, st, a);
+    else if (out_f16)
         hipLaunchKernelGGL(conv1pair_kernel<_Float16>, grid, dim3(256), LDS_BYTES, st, a);
     else
         hipLaunchKernelGGL(conv1pair_kernel<float>, grid, dim3(256), LDS_BYTES, st, a);

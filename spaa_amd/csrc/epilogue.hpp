@@ -214,6 +214,7 @@ struct fast_epi_t {
     __amdgpu_buffer_rsrc_t out, add, gbits, g2bits, mask, aux, rbias;
     float bias[4];
     bool has_gate, relu;
+    bool out_sc1;   // `out` is written with agent-scope (sc1) stores: K-range partial sums another XCD's workgroup reads back (fast_epi_store<.., SC1 = true>)
 };
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_or_empty(const void* ptr, const int64_t bytes) {
     const uint64_t a = reinterpret_cast<uint64_t>(ptr);
@@ -245,6 +246,7 @@ __device__ __forceinline__ fast_epi_t make_fast_epi(const spaa_tapconv_t& p, con
     for (int e = 0; e < 4; ++e) f.bias[e] = __uint_as_float(b[e]);
     f.has_gate = p.gate_bits != nullptr;
     f.relu = p.act == SPAA_ACT_RELU;
+    f.out_sc1 = false;
     return f;
 }
 template <typename T> struct fast_io;
@@ -256,9 +258,10 @@ template <> struct fast_io<_Float16> {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (float)h[e];
     }
+    template <int AUX = 0>
     static __device__ __forceinline__ void st(const __amdgpu_buffer_rsrc_t r, const int off, const float (&v)[4]) {
         const h4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), r, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), r, off, 0, AUX);
     }
 };
 template <> struct fast_io<float> {
@@ -268,9 +271,10 @@ template <> struct fast_io<float> {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(x[e]);
     }
+    template <int AUX = 0>
     static __device__ __forceinline__ void st(const __amdgpu_buffer_rsrc_t r, const int off, const float (&v)[4]) {
         const u32x4 x = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-        __builtin_amdgcn_raw_buffer_store_b128(x, r, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(x, r, off, 0, AUX);
     }
 };
 
@@ -299,7 +303,11 @@ __device__ __forceinline__ fast_pre_t<T> fast_epi_load(const fast_epi_t& fe, con
 }
 // store4_pre()'s arithmetic in its order: bias, residual, ReLU, gate, rounding to the storage type, out, mask of the STORED
 // value, second output gated by the second mask
-template <typename T, typename ACC, bool LOADB = false>
+// SC1 (the canvas / K-range kernels): when fe.out_sc1 is set, `out` (a K range's partial sums) is written with agent-scope stores -- cache
+// policy bit 4 = sc1 on gfx950: written through to the level all XCDs share, so that the workgroup that adds the K ranges, on whichever
+// XCD it runs, reads them back (with sc1 loads) without any cache flush
+constexpr int SPAA_AUX_SC1 = 16;
+template <typename T, typename ACC, bool LOADB = false, bool SC1 = false>
 __device__ __forceinline__ void fast_epi_store(const fast_epi_t& fe, const spaa_tapconv_t& p, const int o, const int n, const bool ok,
                                                const ACC& a, const fast_pre_t<T>& r) {
     constexpr int OOB = (int)0x80000000;
@@ -316,7 +324,12 @@ __device__ __forceinline__ void fast_epi_store(const fast_epi_t& fe, const spaa_
         v[e] = (float)(T)v[e];
         u[e] = ((r.g2 >> e) & 1u) ? v[e] : 0.f;
     }
-    fast_io<T>::st(fe.out, ok ? oi * (int)sizeof(T) : OOB, v);
+    if constexpr (SC1) {
+        if (fe.out_sc1) fast_io<T>::template st<SPAA_AUX_SC1>(fe.out, ok ? oi * (int)sizeof(T) : OOB, v);
+        else fast_io<T>::st(fe.out, ok ? oi * (int)sizeof(T) : OOB, v);
+    } else {
+        fast_io<T>::st(fe.out, ok ? oi * (int)sizeof(T) : OOB, v);
+    }
     const unsigned char mb = (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
     __builtin_amdgcn_raw_buffer_store_b8(mb, fe.mask, ok ? oi >> 2 : OOB, 0, 0);
     fast_io<T>::st(fe.aux, ok ? oi * (int)sizeof(T) : OOB, u);

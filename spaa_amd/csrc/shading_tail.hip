@@ -120,10 +120,23 @@ __global__ __launch_bounds__(64 * FWD_WAVES, sizeof(T6) == 2 ? 8 : 1) void shadi
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* wl = smem;                       // weight planes
     unsigned char* tl = smem + (H16 ? W_BYTES / 3 : W_BYTES);             // X7 tile (fp16 storage: four planes of 8 channels)
-    unsigned char* rl = tl + (H16 ? T_BYTES / 2 : T_BYTES);               // phase-2 partial sums
+    unsigned char* rl = tl + (H16 ? T_BYTES / 2 : T_BYTES);               // phase-2 partial sums (fp16 storage: a 256-byte pad)
+    unsigned char* wa = rl + (H16 ? 256 : RED_BYTES);                     // fp16 storage: conv6's weights as MFMA A operands, see below
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = 2 * H2, W = 2 * W2;
+    if constexpr (H16) {
+        // round 6: conv6 (3 x 3, 32 -> 3) on v_mfma_f32_16x16x32_f16 too: per tap one MFMA with K = the 32 channels, the tile's pixels as
+        // the 16 columns and the weights as rows -- rows 0..2 AND 4..6 hold output channel n = row & 3 (the copy in rows 4..6 puts the
+        // second pixel group's results into lanes 16..31 without a shuffle), every other row zero.  The per-lane operand image
+        // [tap][lane][8 fp16] (lane = (row, 8-channel chunk)) is built once per workgroup: 9 KB
+        if (tid < 9 * 64) {
+            const int t = tid >> 6, l = tid & 63, r = l & 15, gg = l >> 4;
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (r < 8 && (r & 3) < 3) v = *reinterpret_cast<const h8*>(reinterpret_cast<const _Float16*>(w6) + ((r & 3) * 9 + t) * C7 + 8 * gg);
+            *reinterpret_cast<h8*>(wa + tid * 16) = v;
+        }
+    }
     {   // weight planes (rows of 128 B; chunk c of row r at chunk c ^ ((r >> 1) & 7)): 48 pieces over 16 waves
         const uint64_t addr = reinterpret_cast<uint64_t>(w2s);
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)addr);
@@ -248,46 +261,70 @@ __global__ __launch_bounds__(64 * FWD_WAVES, sizeof(T6) == 2 ? 8 : 1) void shadi
         }
         __syncthreads();
         // ---- phase 2: conv6 (3x3, 32 -> 3) over this wave's 16 channels; X7's gate bytes from the centre tap (relu(t) > 0 <=> t > 0)
+        if constexpr (H16) {
+            // wave w < 14 owns interior row w: two groups of 16 pixels (columns 0..15 and 16..31, of which 30 are owned); lane =
+            // (pixel of the group, 8-channel chunk = plane of the tile).  Per tap: one operand read per group + one MFMA per group
+            // (the 14-wave VALU form spent 216 v_dot2 per lane here).  Results: rows 0..2 of group A in lanes 0..15, rows 4..6 of
+            // group B (the same weights) in lanes 16..31 = output pixel `lane` of the row.
+            if (wave < OY) {
+                const int oy = wave;
+                f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+                const unsigned char* pb = tl + g * PLANE + (oy * TX + rx) * 16;
+                const int ox = 16 * g + rx;                    // the output pixel whose result this lane holds (g < 2)
+                const int gy = 2 * a0 + 1 + oy, gx = 2 * b0 + 1 + ox;
+                const bool ok = g < 2 && ox < OX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const size_t o = ((size_t)img * H + (ok ? gy : 0)) * W + (ok ? gx : 0);
+                f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+                if (ok) rv = *reinterpret_cast<const f32x4*>(r1 + o * 4);   // (requested early: used after the taps)
+                // (one tap in flight per wave: 64 registers = eight waves per SIMD hide the LDS latency between them)
+#pragma unroll 1
+                for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll 1
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const h8 a = *reinterpret_cast<const h8*>(wa + ((3 * dy + dx) * 64 + lane) * 16);
+                        const unsigned char* pp = pb + (dy * TX + dx) * 16;
+                        const h8 bA = *reinterpret_cast<const h8*>(pp), bB = *reinterpret_cast<const h8*>(pp + 16 * 16);
+                        accA = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bA, accA, 0, 0, 0);
+                        accB = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bB, accB, 0, 0, 0);
+                    }
+                }
+                const h8 cA = *reinterpret_cast<const h8*>(pb + (TX + 1) * 16), cB = *reinterpret_cast<const h8*>(pb + (TX + 1 + 16) * 16);
+                // X7's gate bytes from the centre tap (relu(t) > 0 <=> t > 0): this lane holds 8 channels = two bytes of each group's pixel
+                {
+                    unsigned int bitsA = 0, bitsB = 0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        bitsA |= (cA[e] > (_Float16)0 ? 1u : 0u) << (8 * (e >> 2) + (e & 3));
+                        bitsB |= (cB[e] > (_Float16)0 ? 1u : 0u) << (8 * (e >> 2) + (e & 3));
+                    }
+                    const int gxa = 2 * b0 + 1 + rx, gxb = gxa + 16;
+                    if (gy >= 0 && gy < H) {
+                        if (gxa >= 0 && gxa < W) *reinterpret_cast<uint16_t*>(mask7 + (((size_t)img * H + gy) * W + gxa) * (C7 / 4) + 2 * g) = (uint16_t)bitsA;
+                        if (rx + 16 < OX && gxb >= 0 && gxb < W) *reinterpret_cast<uint16_t*>(mask7 + (((size_t)img * H + gy) * W + gxb) * (C7 / 4) + 2 * g) = (uint16_t)bitsB;
+                    }
+                }
+                if (ok) {
+                    const f32x4 av = g == 0 ? accA : accB;
+                    f32x4 outv = {0.f, 0.f, 0.f, 0.f}, prev = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int n = 0; n < 3; ++n) {
+                        const float t = fmaxf(av[n] + bias6[n] + rv[n], 0.f);
+                        prev[n] = t;
+                        outv[n] = fminf(t, 1.f);
+                    }
+                    *reinterpret_cast<f32x4*>(y + o * 4) = outv;
+                    *reinterpret_cast<f32x4*>(ypre + o * 4) = prev;
+                }
+            }
+            __syncthreads();   // the tile is free for the next one
+            continue;
+        }
         f2 acc[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
         const int gy = 2 * a0 + 1 + oy_l, gx = 2 * b0 + 1 + ox_l;
         const bool ok = p2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
         const size_t o = ((size_t)img * H + (ok ? gy : 0)) * W + (ok ? gx : 0);
         f32x4 rv = {0.f, 0.f, 0.f, 0.f};
         if (ok && ph == 0) rv = *reinterpret_cast<const f32x4*>(r1 + o * 4);   // (requested early: used after the taps)
-        if constexpr (H16) {
-          if (p2) {
-            unsigned int bits = 0;
-            float a3[3] = {0.f, 0.f, 0.f};
-#pragma unroll 1
-            for (int t = 0; t < 9; ++t) {
-                const unsigned char* pp = p2base + ((t / 3) * TX + t % 3) * 16;
-                h16v w[3];                  // 16 fp16 channels x 3 outputs of this tap: one s_load_dwordx8 per output channel
-#pragma unroll
-                for (int n = 0; n < 3; ++n) w[n] = *(ch16_ptr)(uintptr_t)(reinterpret_cast<const _Float16*>(w6) + (n * 9 + t) * C7 + 16 * ph);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const h8 a = *reinterpret_cast<const h8*>(pp + u * PLANE);
-#pragma unroll
-                    for (int n = 0; n < 3; ++n) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const h2 av = {a[2 * e], a[2 * e + 1]}, wv = {w[n][8 * u + 2 * e], w[n][8 * u + 2 * e + 1]};
-                            a3[n] = __builtin_amdgcn_fdot2(av, wv, a3[n], false);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {   // X7's gate bytes of this pixel: 16 channels = two chunks of 8
-                const h8 a = *reinterpret_cast<const h8*>(p2base + (TX + 1) * 16 + u * PLANE);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bits |= (a[e] > (_Float16)0 ? 1u : 0u) << (16 * u + 8 * (e >> 2) + (e & 3));
-            }
-            if (ok) *reinterpret_cast<uint32_t*>(mask7 + o * (C7 / 4) + 4 * ph) = bits;
-            acc[0] = f2{a3[0], 0.f}, acc[1] = f2{a3[1], 0.f}, acc[2] = f2{a3[2], 0.f};
-            if (ph == 1) *reinterpret_cast<f32x4*>(rl + pix * 16) = f32x4{a3[0], a3[1], a3[2], 0.f};
-          }
-        } else
         if (p2) {
             unsigned int bits = 0;
 #pragma unroll 1
@@ -346,9 +383,9 @@ constexpr int WB_BYTES = 3 * 64 * 256;        // backward weight planes: [plane]
 constexpr int P7_BYTES = 128 * 512;           // 64 KB
 constexpr int GP_BYTES = GP_W * GP_H * 16;    // 9792 B
 
-// 16 waves per workgroup: phase 1 gives a thread one X7 pixel of the tile and ONE half of P7's 32 channels (waves 0-7: channels
-// 0-15, waves 8-15: 16-31; per tap 3 inputs x 16 weights = three scalar loads feeding 24 packed FMAs); phase 2 gives wave w the X6
-// row w & 7 and the N half w >> 3 (two of the four 16-channel blocks of P6).
+// 16 waves per workgroup: phase 1 gives wave w the X7 row w of the tile (two groups of 16 pixels; until round 5 a thread owned one
+// pixel and half of P7's channels and formed them with 216 packed FMAs); phase 2 gives wave w the X6 row w & 7 and the N half w >> 3
+// (two of the four 16-channel blocks of P6).
 // fp16 storage (round 5): P7 lives in LDS as the fp16 it is multiplied as (the rounding used to happen when a fragment was read: the same
 // values, 32 KB instead of 64), the weights are one 16 KB plane: 58 KB and 64 VGPRs -- TWO workgroups per compute unit, one's VALU phase
 // and barriers under the other's matrix-core phase (the fp32 form needs 122 KB: one).
@@ -384,12 +421,41 @@ __global__ __launch_bounds__(1024, sizeof(T6) == 2 ? 8 : 1) void shading_head_bw
     }
     __syncthreads();
     const int rx = lane & 15, g = lane >> 4;
-    const int row = wave & 7, nh = wave >> 3;        // phase 2: X6 row and N half; phase 1: nh = channel half
-    const int pix = (tid & 511);                     // phase 1: X7 pixel of the 16 x 32 tile
-    const int py = pix >> 5, px = pix & 31;
-    // GEMM operand row m = 16 (py >> 1) + (px >> 1), columns k = 32 (2 (py & 1) + (px & 1)) + 16 nh + ...
-    const int m1 = 16 * (py >> 1) + (px >> 1), ch1 = 8 * (2 * (py & 1) + (px & 1)) + 4 * nh;
+    const int row = wave & 7, nh = wave >> 3;        // phase 2: X6 row and N half
+    // (phase 1: wave = X7 row of the 16 x 32 tile, two groups of 16 pixels; the GEMM operand row of X7 pixel (py, px) is
+    // m = 16 (py >> 1) + (px >> 1), its columns k = 32 (2 (py & 1) + (px & 1)) + channel)
     const int ntiles = B * tiles_y * tiles_x;
+    // round 6: conv6^T (3 x 3, 3 -> 32) on the matrix cores (fp16 storage: v_mfma_f32_16x16x32_f16): the 27 products of an X7 pixel are ONE K = 32 step --
+    // k = 8 g + j: j < 3 tap 2 g, channel j; 4 <= j < 7 tap 2 g + 1, channel j - 4; the pad slots of the 4-float pixels carry tap 8
+    // (k = 3, 7, 11: its channels 0, 1, 2), the rest zero.  Rows = P7's channels (two blocks of 16), columns = 16 pixels of a tile row.
+    // Weights: conv6's, rounded to fp16 like the forward kernel's (`w6t` holds the fp32 values, transposed and mirrored); the cotangent
+    // gP enters as hi + lo fp16 halves (two MFMAs): exact to 2^-22, the fp32 FMAs' products to rounding.
+    // fp32 storage: the same K = 32 step with both operands split exactly into three bf16 planes, six of the nine partial products
+    // (the arithmetic of every bf16x6 kernel of this library: products exact to 2^-24 of their operands, fp32 accumulation) -- 12 MFMAs
+    // per 16 pixels where the VALU form spent 216 packed FMAs per lane.
+    h8 a6[2];
+    bf16x8 a6b[2][3];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int c = 16 * nb + rx;
+        float wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int tap = 2 * g + (j >> 2), o = j & 3;
+            if (o == 3) {   // pad slot
+                const int k = 8 * g + j;
+                tap = 8;
+                o = k == 3 ? 0 : (k == 7 ? 1 : (k == 11 ? 2 : 3));
+            }
+            wv[j] = (o < 3 && tap < 9) ? w6t[(3 * tap + o) * C7 + c] : 0.f;
+        }
+        if constexpr (H16) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a6[nb][j] = (_Float16)wv[j];
+        } else {
+            split8(f32x4{wv[0], wv[1], wv[2], wv[3]}, f32x4{wv[4], wv[5], wv[6], wv[7]}, a6b[nb][0], a6b[nb][1], a6b[nb][2]);
+        }
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx_ = tile % tiles_x, ty_ = (tile / tiles_x) % tiles_y, img = tile / (tiles_x * tiles_y);
         const int a0 = RY * ty_, b0 = RX * tx_;   // first X6 row / column
@@ -414,43 +480,66 @@ __global__ __launch_bounds__(1024, sizeof(T6) == 2 ? 8 : 1) void shading_head_bw
             }
             *reinterpret_cast<f32x4*>(gl + tid * 16) = v;
         }
-        // this pixel's gate bytes of the thread's channel half (requested before the barrier)
-        const int gy7 = 2 * a0 + py, gx7 = 2 * b0 + px;
-        uint32_t mbits = 0;
-        if (gy7 < H && gx7 < W) mbits = *reinterpret_cast<const uint32_t*>(mask7 + (((size_t)img * H + gy7) * W + gx7) * (C7 / 4) + 4 * nh);
+        // the gate bytes of this lane's pixels (requested before the barrier)
+        uint64_t mb16[2] = {0, 0};   // (wave = tile row, two groups of 16 pixels: all 8 gate bytes of this lane's pixel of each)
+        {
+            const int gyw = 2 * a0 + wave;
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp) {
+                const int gxw = 2 * b0 + 16 * grp + rx;
+                if (gyw < H && gxw < W) mb16[grp] = *reinterpret_cast<const uint64_t*>(mask7 + (((size_t)img * H + gyw) * W + gxw) * (C7 / 4));
+            }
+        }
         __syncthreads();
         // ---- phase 1: P7[pixel][16 nh ..] = gate7 . sum_{taps, 3 ch} gP[pixel + d] w6t[tap][ch][16 nh ..]
         {
-            f32x4 acc[4];
+            const int pyw = wave;
 #pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) acc[c4] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-            for (int t = 0; t < 9; ++t) {   // (not unrolled: 48 weight SGPRs per tap)
-                const f32x4 gv = *reinterpret_cast<const f32x4*>(gl + ((py + t / 3) * GP_W + px + t % 3) * 16);
-                f16v w[3];
-#pragma unroll
-                for (int o = 0; o < 3; ++o) w[o] = *(cf16_ptr)(uintptr_t)(w6t + (3 * t + o) * C7 + 16 * nh);
-#pragma unroll
-                for (int o = 0; o < 3; ++o) {
-                    const f32x4 g4 = {gv[o], gv[o], gv[o], gv[o]};
-#pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4)
-                        acc[c4] = __builtin_elementwise_fma(g4, f32x4{w[o][4 * c4], w[o][4 * c4 + 1], w[o][4 * c4 + 2], w[o][4 * c4 + 3]}, acc[c4]);
-                }
-            }
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                const unsigned int nib = (mbits >> (8 * c4)) & 15u;
-                f32x4 v = acc[c4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = ((nib >> e) & 1u) ? v[e] : 0.f;
+            for (int grp = 0; grp < 2; ++grp) {
+                const int pxl = 16 * grp + rx;
+                // this lane's 8 of the pixel's 32 K slots: taps 2 g and 2 g + 1 (g = 3: tap 6, 7), tap 8 in the pad slots of g = 0, 1
+                const int t0 = 2 * g, t1 = 2 * g + 1;
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(gl + ((pyw + t0 / 3) * GP_W + pxl + t0 % 3) * 16);
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(gl + ((pyw + t1 / 3) * GP_W + pxl + t1 % 3) * 16);
+                const f32x4 v8 = *reinterpret_cast<const f32x4*>(gl + ((pyw + 2) * GP_W + pxl + 2) * 16);
+                v0[3] = g == 0 ? v8[0] : (g == 1 ? v8[2] : 0.f);
+                v1[3] = g == 0 ? v8[1] : 0.f;
+                h8 bh, bl;
+                bf16x8 bp[3];
                 if constexpr (H16) {
-                    // fp16 row of 16 chunks of 8 values: this quad is half (c4 & 1) of chunk (ch1 + c4) >> 1, at chunk ^ (m1 & 15)
-                    *reinterpret_cast<h4*>(pl + m1 * 256 + ((((ch1 + c4) >> 1) ^ (m1 & 15)) << 4) + 8 * ((ch1 + c4) & 1)) =
-                        h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bh[e] = (_Float16)v0[e];
+                        bh[4 + e] = (_Float16)v1[e];
+                        bl[e] = (_Float16)(v0[e] - (float)bh[e]);
+                        bl[4 + e] = (_Float16)(v1[e] - (float)bh[4 + e]);
+                    }
                 } else {
-                    // 16-byte chunk ch1 + c4 of row m1 at chunk ^ (m1 & 31)
-                    *reinterpret_cast<f32x4*>(pl + m1 * 512 + (((ch1 + c4) ^ (m1 & 31)) << 4)) = v;
+                    split8(v0, v1, bp[0], bp[1], bp[2]);
+                }
+                const int m1w = 16 * (pyw >> 1) + (pxl >> 1), par = 2 * (pyw & 1) + (pxl & 1);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (H16) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a6[nb], bl, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a6[nb], bh, acc, 0, 0, 0);
+                    } else {
+                        acc = mfma6(a6b[nb][0], a6b[nb][1], a6b[nb][2], bp[0], bp[1], bp[2], acc);
+                    }
+                    // D: column = pixel rx, rows = channels 16 nb + 4 g + e: gate byte 4 nb + g of the pixel
+                    const unsigned int nib = (unsigned int)(mb16[grp] >> (8 * (4 * nb + g))) & 15u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = ((nib >> e) & 1u) ? acc[e] : 0.f;
+                    if constexpr (H16) {
+                        // fp16 row m1w of 16 chunks of 8 values: this quad (k = 32 par + 16 nb + 4 g ..) is half g & 1 of chunk
+                        // 4 par + 2 nb + (g >> 1), stored at chunk ^ (m1w & 15)
+                        *reinterpret_cast<h4*>(pl + m1w * 256 + (((4 * par + 2 * nb + (g >> 1)) ^ (m1w & 15)) << 4) + 8 * (g & 1)) =
+                            h4{(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};
+                    } else {
+                        // fp32 row m1w of 32 chunks of 4 values: chunk 8 par + 4 nb + g at chunk ^ (m1w & 31)
+                        *reinterpret_cast<f32x4*>(pl + m1w * 512 + (((8 * par + 4 * nb + g) ^ (m1w & 31)) << 4)) = acc;
+                    }
                 }
             }
         }
@@ -521,7 +610,7 @@ static int launch_tail_fwd(const T6* x6, const uint16_t* w2_split, const float* 
     const int64_t ntiles = (int64_t)B * tiles_y * tiles_x;
     if (ntiles > 0x7fffffff) return hipErrorInvalidValue;
     constexpr bool H16 = sizeof(T6) == 2;
-    const size_t smem = H16 ? (size_t)W_BYTES / 3 + T_BYTES / 2 + RED_BYTES : (size_t)W_BYTES + T_BYTES + RED_BYTES;
+    const size_t smem = H16 ? (size_t)W_BYTES / 3 + T_BYTES / 2 + 256 + 9 * 64 * 16 : (size_t)W_BYTES + T_BYTES + RED_BYTES;
     static bool attr_set[SPAA_MAX_DEVICES] = {};
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&shading_tail_fwd_kernel<T6>), (int)smem, attr_set);
     if (e != hipSuccess) return (int)e;

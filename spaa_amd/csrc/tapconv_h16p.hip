@@ -63,6 +63,8 @@ struct h16p_cv_t {
     unsigned int my, mx;       // v / py == (v * my) >> 20 for every canvas coordinate v (launcher: canvas sides <= 4095, periods <= 255)
     int nsp;                   // workgroup regions of all canvases together
     int order;                 // 1: regions fastest in the workgroup order (an XCD shares one weight slice), 0: N tiles / K ranges fastest
+    int fix;                   // K ranges: 1 = the last-arriving workgroup of a (region, N tile) adds the partial sums and applies the epilogue
+                               // itself (arrival counters at the head of the workspace), 0 = h16p_splitk_reduce_kernel does
 };
 
 // LEAN (round 5; S = 1, 64-wide N tile): TWO workgroups per compute unit -- one patch buffer (reloaded per 32-channel block behind a barrier,
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void h16p_kernel(const spaa_tapc
     const int Cin = p.Cin, H = p.Hin, W = p.Win;
 
     int n_blk, img, oy0, ox0, ks = 0;   // (CV: img = the canvas, (oy0, ox0) = the region's origin on it)
+    int region = 0;                     // (CV: index of the region among all canvases' regions)
     {
         const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
         int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void h16p_kernel(const spaa_tapc
             n_blk = (t % n_tiles) * BN;
             t /= n_tiles;
         }
+        region = t;
         ox0 = (t % wg_x) * OW;
         t /= wg_x;
         oy0 = (t % wg_y) * OH;
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void h16p_kernel(const spaa_tapc
     spaa_tapconv_t pq = p;
     if constexpr (CV) {
         if (geo.ksplit > 1) {
-            pq.out = p.splitk_ws + (size_t)ks * ((size_t)p.B * H * W) * (size_t)((p.Cout + 127) & ~127);
+            pq.out = p.splitk_ws + (geo.fix ? SPAA_SPLITK_HDR_FLOATS : 0) + (size_t)ks * ((size_t)p.B * H * W) * (size_t)((p.Cout + 127) & ~127);
             pq.out_cstride = (p.Cout + 127) & ~127;
             pq.out_coff = 0;
             pq.bias = nullptr;
@@ -554,7 +558,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void h16p_kernel(const spaa_tapc
                 _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
                     const int pr = (i0 + i) * PPI + lane / LPP;                                                    \
                     const f32x4 a = *reinterpret_cast<const f32x4*>(eb + pr * ROWB + ch * 4);                      \
-                    fast_epi_store<T>(fe, e, oo[i], n, okk[i], a, pre[i]);                                         \
+                    fast_epi_store<T, f32x4, false, CV>(fe, e, oo[i], n, okk[i], a, pre[i]);                       \
                 }                                                                                                  \
             }                                                                                                      \
         }                                                                                                          \
@@ -567,7 +571,8 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void h16p_kernel(const spaa_tapc
         const int n = ng - fc * e.Cout;
         const bool n_ok = fc < nfold && n < e.Cout;
         const int fs = nfold > 1 ? 2 : 1, cy = fc >> 1, cx = fc & 1;
-        const fast_epi_t fe = make_fast_epi(e, n_ok ? n : 0);
+        fast_epi_t fe = make_fast_epi(e, n_ok ? n : 0);
+        if constexpr (CV) fe.out_sc1 = geo.ksplit > 1 && geo.fix;
         if (e.io_dtype & SPAA_IO_OUT_F16) {
             H16P_EPI_FAST(_Float16, 0)
             if constexpr (NB == 4) H16P_EPI_FAST(_Float16, 1)
@@ -585,6 +590,47 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void h16p_kernel(const spaa_tapc
 #undef H16P_EPI
 #undef H16P_EPI_FAST
 #undef H16P_TO_LDS
+    // K ranges, round 6: the second pass inside this kernel (as csrc/tapconv_wino.hip).  Every workgroup of a (region, N tile) bumps the
+    // tile's arrival counter once its partial sums are visible device-wide; the LAST to arrive adds the K ranges in the fixed order 0, 1, 2,
+    // ... (its own read back: every bit of the result is the two-pass form's) and applies the layer's epilogue through the same store4_t.
+    // Nobody waits for anybody.  The counters (int32, head of the workspace) are zero before and after every launch.
+    if constexpr (CV) {
+        if (geo.ksplit > 1 && geo.fix) {
+            // (this thread's partial sums were agent-scope stores: once they are acknowledged they are where every XCD reads them)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* const flag = reinterpret_cast<int*>(smem);      // (the epilogue's LDS is free now)
+            if (tid == 0) {
+                int* const cnt = reinterpret_cast<int*>(p.splitk_ws) + region * n_tiles + n_blk / BN;
+                const int old = atomicAdd(cnt, 1);               // (agent scope)
+                const int last = old == geo.ksplit - 1;
+                if (last) atomicExch(cnt, 0);      // (nobody else touches this counter any more in this launch)
+                *flag = last;
+            }
+            __syncthreads();
+            if (*flag == 0) return;
+            const int M = p.B * H * W, npad = (p.Cout + 127) & ~127;
+            const auto rws = rsrc_or_empty(p.splitk_ws + SPAA_SPLITK_HDR_FLOATS, (int64_t)geo.ksplit * M * npad * 4);
+            const bool pvec = !((p.Cout | p.out_cstride | p.out_coff) & 3) &&
+                              (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
+                              (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
+                              (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
+            for (int i = tid; i < OH * OW * LPP; i += 512) {
+                const int qd = i % LPP, pxl = i / LPP;
+                const int n0 = n_blk + 4 * qd;
+                int o;
+                if (!canvas_pixel(oy0 + pxl / OW, ox0 + pxl % OW, o) || n0 >= p.Cout) continue;
+                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                for (int s_ = 0; s_ < geo.ksplit; ++s_) {   // agent-scope loads: served from where the other XCDs' stores went
+                    const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rws, ((s_ * M + o) * npad + n0) * 4, 0, SPAA_AUX_SC1);
+                    sum += f32x4{__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3])};
+                }
+                float v[4] = {sum[0], sum[1], sum[2], sum[3]};
+                if (p.io_dtype & SPAA_IO_OUT_F16) store4_t<_Float16>(p, (size_t)o, n0, v, pvec);
+                else store4_t<float>(p, (size_t)o, n0, v, pvec);
+            }
+        }
+    }
 }
 
 // second pass of a K-split layer: out = epilogue( sum over the K ranges, in fixed order ), 4 channels per thread
@@ -769,6 +815,10 @@ int spaa_launch_tapconv_h16p(const spaa_tapconv_t& d, hipStream_t stream) {
         geo.nsp = (int)(pl.nwg / ((int64_t)pl.n_tiles * pl.ksplit));
         // workgroup order by what an XCD's L2 should keep: the fp16 weights or the activations
         geo.order = (int64_t)((d.Cout + 127) & ~127) * ((d.cls[0].K + 63) & ~63) * 2 > (int64_t)d.B * d.Hin * d.Win * d.Cin * 2;
+        // `reserved1` bit 8: the workspace begins with SPAA_SPLITK_HDR_FLOATS zeroed counter slots -> the K ranges meet inside the kernel
+        // (and the partial sums leave through the branch-free epilogue's agent-scope stores: 4-channel quads, 32-bit offsets)
+        geo.fix = pl.ksplit > 1 && (d.reserved1 & 256) && (int64_t)geo.nsp * pl.n_tiles <= SPAA_SPLITK_HDR_FLOATS && !(d.Cout & 3) &&
+                  (int64_t)pl.ksplit * d.B * d.Hout * d.Wout * ((d.Cout + 127) & ~127) * 4 < ((int64_t)1 << 31);
         spaa_tapconv_t dd = d;
         dd.ksplit = pl.ksplit;
 #define H16P_LAUNCH_CV(N, SLOT)                                                                                            \
@@ -783,7 +833,7 @@ int spaa_launch_tapconv_h16p(const spaa_tapconv_t& d, hipStream_t stream) {
     }
         if (pl.bn == 64) H16P_LAUNCH_CV(64, 4) else H16P_LAUNCH_CV(128, 5)
 #undef H16P_LAUNCH_CV
-        if (pl.ksplit > 1) {
+        if (pl.ksplit > 1 && !geo.fix) {
             const int npad = (d.Cout + 127) & ~127;
             const int64_t M = (int64_t)d.B * d.Hout * d.Wout, nthr = M * ((d.Cout + 3) >> 2);
             if (d.io_dtype & SPAA_IO_OUT_F16)

@@ -103,6 +103,8 @@ struct wino_geo_t {
     unsigned int my, mx;       // v / py == (v * my) >> 20 for every canvas coordinate v (launcher: canvas sides <= 4095, periods <= 255)
     int nsp;                   // workgroup regions of all canvases together
     int order;                 // 1: regions fastest in the workgroup order, 0: N tiles fastest (as in the image-aligned form)
+    int fix;                   // K ranges: 1 = the last-arriving workgroup of a (region, N tile) sums the partial sums and applies the
+                               // epilogue itself (arrival counters at the head of the workspace), 0 = wino_splitk_reduce_kernel does
 };
 
 // TWO: the layer's input channels come from TWO tensors of the same B x H x W (channel blocks [0, Cin - Cin2) from `in`, the rest from
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(64 * NWT, NWT == 4 ? 2 : 1) void wino_x6_kernel(con
 
     // XCD-aware order over (image, patch row, patch column, n tile): an XCD takes a contiguous range
     int n_blk, img, oy0, ox0, ks = 0;   // (CV: img = the canvas, (oy0, ox0) = the region's origin on it)
+    int region = 0;                     // (CV: index of the region among all canvases' regions)
     {
         const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
         int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
@@ -162,6 +165,7 @@ __global__ __launch_bounds__(64 * NWT, NWT == 4 ? 2 : 1) void wino_x6_kernel(con
             n_blk = (t % n_tiles) * BN;
             t /= n_tiles;
         }
+        region = t;
         ox0 = (t % wg_x) * (2 * TX);
         t /= wg_x;
         oy0 = (t % wg_y) * (2 * TY);
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(64 * NWT, NWT == 4 ? 2 : 1) void wino_x6_kernel(con
     spaa_tapconv_t pq = p;
     if constexpr (CV) {
         if (geo.ksplit > 1) {
-            pq.out = p.splitk_ws + (size_t)ks * ((size_t)p.B * H * W) * npad;
+            pq.out = p.splitk_ws + (geo.fix ? SPAA_SPLITK_HDR_FLOATS : 0) + (size_t)ks * ((size_t)p.B * H * W) * npad;
             pq.out_cstride = npad;
             pq.out_coff = 0;
             pq.bias = nullptr;
@@ -487,6 +491,48 @@ __global__ __launch_bounds__(64 * NWT, NWT == 4 ? 2 : 1) void wino_x6_kernel(con
     constexpr int ROWB = BN * 4;          // bytes of a pixel's BN channels in the LDS image
     constexpr int LPP = BN / 4;           // lanes (16-byte chunks) per pixel: 32 or 16
     constexpr int PPI = 64 / LPP;         // pixels per wave store instruction
+    // K ranges, round 6: the second pass inside this kernel.  Every workgroup of a (region, N tile) bumps that tile's arrival counter
+    // after its partial sums are visible device-wide; the LAST to arrive -- whichever it is -- adds the K ranges in the fixed order
+    // 0, 1, 2, ... (its own included, read back: the summation order, and with it every bit of the result, is the two-pass form's)
+    // and applies the layer's epilogue through the same store4_t.  Nobody waits for anybody: no spinning, no dependence on the order
+    // in which workgroups are scheduled.  The counters (int32, head of the workspace) are zero before and after every launch.
+    auto splitk_fixup = [&]() {
+        if constexpr (CV) {
+            if (geo.ksplit <= 1 || !geo.fix) return;
+            // (this thread's partial sums were agent-scope stores: once they are acknowledged they are where every XCD reads them)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* const flag = reinterpret_cast<int*>(smem);      // (the epilogue's LDS is free now)
+            if (tid == 0) {
+                int* const cnt = reinterpret_cast<int*>(p.splitk_ws) + region * n_tiles + n_blk / BN;
+                const int old = atomicAdd(cnt, 1);               // (agent scope)
+                const int last = old == geo.ksplit - 1;
+                if (last) atomicExch(cnt, 0);      // (nobody else touches this counter any more in this launch)
+                *flag = last;
+            }
+            __syncthreads();
+            if (*flag == 0) return;
+            const int M = p.B * H * W;
+            const auto rws = rsrc_or_empty(p.splitk_ws + SPAA_SPLITK_HDR_FLOATS, (int64_t)geo.ksplit * M * npad * 4);
+            const bool pvec = !((p.Cout | p.out_cstride | p.out_coff) & 3) &&
+                              (p.add == nullptr || !((p.add_cstride | p.add_coff) & 3)) &&
+                              (p.gate == nullptr || !((p.gate_cstride | p.gate_coff) & 3)) &&
+                              (p.gate2 == nullptr || !((p.gate2_cstride | p.gate2_coff) & 3));
+            for (int i = tid; i < 2 * TY * 32 * LPP; i += 64 * NW) {
+                const int qd = i & (LPP - 1), pxl = i / LPP;
+                const int n0 = n_blk + 4 * qd;
+                int o;
+                if (!canvas_pixel(oy0 + (pxl >> 5), ox0 + (pxl & 31), o) || n0 >= p.Cout) continue;
+                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                for (int s_ = 0; s_ < geo.ksplit; ++s_) {   // agent-scope loads: served from where the other XCDs' stores went
+                    const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rws, ((s_ * M + o) * npad + n0) * 4, 0, SPAA_AUX_SC1);
+                    sum += f32x4{__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3])};
+                }
+                float v[4] = {sum[0], sum[1], sum[2], sum[3]};
+                store4_t<float>(p, (size_t)o, n0, v, pvec);
+            }
+        }
+    };
     if (fast_epi_ok(e, vec)) {
         // The operand combinations of the attack loops, branch-free (epilogue.hpp: fast_epi_*): a wave's 32 x 2 pixels go
         // through a PRIVATE LDS region (row = 16 (pixel column & 1) + tile column, padded by 16 bytes: conflict-free writes
@@ -495,7 +541,8 @@ __global__ __launch_bounds__(64 * NWT, NWT == 4 ? 2 : 1) void wino_x6_kernel(con
         constexpr int ROWP = BN * 4 + 16;
         const int n = n_blk + 4 * (lane & (LPP - 1));
         const bool n_ok = n < e.Cout;
-        const fast_epi_t fe = make_fast_epi(e, n_ok ? n : 0);
+        fast_epi_t fe = make_fast_epi(e, n_ok ? n : 0);
+        if constexpr (CV) fe.out_sc1 = geo.ksplit > 1 && geo.fix;
         wg_barrier<false>();
         unsigned char* const eb = smem + wave * (32 * ROWP);
 #pragma unroll
@@ -526,11 +573,12 @@ __global__ __launch_bounds__(64 * NWT, NWT == 4 ? 2 : 1) void wino_x6_kernel(con
                 for (int u = 0; u < EB; ++u) {
                     const int r = (it0 + u) * PPI + lane / LPP;
                     const f32x4 y = *reinterpret_cast<const f32x4*>(eb + r * ROWP + ((lane & (LPP - 1)) << 4));
-                    fast_epi_store<float>(fe, e, oo[u], n, ok[u], y, pre[u]);
+                    fast_epi_store<float, f32x4, false, CV>(fe, e, oo[u], n, ok[u], y, pre[u]);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        splitk_fixup();
         return;
     }
 #pragma unroll
@@ -579,6 +627,7 @@ __global__ __launch_bounds__(64 * NWT, NWT == 4 ? 2 : 1) void wino_x6_kernel(con
             }
         }
     }
+    splitk_fixup();
 }
 
 // second pass of a K-split layer: out = epilogue( sum over the splits, in fixed order ), 4 channels per thread
@@ -754,6 +803,10 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
     geo.nsp = (int)(nwg / ((int64_t)n_tiles * pl.ksplit));
     // workgroup order by what an XCD's L2 should keep: the weight planes (16 positions x three bf16) or the activations
     geo.order = (int64_t)((d.Cout + 127) & ~127) * d.cls[0].Kpad * 6 > (int64_t)d.B * d.Hin * d.Win * d.Cin * 4;
+    // `reserved1` bit 8: the workspace begins with SPAA_SPLITK_HDR_FLOATS zeroed counter slots -> the K ranges meet inside the kernel
+    // (and the partial sums leave through the branch-free epilogue's agent-scope stores: 4-channel quads, 32-bit offsets)
+    geo.fix = pl.ksplit > 1 && (d.reserved1 & 256) && (int64_t)geo.nsp * n_tiles <= SPAA_SPLITK_HDR_FLOATS && !(d.Cout & 3) &&
+              (int64_t)pl.ksplit * d.B * d.Hout * d.Wout * ((d.Cout + 127) & ~127) * 4 < ((int64_t)1 << 31);
     if (cv && !pl.canvas && (d.Hout > 4095 || d.Wout > 4095)) return hipErrorInvalidValue;
     if (cv && (int64_t)d.B * d.Hout * d.Wout >= ((int64_t)1 << 24)) return hipErrorInvalidValue;   // (the plan never asks for it: wino_make_plan)
     spaa_tapconv_t dd = d;
@@ -803,7 +856,7 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
             hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino_x6_kernel<64, 2, 0, true, false, 4>), (int)smem, attr_set[14]);
             if (e != hipSuccess) return (int)e;
             hipLaunchKernelGGL((wino_x6_kernel<64, 2, 0, true, false, 4>), dim3((unsigned)nwg), dim3(256), smem, stream, dd, wg_y, wg_x, n_tiles, geo);
-            if (pl.ksplit > 1) {
+            if (pl.ksplit > 1 && !geo.fix) {
                 const int npad = (d.Cout + 127) & ~127;
                 const int64_t M = (int64_t)d.B * d.Hout * d.Wout, nthr = M * ((d.Cout + 3) >> 2);
                 hipLaunchKernelGGL(wino_splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, dd, (int)M, npad);
@@ -817,7 +870,7 @@ int spaa_launch_tapconv_wino(const spaa_tapconv_t& d, hipStream_t stream) {
         if (BN == 64) WINO_LAUNCH_T2(64, 2, 10) else WINO_LAUNCH_T2(128, 3, 11)
     } else if (cv) {   // canvas / K-split form: the default variants only
         if (BN == 64) WINO_LAUNCH_T(64, 2, true, 8) else WINO_LAUNCH_T(128, 3, true, 9)
-        if (pl.ksplit > 1) {
+        if (pl.ksplit > 1 && !geo.fix) {
             const int npad = (d.Cout + 127) & ~127;
             const int64_t M = (int64_t)d.B * d.Hout * d.Wout, nthr = M * ((d.Cout + 3) >> 2);
             hipLaunchKernelGGL(wino_splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, dd, (int)M, npad);

@@ -126,6 +126,57 @@ __global__ void warp_fwd_kernel(const float4* __restrict__ x, const float4* __re
     }
 }
 
+// The same forward pass from the per-attack TAP TABLE (round 6): the four source pixels and weights (x mask) of every camera pixel are
+// computed ONCE by warp_taps_kernel -- the table the deterministic backward pass is built from, so forward and backward use the same
+// weights to the bit (an exact adjoint pair) and no call site re-derives the coordinate arithmetic.  A workgroup owns a 32 x 8 tile of
+// camera pixels (its taps fall into a ~30 x 9 box of the projector image: the 1-D blocks of warp_fwd_kernel fetched every projector row
+// from two workgroups on different XCDs: 217 MB of fabric traffic for 100 MB of algorithmic bytes, profiles/r05_pmc_traffic.json) and
+// FB images, for which the table entry is read once; consecutive tiles run on the same XCD and share their halo in its L2.
+constexpr int FT_W = 32, FT_H = 8, FB = 4;
+__global__ __launch_bounds__(256) void warp_fwd_taps_kernel(const float4* __restrict__ x, const int4* __restrict__ src, const float4* __restrict__ wgt,
+                                                            float4* __restrict__ xw, int B, int HWp, int Hc, int Wc, int ntx, int ntile,
+                                                            int clamp) {
+    int t;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int tile = t % ntile, b0 = (t / ntile) * FB;
+    const int ty = tile / ntx, tx = tile - ty * ntx;
+    const int cy = ty * FT_H + (threadIdx.x >> 5), cx = tx * FT_W + (threadIdx.x & 31);
+    if (cy >= Hc || cx >= Wc) return;
+    const int pix = cy * Wc + cx;
+    const int4 s = src[pix];
+    const float4 w = wgt[pix];
+    const int si[4] = {s.x, s.y, s.z, s.w};
+    const float wi[4] = {w.x, w.y, w.z, w.w};
+    float4 v[FB][4];
+#pragma unroll
+    for (int k = 0; k < FB; ++k) {
+        const float4* xb = x + (size_t)(b0 + k < B ? b0 + k : B - 1) * HWp;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[k][q] = si[q] != 0x7fffffff ? xb[si[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < FB; ++k) {
+        if (b0 + k >= B) break;
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 u = v[k][q];
+            if (clamp) {
+                u.x = clamp01(u.x);
+                u.y = clamp01(u.y);
+                u.z = clamp01(u.z);
+            }
+            r0 += u.x * wi[q];
+            r1 += u.y * wi[q];
+            r2 += u.z * wi[q];
+        }
+        xw[(size_t)(b0 + k) * Hc * Wc + pix] = make_float4(r0, r1, r2, 0.f);
+    }
+}
+
 // Backward w.r.t. the projector image: scatter-add of the four bilinear taps.  The clamp(x,0,1) of the forward
 // passes gradient where 0 <= x <= 1 (ATen clamp_backward).
 __global__ void warp_bwd_kernel(const float4* __restrict__ g_xw, const float4* __restrict__ g_xs,
@@ -258,7 +309,8 @@ __global__ __launch_bounds__(256) void warp_bwd_tiled_kernel(const float4* __res
                                                              const int32_t* __restrict__ off, const int32_t* __restrict__ lidx,
                                                              const float* __restrict__ w_e, const int32_t* __restrict__ tbox,
                                                              float4* __restrict__ g_x, int B, int Hp, int Wp, int Hc, int Wc,
-                                                             int ntx, int box_cap, int clamp) {
+                                                             int ntx, int box_cap, int clamp, float* __restrict__ partial_ss,
+                                                             const int32_t* __restrict__ state, float gray, float prjl2_scale) {
     extern __shared__ __attribute__((aligned(16))) float4 box[];   // [WB][box_cap]
     const int tile = blockIdx.x, b0 = blockIdx.y * WB;
     const int ty = tile / ntx, tx = tile - ty * ntx;
@@ -276,8 +328,9 @@ __global__ __launch_bounds__(256) void warp_bwd_tiled_kernel(const float4* __res
     const int sp = live ? sy * Wp + sx : 0;
     const int e0 = live ? off[sp] : 0, e1 = live ? off[sp + 1] : 0;
     float4 xv[WB];
+    const bool need_x = clamp || (partial_ss != nullptr && prjl2_scale != 0.f);
 #pragma unroll
-    for (int k = 0; k < WB; ++k) xv[k] = (clamp && live) ? x[(size_t)(b0 + k < B ? b0 + k : B - 1) * HWp + sp] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < WB; ++k) xv[k] = (need_x && live) ? x[(size_t)(b0 + k < B ? b0 + k : B - 1) * HWp + sp] : make_float4(0.f, 0.f, 0.f, 0.f);
     int li0[4];
     float w0[4];
 #pragma unroll
@@ -294,7 +347,7 @@ __global__ __launch_bounds__(256) void warp_bwd_tiled_kernel(const float4* __res
             box[k * box_cap + i] = g_xw[(size_t)(b0 + k < B ? b0 + k : B - 1) * HWc + cp];   // (images past B: a copy of the last, never stored)
     }
     __syncthreads();
-    if (!live) return;
+    if (!live && partial_ss == nullptr) return;
     float a0[WB], a1[WB], a2[WB];
 #pragma unroll
     for (int k = 0; k < WB; ++k) a0[k] = a1[k] = a2[k] = 0.f;
@@ -329,18 +382,52 @@ __global__ __launch_bounds__(256) void warp_bwd_tiled_kernel(const float4* __res
             }
         }
     }
+    float ss[WB];
 #pragma unroll
     for (int k = 0; k < WB; ++k) {
-        if (b0 + k >= B) break;
+        ss[k] = 0.f;
+        if (b0 + k >= B || !live) continue;
         const size_t o = (size_t)(b0 + k) * HWp + sp;
         float r0 = a0[k], r1 = a1[k], r2 = a2[k];
+        const float4 v = xv[k];
         if (clamp) {
-            const float4 v = xv[k];
             r0 = (v.x >= 0.f && v.x <= 1.f) ? r0 : 0.f;
             r1 = (v.y >= 0.f && v.y <= 1.f) ? r1 : 0.f;
             r2 = (v.z >= 0.f && v.z <= 1.f) ? r2 : 0.f;
         }
+        if (partial_ss != nullptr) {
+            // spaa_grad_sumsq folded in (round 6): the prjl2 term's gradient for samples taking the colour step
+            // (projector_based_attack.py:275,310: d ||gray - x|| / dx = -(gray - x) / n, zero where the norm is zero), then this
+            // pixel's share of ||g_b||^2 -- the same arithmetic, one launch and one pass over g_x less per iteration
+            if (prjl2_scale != 0.f && state[4 * (b0 + k) + 1] != 0) {
+                const float d0 = gray - v.x, d1 = gray - v.y, d2 = gray - v.z;
+                const float n = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+                if (n != 0.f) {
+                    const float kk = -prjl2_scale / n;
+                    r0 += kk * d0;
+                    r1 += kk * d1;
+                    r2 += kk * d2;
+                }
+            }
+            ss[k] = r0 * r0 + r1 * r1 + r2 * r2;
+        }
         g_x[o] = make_float4(r0, r1, r2, 0.f);
+    }
+    if (partial_ss != nullptr) {
+        // per (image, tile) partial sums in a fixed order: wave shuffles, then the four waves' sums through LDS (the box is free)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(box);
+#pragma unroll
+        for (int k = 0; k < WB; ++k) {
+            float v = ss[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * WB + k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < WB && b0 + threadIdx.x < B)
+            partial_ss[(size_t)(b0 + threadIdx.x) * gridDim.x + tile] =
+                red[threadIdx.x] + red[WB + threadIdx.x] + red[2 * WB + threadIdx.x] + red[3 * WB + threadIdx.x];
     }
 }
 
@@ -440,18 +527,46 @@ int spaa_warp_bwd_gather(const float* g_xw, const float* g_xs, const float* x, c
     return (int)hipGetLastError();
 }
 
-int spaa_warp_bwd_tiled(const float* g_xw, const float* x, const int32_t* off, const int32_t* lidx, const float* w_e,
-                        const int32_t* tbox, int box_cap, float* g_x, int B, int Hp, int Wp, int Hc, int Wc, int clamp,
-                        spaa_stream_t stream) {
+static int launch_warp_bwd_tiled(const float* g_xw, const float* x, const int32_t* off, const int32_t* lidx, const float* w_e,
+                                 const int32_t* tbox, int box_cap, float* g_x, int B, int Hp, int Wp, int Hc, int Wc, int clamp,
+                                 float* partial_ss, const int32_t* state, float gray, float prjl2_scale, spaa_stream_t stream) {
     if (!g_xw || !x || !off || !lidx || !w_e || !tbox || !g_x || B < 1 || Hp < 1 || Wp < 1 || Hc < 1 || Wc < 1 || box_cap < 1 ||
         (size_t)box_cap * WB * 16 > 64 * 1024)
         return hipErrorInvalidValue;
     if ((int64_t)B * Hp * Wp >= ((int64_t)1 << 31) || (int64_t)B * Hc * Wc >= ((int64_t)1 << 31))
         return hipErrorInvalidValue;
     const int ntx = (Wp + TS - 1) / TS, nty = (Hp + TS - 1) / TS;
-    hipLaunchKernelGGL(warp_bwd_tiled_kernel, dim3(ntx * nty, (B + WB - 1) / WB), dim3(256), (size_t)box_cap * WB * 16,
+    size_t smem = (size_t)box_cap * WB * 16;
+    if (partial_ss != nullptr && smem < 4 * WB * sizeof(float)) smem = 4 * WB * sizeof(float);
+    hipLaunchKernelGGL(warp_bwd_tiled_kernel, dim3(ntx * nty, (B + WB - 1) / WB), dim3(256), smem,
                        (hipStream_t)stream, (const float4*)g_xw, (const float4*)x, off, lidx, w_e, tbox, (float4*)g_x, B, Hp, Wp,
-                       Hc, Wc, ntx, box_cap, clamp);
+                       Hc, Wc, ntx, box_cap, clamp, partial_ss, state, gray, prjl2_scale);
+    return (int)hipGetLastError();
+}
+
+int spaa_warp_bwd_tiled(const float* g_xw, const float* x, const int32_t* off, const int32_t* lidx, const float* w_e,
+                        const int32_t* tbox, int box_cap, float* g_x, int B, int Hp, int Wp, int Hc, int Wc, int clamp,
+                        spaa_stream_t stream) {
+    return launch_warp_bwd_tiled(g_xw, x, off, lidx, w_e, tbox, box_cap, g_x, B, Hp, Wp, Hc, Wc, clamp, nullptr, nullptr, 0.f, 0.f, stream);
+}
+
+int spaa_warp_bwd_tiled_sumsq(const float* g_xw, const float* x, const int32_t* off, const int32_t* lidx, const float* w_e,
+                              const int32_t* tbox, int box_cap, float* g_x, int B, int Hp, int Wp, int Hc, int Wc, int clamp,
+                              float gray, float prjl2_scale, const int32_t* state, float* partial_ss, spaa_stream_t stream) {
+    if (!partial_ss || (prjl2_scale != 0.f && !state)) return hipErrorInvalidValue;
+    return launch_warp_bwd_tiled(g_xw, x, off, lidx, w_e, tbox, box_cap, g_x, B, Hp, Wp, Hc, Wc, clamp, partial_ss, state, gray, prjl2_scale,
+                                 stream);
+}
+
+int spaa_warp_fwd_taps(const float* x, const int32_t* tap_src, const float* tap_wgt, float* xw, int B, int Hp, int Wp, int Hc, int Wc,
+                       int clamp, spaa_stream_t stream) {
+    if (!x || !tap_src || !tap_wgt || !xw || B < 1 || Hp < 1 || Wp < 1 || Hc < 1 || Wc < 1) return hipErrorInvalidValue;
+    if ((int64_t)B * Hc * Wc >= ((int64_t)1 << 31) || (int64_t)B * Hp * Wp >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
+    const int ntx = (Wc + FT_W - 1) / FT_W, nty = (Hc + FT_H - 1) / FT_H;
+    const int64_t nwg = (int64_t)ntx * nty * ((B + FB - 1) / FB);
+    if (nwg > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(warp_fwd_taps_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                       (const int4*)tap_src, (const float4*)tap_wgt, (float4*)xw, B, Hp * Wp, Hc, Wc, ntx, ntx * nty, clamp);
     return (int)hipGetLastError();
 }
 
@@ -474,6 +589,6 @@ int spaa_zero(void* p, int64_t bytes, spaa_stream_t stream) {
     return (int)hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
 }
 
-const char* spaa_version(void) { return "spaa_hip 0.1 (gfx950)"; }
+const char* spaa_version(void) { return "spaa_hip 0.6 (gfx950)"; }
 
 }  // extern "C"

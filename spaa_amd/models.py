@@ -265,9 +265,11 @@ def to_nchw(x4, clamp01=False):
 
 
 TILED_WARP_BWD = os.environ.get('SPAA_TILED_WARP_BWD', '1') != '0'   # LDS-staged grid_sample adjoint (0: the untiled gather)
+TAP_TABLE_FWD = os.environ.get('SPAA_TAP_TABLE_FWD', '1') != '0'     # grid_sample forward from the per-attack tap table, 32 x 8 tiles (0: the grid kernel)
+FUSE_SUMSQ = os.environ.get('SPAA_FUSE_SUMSQ', '1') != '0'           # spaa_grad_sumsq as the epilogue of the tiled grid_sample adjoint (0: its own launch)
 
 
-def transposed_taps(grid, prj_size, cam_size, mask=None):
+def transposed_taps(grid, prj_size, cam_size, mask=None, want_table=False):
     """Transposed sampling structure for the deterministic backward of grid_sample (index plumbing, once per grid):
     the 4 bilinear taps of every camera pixel (spaa_warp_taps), sorted by the projector pixel they read (CSR).
     Returns (tap_off [Hp*Wp+1], tap_order [4*Hc*Wc], tap_weight x mask [4*Hc*Wc]) for spaa_warp_bwd_gather."""
@@ -281,6 +283,8 @@ def transposed_taps(grid, prj_size, cam_size, mask=None):
     bounds = torch.searchsorted(tap_src[order].to(torch.int64), torch.arange(hwp + 1, dtype=torch.int64, device=dev))
     # bilinear weight x mask of the camera pixel the tap belongs to (entry 4*campix + tap)
     tap_wm = (tap_w.view(hwc, 4) * mask.view(hwc, 1)).reshape(-1).contiguous() if mask is not None else tap_w
+    if want_table:   # (+ the per-camera-pixel table itself: spaa_warp_fwd_taps reads it, the same weights as the backward pass)
+        return bounds.to(torch.int32).contiguous(), order.to(torch.int32).contiguous(), tap_wm, tap_src
     return bounds.to(torch.int32).contiguous(), order.to(torch.int32).contiguous(), tap_wm
 
 
@@ -372,7 +376,7 @@ class PCNetEngine:
         self.mask = pcnet.mask.detach().float().contiguous().view(-1).to(dev) if pcnet.use_mask else None
         if self.mask is not None:
             assert self.mask.numel() == self.Hc * self.Wc
-        self.tap_off, self.tap_order, self.tap_wm = transposed_taps(self.grid, prj_size, (self.Hc, self.Wc), self.mask)
+        self.tap_off, self.tap_order, self.tap_wm, self.tap_src = transposed_taps(self.grid, prj_size, (self.Hc, self.Wc), self.mask, want_table=True)
         self.tiled = tiled_taps(self.tap_off, self.tap_order, self.tap_wm, prj_size, (self.Hc, self.Wc)) if TILED_WARP_BWD else None
         f, d = {}, {}
         for nm, st in (('conv1', 2), ('conv2', 2), ('conv3', 1), ('conv4', 1), ('conv5', 1), ('conv1_s', 2),
@@ -526,9 +530,14 @@ class PCNetEngine:
         a = self.a
         _lib.check_dev(x4)
         assert x4.shape == (self.B, self.Hp, self.Wp, 4)
-        _lib.call('spaa_warp_fwd', _lib.ptr(x4), _lib.ptr(self.grid), _lib.ptr(self.mask), _lib.ptr(self.scene),
-                  _lib.ptr(a['xw']), _lib.ptr(a['cat8']) if (self.scene is not None and self.pair1 is None) else None, self.B, self.Hp,
-                  self.Wp, self.Hc, self.Wc, int(clamp01))
+        want_cat8 = self.scene is not None and self.pair1 is None
+        if TAP_TABLE_FWD and not want_cat8:
+            _lib.call('spaa_warp_fwd_taps', _lib.ptr(x4), C_ptr(self.tap_src), _lib.ptr(self.tap_wm), _lib.ptr(a['xw']), self.B, self.Hp,
+                      self.Wp, self.Hc, self.Wc, int(clamp01))
+        else:
+            _lib.call('spaa_warp_fwd', _lib.ptr(x4), _lib.ptr(self.grid), _lib.ptr(self.mask), _lib.ptr(self.scene),
+                      _lib.ptr(a['xw']), _lib.ptr(a['cat8']) if want_cat8 else None, self.B, self.Hp,
+                      self.Wp, self.Hc, self.Wc, int(clamp01))
         self._x, self._clamp = x4, int(clamp01)
         return a['xw']
 
@@ -584,7 +593,13 @@ class PCNetEngine:
         cotangents and the clamp gate itself (spaa_shading_head_bwd_select), no spaa_select_grad launch."""
         return bool(self.fuse_tail and (USE_GATE_MASKS or self.storage == 'f16') and FUSE_SELECT)
 
-    def backward(self, gP, select=None, input_grad=True):
+    def sumsq_tiles(self):
+        """Partial sums per sample that `backward(..., sumsq=...)` writes (the tiled adjoint's 16 x 16 projector tiles), or 0 when the
+        fused form is not served (no tiled structure: the caller launches spaa_grad_sumsq itself)."""
+        ok = self.tiled is not None and FUSE_SUMSQ and (USE_GATE_MASKS or self.storage == 'f16')   # (SPAA_GATE_MASKS=0: the A/B backward has no such argument)
+        return ((self.Wp + 15) // 16) * ((self.Hp + 15) // 16) if ok else 0
+
+    def backward(self, gP, select=None, input_grad=True, sumsq=None):
         """gP: gradient w.r.t. conv6's pre-activation (already gated by 0 < Ypre <= 1), [B,Hc,Wc,4]; or None with
         `select` = (g_adv, g_col, state): the two candidate cotangents at the network output [B,Hc,Wc,4] and the loop's state
         int32 [B,4] (projector_based_attack.py:302-315), see `can_select`.
@@ -632,7 +647,7 @@ class PCNetEngine:
             d['conv2'].run(g['P2'], g['P1'], add=g['t1'], gate_bits=m['X1'])
         if not self.rough:   # the surface branch is a constant: the gradient reaches the warped image through conv1 alone
             d['conv1'].run(g['P1'], g['xw'])
-            return self.warp_backward(g['xw']) if input_grad else g['xw']
+            return self.warp_backward(g['xw'], sumsq) if input_grad else g['xw']
         # surface branch (depends on x through the rough input x*s)
         d['conv4_s'].run(g['S4'], g['S3'], add=g['P3'], gate_bits=m['S3'])
         d['conv3_s'].run(g['S3'], g['S2'], add=g['P2'], gate_bits=m['S2'])
@@ -641,7 +656,7 @@ class PCNetEngine:
         # product and the sum are epilogues of the two thin convolutions instead of extra reads in the gather
         d['conv1_s'].run(g['S1'], g['xs'], gate=self.scene, gate_mode=_lib.GATE_MUL)
         d['conv1'].run(g['P1'], g['xw'], add=g['xs'])
-        return self.warp_backward(g['xw']) if input_grad else g['xw']
+        return self.warp_backward(g['xw'], sumsq) if input_grad else g['xw']
 
     def _backward_float_gates(self, gP):
         """The same backward pass reading the fp32 activations as gates (SPAA_GATE_MASKS=0: A/B measurements)."""
@@ -676,10 +691,20 @@ class PCNetEngine:
             self.f['transConv2'].run(dict.__getitem__(self.a, 'X6'), dict.__getitem__(self.a, 'X7'), act=_lib.ACT_RELU)
             self._x7_version = self.version
 
-    def warp_backward(self, g_xw):
+    def warp_backward(self, g_xw, sumsq=None):
         """Adjoint of the masked grid_sample (models.py:184,340): deterministic gather over the transposed tap lists; the
-        mask is folded into the tap weights."""
+        mask is folded into the tap weights.  `sumsq` = (partial [B, sumsq_tiles()], gray, prjl2_scale, state): spaa_grad_sumsq folded
+        into the tiled kernel's epilogue (only with sumsq_tiles() > 0)."""
         g = self.g
+        if sumsq is not None:
+            assert self.sumsq_tiles() > 0
+            part, gray, scale, state = sumsq
+            assert part.shape == (self.B, self.sumsq_tiles()) and part.dtype == torch.float32 and part.is_contiguous()
+            lidx, w_e, tbox, cap = self.tiled
+            _lib.call('spaa_warp_bwd_tiled_sumsq', _lib.ptr(g_xw), _lib.ptr(self._x), C_ptr(self.tap_off), C_ptr(lidx), _lib.ptr(w_e),
+                      C_ptr(tbox), cap, _lib.ptr(g['x']), self.B, self.Hp, self.Wp, self.Hc, self.Wc, self._clamp, float(gray), float(scale),
+                      _lib.ptr(state), _lib.ptr(part))
+            return g['x']
         if self.tiled is not None:
             lidx, w_e, tbox, cap = self.tiled
             _lib.call('spaa_warp_bwd_tiled', _lib.ptr(g_xw), _lib.ptr(self._x), C_ptr(self.tap_off), C_ptr(lidx), _lib.ptr(w_e),

@@ -90,7 +90,10 @@ class AttackState:
         self.nblk_c = (self.HWc + 255) // 256
         self.nblk_p = (self.HWp + 255) // 256
         self.partial_loss = torch.zeros(B, self.nblk_c, 3, device=dev)
-        self.partial_ss = torch.zeros(B, self.nblk_p, device=dev)
+        # ||g_b||^2 partial sums: per 256-pixel block (spaa_grad_sumsq), or per 16 x 16 projector tile when the tiled grid_sample
+        # adjoint computes them in its epilogue
+        self.ss_tiles = self.eng.sumsq_tiles()
+        self.partial_ss = torch.zeros(B, self.ss_tiles or self.nblk_p, device=dev)
         self.g_col = torch.zeros(B, Hc, Wc, 4, device=dev)
         self.gP = torch.zeros(B, Hc, Wc, 4, device=dev)
         self.g_logits = torch.zeros(B, self.clf.ncls, device=dev)
@@ -134,15 +137,17 @@ class AttackState:
     def _backward_step(self, adv_lr, col_lr):
         B, p, y = self.B, _lib.ptr, self._y
         g_adv = self.clf.backward(self.g_logits)                                     # :302 (classifier part)
+        prjl2_scale = self.prjl2_w / (B * self.HWp) * self.gs_col
+        ss = (self.partial_ss, self.gray, prjl2_scale, self.state) if self.ss_tiles else None   # (||g||^2 from the adjoint's epilogue)
         if self.eng.can_select():   # (the per-sample choice and the clamp gate as the first phase of the fused head kernel)
-            gx = self.eng.backward(None, select=(g_adv, self.g_col, self.state))     # :302 / :310 (PCNet part)
+            gx = self.eng.backward(None, select=(g_adv, self.g_col, self.state), sumsq=ss)   # :302 / :310 (PCNet part)
         else:
             _lib.call('spaa_select_grad', p(g_adv), p(self.g_col), p(self.state), p(self.eng.a['Ypre']), p(self.gP), B,
                       self.HWc)
-            gx = self.eng.backward(self.gP)                                          # :302 / :310 (PCNet part)
-        _lib.call('spaa_grad_sumsq', p(gx), p(self.x), self.gray, self.prjl2_w / (B * self.HWp) * self.gs_col, p(self.state),
-                  p(self.partial_ss), B, self.HWp)
-        _lib.call('spaa_step_and_track', p(self.x), p(gx), p(self.partial_ss), p(self.state), float(adv_lr),
+            gx = self.eng.backward(self.gP, sumsq=ss)                                # :302 / :310 (PCNet part)
+        if not self.ss_tiles:
+            _lib.call('spaa_grad_sumsq', p(gx), p(self.x), self.gray, prjl2_scale, p(self.state), p(self.partial_ss), B, self.HWp)
+        _lib.call('spaa_step_and_track_n', p(self.x), p(gx), p(self.partial_ss), self.partial_ss.shape[1], p(self.state), float(adv_lr),
                   float(col_lr), p(self.x_best), p(y), p(self.cam_best), B, self.HWp, self.HWc)   # :307,315,323-328
 
     def results(self):

@@ -186,7 +186,7 @@ class PCNetTrainer:
         _lib.call('spaa_warp_finish_grid', _lib.ptr(ws['coarse']), _lib.ptr(ws['refine']), _lib.ptr(ws['fine']), H * W)
         eng = self.eng
         eng.grid = ws['fine']
-        eng.tap_off, eng.tap_order, eng.tap_wm = transposed_taps(eng.grid, prj_size, (H, W), eng.mask)
+        eng.tap_off, eng.tap_order, eng.tap_wm, eng.tap_src = transposed_taps(eng.grid, prj_size, (H, W), eng.mask, want_table=True)
         eng.tiled = None   # (the grid changes every step: the per-tile boxes of the LDS-staged gather are not rebuilt)
 
     def _set_scene(self):

@@ -350,6 +350,24 @@ def test_winograd_canvas_and_k_ranges(hip, ci, co, h, w, b, tile, ks):
         mask = torch.zeros(b, h, w, co // 4, dtype=torch.uint8, device=DEV)
         plan.run(xin, out, add=nhwc(add).to(DEV), act=lib.ACT_RELU, mask_out=mask)
         assert rel_inf(nchw(out.cpu()), F.relu(ref + add)) < 1e-5 and torch.equal(mask, lib.pack_gate_mask(out))
+        if wp[1] > 1:
+            # round 6: the K ranges meeting INSIDE the kernel (SPAA_SPLITK_FIXUP=1: the last-arriving workgroup of a tile adds them in
+            # fixed order, arrival counters at the head of the workspace; off by default -- measured slower, spaa_amd/convplan.py) is
+            # bitwise the separate second pass, whichever workgroup arrives last, launch after launch on the same workspace (the
+            # counters are left zero)
+            keep = cp.WINO_SPLITK_FIXUP
+            try:
+                cp.WINO_SPLITK_FIXUP = True
+                out_fx, mask_fx = torch.zeros_like(out), torch.zeros_like(mask)
+                plan.run(xin, out_fx, add=nhwc(add).to(DEV), act=lib.ACT_RELU, mask_out=mask_fx)
+                assert plan.wino._ws_fix is not None and plan.wino.last_wino_plan[1] == wp[1]
+                assert torch.equal(out, out_fx) and torch.equal(mask, mask_fx)
+                for _ in range(3):
+                    plan.run(xin, out3)
+                    assert torch.equal(out3, out2)
+                assert int(plan.wino._ws_fix[:cp.SPLITK_HDR].view(torch.int32).abs().max()) == 0
+            finally:
+                cp.WINO_SPLITK_FIXUP = keep
         gbits = lib.pack_gate_mask(nhwc(gate).to(DEV))
         plan.run(xin, out, gate_bits=gbits)
         assert rel_inf(nchw(out.cpu()), ref * (gate > 0)) < 1e-5
@@ -896,7 +914,7 @@ TEACHER_FORCED_ITERS = {'spaa_256_untargeted': 16, 'spaa_256_near': 16}
 
 
 @pytest.mark.parametrize('name', ['spaa_64_near', 'spaa_64_prjl2', 'spaa_64_caml2_dthr', 'spaa_64_camdE', 'spaa_256_untargeted',
-                                  'spaa_256_near'])
+                                  'spaa_256_near', 'spaa_256_untargeted+oracle_grid', 'spaa_256_near+oracle_grid'])
 def test_spaa_teacher_forced_iterations(hip, golden_dir, name):
     """One HIP iteration from the oracle's state at iteration k must reproduce the oracle's iteration k: losses, masks,
     top-1, and the updated projector image to 1e-4 relative L-inf (BASELINE.json's bar) — on EVERY sample whose ReLU /
@@ -905,12 +923,17 @@ def test_spaa_teacher_forced_iterations(hip, golden_dir, name):
     The best-so-far bookkeeping of the same iteration (projector_based_attack.py:318-328) is checked as well: `best`, and the copies
     into prj_adv_best (the POST-step image, Q4) / cam_infer_best (the pre-step inference) for exactly the successful samples."""
     import gates
+    name, _, variant = name.partition('+')
     z = load(golden_dir, name)
     sd, pc, clf, oclf, scene, setup = _setup_case(hip, z)
     targets, targeted = [int(t) for t in z['targets']], bool(z['targeted'])
     d_thr, stealth = float(z['d_thr']), str(z['stealth'])
     csd = syn.resnet18_state_dict(2, logit_gain=float(z['gain']))
     crop, insz, cam_sz = setup['classifier_crop_sz'], tuple(int(v) for v in z['input_sz']), setup['prj_im_sz']
+    if variant == 'oracle_grid':
+        # the HIP path samples through the ORACLE's fine grid (WarpingNet.fine_grid, the reference's own cache attribute, models.py:176):
+        # what is left is the arithmetic of the loop's kernels -- held to the 64 x 64 bars
+        pc.warping_net.fine_grid = so.warping_fine_grid(sd, (1, 3) + tuple(cam_sz), tuple(cam_sz)).to(DEV)
     tr = []
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     so.spaa(sd, oclf, targets, targeted, scene, d_thr, stealth, setup, iters=TEACHER_FORCED_ITERS.get(name, 14), trace=tr)
@@ -922,6 +945,17 @@ def test_spaa_teacher_forced_iterations(hip, golden_dir, name):
     worst_clean = worst_forced = worst_plain = 0.0
     n_flip_samples = n_flips = n_clean = 0
     n_col_steps = n_best = n_tracked = 0
+    # Intermediate activations at 256 x 256 with the engine's OWN fine grid: the two fp32 constructions of the sampling grid (affine o TPS
+    # o refine, ~10 roundings each) differ by ~1e-6 in normalised coordinates = 1e-4 pixels; on the high-contrast projector images of the
+    # later iterations that moves the warped image by 2e-5 of its scale and the deepest activations by 2e-4 (measured, round 6: 2.2e-4 /
+    # 2.0e-4; with the oracle's grid injected -- the `+oracle_grid` variants -- 1.7e-6 / 3.0e-6, image 1.1e-6).  The bars for the
+    # activations and for "a flipped unit sits within the value error of zero" are 3 x those measurements here; the bar on the RESULT --
+    # the projector image to 1e-4 -- is the same everywhere.
+    own_256 = setup['prj_im_sz'][1] > 64 and variant != 'oracle_grid'
+    tol_scale = 50.0 if own_256 else 1.0       # (VALUE_TOL 1.3e-5 -> 6.5e-4, NEAR_ZERO 1.3e-6 -> 6.5e-5: measured 2.2e-4 / 3.3e-5)
+    if os.environ.get('SPAA_TF_TOL_SCALE'):      # (measurement runs: how large are the intermediate differences)
+        tol_scale = float(os.environ['SPAA_TF_TOL_SCALE'])
+    measured = dict(value=0.0, near=0.0, tie=0.0) if setup['prj_im_sz'][1] > 64 else None
     layers = {}
     for k in range(len(tr)):
         t = tr[k]
@@ -937,7 +971,8 @@ def test_spaa_teacher_forced_iterations(hip, golden_dir, name):
             st.forward_decide(targeted, d_thr, 0.9)
             pairs = gates.pcnet_pairs(st.eng, acts) + gates.resnet18_pairs(st.clf.body, cacts)
             if mode == 'plain':
-                flips, per_layer = gates.count_flips(pairs)
+                flips, per_layer = gates.count_flips(pairs, near_zero=gates.NEAR_ZERO * tol_scale, value_tol=gates.VALUE_TOL * tol_scale,
+                                                     measured=measured)
                 for kk, vv in per_layer.items():
                     layers[kk] = layers.get(kk, 0) + vv
                 stt, sts = st.state.cpu().numpy(), st.stats.cpu().numpy()
@@ -988,6 +1023,9 @@ def test_spaa_teacher_forced_iterations(hip, golden_dir, name):
           f'of zero): plain max {worst_plain:.2e}, with the oracle\'s gates max {worst_forced:.2e}; {n_col_steps} sample-iterations took the '
           f'colour step, {n_best} set a new best, {n_tracked} best-so-far copies checked')
     assert n_clean > 0
+    if measured is not None:
+        print(f'    measured at this size: activations {measured["value"]:.2e} (bar {gates.VALUE_TOL * tol_scale:.1e}), flipped units within '
+              f'{measured["near"]:.2e} of zero (bar {gates.NEAR_ZERO * tol_scale:.1e}), arg-max ties {measured["tie"]:.2e}')
     if name in TEACHER_FORCED_ITERS:   # the colour-step branch and the best tracking must have been exercised at the benchmarked size
         assert n_col_steps >= 4 and n_best >= 2 and n_tracked >= 4, (n_col_steps, n_best, n_tracked)
 
@@ -2038,6 +2076,78 @@ def test_warp_backward_tiled_equals_gather(hip, cam, prj, b):
     assert rel_inf(a[..., :3].permute(0, 3, 1, 2), xc.grad) < 5e-5   # (border pixels sum hundreds of taps: another order on the CPU)
 
 
+@pytest.mark.parametrize('cam,prj,b', [((64, 64), (64, 64), 5), ((240, 320), (256, 256), 3), ((44, 68), (56, 40), 9), ((256, 256), (256, 256), 6)])
+def test_warp_forward_from_tap_table_and_fused_sumsq(hip, cam, prj, b):
+    """Round 6, csrc/warp.hip.  (a) spaa_warp_fwd_taps -- grid_sample from the per-attack tap table (32 x 8 camera tiles, four images per
+    workgroup) -- against the grid kernel (same taps; weights x mask folded: equal to rounding), against F.grid_sample on the CPU, and as
+    the exact adjoint of the tiled backward pass (<fwd(x), g> == <x, bwd(g)> to fp32 summation noise).  (b) spaa_warp_bwd_tiled_sumsq: the
+    gradient is bitwise that of spaa_warp_bwd_tiled (+ spaa_grad_sumsq's prjl2 term for colour-step samples), and its per-tile partial sums
+    add up to spaa_grad_sumsq's ||g_b||^2; spaa_step_and_track_n on them moves x like spaa_step_and_track on the block sums."""
+    M, lib = hip['models'], hip['lib']
+    sd = syn.pcnet_state_dict(3, cam_sz=cam, mask='rect')
+    pc = make_pcnet(hip, sd, cam)
+    eng = M.PCNetEngine(pc, b, prj)
+    assert eng.tiled is not None and eng.sumsq_tiles() == ((prj[1] + 15) // 16) * ((prj[0] + 15) // 16)
+    torch.manual_seed(b + cam[0])
+    x = torch.rand(b, prj[0], prj[1], 4, device=DEV) * 1.4 - 0.2       # (values outside [0, 1]: the clamp and its gate)
+    x[..., 3] = 0
+    scene = torch.rand(b, cam[0], cam[1], 4, device=DEV)
+    scene[..., 3] = 0
+    eng.set_scene(scene)
+    old = M.TAP_TABLE_FWD
+    try:
+        M.TAP_TABLE_FWD = True
+        xw_t = eng.warp(x, True).clone()
+        M.TAP_TABLE_FWD = False
+        xw_g = eng.warp(x, True).clone()
+    finally:
+        M.TAP_TABLE_FWD = old
+    assert rel_inf(xw_t, xw_g) < 2e-6 and float(xw_t[..., 3].abs().max()) == 0.0
+    xc = x[..., :3].permute(0, 3, 1, 2).cpu()
+    grid = eng.grid[..., :2].cpu()[None].expand(b, -1, -1, -1)
+    y = F.grid_sample(xc.clamp(0, 1), grid, mode='bilinear', padding_mode='zeros', align_corners=True) * sd['mask']
+    assert rel_inf(xw_t[..., :3].permute(0, 3, 1, 2), y) < 2e-5
+    # adjoint pair (no clamp: a linear map)
+    g = torch.randn(b, cam[0], cam[1], 4, device=DEV)
+    g[..., 3] = 0
+    M.TAP_TABLE_FWD, keep = True, M.TAP_TABLE_FWD
+    try:
+        fx = eng.warp(x, False).clone()
+    finally:
+        M.TAP_TABLE_FWD = keep
+    eng._x, eng._clamp = x, 0
+    bg = eng.warp_backward(g).clone()
+    lhs, rhs = (fx.double() * g.double()).sum(), (x.double() * bg.double()).sum()
+    assert abs(float(lhs - rhs)) < 1e-5 * max(1.0, abs(float(lhs)))
+    # (b) fused sum of squares, with and without the prjl2 term
+    eng._x, eng._clamp = x, 1
+    state = torch.zeros(b, 4, dtype=torch.int32, device=DEV)
+    state[::2, 1] = 1                                             # every other sample takes the colour step
+    state[1::3, 0] = 1
+    for scale in (0.0, 0.37):
+        ref = eng.warp_backward(g).clone()
+        nblk = (prj[0] * prj[1] + 255) // 256
+        part_ref = torch.zeros(b, nblk, device=DEV)
+        lib.call('spaa_grad_sumsq', lib.ptr(ref), lib.ptr(x), 0.5, scale, lib.ptr(state), lib.ptr(part_ref), b, prj[0] * prj[1])
+        part = torch.zeros(b, eng.sumsq_tiles(), device=DEV)
+        got = eng.warp_backward(g, sumsq=(part, 0.5, scale, state)).clone()
+        # (ref was updated in place by spaa_grad_sumsq.  Without the prjl2 term: the same bits; with it: the same formula, whose
+        # multiply-adds the compiler contracts per kernel)
+        assert torch.equal(got, ref) if scale == 0.0 else rel_inf(got, ref) < 1e-6, scale
+        assert rel_inf(part.double().sum(1), part_ref.double().sum(1)) < 1e-6, scale
+        part2 = torch.zeros_like(part)
+        eng.warp_backward(g, sumsq=(part2, 0.5, scale, state))
+        assert torch.equal(part, part2)                               # fixed order: bitwise run to run
+        xa, xb_ = x.clone(), x.clone()
+        best_a, best_b = torch.zeros_like(x), torch.zeros_like(x)
+        cam_im, cb_a, cb_b = torch.rand(b, cam[0], cam[1], 4, device=DEV), torch.zeros(b, cam[0], cam[1], 4, device=DEV), torch.zeros(b, cam[0], cam[1], 4, device=DEV)
+        lib.call('spaa_step_and_track', lib.ptr(xa), lib.ptr(ref), lib.ptr(part_ref), lib.ptr(state), 2.0, 1.0, lib.ptr(best_a), lib.ptr(cam_im),
+                 lib.ptr(cb_a), b, prj[0] * prj[1], cam[0] * cam[1])
+        lib.call('spaa_step_and_track_n', lib.ptr(xb_), lib.ptr(got), lib.ptr(part), part.shape[1], lib.ptr(state), 2.0, 1.0, lib.ptr(best_b),
+                 lib.ptr(cam_im), lib.ptr(cb_b), b, prj[0] * prj[1], cam[0] * cam[1])
+        assert rel_inf(xb_, xa) < 1e-6 and rel_inf(best_b, best_a) < 1e-6 and torch.equal(cb_a, cb_b)
+
+
 def test_vgg16_attack_loop_first_iteration(hip):
     """configs[4]'s classifier inside the SPAA loop (not just as a bare classifier)."""
     csd = syn.vgg16_state_dict(3, logit_gain=5.0, fc_width=512)
@@ -2425,7 +2535,24 @@ def test_fused_conv1_pair(hip, cam_sz, prj_sz, b, storage):
     flips_all = int((ma1 != ma0).sum())      # (later layers' units within rounding of zero see the 1e-7 differences)
     print(f'conv1 pair fused vs separate at {cam_sz} B={b} {storage}: S1 {rel_inf(s11, s10):.1e}, X1 {rel_inf(x11, x10):.1e}, gate bytes '
           f'differing {flips} of {2 * ms0.numel()} (all eleven masks: {flips_all}), Y {rel_inf(y1, y0):.1e}, input gradient rel L2 {rel_l2(gx1, gx0):.1e}')
-    assert rel_inf(s11, s10) < tol and rel_inf(x11, x10) < tol and flips <= 2e-5 * 2 * ms0.numel() + (2 if storage == 'f16' else 0)
+    if storage == 'f32':
+        assert rel_inf(s11, s10) < tol and rel_inf(x11, x10) < tol and flips <= 2e-5 * 2 * ms0.numel()
+    else:
+        # fp16 storage, round 6: the fused kernel multiplies fp16 operands (xw, s and the fp32 product xw * s rounded in registers, fp16
+        # weights) on v_mfma_f32_16x16x32_f16, like every other layer of the mode.  Its reference is float64 on the SAME rounded operands
+        # (what is left: accumulation order + the fp16 rounding of the stored value); the separate launches (conv1_s over the fp32
+        # concatenation: exact image operands) differ by the operands' rounding on top of that
+        xw32 = e1.a['xw'][..., :3].permute(0, 3, 1, 2).cpu()
+        sc32 = scene.clone()
+        hx, hs, hxs = _h(xw32), _h(sc32), _h(xw32 * sc32)
+        w1, ws = _h(sd['shading_net.conv1.weight']), _h(sd['shading_net.conv1_s.weight'])
+        s_ref = F.relu(F.conv2d(torch.cat([hs, hxs], 1).double(), ws.double(), sd['shading_net.conv1_s.bias'].double(), 2, 1))
+        s_ref_h = s_ref.float().half().float()
+        x_ref = F.relu(F.conv2d(hx.double(), w1.double(), sd['shading_net.conv1.bias'].double(), 2, 1) + s_ref_h.double())
+        es, ex = rel_inf(nchw(s11.cpu(), 32), s_ref), rel_inf(nchw(x11.cpu(), 32), x_ref)
+        print(f'    fused fp16 pair vs float64 on the same fp16 operands: S1 {es:.1e}, X1 {ex:.1e}')
+        assert es < 1.5e-3 and ex < 1.5e-3
+        assert rel_inf(s11, s10) < 4e-3 and rel_inf(x11, x10) < 4e-3 and flips <= 2e-3 * 2 * ms0.numel()
     lib = hip['lib']
     assert torch.equal(ms1, lib.pack_gate_mask(e1.a['S1'])) and torch.equal(mx1, lib.pack_gate_mask(e1.a['X1']))
     assert rel_inf(y1, y0) < (5e-6 if storage == 'f32' else 2e-2)
@@ -2531,6 +2658,18 @@ def test_h16p_canvas_and_k_ranges(hip):
             out_b = torch.zeros_like(out)
             plan.run(xin, out_b, add=nhwc(add, cs).half().to(DEV), act=lib.ACT_RELU)
             assert torch.equal(out_b, out)                      # (fixed summation order: bitwise run to run)
+            if plan.last_h16p_plan[1] > 1 and co % 4 == 0:
+                # round 6: the K ranges meeting inside the kernel (SPAA_SPLITK_FIXUP=1; last-arriving workgroup, fixed order) is bitwise the
+                # separate second pass, and the arrival counters at the head of the workspace are left zero
+                keep = cp.WINO_SPLITK_FIXUP
+                try:
+                    cp.WINO_SPLITK_FIXUP = True
+                    out_fx, mask_fx = torch.zeros_like(out), torch.zeros_like(mask)
+                    plan.run(xin, out_fx, add=nhwc(add, cs).half().to(DEV), act=lib.ACT_RELU, mask_out=mask_fx)
+                    assert torch.equal(out_fx, out) and torch.equal(mask_fx, mask), (ci, co, cv)
+                    assert int(plan._ws_fix[:cp.SPLITK_HDR].view(torch.int32).abs().max()) == 0
+                finally:
+                    cp.WINO_SPLITK_FIXUP = keep
             out32 = torch.zeros(b, h, w, cs, device=DEV)
             plan.run(xin, out32)
             assert plan.last_tile == 68 and rel_inf(nchw(out32.cpu(), co), y) < 2e-5, (ci, co, cv, rel_inf(nchw(out32.cpu(), co), y))
@@ -3243,12 +3382,13 @@ def test_perc_al_vgg16_f16_full_batch_properties(hip):
     # differs by 0.135 in this statistic, fp32 storage by 3e-3 between the batch sizes.  Bisected in round 6 (tools/lab/vgg_f16_bisect.py
     # -> profiles/r06_vgg_f16_bisect.txt): 0.046 in rounds 3-4 (one kernel family at both batch sizes), 0.098 with round 5's
     # batch-size-dependent forms, 0.137 at the end of round 5 when the fp16-operand first layer (tile 76) ran at batch 64 only --
-    # fixed in round 6 (it runs at every batch size).  The bound is 1.3 x the measured value; what a dependence between samples
+    # fixed in round 6 (it runs at every batch size): 0.0686 now, 0.0136 without the canvas / K-range form that only the batch of 8
+    # takes, 0.0 (bitwise) with one kernel family and no K ranges at both sizes.  The bound is 1.3 x the measured value; what a dependence between samples
     # would look like is asserted exactly above, and bounded here: hardly an element may move by a tenth of the largest step)
     diff = (d8[0] - d[0][8:16]).abs()
     far = float((diff > 0.1 * d[0].abs().max()).float().mean())
     print(f'    elements further apart than 10 % of the largest |delta|: {far:.2e}; mean |difference| / mean |delta| {float(diff.mean() / d[0].abs().mean()):.3f}')
-    assert e8 < 0.15 and far < 1e-4 and torch.isfinite(st.stats).all() and torch.isfinite(st8.stats).all()
+    assert e8 < 0.09 and far < 1e-4 and torch.isfinite(st.stats).all() and torch.isfinite(st8.stats).all()
 
 
 # ---------------------------------------------------------------------------------------------------------------
