@@ -401,11 +401,13 @@ extern "C" int spaa_conv1_pair_fwd(const float* xw, const float* s, const float*
     a.tiles_x = (a.Wm + TW - 1) / TW, a.tiles_y = (a.Hm + TH - 1) / TH;
     const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * B), 1, 1);
     hipStream_t st = (hipStream_t)stream;
-    // SPAA_C1P_MFMA: 1 (default) the 16 x 16 x 32 forms of round 6 (fp16 operands in fp16 storage, bf16x6 in fp32); 0: the fp32-MFMA form (A/B runs)
-    static const bool mfma = []() { const char* e = getenv("SPAA_C1P_MFMA"); return !(e && e[0] == '0'); }();
-    if (out_f16 && mfma)
+    // SPAA_C1P_MFMA: 1 (default) fp16 storage on the 16 x 16 x 32 fp16 form of round 6 (100 -> 79 us at batch 64, 256 x 256), fp32 on the
+    // fp32-MFMA form; 2: fp32 on the bf16x6 16 x 16 x 32 form too (measured 119 against 116 us: three 44-instruction operand splits
+    // per 16 pixels cost what the shorter matrix instructions save -- kept for A/B runs and its test); 0: the fp32-MFMA form everywhere
+    static const int mfma = []() { const char* e = getenv("SPAA_C1P_MFMA"); return e ? atoi(e) : 1; }();
+    if (out_f16 && mfma >= 1)
         hipLaunchKernelGGL(conv1pair_mfma_kernel<true>, grid, dim3(256), LDS_BYTES, st, a);
-    else if (mfma)
+    else if (!out_f16 && mfma >= 2)
         hipLaunchKernelGGL(conv1pair_mfma_kernel<false>, grid, dim3(256), LDS_BYTES, st, a);
     else if (out_f16)
         hipLaunchKernelGGL(conv1pair_kernel<_Float16>, grid, dim3(256), LDS_BYTES, st, a);
