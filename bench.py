@@ -329,7 +329,10 @@ def instrumented_pass(st, args, n_prof=3):
 
 PCNET_LAYERS = ('conv1', 'conv2', 'conv3', 'conv4', 'conv5', 'conv1_s', 'conv2_s', 'conv3_s', 'conv4_s', 'conv6', 'skipConv2',
                 'skipConv3', 'transConv1', 'transConv2')
-PCNET_ENTRY_POINTS = ('spaa_conv1_pair_fwd', 'spaa_warp_fwd', 'spaa_warp_bwd_gather', 'spaa_warp_bwd_tiled', 'spaa_shading_tail_fwd', 'spaa_shading_tail_fwd_f16',
+# (round 6: spaa_warp_fwd_taps = grid_sample from the tap table; spaa_warp_bwd_tiled_sumsq = its adjoint WITH spaa_grad_sumsq in the
+# epilogue -- counted in full although the ||g||^2 part is the attack step's, not PCNet's)
+PCNET_ENTRY_POINTS = ('spaa_conv1_pair_fwd', 'spaa_conv1_pair_bwd_f16', 'spaa_warp_fwd', 'spaa_warp_fwd_taps', 'spaa_warp_bwd_gather', 'spaa_warp_bwd_tiled', 'spaa_warp_bwd_tiled_sumsq',
+                      'spaa_shading_tail_fwd', 'spaa_shading_tail_fwd_f16',
                       'spaa_shading_head_bwd', 'spaa_shading_head_bwd_f16', 'spaa_stealth_loss_fwd_bwd')
 MB_PCNET_DE_PER_SCENE_256 = 214.0   # PCNet + dE2000 forward / backward, fp32, per scene-iteration
 
@@ -572,9 +575,12 @@ def main():
         mb_group = dict(MB_PER_SCENE_256)
         if 'spaa_conv1_pair_fwd' in other:
             mb_group['warp_fwd'], mb_group['conv1_pair'] = MB_WARP_FWD_NO_CAT, MB_CONV1_PAIR
-        for gname, entry in (('conv1_pair', 'spaa_conv1_pair_fwd'), ('warp_fwd', 'spaa_warp_fwd'), ('warp_bwd_gather', 'spaa_warp_bwd_gather'),
+        for gname, entry in (('conv1_pair', 'spaa_conv1_pair_fwd'), ('warp_fwd', 'spaa_warp_fwd'), ('warp_fwd', 'spaa_warp_fwd_taps'),
+                             ('warp_bwd_gather', 'spaa_warp_bwd_gather'),
                              ('warp_bwd_gather', 'spaa_warp_bwd_tiled'),   # (the LDS-staged form of the same adjoint)
-                             ('stealth_loss', 'spaa_stealth_loss_fwd_bwd'), ('step_and_track', 'spaa_step_and_track')):
+                             ('warp_bwd_gather', 'spaa_warp_bwd_tiled_sumsq'),   # (... with ||g||^2 in its epilogue: same algorithmic bytes)
+                             ('stealth_loss', 'spaa_stealth_loss_fwd_bwd'), ('step_and_track', 'spaa_step_and_track'),
+                             ('step_and_track', 'spaa_step_and_track_n')):
             if entry in other:
                 us = other[entry][0] * 1e3 / other[entry][1]
                 gb = mb_group[gname] * scale

@@ -210,6 +210,15 @@ int spaa_linear_small(const float* x, const float* w, const float* bias, float* 
 int spaa_conv1_pair_fwd(const float* xw, const float* s, const float* w_pair, const float* bias1, const float* bias_s,
                         void* S1, void* X1, uint8_t* mask_S1, uint8_t* mask_X1, int B, int H, int W, int out_f16,
                         spaa_stream_t stream);
+/* the ADJOINT of the pair in fp16-storage mode (round 6): g_xw = conv1^T(g_x1) + scene * conv1_s^T(g_s1)[rough channels 3..5]
+ * (models.py:284-285,295,342 under autograd: aten::convolution_backward(input) of both layers, the product with the surface image and the
+ * sum), ONE launch instead of two thin-output launches with a round trip between them.  g_x1 / g_s1: fp16 [B,H/2,W/2,32] (already
+ * ReLU-gated); scene, g_xw: fp32 [B,H,W,4]; w_image: the two layers' weights rounded to fp16 as the kernel's matrix operands,
+ * [2 sources][4 operands (r, q)][64 lanes][8]: lane = (row 4 (2 cy + cx) + c, 8-channel chunk g), element e = weight[n = 8 g + e][c (+ 3
+ * for the rough source)][ky][kx] with ky = (cy == 0 ? 1 : r == 0 ? 2 : 0), kx likewise, zero unless c < 3, r <= cy, q <= cx
+ * (spaa_amd/models.py: pack_pair1_bwd); products on v_mfma_f32_16x16x32_f16, fp32 accumulation */
+int spaa_conv1_pair_bwd_f16(const void* g_x1, const void* g_s1, const float* scene, const void* w_image, float* g_xw, int B, int H, int W,
+                            spaa_stream_t stream);
 /* Backward of the above w.r.t. x (grid_sampler_2d_backward + clamp mask): g_x must be zeroed by the caller
  * (spaa_zero); contributions are accumulated with float atomics.
  * g_xw: [B,Hc,Wc,4] gradient w.r.t. xw (conv1 path); g_xs: [B,Hc,Wc,4] gradient w.r.t. xw*s (channels 3..5 of
@@ -285,9 +294,13 @@ int spaa_shading_head_bwd(const float* gp, const float* w6t, const uint16_t* w2t
  * separate transConv2 launch of this mode would store) and takes conv6's weights rounded to fp16 as well: `w6` of
  * spaa_shading_tail_fwd_f16 points at [3][9][32] fp16 ([o][3 ky + kx][c]), its taps accumulate in fp32 (v_dot2_f32_f16).  Images, res1,
  * gp and conv6's transpose (`w6t`) stay fp32 */
-int spaa_shading_tail_fwd_f16(const void* x6, const uint16_t* w2_split, const float* bias2, const float* w6, const float* bias6,
+/* (spaa_hip 0.6: the fp16 operands are typed `const void*` -- `w2_half` / `w2t_half` ONE fp16 matrix, `w6_half` fp16 [3][9][32] -- so that a
+ * caller written against the bf16-plane / fp32 meaning these arguments had before round 5 no longer compiles against this header; round 6:
+ * conv6 and its transpose run on v_mfma_f32_16x16x32_f16 as well (backward: conv6's weights `w6t` fp32 [27][32] are rounded to fp16 in the
+ * kernel, the values the forward pass multiplies; the cotangent enters as hi + lo fp16 halves, exact to 2^-22)) */
+int spaa_shading_tail_fwd_f16(const void* x6, const void* w2_half, const float* bias2, const void* w6_half, const float* bias6,
                               const float* res1, float* y, float* ypre, uint8_t* mask7, int B, int H2, int W2, spaa_stream_t stream);
-int spaa_shading_head_bwd_f16(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7,
+int spaa_shading_head_bwd_f16(const float* gp, const float* w6t, const void* w2t_half, const uint8_t* mask7,
                               const uint8_t* mask6, void* p6, int B, int H2, int W2, spaa_stream_t stream);
 
 /* the backward head with spaa_select_grad folded into its first phase (one launch and one [B,H,W,4] round trip less per iteration):
@@ -297,7 +310,7 @@ int spaa_shading_head_bwd_select(const float* g_adv, const float* g_col, const i
                                  const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6, float* p6, int B, int H2,
                                  int W2, spaa_stream_t stream);
 int spaa_shading_head_bwd_select_f16(const float* g_adv, const float* g_col, const int32_t* state, const float* ypre, const float* w6t,
-                                     const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6, void* p6, int B, int H2,
+                                     const void* w2t_half, const uint8_t* mask7, const uint8_t* mask6, void* p6, int B, int H2,
                                      int W2, spaa_stream_t stream);
 
 /* ReLU backward as a stand-alone op: out = (act > 0) ? g : 0, n floats (n % 4 == 0, 16-byte aligned) */

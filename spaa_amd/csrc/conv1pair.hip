@@ -387,7 +387,89 @@ __global__ __launch_bounds__(256, 2) void conv1pair_mfma_kernel(const c1p_args p
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The ADJOINT of the pair in fp16-storage mode (round 6): the input gradients of conv1 and conv1_s meet at the warped image,
+//     g_xw = conv1^T(gX1) + s * conv1_s^T(gS1)[rough channels]          (models.py:284-285,295,342 of the reference under autograd)
+// until now two thin-output launches with a 67 MB round trip of the rough part between them (402 MB per step at batch 64).  Here a wave
+// owns an INPUT row segment of 16 half-resolution pixels; they feed the 2 x 2 output pixels (2 y + cy, 2 x + cx) through at most four
+// operands -- I00 = in[y][x], I01 = in[y][x + 1], I10 = in[y + 1][x], I11 = in[y + 1][x + 1] -- and with the MFMA's rows = (parity class,
+// channel) = 4 (2 cy + cx) + c ONE v_mfma_f32_16x16x32_f16 per operand (K = the 32 channels) adds that operand's taps to all four classes:
+// class (cy, cx) takes operand I_rq iff r <= cy and q <= cx, through tap ky = (cy == 0 ? 1 : r == 0 ? 2 : 0), kx likewise.  Four MFMAs
+// per source for 64 output pixels, and every lane ends with ONE output pixel's three channels of both sources: scene load, multiply-add,
+// one 16-byte store.  The operands are 16-byte-per-lane global loads of whole 1 KB row segments (no LDS at all); the weights (fp16, as
+// the separate launches round them) live in registers.  HBM: read gX1, gS1 (fp16) and the scene, write g_xw: 268 MB.
+struct c1b_args {
+    const _Float16* gx1;
+    const _Float16* gs1;
+    const float* scene;
+    const _Float16* wimg;   // [2 sources][4 operands][64 lanes][8] fp16: the MFMA A operands (see the kernel)
+    float* g_xw;
+    int B, H2, W2, ngrp;   // half-resolution size; 16-pixel column groups per row
+};
+
+__global__ __launch_bounds__(256, 4) void conv1pair_bwd_h16_kernel(const c1b_args p) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, g = lane >> 4;
+    // A operands: row = 4 cl + c (cl = 2 cy + cx), k = input channel n = 8 g + e; operand (r, q); source 0 = conv1, 1 = conv1_s rough:
+    // the per-lane image [source][operand][lane][8 fp16] is packed once per model by the host (spaa_amd/models.py: pack_pair1_bwd)
+    h8 A[2][4];
+#pragma unroll
+    for (int src = 0; src < 2; ++src)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) A[src][rq] = *reinterpret_cast<const h8*>(p.wimg + ((src * 4 + rq) * 64 + lane) * 8);
+    const int nrows = p.B * p.H2 * p.ngrp;               // wave tasks: (image, input row, column group)
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const int H = 2 * p.H2, W = 2 * p.W2;
+    for (int t = wid; t < nrows; t += nw) {
+        const int grp = t % p.ngrp, y = (t / p.ngrp) % p.H2, b = t / (p.ngrp * p.H2);
+        const int x = 16 * grp + j;
+        const bool x0ok = x < p.W2, x1ok = x + 1 < p.W2, y1ok = y + 1 < p.H2;
+        const size_t row0 = ((size_t)b * p.H2 + y) * p.W2, row1 = row0 + p.W2;
+        const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        h8 I[2][4];
+#pragma unroll
+        for (int src = 0; src < 2; ++src) {
+            const _Float16* base = src == 0 ? p.gx1 : p.gs1;
+            I[src][0] = x0ok ? *reinterpret_cast<const h8*>(base + (row0 + x) * 32 + 8 * g) : z;
+            I[src][1] = x1ok ? *reinterpret_cast<const h8*>(base + (row0 + x + 1) * 32 + 8 * g) : z;
+            I[src][2] = (x0ok && y1ok) ? *reinterpret_cast<const h8*>(base + (row1 + x) * 32 + 8 * g) : z;
+            I[src][3] = (x1ok && y1ok) ? *reinterpret_cast<const h8*>(base + (row1 + x + 1) * 32 + 8 * g) : z;
+        }
+        // this lane's output pixel: class g of input pixel (y, x)
+        const int Y = 2 * y + (g >> 1), X = 2 * x + (g & 1);
+        const size_t o = ((size_t)b * H + Y) * W + X;
+        f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+        if (x0ok) sv = *reinterpret_cast<const f32x4*>(p.scene + o * 4);
+        f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0][rq], I[0][rq], a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[1][rq], I[1][rq], a2, 0, 0, 0);
+        }
+        // D: column = input pixel j, rows 4 g + e = (class g, channel e)
+        if (x0ok) *reinterpret_cast<f32x4*>(p.g_xw + o * 4) = f32x4{a1[0] + a2[0] * sv[0], a1[1] + a2[1] * sv[1], a1[2] + a2[2] * sv[2], 0.f};
+    }
+}
+
 }  // namespace
+
+extern "C" int spaa_conv1_pair_bwd_f16(const void* g_x1, const void* g_s1, const float* scene, const void* w_image, float* g_xw, int B, int H,
+                                       int W, spaa_stream_t stream) {
+    if (!g_x1 || !g_s1 || !scene || !w_image || !g_xw || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return hipErrorInvalidValue;
+    if ((uint64_t)B * H * W * 16u >= (1ull << 40)) return hipErrorInvalidValue;
+    c1b_args a;
+    a.gx1 = reinterpret_cast<const _Float16*>(g_x1), a.gs1 = reinterpret_cast<const _Float16*>(g_s1);
+    a.scene = scene, a.wimg = reinterpret_cast<const _Float16*>(w_image), a.g_xw = g_xw;
+    a.B = B, a.H2 = H / 2, a.W2 = W / 2, a.ngrp = (a.W2 + 15) / 16;
+    const int64_t tasks = (int64_t)B * a.H2 * a.ngrp;
+    if (tasks > 0x7fffffff) return hipErrorInvalidValue;
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
+    int64_t nwg = (tasks + 3) / 4;                        // four waves per workgroup, a task per wave and round
+    if (nwg > 4 * (int64_t)ncu) nwg = 4 * (int64_t)ncu;   // persistent: four workgroups per compute unit walk the tasks
+    hipLaunchKernelGGL(conv1pair_bwd_h16_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
 
 extern "C" int spaa_conv1_pair_fwd(const float* xw, const float* s, const float* w_pair, const float* bias1, const float* bias_s,
                                    void* S1, void* X1, uint8_t* mask_S1, uint8_t* mask_X1, int B, int H, int W, int out_f16,

@@ -103,6 +103,7 @@ __device__ __forceinline__ void stage_planes(const uint16_t* w, unsigned char* d
 constexpr int FWD_WAVES = 16;
 constexpr int PW2 = (OY * TX + 63) / 64;            // waves per channel half in phase 2 (7: 14 rows of 32 lanes, 30 of them pixels)
 constexpr int RED_BYTES = PW2 * 64 * 16;            // partial sums of the second half
+constexpr int SCR_BYTES = 3 * 34 * 16;              // fp16 storage, phase 2: a wave's [dx][34 columns][4 floats]
 
 // fp16 storage (round 5): the X7 tile lives in LDS as fp16 -- the value a separate transConv2 launch of this mode would store -- in
 // chunks of 8 channels (32 KB instead of 64), conv6's weights come rounded to fp16 like every other layer's of the mode (`w6` then
@@ -122,18 +123,22 @@ __global__ __launch_bounds__(64 * FWD_WAVES, sizeof(T6) == 2 ? 8 : 1) void shadi
     unsigned char* tl = smem + (H16 ? W_BYTES / 3 : W_BYTES);             // X7 tile (fp16 storage: four planes of 8 channels)
     unsigned char* rl = tl + (H16 ? T_BYTES / 2 : T_BYTES);               // phase-2 partial sums (fp16 storage: a 256-byte pad)
     unsigned char* wa = rl + (H16 ? 256 : RED_BYTES);                     // fp16 storage: conv6's weights as MFMA A operands, see below
+    unsigned char* scr = wa + 3 * 64 * 16;                                // fp16 storage: per-wave scratch of the shifted partial sums
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = 2 * H2, W = 2 * W2;
     if constexpr (H16) {
-        // round 6: conv6 (3 x 3, 32 -> 3) on v_mfma_f32_16x16x32_f16 too: per tap one MFMA with K = the 32 channels, the tile's pixels as
-        // the 16 columns and the weights as rows -- rows 0..2 AND 4..6 hold output channel n = row & 3 (the copy in rows 4..6 puts the
-        // second pixel group's results into lanes 16..31 without a shuffle), every other row zero.  The per-lane operand image
-        // [tap][lane][8 fp16] (lane = (row, 8-channel chunk)) is built once per workgroup: 9 KB
-        if (tid < 9 * 64) {
-            const int t = tid >> 6, l = tid & 63, r = l & 15, gg = l >> 4;
+        // round 6: conv6 (3 x 3, 32 -> 3) on v_mfma_f32_16x16x32_f16 too.  K = the 32 channels, columns = 16 pixels of an X7 row, ROWS =
+        // (tap column dx, output channel n): row 4 dx + n holds conv6's weights of tap (dy, dx) -- ONE MFMA per tap ROW dy gives, for
+        // all three dx at once, P_dx[n][xc] = sum_c w[n][dy][dx][c] X7[c][y + dy][xc] at the UNSHIFTED pixel xc; the accumulator sums the
+        // three dy, and out[n][ox] = P_0[n][ox] + P_1[n][ox + 1] + P_2[n][ox + 2] is formed through a per-wave LDS scratch.  Three
+        // operand reads + three MFMAs per 16 pixels (a tap per MFMA took nine + nine: the kernel sat on the LDS pipe).  The per-lane
+        // operand image [dy][lane][8 fp16] (lane = (row, 8-channel chunk)) is built once per workgroup: 3 KB
+        if (tid < 3 * 64) {
+            const int dy = tid >> 6, l = tid & 63, r = l & 15, gg = l >> 4;
+            const int dx = r >> 2, n = r & 3;
             h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (r < 8 && (r & 3) < 3) v = *reinterpret_cast<const h8*>(reinterpret_cast<const _Float16*>(w6) + ((r & 3) * 9 + t) * C7 + 8 * gg);
+            if (dx < 3 && n < 3) v = *reinterpret_cast<const h8*>(reinterpret_cast<const _Float16*>(w6) + (n * 9 + 3 * dy + dx) * C7 + 8 * gg);
             *reinterpret_cast<h8*>(wa + tid * 16) = v;
         }
     }
@@ -262,31 +267,41 @@ __global__ __launch_bounds__(64 * FWD_WAVES, sizeof(T6) == 2 ? 8 : 1) void shadi
         __syncthreads();
         // ---- phase 2: conv6 (3x3, 32 -> 3) over this wave's 16 channels; X7's gate bytes from the centre tap (relu(t) > 0 <=> t > 0)
         if constexpr (H16) {
-            // wave w < 14 owns interior row w: two groups of 16 pixels (columns 0..15 and 16..31, of which 30 are owned); lane =
-            // (pixel of the group, 8-channel chunk = plane of the tile).  Per tap: one operand read per group + one MFMA per group
-            // (the 14-wave VALU form spent 216 v_dot2 per lane here).  Results: rows 0..2 of group A in lanes 0..15, rows 4..6 of
-            // group B (the same weights) in lanes 16..31 = output pixel `lane` of the row.
+            // wave w < 14 owns interior row w: two groups of 16 X7 columns (0..15 and 16..31); lane = (column of the group, 8-channel
+            // chunk = plane of the tile) for the operands, (column, dx) for the accumulators (rows 4 dx + n).
             if (wave < OY) {
                 const int oy = wave;
                 f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
                 const unsigned char* pb = tl + g * PLANE + (oy * TX + rx) * 16;
-                const int ox = 16 * g + rx;                    // the output pixel whose result this lane holds (g < 2)
+                const int ox = 16 * g + rx;                    // the output pixel this lane finishes (g < 2)
                 const int gy = 2 * a0 + 1 + oy, gx = 2 * b0 + 1 + ox;
                 const bool ok = g < 2 && ox < OX && gy >= 0 && gy < H && gx >= 0 && gx < W;
                 const size_t o = ((size_t)img * H + (ok ? gy : 0)) * W + (ok ? gx : 0);
                 f32x4 rv = {0.f, 0.f, 0.f, 0.f};
                 if (ok) rv = *reinterpret_cast<const f32x4*>(r1 + o * 4);   // (requested early: used after the taps)
-                // (one tap in flight per wave: 64 registers = eight waves per SIMD hide the LDS latency between them)
+                // (one tap row in flight per wave: 64 registers = eight waves per SIMD hide the LDS latency between them)
 #pragma unroll 1
                 for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll 1
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const h8 a = *reinterpret_cast<const h8*>(wa + ((3 * dy + dx) * 64 + lane) * 16);
-                        const unsigned char* pp = pb + (dy * TX + dx) * 16;
-                        const h8 bA = *reinterpret_cast<const h8*>(pp), bB = *reinterpret_cast<const h8*>(pp + 16 * 16);
-                        accA = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bA, accA, 0, 0, 0);
-                        accB = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bB, accB, 0, 0, 0);
-                    }
+                    const h8 a = *reinterpret_cast<const h8*>(wa + (dy * 64 + lane) * 16);
+                    const unsigned char* pp = pb + dy * TX * 16;
+                    const h8 bA = *reinterpret_cast<const h8*>(pp), bB = *reinterpret_cast<const h8*>(pp + 16 * 16);
+                    accA = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bA, accA, 0, 0, 0);
+                    accB = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bB, accB, 0, 0, 0);
+                }
+                // lane (xc, dx = g) holds P_dx[n = 0..2][xc] of both groups: through the wave's scratch [dx][34 columns][4 floats], then
+                // lane ox (< 30) adds its three shifted partial sums (LDS operations of one wave execute in order: no barrier)
+                unsigned char* const sc = scr + wave * SCR_BYTES;
+                if (g < 3) {
+                    *reinterpret_cast<f32x4*>(sc + (g * 34 + rx) * 16) = accA;
+                    *reinterpret_cast<f32x4*>(sc + (g * 34 + 16 + rx) * 16) = accB;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                f32x4 av = {0.f, 0.f, 0.f, 0.f};
+                if (g < 2) {
+                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(sc + (0 * 34 + ox) * 16);
+                    const f32x4 p1 = *reinterpret_cast<const f32x4*>(sc + (1 * 34 + ox + 1) * 16);
+                    const f32x4 p2 = *reinterpret_cast<const f32x4*>(sc + (2 * 34 + ox + 2) * 16);
+                    av = p0 + p1 + p2;
                 }
                 const h8 cA = *reinterpret_cast<const h8*>(pb + (TX + 1) * 16), cB = *reinterpret_cast<const h8*>(pb + (TX + 1 + 16) * 16);
                 // X7's gate bytes from the centre tap (relu(t) > 0 <=> t > 0): this lane holds 8 channels = two bytes of each group's pixel
@@ -304,7 +319,6 @@ __global__ __launch_bounds__(64 * FWD_WAVES, sizeof(T6) == 2 ? 8 : 1) void shadi
                     }
                 }
                 if (ok) {
-                    const f32x4 av = g == 0 ? accA : accB;
                     f32x4 outv = {0.f, 0.f, 0.f, 0.f}, prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int n = 0; n < 3; ++n) {
@@ -610,7 +624,7 @@ static int launch_tail_fwd(const T6* x6, const uint16_t* w2_split, const float* 
     const int64_t ntiles = (int64_t)B * tiles_y * tiles_x;
     if (ntiles > 0x7fffffff) return hipErrorInvalidValue;
     constexpr bool H16 = sizeof(T6) == 2;
-    const size_t smem = H16 ? (size_t)W_BYTES / 3 + T_BYTES / 2 + 256 + 9 * 64 * 16 : (size_t)W_BYTES + T_BYTES + RED_BYTES;
+    const size_t smem = H16 ? (size_t)W_BYTES / 3 + T_BYTES / 2 + 256 + 3 * 64 * 16 + OY * SCR_BYTES : (size_t)W_BYTES + T_BYTES + RED_BYTES;
     static bool attr_set[SPAA_MAX_DEVICES] = {};
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&shading_tail_fwd_kernel<T6>), (int)smem, attr_set);
     if (e != hipSuccess) return (int)e;
@@ -653,10 +667,10 @@ int spaa_shading_tail_fwd(const float* x6, const uint16_t* w2_split, const float
                           const float* res1, float* y, float* ypre, uint8_t* mask7, int B, int H2, int W2, spaa_stream_t stream) {
     return launch_tail_fwd<float>(x6, w2_split, bias2, w6, bias6, res1, y, ypre, mask7, B, H2, W2, stream);
 }
-int spaa_shading_tail_fwd_f16(const void* x6, const uint16_t* w2_split, const float* bias2, const float* w6, const float* bias6,
+int spaa_shading_tail_fwd_f16(const void* x6, const void* w2_half, const float* bias2, const void* w6_half, const float* bias6,
                               const float* res1, float* y, float* ypre, uint8_t* mask7, int B, int H2, int W2, spaa_stream_t stream) {
-    return launch_tail_fwd<_Float16>(reinterpret_cast<const _Float16*>(x6), w2_split, bias2, w6, bias6, res1, y, ypre, mask7, B, H2, W2,
-                                     stream);
+    return launch_tail_fwd<_Float16>(reinterpret_cast<const _Float16*>(x6), reinterpret_cast<const uint16_t*>(w2_half), bias2,
+                                     reinterpret_cast<const float*>(w6_half), bias6, res1, y, ypre, mask7, B, H2, W2, stream);
 }
 int spaa_shading_head_bwd(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6,
                           float* p6, int B, int H2, int W2, spaa_stream_t stream) {
@@ -669,14 +683,16 @@ int spaa_shading_head_bwd_select(const float* g_adv, const float* g_col, const i
     return launch_head_bwd<float>(g_adv, g_col, state, ypre, w6t, w2t_split, mask7, mask6, p6, B, H2, W2, stream);
 }
 int spaa_shading_head_bwd_select_f16(const float* g_adv, const float* g_col, const int32_t* state, const float* ypre, const float* w6t,
-                                     const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6, void* p6, int B, int H2, int W2,
+                                     const void* w2t_half, const uint8_t* mask7, const uint8_t* mask6, void* p6, int B, int H2, int W2,
                                      spaa_stream_t stream) {
     if (!state) return hipErrorInvalidValue;
-    return launch_head_bwd<_Float16>(g_adv, g_col, state, ypre, w6t, w2t_split, mask7, mask6, reinterpret_cast<_Float16*>(p6), B, H2, W2, stream);
+    return launch_head_bwd<_Float16>(g_adv, g_col, state, ypre, w6t, reinterpret_cast<const uint16_t*>(w2t_half), mask7, mask6,
+                                     reinterpret_cast<_Float16*>(p6), B, H2, W2, stream);
 }
-int spaa_shading_head_bwd_f16(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6,
+int spaa_shading_head_bwd_f16(const float* gp, const float* w6t, const void* w2t_half, const uint8_t* mask7, const uint8_t* mask6,
                               void* p6, int B, int H2, int W2, spaa_stream_t stream) {
-    return launch_head_bwd<_Float16>(gp, nullptr, nullptr, nullptr, w6t, w2t_split, mask7, mask6, reinterpret_cast<_Float16*>(p6), B, H2, W2, stream);
+    return launch_head_bwd<_Float16>(gp, nullptr, nullptr, nullptr, w6t, reinterpret_cast<const uint16_t*>(w2t_half), mask7, mask6,
+                                     reinterpret_cast<_Float16*>(p6), B, H2, W2, stream);
 }
 
 }  // extern "C"

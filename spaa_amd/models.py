@@ -266,6 +266,7 @@ def to_nchw(x4, clamp01=False):
 
 TILED_WARP_BWD = os.environ.get('SPAA_TILED_WARP_BWD', '1') != '0'   # LDS-staged grid_sample adjoint (0: the untiled gather)
 TAP_TABLE_FWD = os.environ.get('SPAA_TAP_TABLE_FWD', '1') != '0'     # grid_sample forward from the per-attack tap table, 32 x 8 tiles (0: the grid kernel)
+FUSE_C1BWD = os.environ.get('SPAA_FUSE_C1BWD', '1') != '0'           # fp16 storage: the input gradients of conv1 / conv1_s as one launch (0: two thin-output launches)
 FUSE_SUMSQ = os.environ.get('SPAA_FUSE_SUMSQ', '1') != '0'           # spaa_grad_sumsq as the epilogue of the tiled grid_sample adjoint (0: its own launch)
 
 
@@ -327,6 +328,27 @@ def tiled_taps(tap_off, tap_order, tap_wm, prj_size, cam_size):
     w_e = tap_wm[order].contiguous()
     tbox = torch.stack([y0, x0, torch.where(direct, -1, ch), cw], 1).to(torch.int32).contiguous()
     return lidx, w_e, tbox, max(cap, 1)
+
+
+def pack_pair1_bwd(w_conv1, w_conv1_s):
+    """MFMA A operands of spaa_conv1_pair_bwd_f16 (include/spaa_hip.h): [2 sources][4 operands (r, q)][64 lanes][8] fp16.  Lane = (row
+    4 (2 cy + cx) + c, 8-channel chunk g); element e = weight[n = 8 g + e][c (+ 3: conv1_s's rough input channels)][ky][kx] of the tap
+    through which output-parity class (cy, cx) reads operand in[y + r][x + q] (k3 / s2 / p1: ky = 1 for even rows, 2 / 0 for odd rows)."""
+    w1, ws = w_conv1.detach().float().cpu(), w_conv1_s.detach().float().cpu()
+    assert tuple(w1.shape) == (32, 3, 3, 3) and tuple(ws.shape) == (32, 6, 3, 3)
+    img = torch.zeros(2, 4, 64, 8)
+    for src, w, c0 in ((0, w1, 0), (1, ws, 3)):
+        for rq in range(4):
+            r, q = rq >> 1, rq & 1
+            for lane in range(64):
+                row, g = lane & 15, lane >> 4
+                cl, c = row >> 2, row & 3
+                cy, cx = cl >> 1, cl & 1
+                if c < 3 and r <= cy and q <= cx:
+                    ky = 1 if cy == 0 else (2 if r == 0 else 0)
+                    kx = 1 if cx == 0 else (2 if q == 0 else 0)
+                    img[src, rq, lane] = w[8 * g:8 * g + 8, c0 + c, ky, kx]
+    return img.half().contiguous()
 
 
 class _Activations(dict):
@@ -446,6 +468,11 @@ class PCNetEngine:
                 wp[gi, :, :, :3] = wsrc.permute(0, 2, 3, 1).reshape(32, 9, 3)
             self.pair1 = (wp.contiguous(), sn.conv1.bias.detach().float().contiguous().to(dev),
                           sn.conv1_s.bias.detach().float().contiguous().to(dev))
+        # fp16 storage: the ADJOINT of that pair as one launch too (csrc/conv1pair.hip: conv1^T(g_x1) + s * conv1_s^T(g_s1)[rough] on the
+        # fp16 matrix instruction: 268 MB instead of the two thin-output launches' 402 MB per step at batch 64); the raw fp32 weights
+        self.pair1_bwd = None
+        if FUSE_C1BWD and self.pair1 is not None and storage == 'f16':
+            self.pair1_bwd = pack_pair1_bwd(sn.conv1.weight, sn.conv1_s.weight).to(dev)
         f['transConv2'] = cp.deconv_fwd_plan(sn.transConv2.weight, sn.transConv2.bias, 2, 0, dev, 'transConv2')
         d['transConv2'] = cp.deconv_dgrad_plan(sn.transConv2.weight, 2, 0, dev, 'transConv2_dgrad')
         sk = sn.skipConv1
@@ -654,8 +681,12 @@ class PCNetEngine:
         d['conv2_s'].run(g['S2'], g['S1'], add=g['P1'], gate_bits=m['S1'])
         # the two 3-channel gradients meet at the warped image: d/d(x_w) = g_direct + g_rough * s (models.py:342); the
         # product and the sum are epilogues of the two thin convolutions instead of extra reads in the gather
-        d['conv1_s'].run(g['S1'], g['xs'], gate=self.scene, gate_mode=_lib.GATE_MUL)
-        d['conv1'].run(g['P1'], g['xw'], add=g['xs'])
+        if self.pair1_bwd is not None:
+            _lib.call('spaa_conv1_pair_bwd_f16', _lib.hptr(g['P1']), _lib.hptr(g['S1']), _lib.ptr(self.scene), _lib.hptr(self.pair1_bwd),
+                      _lib.ptr(g['xw']), self.B, self.Hc, self.Wc)
+        else:
+            d['conv1_s'].run(g['S1'], g['xs'], gate=self.scene, gate_mode=_lib.GATE_MUL)
+            d['conv1'].run(g['P1'], g['xw'], add=g['xs'])
         return self.warp_backward(g['xw'], sumsq) if input_grad else g['xw']
 
     def _backward_float_gates(self, gP):

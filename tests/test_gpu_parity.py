@@ -2513,8 +2513,8 @@ def test_fused_conv1_pair(hip, cam_sz, prj_sz, b, storage):
     pc = make_pcnet(hip, sd, cam_sz)
     e1 = M.PCNetEngine(pc, b, prj_sz, storage)
     e0 = M.PCNetEngine(pc, b, prj_sz, storage)
-    assert e1.pair1 is not None
-    e0.pair1 = None
+    assert e1.pair1 is not None and (e1.pair1_bwd is not None) == (storage == 'f16')
+    e0.pair1 = e0.pair1_bwd = None
     torch.manual_seed(b + cam_sz[0])
     scene = syn.scenes(3, b, cam_sz)
     x = torch.rand(b, 3, *prj_sz) * 1.2 - 0.1
@@ -2553,6 +2553,13 @@ def test_fused_conv1_pair(hip, cam_sz, prj_sz, b, storage):
         print(f'    fused fp16 pair vs float64 on the same fp16 operands: S1 {es:.1e}, X1 {ex:.1e}')
         assert es < 1.5e-3 and ex < 1.5e-3
         assert rel_inf(s11, s10) < 4e-3 and rel_inf(x11, x10) < 4e-3 and flips <= 2e-3 * 2 * ms0.numel()
+        # the pair's ADJOINT as one launch (spaa_conv1_pair_bwd_f16) against the two thin-output launches on the SAME fp16 gradients:
+        # the same fp16 products, fp32 accumulation in another order
+        gxw_f = e1.g['xw'].clone()
+        e1.d['conv1_s'].run(e1.g['S1'], e1.g['xs'], gate=e1.scene, gate_mode=hip['lib'].GATE_MUL)
+        e1.d['conv1'].run(e1.g['P1'], e1.g['xw'], add=e1.g['xs'])
+        print(f'    fused adjoint of the pair vs the two thin-output launches: g_xw {rel_inf(gxw_f, e1.g["xw"]):.1e}')
+        assert rel_inf(gxw_f, e1.g['xw']) < 5e-6 and float(gxw_f[..., 3].abs().max()) == 0.0
     lib = hip['lib']
     assert torch.equal(ms1, lib.pack_gate_mask(e1.a['S1'])) and torch.equal(mx1, lib.pack_gate_mask(e1.a['X1']))
     assert rel_inf(y1, y0) < (5e-6 if storage == 'f32' else 2e-2)
