@@ -313,6 +313,22 @@ int spaa_shading_head_bwd_select_f16(const float* g_adv, const float* g_col, con
                                      const void* w2t_half, const uint8_t* mask7, const uint8_t* mask6, void* p6, int B, int H2,
                                      int W2, spaa_stream_t stream);
 
+/* round 6: the same kernels with the clamp gate of the network output (models.py:301: backward of clamp(relu(.), max = 1) passes where
+ * 0 < pre <= 1) as ONE byte per pixel -- gate_y [B,2 H2,2 W2], bit e = channel e passes -- instead of the 16-byte pre-clamp pixel: the tail
+ * writes it (`ypre` may then be NULL: 63 MB less per batch-64 pass), the select head reads it instead of `ypre` (63 MB less) */
+int spaa_shading_tail_fwd_g(const float* x6, const uint16_t* w2_split, const float* bias2, const float* w6, const float* bias6,
+                            const float* res1, float* y, float* ypre, uint8_t* mask7, uint8_t* gate_y, int B, int H2, int W2,
+                            spaa_stream_t stream);
+int spaa_shading_tail_fwd_f16_g(const void* x6, const void* w2_half, const float* bias2, const void* w6_half, const float* bias6,
+                                const float* res1, float* y, float* ypre, uint8_t* mask7, uint8_t* gate_y, int B, int H2, int W2,
+                                spaa_stream_t stream);
+int spaa_shading_head_bwd_select_g(const float* g_adv, const float* g_col, const int32_t* state, const uint8_t* gate_y, const float* w6t,
+                                   const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6, float* p6, int B, int H2,
+                                   int W2, spaa_stream_t stream);
+int spaa_shading_head_bwd_select_f16_g(const float* g_adv, const float* g_col, const int32_t* state, const uint8_t* gate_y,
+                                       const float* w6t, const void* w2t_half, const uint8_t* mask7, const uint8_t* mask6, void* p6,
+                                       int B, int H2, int W2, spaa_stream_t stream);
+
 /* ReLU backward as a stand-alone op: out = (act > 0) ? g : 0, n floats (n % 4 == 0, 16-byte aligned) */
 int spaa_relu_gate(const float* g, const float* act, float* out, int64_t n, spaa_stream_t stream);
 /* torch.optim.Adam step on one flat parameter tensor (train_network.py:252-254: betas (0.9, 0.999), eps 1e-8, L2 weight

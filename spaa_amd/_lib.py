@@ -75,6 +75,10 @@ _SIGNATURES = {
     'spaa_shading_head_bwd_select': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     'spaa_shading_head_bwd_select_f16': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     'spaa_shading_head_bwd_f16': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    'spaa_shading_tail_fwd_g': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    'spaa_shading_tail_fwd_f16_g': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    'spaa_shading_head_bwd_select_g': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    'spaa_shading_head_bwd_select_f16_g': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     'spaa_relu_gate': [_p, _p, _p, _l, _p],
     'spaa_adam_step': [_p, _p, _p, _p, _l, _f, _d, _d, _f, _f, _i, _p],
     'spaa_rgb2lab': [_p, _p, _i, _p],

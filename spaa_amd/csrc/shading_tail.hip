@@ -113,7 +113,9 @@ template <typename T6>   // storage type of X6: float, or _Float16 in fp16-stora
 __global__ __launch_bounds__(64 * FWD_WAVES, sizeof(T6) == 2 ? 8 : 1) void shading_tail_fwd_kernel(
     const T6* __restrict__ x6, const uint16_t* __restrict__ w2s, const float* __restrict__ bias2, const float* __restrict__ w6,
     const float* __restrict__ bias6, const float* __restrict__ r1, float* __restrict__ y, float* __restrict__ ypre,
-    uint8_t* __restrict__ mask7, const int B, const int H2, const int W2, const int tiles_y, const int tiles_x) {
+    uint8_t* __restrict__ mask7, uint8_t* __restrict__ gate_y, const int B, const int H2, const int W2, const int tiles_y, const int tiles_x) {
+    // (`ypre` may be NULL and `gate_y` set: the clamp gate 0 < pre <= 1 of the three output channels as ONE byte per pixel -- what the
+    // backward head reads instead of the 16-byte pre-clamp pixel: 63 MB less written here and read there per batch-64 pass)
     // fp16 storage (configs[4]): X6's fp16 values and the weights ROUNDED TO fp16 -- `w2s` is then ONE [128][64] fp16 matrix, as the
     // `w_half` of every other layer of this mode -- on v_mfma_f32_16x16x32_f16: one MFMA per product and no operand split (the
     // bf16x6 form spent 48 MFMAs + 88 split instructions per wave and tile on operands that carry 11 bits)
@@ -327,7 +329,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES, sizeof(T6) == 2 ? 8 : 1) void shadi
                         outv[n] = fminf(t, 1.f);
                     }
                     *reinterpret_cast<f32x4*>(y + o * 4) = outv;
-                    *reinterpret_cast<f32x4*>(ypre + o * 4) = prev;
+                    if (ypre != nullptr) *reinterpret_cast<f32x4*>(ypre + o * 4) = prev;
+                    if (gate_y != nullptr)
+                        gate_y[o] = (uint8_t)((prev[0] > 0.f && prev[0] <= 1.f ? 1u : 0u) | (prev[1] > 0.f && prev[1] <= 1.f ? 2u : 0u) |
+                                              (prev[2] > 0.f && prev[2] <= 1.f ? 4u : 0u));
                 }
             }
             __syncthreads();   // the tile is free for the next one
@@ -380,7 +385,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES, sizeof(T6) == 2 ? 8 : 1) void shadi
                 outv[n] = fminf(t, 1.f);
             }
             *reinterpret_cast<f32x4*>(y + o * 4) = outv;
-            *reinterpret_cast<f32x4*>(ypre + o * 4) = prev;
+            if (ypre != nullptr) *reinterpret_cast<f32x4*>(ypre + o * 4) = prev;
+            if (gate_y != nullptr)
+                gate_y[o] = (uint8_t)((prev[0] > 0.f && prev[0] <= 1.f ? 1u : 0u) | (prev[1] > 0.f && prev[1] <= 1.f ? 2u : 0u) |
+                                      (prev[2] > 0.f && prev[2] <= 1.f ? 4u : 0u));
         }
         // (the next tile's phase 1 writes `tl` only; `rl` is rewritten after its barrier: no third barrier needed, since the
         // first-half waves read `rl` before they reach that barrier)
@@ -410,6 +418,7 @@ __global__ __launch_bounds__(1024, sizeof(T6) == 2 ? 8 : 1) void shading_head_bw
                                                                    const uint16_t* __restrict__ w2ts,
                                                                    const uint8_t* __restrict__ mask7,
                                                                    const uint8_t* __restrict__ mask6, T6* __restrict__ p6,
+                                                                   const uint8_t* __restrict__ gate_y,
                                                                    const int B, const int H2, const int W2, const int tiles_y,
                                                                    const int tiles_x) {
     constexpr bool H16 = sizeof(T6) == 2;   // fp16 storage: `w2ts` = ONE [64][128] fp16 matrix, P7 rounded to fp16 as the operand of
@@ -484,9 +493,15 @@ __global__ __launch_bounds__(1024, sizeof(T6) == 2 ? 8 : 1) void shading_head_bw
                     // spaa_select_grad folded in (projector_based_attack.py:302,310: the sample's cotangent is the classifier
                     // path's gradient `gp` or the stealth loss's `gcol`; models.py:301: backward of clamp(relu(.), max = 1))
                     v = *reinterpret_cast<const f32x4*>((state[4 * img + 1] != 0 ? gcol : gp) + o);
-                    const f32x4 y = *reinterpret_cast<const f32x4*>(ypre + o);
+                    if (gate_y != nullptr) {      // the clamp gate as the forward tail's byte (bit e: 0 < pre_e <= 1)
+                        const unsigned int gb = gate_y[o >> 2];
 #pragma unroll
-                    for (int e = 0; e < 3; ++e) v[e] = (y[e] > 0.f && y[e] <= 1.f) ? v[e] : 0.f;
+                        for (int e = 0; e < 3; ++e) v[e] = ((gb >> e) & 1u) ? v[e] : 0.f;
+                    } else {
+                        const f32x4 y = *reinterpret_cast<const f32x4*>(ypre + o);
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) v[e] = (y[e] > 0.f && y[e] <= 1.f) ? v[e] : 0.f;
+                    }
                     v[3] = 0.f;
                 } else {
                     v = *reinterpret_cast<const f32x4*>(gp + o);
@@ -614,8 +629,8 @@ __global__ __launch_bounds__(1024, sizeof(T6) == 2 ? 8 : 1) void shading_head_bw
 
 template <typename T6>
 static int launch_tail_fwd(const T6* x6, const uint16_t* w2_split, const float* bias2, const float* w6, const float* bias6,
-                           const float* res1, float* y, float* ypre, uint8_t* mask7, int B, int H2, int W2, spaa_stream_t stream_) {
-    if (!x6 || !w2_split || !bias2 || !w6 || !bias6 || !res1 || !y || !ypre || !mask7 || B <= 0 || H2 <= 0 || W2 <= 0)
+                           const float* res1, float* y, float* ypre, uint8_t* mask7, uint8_t* gate_y, int B, int H2, int W2, spaa_stream_t stream_) {
+    if (!x6 || !w2_split || !bias2 || !w6 || !bias6 || !res1 || !y || (!ypre && !gate_y) || !mask7 || B <= 0 || H2 <= 0 || W2 <= 0)
         return hipErrorInvalidValue;
     if ((int64_t)B * H2 * W2 * 4 * C7 * 4 >= (int64_t)1 << 40) return hipErrorInvalidValue;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -633,16 +648,16 @@ static int launch_tail_fwd(const T6* x6, const uint16_t* w2_split, const float* 
     const int64_t slots = (int64_t)(H16 ? 2 : 1) * ncu;      // (fp16 storage: two resident workgroups per compute unit)
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
     hipLaunchKernelGGL(shading_tail_fwd_kernel<T6>, dim3(grid), dim3(64 * FWD_WAVES), smem, stream, x6, w2_split, bias2, w6, bias6, res1,
-                       y, ypre, mask7, B, H2, W2, tiles_y, tiles_x);
+                       y, ypre, mask7, gate_y, B, H2, W2, tiles_y, tiles_x);
     return (int)hipGetLastError();
 }
 
 template <typename T6>
 static int launch_head_bwd(const float* gp, const float* gcol, const int32_t* state, const float* ypre, const float* w6t,
                            const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6,
-                           T6* p6, int B, int H2, int W2, spaa_stream_t stream_) {
+                           T6* p6, const uint8_t* gate_y, int B, int H2, int W2, spaa_stream_t stream_) {
     if (!gp || !w6t || !w2t_split || !mask7 || !mask6 || !p6 || B <= 0 || H2 <= 0 || W2 <= 0) return hipErrorInvalidValue;
-    if (state != nullptr && (!gcol || !ypre)) return hipErrorInvalidValue;
+    if (state != nullptr && (!gcol || (!ypre && !gate_y))) return hipErrorInvalidValue;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const int tiles_y = (H2 + RY - 1) / RY, tiles_x = (W2 + RX - 1) / RX;
     const int64_t ntiles = (int64_t)B * tiles_y * tiles_x;
@@ -657,7 +672,7 @@ static int launch_head_bwd(const float* gp, const float* gcol, const int32_t* st
     const int64_t slots = (int64_t)(H16 ? 2 : 1) * ncu;      // (fp16 storage: two resident workgroups per compute unit)
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
     hipLaunchKernelGGL(shading_head_bwd_kernel<T6>, dim3(grid), dim3(1024), smem, stream, gp, gcol, state, ypre, w6t, w2t_split, mask7, mask6, p6,
-                       B, H2, W2, tiles_y, tiles_x);
+                       gate_y, B, H2, W2, tiles_y, tiles_x);
     return (int)hipGetLastError();
 }
 
@@ -665,34 +680,62 @@ extern "C" {
 
 int spaa_shading_tail_fwd(const float* x6, const uint16_t* w2_split, const float* bias2, const float* w6, const float* bias6,
                           const float* res1, float* y, float* ypre, uint8_t* mask7, int B, int H2, int W2, spaa_stream_t stream) {
-    return launch_tail_fwd<float>(x6, w2_split, bias2, w6, bias6, res1, y, ypre, mask7, B, H2, W2, stream);
+    return launch_tail_fwd<float>(x6, w2_split, bias2, w6, bias6, res1, y, ypre, mask7, nullptr, B, H2, W2, stream);
 }
 int spaa_shading_tail_fwd_f16(const void* x6, const void* w2_half, const float* bias2, const void* w6_half, const float* bias6,
                               const float* res1, float* y, float* ypre, uint8_t* mask7, int B, int H2, int W2, spaa_stream_t stream) {
     return launch_tail_fwd<_Float16>(reinterpret_cast<const _Float16*>(x6), reinterpret_cast<const uint16_t*>(w2_half), bias2,
-                                     reinterpret_cast<const float*>(w6_half), bias6, res1, y, ypre, mask7, B, H2, W2, stream);
+                                     reinterpret_cast<const float*>(w6_half), bias6, res1, y, ypre, mask7, nullptr, B, H2, W2, stream);
 }
 int spaa_shading_head_bwd(const float* gp, const float* w6t, const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6,
                           float* p6, int B, int H2, int W2, spaa_stream_t stream) {
-    return launch_head_bwd<float>(gp, nullptr, nullptr, nullptr, w6t, w2t_split, mask7, mask6, p6, B, H2, W2, stream);
+    return launch_head_bwd<float>(gp, nullptr, nullptr, nullptr, w6t, w2t_split, mask7, mask6, p6, nullptr, B, H2, W2, stream);
 }
 int spaa_shading_head_bwd_select(const float* g_adv, const float* g_col, const int32_t* state, const float* ypre, const float* w6t,
                                  const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6, float* p6, int B, int H2, int W2,
                                  spaa_stream_t stream) {
     if (!state) return hipErrorInvalidValue;
-    return launch_head_bwd<float>(g_adv, g_col, state, ypre, w6t, w2t_split, mask7, mask6, p6, B, H2, W2, stream);
+    return launch_head_bwd<float>(g_adv, g_col, state, ypre, w6t, w2t_split, mask7, mask6, p6, nullptr, B, H2, W2, stream);
 }
 int spaa_shading_head_bwd_select_f16(const float* g_adv, const float* g_col, const int32_t* state, const float* ypre, const float* w6t,
                                      const void* w2t_half, const uint8_t* mask7, const uint8_t* mask6, void* p6, int B, int H2, int W2,
                                      spaa_stream_t stream) {
     if (!state) return hipErrorInvalidValue;
     return launch_head_bwd<_Float16>(g_adv, g_col, state, ypre, w6t, reinterpret_cast<const uint16_t*>(w2t_half), mask7, mask6,
-                                     reinterpret_cast<_Float16*>(p6), B, H2, W2, stream);
+                                     reinterpret_cast<_Float16*>(p6), nullptr, B, H2, W2, stream);
 }
 int spaa_shading_head_bwd_f16(const float* gp, const float* w6t, const void* w2t_half, const uint8_t* mask7, const uint8_t* mask6,
                               void* p6, int B, int H2, int W2, spaa_stream_t stream) {
     return launch_head_bwd<_Float16>(gp, nullptr, nullptr, nullptr, w6t, reinterpret_cast<const uint16_t*>(w2t_half), mask7, mask6,
-                                     reinterpret_cast<_Float16*>(p6), B, H2, W2, stream);
+                                     reinterpret_cast<_Float16*>(p6), nullptr, B, H2, W2, stream);
+}
+
+// round 6: the clamp gate of the network output as ONE byte per pixel (`gate_y` [B,2 H2,2 W2], bit e = 0 < pre_e <= 1) instead of the
+// 16-byte pre-clamp pixel: the tail writes it (ypre may then be NULL), the select head reads it (ypre is then ignored)
+int spaa_shading_tail_fwd_g(const float* x6, const uint16_t* w2_split, const float* bias2, const float* w6, const float* bias6,
+                            const float* res1, float* y, float* ypre, uint8_t* mask7, uint8_t* gate_y, int B, int H2, int W2, spaa_stream_t stream) {
+    if (!gate_y) return hipErrorInvalidValue;
+    return launch_tail_fwd<float>(x6, w2_split, bias2, w6, bias6, res1, y, ypre, mask7, gate_y, B, H2, W2, stream);
+}
+int spaa_shading_tail_fwd_f16_g(const void* x6, const void* w2_half, const float* bias2, const void* w6_half, const float* bias6,
+                                const float* res1, float* y, float* ypre, uint8_t* mask7, uint8_t* gate_y, int B, int H2, int W2,
+                                spaa_stream_t stream) {
+    if (!gate_y) return hipErrorInvalidValue;
+    return launch_tail_fwd<_Float16>(reinterpret_cast<const _Float16*>(x6), reinterpret_cast<const uint16_t*>(w2_half), bias2,
+                                     reinterpret_cast<const float*>(w6_half), bias6, res1, y, ypre, mask7, gate_y, B, H2, W2, stream);
+}
+int spaa_shading_head_bwd_select_g(const float* g_adv, const float* g_col, const int32_t* state, const uint8_t* gate_y, const float* w6t,
+                                   const uint16_t* w2t_split, const uint8_t* mask7, const uint8_t* mask6, float* p6, int B, int H2, int W2,
+                                   spaa_stream_t stream) {
+    if (!state || !gate_y) return hipErrorInvalidValue;
+    return launch_head_bwd<float>(g_adv, g_col, state, nullptr, w6t, w2t_split, mask7, mask6, p6, gate_y, B, H2, W2, stream);
+}
+int spaa_shading_head_bwd_select_f16_g(const float* g_adv, const float* g_col, const int32_t* state, const uint8_t* gate_y, const float* w6t,
+                                       const void* w2t_half, const uint8_t* mask7, const uint8_t* mask6, void* p6, int B, int H2, int W2,
+                                       spaa_stream_t stream) {
+    if (!state || !gate_y) return hipErrorInvalidValue;
+    return launch_head_bwd<_Float16>(g_adv, g_col, state, nullptr, w6t, reinterpret_cast<const uint16_t*>(w2t_half), mask7, mask6,
+                                     reinterpret_cast<_Float16*>(p6), gate_y, B, H2, W2, stream);
 }
 
 }  // extern "C"

@@ -266,6 +266,7 @@ def to_nchw(x4, clamp01=False):
 
 TILED_WARP_BWD = os.environ.get('SPAA_TILED_WARP_BWD', '1') != '0'   # LDS-staged grid_sample adjoint (0: the untiled gather)
 TAP_TABLE_FWD = os.environ.get('SPAA_TAP_TABLE_FWD', '1') != '0'     # grid_sample forward from the per-attack tap table, 32 x 8 tiles (0: the grid kernel)
+GATE_BYTE_Y = os.environ.get('SPAA_GATE_BYTE_Y', '1') != '0'         # fused tail / head: the output's clamp gate as one byte per pixel, no pre-clamp tensor in HBM (0: Ypre written and read)
 FUSE_C1BWD = os.environ.get('SPAA_FUSE_C1BWD', '1') != '0'           # fp16 storage: the input gradients of conv1 / conv1_s as one launch (0: two thin-output launches)
 FUSE_SUMSQ = os.environ.get('SPAA_FUSE_SUMSQ', '1') != '0'           # spaa_grad_sumsq as the epilogue of the tiled grid_sample adjoint (0: its own launch)
 
@@ -361,6 +362,8 @@ class _Activations(dict):
     def __getitem__(self, k):
         if k == 'X7':
             self._eng._materialize_x7()
+        elif k == 'Ypre':
+            self._eng._materialize_ypre()
         return dict.__getitem__(self, k)
 
 
@@ -516,6 +519,10 @@ class PCNetEngine:
         # training step (weight gradients read X7 and P7) switches it off
         self.fuse_tail = FUSE_TAIL and (USE_GATE_MASKS or storage == 'f16') and H % 2 == 0 and W % 2 == 0
         self._x7_version = -1    # `version` for which a['X7'] holds the activation
+        # the output's clamp gate (0 < pre <= 1 per channel) as one byte per pixel: written by the fused tail, read by the fused select head;
+        # the pre-clamp tensor a['Ypre'] is then produced on demand only (whoever asks gets it from the same kernel: _materialize_ypre)
+        self.gate_y = torch.zeros(B, H, W, dtype=torch.uint8, device=dev) if (self.fuse_tail and GATE_BYTE_Y) else None
+        self._ypre_version = -1  # `version` for which a['Ypre'] holds the pre-clamp output
         wt, w6 = sn.transConv2.weight.detach().float().cpu(), sn.conv6.weight.detach().float().cpu()
         assert wt.shape == (64, 32, 2, 2) and w6.shape == (3, 32, 3, 3)
         self.tail = dict(
@@ -605,15 +612,39 @@ class PCNetEngine:
         if self.fuse_tail:
             t = self.tail
             f16 = self.storage == 'f16'   # (X6 and both layers' weights fp16, fp32 accumulation; X7 in LDS as the fp16 a separate launch would store)
-            _lib.call('spaa_shading_tail_fwd_f16' if f16 else 'spaa_shading_tail_fwd', _lib.hptr(a['X6']) if f16 else _lib.ptr(a['X6']),
-                      _lib.hptr(t['w2h']) if f16 else _lib.ptr(t['w2s']), _lib.ptr(t['b2']), _lib.hptr(t['w6h']) if f16 else _lib.ptr(t['w6']), _lib.ptr(t['b6']), _lib.ptr(a['R1']), _lib.ptr(a['Y']),
-                      _lib.ptr(a['Ypre']), _lib.ptr(m['X7']), self.B, self.Hc // 2, self.Wc // 2)
+            self._tail(dict.__getitem__(a, 'Y'), None if self.gate_y is not None else dict.__getitem__(a, 'Ypre'), m['X7'], self.gate_y)
+            if self.gate_y is None:
+                self._ypre_version = self.version
             return a['Y']
         x7 = dict.__getitem__(a, 'X7')
         f['transConv2'].run(a['X6'], x7, act=R, mask_out=m['X7'])
-        f['conv6'].run(x7, a['Y'], add=a['R1'], act=_lib.ACT_RELU_CLAMP1, aux_out=a['Ypre'])
-        self._x7_version = self.version
+        f['conv6'].run(x7, a['Y'], add=a['R1'], act=_lib.ACT_RELU_CLAMP1, aux_out=dict.__getitem__(a, 'Ypre'))
+        self._x7_version = self._ypre_version = self.version
         return a['Y']
+
+    def _tail(self, y, ypre, mask7, gate_y):
+        """The fused tail launch (csrc/shading_tail.hip) from a['X6'] into the given outputs; `ypre` or `gate_y` may be None."""
+        a, t = self.a, self.tail
+        f16 = self.storage == 'f16'   # (X6 and both layers' weights fp16, fp32 accumulation; X7 in LDS as the fp16 a separate launch would store)
+        args = [_lib.hptr(a['X6']) if f16 else _lib.ptr(a['X6']), _lib.hptr(t['w2h']) if f16 else _lib.ptr(t['w2s']), _lib.ptr(t['b2']),
+                _lib.hptr(t['w6h']) if f16 else _lib.ptr(t['w6']), _lib.ptr(t['b6']), _lib.ptr(a['R1']), _lib.ptr(y),
+                _lib.ptr(ypre) if ypre is not None else None, _lib.ptr(mask7)]
+        if gate_y is not None:
+            _lib.call('spaa_shading_tail_fwd_f16_g' if f16 else 'spaa_shading_tail_fwd_g', *args, _lib.ptr(gate_y), self.B, self.Hc // 2, self.Wc // 2)
+        else:
+            _lib.call('spaa_shading_tail_fwd_f16' if f16 else 'spaa_shading_tail_fwd', *args, self.B, self.Hc // 2, self.Wc // 2)
+
+    def _materialize_ypre(self):
+        """With the gate byte the pre-clamp output never reaches HBM in the loop; whoever asks for a['Ypre'] (parity tests, the unfused
+        select path, the autograd route) gets it from the SAME fused kernel run once more on the same X6 (deterministic: bitwise the values
+        the gate byte was formed from), into scratch outputs."""
+        if self.gate_y is None or self._ypre_version == self.version or self.scene is None:
+            return
+        if getattr(self, '_ypre_scratch', None) is None:
+            self._ypre_scratch = (torch.zeros_like(dict.__getitem__(self.a, 'Y')), torch.zeros_like(self.m['X7']), torch.zeros_like(self.gate_y))
+        ys, ms, gs = self._ypre_scratch
+        self._tail(ys, dict.__getitem__(self.a, 'Ypre'), ms, gs)
+        self._ypre_version = self.version
 
     def can_select(self):
         """True when `backward(None, select=...)` is served: the fused head kernel takes the per-sample choice between the two
@@ -645,9 +676,14 @@ class PCNetEngine:
                 _lib.check_dev(ga, gc)
                 assert ga.shape == gc.shape == (self.B, self.Hc, self.Wc, 4)
                 assert state.shape == (self.B, 4) and state.dtype == torch.int32 and state.is_contiguous() and state.device == ga.device
-                _lib.call('spaa_shading_head_bwd_select' if self.storage == 'f32' else 'spaa_shading_head_bwd_select_f16', _lib.ptr(ga),
-                          _lib.ptr(gc), _lib.ptr(state), _lib.ptr(self.a['Ypre']), _lib.ptr(t['w6t']), w2t,
-                          _lib.ptr(m['X7']), _lib.ptr(m['X6']), p6, self.B, self.Hc // 2, self.Wc // 2)
+                if self.gate_y is not None:   # (the clamp gate as the tail's byte per pixel)
+                    _lib.call('spaa_shading_head_bwd_select_g' if self.storage == 'f32' else 'spaa_shading_head_bwd_select_f16_g', _lib.ptr(ga),
+                              _lib.ptr(gc), _lib.ptr(state), _lib.ptr(self.gate_y), _lib.ptr(t['w6t']), w2t,
+                              _lib.ptr(m['X7']), _lib.ptr(m['X6']), p6, self.B, self.Hc // 2, self.Wc // 2)
+                else:
+                    _lib.call('spaa_shading_head_bwd_select' if self.storage == 'f32' else 'spaa_shading_head_bwd_select_f16', _lib.ptr(ga),
+                              _lib.ptr(gc), _lib.ptr(state), _lib.ptr(self.a['Ypre']), _lib.ptr(t['w6t']), w2t,
+                              _lib.ptr(m['X7']), _lib.ptr(m['X6']), p6, self.B, self.Hc // 2, self.Wc // 2)
             else:
                 _lib.check_dev(gP)
                 assert gP.shape == (self.B, self.Hc, self.Wc, 4) and gP.dtype == torch.float32
@@ -714,6 +750,10 @@ class PCNetEngine:
         """Recompute the gate masks from the activation buffers (after a test has overwritten the activations)."""
         for k, mk in self.m.items():
             mk.copy_(_lib.pack_gate_mask(self.a[k].float()))
+        if self.gate_y is not None:   # (... and the output's clamp gate from the pre-clamp tensor a test has materialised / overwritten)
+            yp = self.a['Ypre'][..., :3]
+            ok = (yp > 0) & (yp <= 1)
+            self.gate_y.copy_((ok[..., 0].to(torch.uint8) | (ok[..., 1].to(torch.uint8) << 1) | (ok[..., 2].to(torch.uint8) << 2)))
 
     def _materialize_x7(self):
         """With the fused tail X7 lives in LDS only; whoever asks for a['X7'] (parity tests, tools) gets it recomputed from X6
