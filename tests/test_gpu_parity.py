@@ -2593,6 +2593,12 @@ def test_fused_shading_tail_and_head(hip, cam_sz, b, storage):
     eng.set_scene(scene)
     y_f = eng.forward(x).clone()
     ypre_f, m7_f = eng.a['Ypre'].clone(), eng.m['X7'].clone()
+    # round 6: in the loop the tail writes the output's clamp gate as ONE byte per pixel and no pre-clamp tensor; a['Ypre'] above came
+    # from the same kernel run once more (bitwise the values the byte was formed from): byte == (0 < Ypre <= 1) per channel, Y == clamp
+    assert eng.gate_y is not None
+    ok3 = (ypre_f[..., :3] > 0) & (ypre_f[..., :3] <= 1)
+    assert torch.equal(eng.gate_y, ok3[..., 0].to(torch.uint8) | (ok3[..., 1].to(torch.uint8) << 1) | (ok3[..., 2].to(torch.uint8) << 2))
+    assert torch.equal(y_f[..., :3], ypre_f[..., :3].clamp(max=1.0)) and torch.equal(eng.m['X7'], m7_f)
     x6 = eng.a['X6'].clone()
     gP = torch.randn(b, cam_sz[0], cam_sz[1], 4, device=DEV)
     gP[..., 3] = 0
