@@ -210,6 +210,22 @@ int spaa_linear_small(const float* x, const float* w, const float* bias, float* 
 int spaa_conv1_pair_fwd(const float* xw, const float* s, const float* w_pair, const float* bias1, const float* bias_s,
                         void* S1, void* X1, uint8_t* mask_S1, uint8_t* mask_X1, int B, int H, int W, int out_f16,
                         spaa_stream_t stream);
+/* fp16-storage mode, round 6: a FRACTIONAL-STRIDE 3 x 3 layer -- nn.ConvTranspose2d(Cin, Cout, 3, 2, 1, 1) forward (models.py:237,299
+ * transConv1) or aten::convolution_backward(input) of nn.Conv2d(Cout, Cin, 3, 2, 1) (conv2, conv2_s: models.py:224,230 under autograd) --
+ * written per INPUT pixel: exactly the nine real (output-parity class, tap) products, all weights resident in LDS, one persistent
+ * workgroup per compute unit, no barrier after the prologue (csrc/fs2_h16.hip).  in: fp16 [B,Hi,Wi,in_cstride] (channels [0,Cin), Cin % 32
+ * == 0); out: fp16 [B,2 Hi,2 Wi,Cout], Cout = 32 or 64.  w_img: the weights as the kernel's matrix operands, [Cin/32][9 pairs][Cout/16][64
+ * lanes][8] fp16 (spaa_amd/models.py: pack_fs2 -- pair p = (operand in[y + r][x + q], class (cy, cx)) in the order (0,0) (0,1) (0,2) (0,3)
+ * (1,1) (1,3) (2,2) (2,3) (3,3) of (2 r + q, 2 cy + cx); lane = (row n & 15, chunk g): element e = W[ky][kx][16 rb + (lane & 15)][32 ks +
+ * 8 g + e] with ky = (cy == 0 ? 1 : r == 0 ? 2 : 0), kx likewise).  Optional second source at OUTPUT resolution (a 1 x 1 convolution added
+ * before the epilogue: models.py:293,299 `+ skipConv2(x1)` and its mirror image in the backward pass): in2 fp16 [B,2 Hi,2 Wi,in2_cstride],
+ * w2_img [Cin2/32][Cout/16][64][8].  Epilogue: + bias [Cout] (fp32, may be NULL), + add (fp16 [B,2 Hi,2 Wi,Cout], may be NULL), ReLU if
+ * `relu`, gate_bits (byte masks of the output's shape: out = bit ? v : 0; may be NULL), fp16 store, mask_out = gate bytes of the stored
+ * values (may be NULL).  LDS: (9 Cin/32 + Cin2/32) x Cout/16 KB <= 160 KB. */
+int spaa_fs2_h16(const void* in, int in_cstride, int Cin, const void* w_img, const void* in2, int in2_cstride, int Cin2,
+                 const void* w2_img, const float* bias, const void* add, const uint8_t* gate_bits, int relu, void* out,
+                 uint8_t* mask_out, int Cout, int B, int Hi, int Wi, spaa_stream_t stream);
+
 /* the ADJOINT of the pair in fp16-storage mode (round 6): g_xw = conv1^T(g_x1) + scene * conv1_s^T(g_s1)[rough channels 3..5]
  * (models.py:284-285,295,342 under autograd: aten::convolution_backward(input) of both layers, the product with the surface image and the
  * sum), ONE launch instead of two thin-output launches with a round trip between them.  g_x1 / g_s1: fp16 [B,H/2,W/2,32] (already

@@ -267,6 +267,7 @@ def to_nchw(x4, clamp01=False):
 TILED_WARP_BWD = os.environ.get('SPAA_TILED_WARP_BWD', '1') != '0'   # LDS-staged grid_sample adjoint (0: the untiled gather)
 TAP_TABLE_FWD = os.environ.get('SPAA_TAP_TABLE_FWD', '1') != '0'     # grid_sample forward from the per-attack tap table, 32 x 8 tiles (0: the grid kernel)
 GATE_BYTE_Y = os.environ.get('SPAA_GATE_BYTE_Y', '1') != '0'         # fused tail / head: the output's clamp gate as one byte per pixel, no pre-clamp tensor in HBM (0: Ypre written and read)
+FS2_H16 = os.environ.get('SPAA_FS2_H16', '1') != '0'                 # fp16 storage: the fractional-stride 3 x 3 layers on csrc/fs2_h16.hip (0: the patch-staged kernel's folded form)
 FUSE_C1BWD = os.environ.get('SPAA_FUSE_C1BWD', '1') != '0'           # fp16 storage: the input gradients of conv1 / conv1_s as one launch (0: two thin-output launches)
 FUSE_SUMSQ = os.environ.get('SPAA_FUSE_SUMSQ', '1') != '0'           # spaa_grad_sumsq as the epilogue of the tiled grid_sample adjoint (0: its own launch)
 
@@ -329,6 +330,38 @@ def tiled_taps(tap_off, tap_order, tap_wm, prj_size, cam_size):
     w_e = tap_wm[order].contiguous()
     tbox = torch.stack([y0, x0, torch.where(direct, -1, ch), cw], 1).to(torch.int32).contiguous()
     return lidx, w_e, tbox, max(cap, 1)
+
+
+FS2_PAIRS = ((0, 0), (0, 1), (0, 2), (0, 3), (1, 1), (1, 3), (2, 2), (2, 3), (3, 3))   # (operand 2 r + q, class 2 cy + cx): csrc/fs2_h16.hip
+
+
+def _fs2_lanes(wt):
+    """[N, K] matrix -> MFMA A operands [K / 32][N / 16][64 lanes][8]: lane = (row & 15, 8-value chunk g), element e = W[chan(row)][32 ks + 8 g + e].
+    MFMA row 16 rb + 4 gr + er carries output channel 32 (rb >> 1) + 8 gr + 4 (rb & 1) + er: a lane of the kernel (which holds rows 4 g ..
+    4 g + 3 of every row block) then owns eight consecutive channels per pair of row blocks -- 16-byte stores (csrc/fs2_h16.hip)."""
+    n, k = wt.shape
+    r = torch.arange(n)
+    rb, gr, er = r // 16, (r % 16) // 4, r % 4
+    chan = 32 * (rb // 2) + 8 * gr + 4 * (rb % 2) + er
+    wp = wt[chan]                                                          # row r of the GEMM = channel chan[r]
+    v = wp.reshape(n // 16, 16, k // 32, 4, 8).permute(2, 0, 3, 1, 4)      # [ks][rb][g][row][e]
+    return v.reshape(k // 32, n // 16, 64, 8)
+
+
+def pack_fs2(w_eff, w2=None):
+    """Weight images of spaa_fs2_h16 (include/spaa_hip.h).  `w_eff` [3, 3, N, K]: the layer as out[2 y' - 1 + ky] += W[ky][kx][n][k] in[y'][k]
+    -- ConvTranspose2d(K, N, 3, 2, 1, 1): weight.permute(2, 3, 1, 0); input gradient of Conv2d(N, K, 3, 2, 1): weight.permute(2, 3, 1, 0) too.
+    Returns (w_img fp16 [K/32][9][N/16][64][8], w2_img fp16 [K2/32][N/16][64][8] or None)."""
+    w_eff = w_eff.detach().float().cpu()
+    imgs = []
+    for rq, cl in FS2_PAIRS:
+        r, q, cy, cx = rq >> 1, rq & 1, cl >> 1, cl & 1
+        ky = 1 if cy == 0 else (2 if r == 0 else 0)
+        kx = 1 if cx == 0 else (2 if q == 0 else 0)
+        imgs.append(_fs2_lanes(w_eff[ky, kx]))
+    w_img = torch.stack(imgs, 1).half().contiguous()                          # [ks][9][rb][64][8]
+    w2_img = _fs2_lanes(w2.detach().float().cpu()).half().contiguous() if w2 is not None else None
+    return w_img, w2_img
 
 
 def pack_pair1_bwd(w_conv1, w_conv1_s):
@@ -450,6 +483,18 @@ class PCNetEngine:
                 if FUSE_SKIP2 & 2:
                     d['conv2x'] = c2
                 self.fuse_skip2 = True
+        # round 6, fp16 storage: the three fractional-stride layers (transConv1 + skipConv2, conv2^T + skipConv2^T, conv2_s^T) on the
+        # persistent per-input-pixel kernel: exactly the nine real (class, tap) products, all weights resident in LDS (csrc/fs2_h16.hip)
+        self.fs2 = None
+        if (FS2_H16 and storage == 'f16' and self.fuse_skip2 and 'transConv1x' in f and 'conv2x' in d and self.rough
+                and tuple(sn.transConv1.weight.shape) == (128, 64, 3, 3) and tuple(sn.conv2.weight.shape) == (64, 32, 3, 3)
+                and tuple(sn.conv2_s.weight.shape) == (64, 32, 3, 3) and tuple(sn.skipConv2.weight.shape) == (64, 32, 1, 1)):
+            sk = sn.skipConv2.weight.detach()[:, :, 0, 0]
+            t_img, t_img2 = pack_fs2(sn.transConv1.weight.permute(2, 3, 1, 0), sk)
+            c_img, c_img2 = pack_fs2(sn.conv2.weight.permute(2, 3, 1, 0), sk.t())
+            s_img, _ = pack_fs2(sn.conv2_s.weight.permute(2, 3, 1, 0))
+            self.fs2 = dict(tc=(t_img.to(dev), t_img2.to(dev), (sn.transConv1.bias.detach().float() + sn.skipConv2.bias.detach().float()).contiguous().to(dev)),
+                            c2=(c_img.to(dev), c_img2.to(dev)), c2s=(s_img.to(dev),))
         # likewise `conv5(x4) + skipConv3(x2)` (models.py:294,298) and `conv3^T(g3) + skipConv3^T(g5)`: one Winograd launch each over
         # the concatenated input channels, read from two tensors (cp.conv_fwd_plan_2src)
         self.fuse_skip3 = False
@@ -605,7 +650,11 @@ class PCNetEngine:
             f['conv5x'].run(a['X4'], a['X5'], inp2=a['X2'], act=R, mask_out=m['X5'])
         else:
             f['conv5'].run(a['X4'], a['X5'], add=a['R3'], act=R, mask_out=m['X5'])
-        if self.fuse_skip2 and 'transConv1x' in f:
+        if self.fs2 is not None:
+            w1, w2, bsum = self.fs2['tc']
+            _lib.call('spaa_fs2_h16', _lib.hptr(a['X5']), 128, 128, _lib.hptr(w1), _lib.hptr(a['X1']), 32, 32, _lib.hptr(w2), _lib.ptr(bsum), None,
+                      None, 1, _lib.hptr(a['X6']), _lib.ptr(m['X6']), 64, self.B, self.Hc // 4, self.Wc // 4)
+        elif self.fuse_skip2 and 'transConv1x' in f:
             f['transConv1x'].run(a['X5'], a['X6'], inp2=a['X1'], act=R, mask_out=m['X6'])
         else:
             f['transConv1'].run(a['X5'], a['X6'], add=a['R2'], act=R, mask_out=m['X6'])
@@ -703,7 +752,11 @@ class PCNetEngine:
         else:
             d['skipConv3'].run(g['P5'], g['t2'])
             d['conv3'].run(g['P3'], g['P2'], add=g['t2'], gate_bits=m['X2'])
-        if self.fuse_skip2 and 'conv2x' in d:
+        if self.fs2 is not None:
+            w1, w2 = self.fs2['c2']
+            _lib.call('spaa_fs2_h16', _lib.hptr(g['P2']), 64, 64, _lib.hptr(w1), _lib.hptr(g['P6']), 64, 64, _lib.hptr(w2), None, None,
+                      _lib.ptr(m['X1']), 0, _lib.hptr(g['P1']), None, 32, self.B, self.Hc // 4, self.Wc // 4)
+        elif self.fuse_skip2 and 'conv2x' in d:
             d['conv2x'].run(g['P2'], g['P1'], inp2=g['P6'], gate_bits=m['X1'])
         else:
             d['skipConv2'].run(g['P6'], g['t1'])
@@ -714,7 +767,11 @@ class PCNetEngine:
         # surface branch (depends on x through the rough input x*s)
         d['conv4_s'].run(g['S4'], g['S3'], add=g['P3'], gate_bits=m['S3'])
         d['conv3_s'].run(g['S3'], g['S2'], add=g['P2'], gate_bits=m['S2'])
-        d['conv2_s'].run(g['S2'], g['S1'], add=g['P1'], gate_bits=m['S1'])
+        if self.fs2 is not None:
+            _lib.call('spaa_fs2_h16', _lib.hptr(g['S2']), 64, 64, _lib.hptr(self.fs2['c2s'][0]), None, 0, 0, None, None, _lib.hptr(g['P1']),
+                      _lib.ptr(m['S1']), 0, _lib.hptr(g['S1']), None, 32, self.B, self.Hc // 4, self.Wc // 4)
+        else:
+            d['conv2_s'].run(g['S2'], g['S1'], add=g['P1'], gate_bits=m['S1'])
         # the two 3-channel gradients meet at the warped image: d/d(x_w) = g_direct + g_rough * s (models.py:342); the
         # product and the sum are epilogues of the two thin convolutions instead of extra reads in the gather
         if self.pair1_bwd is not None:

@@ -2477,7 +2477,9 @@ def test_fused_skipconv2_fp16_storage(hip, cam_sz, prj_sz, b):
         x5, x1 = e.a['X5'].clone(), e.a['X1'].clone()
         gx = e.backward(g).clone()
         outs.append((y, gx, e.a['X6'].float().clone(), e.g['P1'].float().clone(), x5, x1, e.g['P2'].clone(), e.g['P6'].clone()))
-    assert e1.f['transConv1x'].last_tile == 68 and e1.d['conv2x'].last_tile == 68
+    # (round 6: the fused pair runs on csrc/fs2_h16.hip -- per input pixel, the nine real (class, tap) products -- instead of the patch-staged
+    # kernel's folded form; SPAA_FS2_H16=0 restores that)
+    assert e1.fs2 is not None or (e1.f['transConv1x'].last_tile == 68 and e1.d['conv2x'].last_tile == 68)
     # (and `conv5(x4) + skipConv3(x2)` / `conv3^T + skipConv3^T` as two-source launches of the same kernel: K-concatenated channels)
     assert e1.fuse_skip3 and not e0.fuse_skip3 and e1.f['conv5x'].last_tile == 68 and e1.d['conv3x'].last_tile == 68
     (y1, gx1, x61, p11, x51, x11, p21, p61), (y0, gx0, x60, p10, x50, x10, p20, p60) = outs
@@ -2699,6 +2701,60 @@ def test_h16p_canvas_and_k_ranges(hip):
                 assert rel_inf(nchw(gin.float().cpu(), ci), wantg) < 1.5e-3, (ci, co, cv)
     finally:
         cp.H16P_CV = old
+
+
+@pytest.mark.parametrize('kind,ci,co,ci2,h,w,b', [('deconv', 128, 64, 32, 16, 16, 2), ('deconv', 64, 32, 0, 9, 37, 3), ('dgrad', 64, 32, 64, 12, 20, 2),
+                                                  ('dgrad', 64, 32, 0, 16, 33, 2), ('dgrad', 128, 64, 0, 7, 5, 5), ('deconv', 32, 64, 64, 10, 48, 2)])
+def test_fs2_h16_fractional_stride_layers(hip, kind, ci, co, ci2, h, w, b):
+    """csrc/fs2_h16.hip (round 6, fp16 storage): ConvTranspose2d(k3, s2, p1, op1) forward and the input gradient of Conv2d(k3, s2, p1) per INPUT
+    pixel -- the nine real (class, tap) products, weights resident in LDS -- with the optional 1 x 1 second source at output resolution,
+    against float64 on the same fp16 operands: plain; bias + ReLU + byte mask out (transConv1 + skipConv2, models.py:293,299); residual + byte-mask
+    gate (conv2_s^T); ragged sizes (rows / columns that are not multiples of the 32-pixel segments); bitwise run to run."""
+    M, lib = hip['models'], hip['lib']
+    torch.manual_seed(ci + co + h + ci2)
+    x = _h(torch.randn(b, ci, h, w))
+    if kind == 'deconv':
+        wt = _h(torch.randn(ci, co, 3, 3) / (ci * 2.25) ** 0.5)
+        ref = F.conv_transpose2d(x.double(), wt.double(), None, 2, 1, 1)
+        w_eff = wt.permute(2, 3, 1, 0)
+    else:   # input gradient of Conv2d(co -> ci, k3, s2, p1): x plays the output gradient
+        wc = _h(torch.randn(ci, co, 3, 3) / (ci * 2.25) ** 0.5)
+        ref = F.conv_transpose2d(x.double(), wc.double(), None, 2, 1, 1)      # (the adjoint of the strided convolution)
+        w_eff = wc.permute(2, 3, 1, 0)
+    x2 = w2 = None
+    if ci2:
+        x2 = _h(torch.randn(b, ci2, 2 * h, 2 * w))
+        w2 = _h(torch.randn(co, ci2) / ci2 ** 0.5)
+        ref = ref + torch.einsum('bkyx,nk->bnyx', x2.double(), w2.double())
+    w_img, w2_img = M.pack_fs2(w_eff, w2)
+    w_img, w2_img = w_img.to(DEV), (w2_img.to(DEV) if w2_img is not None else None)
+    xin = nhwc(x).half().to(DEV)
+    x2in = nhwc(x2).half().to(DEV) if ci2 else None
+    bias = torch.randn(co)
+    add = _h(torch.randn(b, co, 2 * h, 2 * w))
+    gate = torch.randn(b, co, 2 * h, 2 * w)
+
+    def run(bias_=None, add_=None, gate_=None, relu=0, mask=None):
+        out = torch.full((b, 2 * h, 2 * w, co), 7.0, device=DEV, dtype=torch.float16)
+        lib.call('spaa_fs2_h16', lib.hptr(xin), ci, ci, lib.hptr(w_img), lib.hptr(x2in) if ci2 else None, ci2, ci2,
+                 lib.hptr(w2_img) if ci2 else None, lib.ptr(bias_) if bias_ is not None else None, lib.hptr(add_) if add_ is not None else None,
+                 lib.ptr(gate_) if gate_ is not None else None, relu, lib.hptr(out), lib.ptr(mask) if mask is not None else None, co, b, h, w)
+        return out
+
+    out = run()
+    e0 = rel_inf(nchw(out.float().cpu(), co), ref)
+    assert e0 < 1.5e-3, (kind, ci, co, e0)
+    assert torch.equal(out, run())
+    mask = torch.zeros(b, 2 * h, 2 * w, co // 4, dtype=torch.uint8, device=DEV)
+    out1 = run(bias_=bias.to(DEV), relu=1, mask=mask)
+    want1 = F.relu(ref + bias.view(1, -1, 1, 1).double())
+    assert rel_inf(nchw(out1.float().cpu(), co), want1) < 1.5e-3 and torch.equal(mask, lib.pack_gate_mask(out1.float()))
+    gbits = lib.pack_gate_mask(nhwc(gate).to(DEV))
+    out2 = run(add_=nhwc(add).half().to(DEV), gate_=gbits)
+    want2 = (ref + add.double()) * (gate > 0)
+    e2 = rel_inf(nchw(out2.float().cpu(), co), want2)
+    assert e2 < 1.5e-3, (kind, e2)
+    print(f'fs2_h16 {kind} {ci}->{co} (+{ci2}) {h}x{w} B={b}: rel err vs fp64 {e0:.1e} plain, {e2:.1e} residual + gate')
 
 
 def test_h16p_two_workgroups_per_cu(hip):
