@@ -331,7 +331,7 @@ PCNET_LAYERS = ('conv1', 'conv2', 'conv3', 'conv4', 'conv5', 'conv1_s', 'conv2_s
                 'skipConv3', 'transConv1', 'transConv2')
 # (round 6: spaa_warp_fwd_taps = grid_sample from the tap table; spaa_warp_bwd_tiled_sumsq = its adjoint WITH spaa_grad_sumsq in the
 # epilogue -- counted in full although the ||g||^2 part is the attack step's, not PCNet's)
-PCNET_ENTRY_POINTS = ('spaa_conv1_pair_fwd', 'spaa_conv1_pair_bwd_f16', 'spaa_fs2_h16', 'spaa_warp_fwd', 'spaa_warp_fwd_taps', 'spaa_warp_bwd_gather', 'spaa_warp_bwd_tiled', 'spaa_warp_bwd_tiled_sumsq',
+PCNET_ENTRY_POINTS = ('spaa_conv1_pair_fwd', 'spaa_conv1_pair_bwd_f16', 'spaa_fs2_h16', 'spaa_s2f_h16', 'spaa_warp_fwd', 'spaa_warp_fwd_taps', 'spaa_warp_bwd_gather', 'spaa_warp_bwd_tiled', 'spaa_warp_bwd_tiled_sumsq',
                       'spaa_shading_tail_fwd', 'spaa_shading_tail_fwd_f16', 'spaa_shading_tail_fwd_g', 'spaa_shading_tail_fwd_f16_g',
                       'spaa_shading_head_bwd_select', 'spaa_shading_head_bwd_select_f16', 'spaa_shading_head_bwd_select_g', 'spaa_shading_head_bwd_select_f16_g',
                       'spaa_shading_head_bwd', 'spaa_shading_head_bwd_f16', 'spaa_stealth_loss_fwd_bwd')

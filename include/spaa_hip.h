@@ -226,6 +226,15 @@ int spaa_fs2_h16(const void* in, int in_cstride, int Cin, const void* w_img, con
                  const void* w2_img, const float* bias, const void* add, const uint8_t* gate_bits, int relu, void* out,
                  uint8_t* mask_out, int Cout, int B, int Hi, int Wi, spaa_stream_t stream);
 
+/* fp16-storage mode, round 6: the FORWARD form of a 3 x 3 / stride-2 / padding-1 convolution -- nn.Conv2d(Cin, Cout, 3, 2, 1) (models.py:224,230
+ * conv2 / conv2_s) or aten::convolution_backward(input) of nn.ConvTranspose2d(Cout, Cin, 3, 2, 1, 1) (transConv1, models.py:237 under autograd)
+ * -- as a persistent, barrier-free kernel with all weights resident in LDS (csrc/s2f_h16.hip).  in: fp16 [B,Hi,Wi,in_cstride] (Hi, Wi even,
+ * channels [0,Cin), Cin % 32 == 0); out: fp16 [B,Hi/2,Wi/2,Cout], Cout = 64 or 128.  w_img: [Cin/32][9 taps 3 ky + kx][Cout/16][64 lanes][8]
+ * fp16 (spaa_amd/models.py: pack_s2f; rows permuted as for spaa_fs2_h16).  Epilogue as spaa_fs2_h16: bias, add, ReLU, gate_bits, mask_out.
+ * LDS: 9 Cin/32 x Cout/16 KB <= 160 KB; every tensor below 2 GiB (32-bit buffer offsets). */
+int spaa_s2f_h16(const void* in, int in_cstride, int Cin, const void* w_img, const float* bias, const void* add, const uint8_t* gate_bits,
+                 int relu, void* out, uint8_t* mask_out, int Cout, int B, int Hi, int Wi, spaa_stream_t stream);
+
 /* the ADJOINT of the pair in fp16-storage mode (round 6): g_xw = conv1^T(g_x1) + scene * conv1_s^T(g_s1)[rough channels 3..5]
  * (models.py:284-285,295,342 under autograd: aten::convolution_backward(input) of both layers, the product with the surface image and the
  * sum), ONE launch instead of two thin-output launches with a round trip between them.  g_x1 / g_s1: fp16 [B,H/2,W/2,32] (already

@@ -60,6 +60,7 @@ _SIGNATURES = {
     'spaa_linear_small': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'spaa_conv1_pair_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'spaa_conv1_pair_bwd_f16': [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    'spaa_s2f_h16': [_p, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p],
     'spaa_fs2_h16': [_p, _i, _i, _p, _p, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p],
     'spaa_warp_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'spaa_warp_taps': [_p, _i, _i, _i, _i, _p, _p, _p],

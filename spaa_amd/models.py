@@ -267,6 +267,7 @@ def to_nchw(x4, clamp01=False):
 TILED_WARP_BWD = os.environ.get('SPAA_TILED_WARP_BWD', '1') != '0'   # LDS-staged grid_sample adjoint (0: the untiled gather)
 TAP_TABLE_FWD = os.environ.get('SPAA_TAP_TABLE_FWD', '1') != '0'     # grid_sample forward from the per-attack tap table, 32 x 8 tiles (0: the grid kernel)
 GATE_BYTE_Y = os.environ.get('SPAA_GATE_BYTE_Y', '1') != '0'         # fused tail / head: the output's clamp gate as one byte per pixel, no pre-clamp tensor in HBM (0: Ypre written and read)
+S2F_H16 = os.environ.get('SPAA_S2F_H16', '1') != '0'                 # fp16 storage: the stride-2 forward forms on csrc/s2f_h16.hip (0: the patch-staged kernel's stride-2 form)
 FS2_H16 = os.environ.get('SPAA_FS2_H16', '1') != '0'                 # fp16 storage: the fractional-stride 3 x 3 layers on csrc/fs2_h16.hip (0: the patch-staged kernel's folded form)
 FUSE_C1BWD = os.environ.get('SPAA_FUSE_C1BWD', '1') != '0'           # fp16 storage: the input gradients of conv1 / conv1_s as one launch (0: two thin-output launches)
 FUSE_SUMSQ = os.environ.get('SPAA_FUSE_SUMSQ', '1') != '0'           # spaa_grad_sumsq as the epilogue of the tiled grid_sample adjoint (0: its own launch)
@@ -362,6 +363,14 @@ def pack_fs2(w_eff, w2=None):
     w_img = torch.stack(imgs, 1).half().contiguous()                          # [ks][9][rb][64][8]
     w2_img = _fs2_lanes(w2.detach().float().cpu()).half().contiguous() if w2 is not None else None
     return w_img, w2_img
+
+
+def pack_s2f(w_eff):
+    """Weight image of spaa_s2f_h16 (include/spaa_hip.h).  `w_eff` [3, 3, N, K]: out[y][n] = sum W[ky][kx][n][k] in[2 y - 1 + ky][2 x - 1 + kx][k]
+    -- Conv2d(K, N, 3, 2, 1): weight.permute(2, 3, 0, 1); input gradient of ConvTranspose2d(N, K, 3, 2, 1, 1): weight.permute(2, 3, 0, 1) too.
+    Returns fp16 [K/32][9][N/16][64][8]."""
+    w_eff = w_eff.detach().float().cpu()
+    return torch.stack([_fs2_lanes(w_eff[t // 3, t % 3]) for t in range(9)], 1).half().contiguous()
 
 
 def pack_pair1_bwd(w_conv1, w_conv1_s):
@@ -495,6 +504,11 @@ class PCNetEngine:
             s_img, _ = pack_fs2(sn.conv2_s.weight.permute(2, 3, 1, 0))
             self.fs2 = dict(tc=(t_img.to(dev), t_img2.to(dev), (sn.transConv1.bias.detach().float() + sn.skipConv2.bias.detach().float()).contiguous().to(dev)),
                             c2=(c_img.to(dev), c_img2.to(dev)), c2s=(s_img.to(dev),))
+            # ... and the three stride-2 FORWARD forms (conv2, conv2_s, transConv1's input gradient) on its sibling (csrc/s2f_h16.hip)
+            if S2F_H16 and self.Hc % 4 == 0 and self.Wc % 4 == 0:
+                self.fs2.update(f2=(pack_s2f(sn.conv2.weight.permute(2, 3, 0, 1)).to(dev), sn.conv2.bias.detach().float().contiguous().to(dev)),
+                                f2s=(pack_s2f(sn.conv2_s.weight.permute(2, 3, 0, 1)).to(dev), sn.conv2_s.bias.detach().float().contiguous().to(dev)),
+                                tcd=(pack_s2f(sn.transConv1.weight.permute(2, 3, 0, 1)).to(dev),))
         # likewise `conv5(x4) + skipConv3(x2)` (models.py:294,298) and `conv3^T(g3) + skipConv3^T(g5)`: one Winograd launch each over
         # the concatenated input channels, read from two tensors (cp.conv_fwd_plan_2src)
         self.fuse_skip3 = False
@@ -601,7 +615,12 @@ class PCNetEngine:
         m = self.m if (USE_GATE_MASKS or self.storage == 'f16') else {k: None for k in self.m}
         if inp is not None:   # (None: S1 already written by the fused conv1 pair)
             f['conv1_s'].run(inp, a['S1'], act=R, mask_out=m['S1'])
-        f['conv2_s'].run(a['S1'], a['S2'], act=R, mask_out=m['S2'])
+        if self.fs2 is not None and 'f2s' in self.fs2:
+            w, bb = self.fs2['f2s']
+            _lib.call('spaa_s2f_h16', _lib.hptr(a['S1']), 32, 32, _lib.hptr(w), _lib.ptr(bb), None, None, 1, _lib.hptr(a['S2']), _lib.ptr(m['S2']), 64,
+                      self.B, self.Hc // 2, self.Wc // 2)
+        else:
+            f['conv2_s'].run(a['S1'], a['S2'], act=R, mask_out=m['S2'])
         f['conv3_s'].run(a['S2'], a['S3'], act=R, mask_out=m['S3'])
         f['conv4_s'].run(a['S3'], a['S4'], act=R, mask_out=m['S4'])
 
@@ -641,7 +660,12 @@ class PCNetEngine:
             f['conv1'].run(a['xw'], a['X1'], add=a['S1'], act=R, mask_out=m['X1'])
         if not (self.fuse_skip2 and 'transConv1x' in f):
             f['skipConv2'].run(a['X1'], a['R2'], act=N)
-        f['conv2'].run(a['X1'], a['X2'], add=a['S2'], act=R, mask_out=m['X2'])
+        if self.fs2 is not None and 'f2' in self.fs2:
+            w, bb = self.fs2['f2']
+            _lib.call('spaa_s2f_h16', _lib.hptr(a['X1']), 32, 32, _lib.hptr(w), _lib.ptr(bb), _lib.hptr(a['S2']), None, 1, _lib.hptr(a['X2']),
+                      _lib.ptr(m['X2']), 64, self.B, self.Hc // 2, self.Wc // 2)
+        else:
+            f['conv2'].run(a['X1'], a['X2'], add=a['S2'], act=R, mask_out=m['X2'])
         if not self.fuse_skip3:
             f['skipConv3'].run(a['X2'], a['R3'], act=N)
         f['conv3'].run(a['X2'], a['X3'], add=a['S3'], act=R, mask_out=m['X3'])
@@ -741,7 +765,11 @@ class PCNetEngine:
         else:
             d['conv6'].run(gP, g['P7'], gate_bits=m['X7'])
             d['transConv2'].run(g['P7'], g['P6'], gate_bits=m['X6'])
-        d['transConv1'].run(g['P6'], g['P5'], gate_bits=m['X5'])
+        if self.fs2 is not None and 'tcd' in self.fs2:
+            _lib.call('spaa_s2f_h16', _lib.hptr(g['P6']), 64, 64, _lib.hptr(self.fs2['tcd'][0]), None, None, _lib.ptr(m['X5']), 0, _lib.hptr(g['P5']), None,
+                      128, self.B, self.Hc // 2, self.Wc // 2)
+        else:
+            d['transConv1'].run(g['P6'], g['P5'], gate_bits=m['X5'])
         if self.rough:
             d['conv5'].run(g['P5'], g['P4'], gate_bits=m['X4'], aux_out=g['S4'], gate2_bits=m['S4'])
         else:

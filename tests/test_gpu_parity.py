@@ -2757,6 +2757,47 @@ def test_fs2_h16_fractional_stride_layers(hip, kind, ci, co, ci2, h, w, b):
     print(f'fs2_h16 {kind} {ci}->{co} (+{ci2}) {h}x{w} B={b}: rel err vs fp64 {e0:.1e} plain, {e2:.1e} residual + gate')
 
 
+@pytest.mark.parametrize('ci,co,h,w,b', [(32, 64, 32, 32, 2), (64, 128, 20, 36, 2), (32, 64, 18, 70, 3), (64, 64, 8, 6, 5), (128, 64, 12, 12, 2)])
+def test_s2f_h16_stride2_forward(hip, ci, co, h, w, b):
+    """csrc/s2f_h16.hip (round 6, fp16 storage): Conv2d(k3, s2, p1) forward -- conv2 / conv2_s, the input gradient of transConv1 -- with all weights
+    resident in LDS, against float64 on the same fp16 operands: plain; bias + residual + ReLU + byte mask out; byte-mask gate; ragged widths
+    (rows that are not multiples of the 32-pixel segments), the zero padding on all four sides; bitwise run to run."""
+    M, lib = hip['models'], hip['lib']
+    torch.manual_seed(ci + co + h)
+    x = _h(torch.randn(b, ci, h, w))
+    wt = _h(torch.randn(co, ci, 3, 3) / (ci * 9) ** 0.5)
+    ref = F.conv2d(x.double(), wt.double(), None, 2, 1)
+    w_img = M.pack_s2f(wt.permute(2, 3, 0, 1)).to(DEV)
+    xin = nhwc(x).half().to(DEV)
+    ho, wo = h // 2, w // 2
+    bias = torch.randn(co)
+    add = _h(torch.randn(b, co, ho, wo))
+    gate = torch.randn(b, co, ho, wo)
+
+    def run(bias_=None, add_=None, gate_=None, relu=0, mask=None):
+        out = torch.full((b, ho, wo, co), 7.0, device=DEV, dtype=torch.float16)
+        lib.call('spaa_s2f_h16', lib.hptr(xin), ci, ci, lib.hptr(w_img), lib.ptr(bias_) if bias_ is not None else None,
+                 lib.hptr(add_) if add_ is not None else None, lib.ptr(gate_) if gate_ is not None else None, relu, lib.hptr(out),
+                 lib.ptr(mask) if mask is not None else None, co, b, h, w)
+        return out
+
+    out = run()
+    e0 = rel_inf(nchw(out.float().cpu(), co), ref)
+    assert e0 < 1.5e-3, (ci, co, e0)
+    assert torch.equal(out, run())
+    mask = torch.zeros(b, ho, wo, co // 4, dtype=torch.uint8, device=DEV)
+    out1 = run(bias_=bias.to(DEV), add_=nhwc(add).half().to(DEV), relu=1, mask=mask)
+    want1 = F.relu(ref + bias.view(1, -1, 1, 1).double() + add.double())
+    e1 = rel_inf(nchw(out1.float().cpu(), co), want1)
+    assert e1 < 1.5e-3 and torch.equal(mask, lib.pack_gate_mask(out1.float())), (ci, co, e1)
+    out2 = run(gate_=lib.pack_gate_mask(nhwc(gate).to(DEV)))
+    assert rel_inf(nchw(out2.float().cpu(), co), ref * (gate > 0)) < 1.5e-3
+    print(f's2f_h16 {ci}->{co} {h}x{w} B={b}: rel err vs fp64 {e0:.1e} plain, {e1:.1e} bias + residual + ReLU')
+    if ci == 128:     # a weight image that does not fit the 160 KB of LDS is refused, not truncated
+        with pytest.raises(RuntimeError):
+            lib.call('spaa_s2f_h16', lib.hptr(xin), ci, ci, lib.hptr(w_img), None, None, None, 0, lib.hptr(out), None, 128, b, h, w)
+
+
 def test_h16p_two_workgroups_per_cu(hip):
     """The patch-staged fp16 kernel's 64-wide stride-1 form with TWO workgroups per compute unit (csrc/tapconv_h16p.hip LEAN: one patch
     buffer reloaded per channel block, weight stages packed to 12 KiB, pad DMA slots into the patch buffer's pad piece -- VGG-16

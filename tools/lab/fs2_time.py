@@ -47,3 +47,24 @@ for name, ci, co, ci2, relu, use_bias, use_add, use_gate, use_mask in (('transCo
     gf = 2 * B * H * W * (9 * ci * co + 4 * ci2 * co) / 1e9
     mb = (x.numel() + (x2.numel() if ci2 else 0) + out.numel() + (add.numel() if use_add else 0)) * 2 / 1e6
     print(f'{name:24s} {us:7.1f} us  {gf / us * 1e-3:7.1f} TF  {mb / us * 1e-6 * 1e6 / 1e6:6.2f} TB/s ({mb:.0f} MB)', flush=True)
+
+
+print('--- csrc/s2f_h16.hip: stride-2 forward forms')
+for name, ci, co, hi, use_add, use_gate, use_mask, relu in (('conv2 (+res2_s, ReLU, mask)', 32, 64, 128, 1, 0, 1, 1), ('conv2_s (ReLU, mask)', 32, 64, 128, 0, 0, 1, 1),
+                                                            ('transConv1^T (gate)', 64, 128, 128, 0, 1, 0, 0), ('32->64 plain', 32, 64, 128, 0, 0, 0, 0),
+                                                            ('64->128 plain', 64, 128, 128, 0, 0, 0, 0)):
+    w_img = M.pack_s2f(torch.randn(3, 3, co, ci) / (ci * 9) ** 0.5).to(DEV)
+    x = torch.randn(B, hi, hi, ci, device=DEV).half()
+    ho = hi // 2
+    out = torch.zeros(B, ho, ho, co, device=DEV, dtype=torch.float16)
+    bias = torch.randn(co, device=DEV)
+    add = torch.randn(B, ho, ho, co, device=DEV).half() if use_add else None
+    gate = torch.randint(0, 16, (B, ho, ho, co // 4), device=DEV, dtype=torch.uint8) if use_gate else None
+    mask = torch.zeros(B, ho, ho, co // 4, device=DEV, dtype=torch.uint8) if use_mask else None
+
+    def run():
+        _lib.call('spaa_s2f_h16', _lib.hptr(x), ci, ci, _lib.hptr(w_img), _lib.ptr(bias), _lib.hptr(add) if use_add else None,
+                  _lib.ptr(gate) if use_gate else None, relu, _lib.hptr(out), _lib.ptr(mask) if use_mask else None, co, B, hi, hi)
+    us = timeit(run)
+    mb = (x.numel() + out.numel() + (add.numel() if use_add else 0)) * 2 / 1e6
+    print(f'{name:28s} {us:7.1f} us  ({mb:.0f} MB)', flush=True)
