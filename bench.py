@@ -309,6 +309,8 @@ def instrumented_pass(st, args, n_prof=3):
         # (a Winograd launch executes 16 of the 36 products of a 3 x 3 tap set: its ceiling for ALGORITHMIC FLOPs is 36/16 of the
         # direct bf16x6 kernels' -- each layer is priced against the ceiling of the kernel that runs it, the saving is credited once)
         peak_x6 = PEAK_BF16_MFMA_TFLOPS / 6.0 * (WINO_ALGORITHMIC_GAIN if base.startswith('wino') else 1.0)
+        if args.dtype == 'f16s':   # (fp16 storage: every convolution launch is one fp16 MFMA per product -- the dense 16-bit peak;
+            peak_x6 = PEAK_BF16_MFMA_TFLOPS   # rounds 3-6 priced these launches at the bf16x6 ceiling: step.frac > 1 on the f16s line)
         t_roof_x6 += max(t_hbm, flops / (peak_x6 * 1e12)) / n_prof
         t_roof_f32 += max(t_hbm, flops / (PEAK_F32_MFMA_TFLOPS * 1e12)) / n_prof
     # second pass: the non-convolution entry points
@@ -331,7 +333,7 @@ PCNET_LAYERS = ('conv1', 'conv2', 'conv3', 'conv4', 'conv5', 'conv1_s', 'conv2_s
                 'skipConv3', 'transConv1', 'transConv2')
 # (round 6: spaa_warp_fwd_taps = grid_sample from the tap table; spaa_warp_bwd_tiled_sumsq = its adjoint WITH spaa_grad_sumsq in the
 # epilogue -- counted in full although the ||g||^2 part is the attack step's, not PCNet's)
-PCNET_ENTRY_POINTS = ('spaa_conv1_pair_fwd', 'spaa_conv1_pair_bwd_f16', 'spaa_fs2_h16', 'spaa_s2f_h16', 'spaa_warp_fwd', 'spaa_warp_fwd_taps', 'spaa_warp_bwd_gather', 'spaa_warp_bwd_tiled', 'spaa_warp_bwd_tiled_sumsq',
+PCNET_ENTRY_POINTS = ('spaa_conv1_pair_fwd', 'spaa_conv1_pair_bwd_f16', 'spaa_fs2_h16', 'spaa_s2f_h16', 'spaa_s2f_x6', 'spaa_warp_fwd', 'spaa_warp_fwd_taps', 'spaa_warp_bwd_gather', 'spaa_warp_bwd_tiled', 'spaa_warp_bwd_tiled_sumsq',
                       'spaa_shading_tail_fwd', 'spaa_shading_tail_fwd_f16', 'spaa_shading_tail_fwd_g', 'spaa_shading_tail_fwd_f16_g',
                       'spaa_shading_head_bwd_select', 'spaa_shading_head_bwd_select_f16', 'spaa_shading_head_bwd_select_g', 'spaa_shading_head_bwd_select_f16_g',
                       'spaa_shading_head_bwd', 'spaa_shading_head_bwd_f16', 'spaa_stealth_loss_fwd_bwd')
@@ -633,8 +635,9 @@ def main():
                          'ms_per_step': round(ms_step, 3),
                          'frac': round((t_roof_x6 * 1e3 + other_roof) / ms_step, 4),
                          'note': 'T_roof = sum over launches of max(algorithmic bytes / 8 TB/s, FLOP / peak) (SURVEY 8d); '
-                                 'conv peak 419.3 TF (direct bf16x6 launches), 943.5 TF (Winograd bf16x6 launches: 36/16 of it) '
-                                 'resp. 157.3 TF (fp32 MFMA)'}}
+                                 + ('conv peak 2516 TF (fp16 storage: one fp16 MFMA per product)' if args.dtype == 'f16s' else
+                                    'conv peak 419.3 TF (direct bf16x6 launches), 943.5 TF (Winograd bf16x6 launches: 36/16 of it)')
+                                 + ' resp. 157.3 TF (fp32 MFMA)'}}
         table = {k: {'tile': v[3], 'gflop_per_launch': v[0] / v[2] / 1e9, 'us_per_launch': v[1] * 1e3 / v[2],
                      'tflops': v[0] / (v[1] * 1e-3) / 1e12, 'algorithmic_tb_s': v[4] / (v[1] * 1e-3) / 1e12}
                  for k, v in per_layer.items()}

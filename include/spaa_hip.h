@@ -235,6 +235,15 @@ int spaa_fs2_h16(const void* in, int in_cstride, int Cin, const void* w_img, con
 int spaa_s2f_h16(const void* in, int in_cstride, int Cin, const void* w_img, const float* bias, const void* add, const uint8_t* gate_bits,
                  int relu, void* out, uint8_t* mask_out, int Cout, int B, int Hi, int Wi, spaa_stream_t stream);
 
+/* fp32 mode, round 6: nn.Conv2d(Cin, 64, 3, 2, 1) forward (models.py:224,230 conv2 / conv2_s) on the same persistent weights-in-LDS form
+ * with the bf16x6 arithmetic of the other fp32 kernels (exact fp32 operands split into three bf16 planes, six of the nine partial products,
+ * fp32 accumulation; csrc/s2f_x6.hip).  in: fp32 [B,Hi,Wi,in_cstride] (Hi, Wi even, channels [0,Cin), Cin % 32 == 0); out: fp32
+ * [B,Hi/2,Wi/2,64].  w_img: [Cin/32][9 taps 3 ky + kx][3 planes][4][64 lanes][8] bf16 (spaa_amd/models.py: pack_s2f_x6).  Epilogue: bias,
+ * add (fp32, the output's shape), ReLU, gate_bits, mask_out (1 byte per 4 channels), any of them NULL.  LDS: 108 Cin/32 KB <= 160 KB (Cin =
+ * 32); every tensor below 2 GiB. */
+int spaa_s2f_x6(const float* in, int in_cstride, int Cin, const void* w_img, const float* bias, const float* add, const uint8_t* gate_bits,
+                int relu, float* out, uint8_t* mask_out, int Cout, int B, int Hi, int Wi, spaa_stream_t stream);
+
 /* the ADJOINT of the pair in fp16-storage mode (round 6): g_xw = conv1^T(g_x1) + scene * conv1_s^T(g_s1)[rough channels 3..5]
  * (models.py:284-285,295,342 under autograd: aten::convolution_backward(input) of both layers, the product with the surface image and the
  * sum), ONE launch instead of two thin-output launches with a round trip between them.  g_x1 / g_s1: fp16 [B,H/2,W/2,32] (already
@@ -272,10 +281,13 @@ int spaa_warp_bwd_tiled(const float* g_xw, const float* x, const int32_t* off, c
 /* ... with spaa_grad_sumsq folded into its epilogue (round 6: one launch and one pass over g_x less per iteration): g_x additionally takes
  * the prjl2 term's gradient for colour-step samples (prjl2_scale != 0: `state`, `gray` as spaa_grad_sumsq), and partial_ss
  * [B][ceil(Wp/16) * ceil(Hp/16)] receives the per-(image, 16 x 16 tile) sums of ||g_x||^2 in a fixed order -- consumed by
- * spaa_step_and_track_n with npartial = that tile count */
+ * spaa_step_and_track_n with npartial = that tile count.  clamp_bits (may be NULL) [B][Hp*Wp]: the clamp gate's comparisons as written by
+ * spaa_step_and_track_n for THIS x (bit c: channel c inside [0, 1]): the gate then reads 1 byte per pixel instead of x's 16 (x is still
+ * read when prjl2_scale != 0); the caller answers for the bytes describing the x the forward pass read */
 int spaa_warp_bwd_tiled_sumsq(const float* g_xw, const float* x, const int32_t* off, const int32_t* lidx, const float* w_e,
                               const int32_t* tbox, int box_cap, float* g_x, int B, int Hp, int Wp, int Hc, int Wc, int clamp01,
-                              float gray, float prjl2_scale, const int32_t* state, float* partial_ss, spaa_stream_t stream);
+                              float gray, float prjl2_scale, const int32_t* state, float* partial_ss, const uint8_t* clamp_bits,
+                              spaa_stream_t stream);
 /* F.grid_sample forward (models.py:184,340) from the per-attack TAP TABLE of spaa_warp_taps instead of the grid: tap_src [Hc*Wc][4]
  * projector pixel of every bilinear tap (0x7fffffff: outside, weight 0), tap_wgt [Hc*Wc][4] its weight x mask -- the table the
  * deterministic backward pass is built from, so the pair is an exact adjoint.  A workgroup owns a 32 x 8 tile of camera pixels and four
@@ -488,10 +500,12 @@ int spaa_grad_sumsq(float* g, const float* x, float gray, float prjl2_scale, con
 int spaa_step_and_track(float* x, const float* g, const float* partial, const int32_t* state, float adv_lr,
                         float col_lr, float* x_best, const float* cam, float* cam_best, int B, int HWp, int HWc,
                         spaa_stream_t stream);
-/* the same with the number of partial sums per sample stated (partial [B][npartial]: spaa_warp_bwd_tiled_sumsq's tile sums) */
+/* the same with the number of partial sums per sample stated (partial [B][npartial]: spaa_warp_bwd_tiled_sumsq's tile sums);
+ * clamp_bits (may be NULL) [B][HWp]: receives, per pixel of the UPDATED x, bit c = (0 <= x_c <= 1) -- the clamp gate of the next
+ * iteration's backward pass (models.py:337 `x.clamp(0, 1)` under autograd) */
 int spaa_step_and_track_n(float* x, const float* g, const float* partial, int npartial, const int32_t* state, float adv_lr,
                           float col_lr, float* x_best, const float* cam, float* cam_best, int B, int HWp, int HWc,
-                          spaa_stream_t stream);
+                          uint8_t* clamp_bits, spaa_stream_t stream);
 
 /* ---- PerC_AL.adversary_projector (perc_al/__init__.py:133-256) ------------------------------------------ */
 /* x = a + b (inputs + delta), NHWC4 */

@@ -61,12 +61,13 @@ _SIGNATURES = {
     'spaa_conv1_pair_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'spaa_conv1_pair_bwd_f16': [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     'spaa_s2f_h16': [_p, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p],
+    'spaa_s2f_x6': [_p, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p],
     'spaa_fs2_h16': [_p, _i, _i, _p, _p, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p],
     'spaa_warp_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'spaa_warp_taps': [_p, _i, _i, _i, _i, _p, _p, _p],
     'spaa_warp_bwd_gather': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'spaa_warp_bwd_tiled': [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
-    'spaa_warp_bwd_tiled_sumsq': [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _f, _p, _p, _p],
+    'spaa_warp_bwd_tiled_sumsq': [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _f, _p, _p, _p, _p],
     'spaa_warp_fwd_taps': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'spaa_warp_bwd_grid': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'spaa_warp_finish_grid_bwd': [_p, _p, _p, _p, _p, _i, _p],
@@ -122,7 +123,7 @@ _SIGNATURES = {
     'spaa_prjl2_fwd': [_p, _f, _p, _i, _i, _p],
     'spaa_grad_sumsq': [_p, _p, _f, _f, _p, _p, _i, _i, _p],
     'spaa_step_and_track': [_p, _p, _p, _p, _f, _f, _p, _p, _p, _i, _i, _i, _p],
-    'spaa_step_and_track_n': [_p, _p, _p, _i, _p, _f, _f, _p, _p, _p, _i, _i, _i, _p],
+    'spaa_step_and_track_n': [_p, _p, _p, _i, _p, _f, _f, _p, _p, _p, _i, _i, _i, _p, _p],
     'spaa_zero': [_p, _l, _p],
 }
 

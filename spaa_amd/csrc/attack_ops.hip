@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(float4* __restrict__ g,
 __global__ __launch_bounds__(256) void step_kernel(float4* __restrict__ x, const float4* __restrict__ g,
                                                    const float* __restrict__ partial, int nblk,
                                                    const int32_t* __restrict__ state, float adv_lr, float col_lr,
-                                                   float4* __restrict__ x_best, int HW) {
+                                                   float4* __restrict__ x_best, int HW, uint8_t* __restrict__ clamp_bits) {
     __shared__ float red[4];
     const int b = blockIdx.y;
     float a = 0.f;
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void step_kernel(float4* __restrict__ x, const
     const float lr = (state[4 * b + 1] != 0) ? col_lr : adv_lr;
     const bool succ = state[4 * b] != 0;
     const int pix = blockIdx.x * 256 + threadIdx.x;
+    unsigned int bits = 0;
     if (pix < HW) {
         const size_t idx = (size_t)b * HW + pix;
         float4 xv = x[idx];
@@ -212,6 +213,19 @@ __global__ __launch_bounds__(256) void step_kernel(float4* __restrict__ x, const
         xv.z -= lr * (gv.z / nrm);
         x[idx] = xv;
         if (succ) x_best[idx] = xv;
+        bits = (xv.x >= 0.f && xv.x <= 1.f ? 1u : 0u) | (xv.y >= 0.f && xv.y <= 1.f ? 2u : 0u) | (xv.z >= 0.f && xv.z <= 1.f ? 4u : 0u);
+    }
+    // the clamp gate of the NEXT iteration's backward pass (x.clamp(0, 1), projector_based_attack.py:265 -> models.py:337): one byte per
+    // pixel, bit c = channel c inside [0, 1] -- the grid_sample adjoint then reads 1 byte per pixel instead of x's 16.  Four lanes' bytes
+    // leave as one 4-byte store where the image's rows allow it (HW % 4 == 0: every group of four pixels lies in one image, aligned).
+    if (clamp_bits != nullptr) {
+        if ((HW & 3) == 0) {
+            unsigned int w = bits | (__shfl_down(bits, 1, 64) << 8);
+            w |= __shfl_down(w, 2, 64) << 16;
+            if ((threadIdx.x & 3) == 0 && pix < HW) *reinterpret_cast<unsigned int*>(clamp_bits + (size_t)b * HW + pix) = w;
+        } else if (pix < HW) {
+            clamp_bits[(size_t)b * HW + pix] = (uint8_t)bits;
+        }
     }
 }
 
@@ -266,18 +280,18 @@ int spaa_grad_sumsq(float* g, const float* x, float gray, float prjl2_scale, con
 int spaa_step_and_track(float* x, const float* g, const float* partial, const int32_t* state, float adv_lr,
                         float col_lr, float* x_best, const float* cam, float* cam_best, int B, int HWp, int HWc,
                         spaa_stream_t stream) {
-    return spaa_step_and_track_n(x, g, partial, (HWp + 255) / 256, state, adv_lr, col_lr, x_best, cam, cam_best, B, HWp, HWc, stream);
+    return spaa_step_and_track_n(x, g, partial, (HWp + 255) / 256, state, adv_lr, col_lr, x_best, cam, cam_best, B, HWp, HWc, nullptr, stream);
 }
 
 int spaa_step_and_track_n(float* x, const float* g, const float* partial, int npartial, const int32_t* state, float adv_lr,
                           float col_lr, float* x_best, const float* cam, float* cam_best, int B, int HWp, int HWc,
-                          spaa_stream_t stream) {
+                          uint8_t* clamp_bits, spaa_stream_t stream) {
     if (!x || !g || !partial || !state || !x_best || !cam || !cam_best || B < 1 || HWp < 1 || HWc < 1 || npartial < 1)
         return hipErrorInvalidValue;
     const int nblk = (HWp + 255) / 256;
     dim3 grid(nblk, B);
     hipLaunchKernelGGL(step_kernel, grid, dim3(256), 0, (hipStream_t)stream, (float4*)x, (const float4*)g, partial,
-                       npartial, state, adv_lr, col_lr, (float4*)x_best, HWp);
+                       npartial, state, adv_lr, col_lr, (float4*)x_best, HWp, clamp_bits);
     hipLaunchKernelGGL(track_cam_kernel, dim3((int)(((int64_t)B * HWc + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)cam, (float4*)cam_best, state, B, HWc);
     return (int)hipGetLastError();

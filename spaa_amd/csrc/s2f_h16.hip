@@ -10,7 +10,7 @@
 //     fp16], rows permuted so that a lane ends with eight consecutive channels per pair of row blocks); no barrier after the prologue;
 //   * a wave owns 32 consecutive output pixels of a row (two groups of 16: every weight operand read feeds two MFMAs) and walks tasks
 //     (image, row, 32-pixel segment) on its own; its pixel operands are 16-byte-per-lane buffer loads of every second input pixel
-//     (a pixel that does not exist = the out-of-range offset = the zero padding), tap t + 1 requested before the products of tap t;
+//     (a pixel that does not exist = the out-of-range offset = the zero padding), tap t + 2 requested before the products of tap t;
 //   * epilogue from the accumulators: bias, residual, ReLU, byte-mask gate, 16-byte stores, 2-byte gate stores.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -92,9 +92,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void s2f_h16_kernel(const
             const bool ok = x < Wo && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
             return ok ? ((b * p.Hi + iy) * p.Wi + ix) * pxb + 16 * g : OOB;
         };
-        // two operand buffers (tap t in I[t & 1]): the operand of the NEXT tap -- of the next K step's first tap after the ninth -- is
-        // requested before the products of the current one; past the last step: nothing (out-of-range offset).  No branch depends on it.
-        h8 I[2][2];
+        // THREE operand buffers (tap t in I[t % 3]): the operand of tap t + 2 -- of the next K step's first taps after the eighth -- is
+        // requested before the products of tap t (nine taps per trip: the buffer index is a compile-time constant and no branch sits
+        // between the loads and their waits); past the last step: nothing (out-of-range offset).
+        h8 I[3][2];
         auto fetch = [&](const int buf, const int tap, const int ks) {
             const bool live = ks < p.ks1;      // (uniform)
 #pragma unroll
@@ -104,23 +105,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void s2f_h16_kernel(const
             }
         };
         fetch(0, 0, 0);
+        fetch(1, 1, 0);
 #pragma unroll 1
-        for (int ks = 0; ks < p.ks1; ks += 2) {
-            // (two K steps per trip: 18 taps, so that the buffer index t & 1 is a compile-time constant and no branch sits between the
-            // loads and their waits; the padded half of an odd K-step count multiplies the zeros of the out-of-range offset with the
-            // last real step's weights: adds nothing)
+        for (int ks = 0; ks < p.ks1; ++ks) {
 #pragma unroll
-            for (int u = 0; u < 18; ++u) {
-                const int kk = ks + u / 9, tap = u % 9;
-                const int nu = u + 1, nkk = ks + nu / 9, ntap = nu % 9;
-                fetch((u + 1) & 1, ntap, nkk);
-                const int kw = kk < p.ks1 ? kk : p.ks1 - 1;
-                const unsigned char* wk = wl + (kw * 9 + tap) * (NRB * 1024);
+            for (int u = 0; u < 9; ++u) {
+                const int nu = u + 2;
+                fetch(nu % 3, nu % 9, ks + nu / 9);
+                __builtin_amdgcn_sched_barrier(0);      // (the requests stay ahead of the products: two taps of latency cover)
+                const unsigned char* wk = wl + (ks * 9 + u) * (NRB * 1024);
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
                     const h8 A = *reinterpret_cast<const h8*>(wk + rb * 1024);
-                    acc[0][rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, I[u & 1][0], acc[0][rb], 0, 0, 0);
-                    acc[1][rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, I[u & 1][1], acc[1][rb], 0, 0, 0);
+                    acc[0][rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, I[u % 3][0], acc[0][rb], 0, 0, 0);
+                    acc[1][rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, I[u % 3][1], acc[1][rb], 0, 0, 0);
                 }
             }
         }

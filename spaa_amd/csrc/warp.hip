@@ -310,7 +310,8 @@ __global__ __launch_bounds__(256) void warp_bwd_tiled_kernel(const float4* __res
                                                              const float* __restrict__ w_e, const int32_t* __restrict__ tbox,
                                                              float4* __restrict__ g_x, int B, int Hp, int Wp, int Hc, int Wc,
                                                              int ntx, int box_cap, int clamp, float* __restrict__ partial_ss,
-                                                             const int32_t* __restrict__ state, float gray, float prjl2_scale) {
+                                                             const int32_t* __restrict__ state, float gray, float prjl2_scale,
+                                                             const uint8_t* __restrict__ clamp_bits) {
     extern __shared__ __attribute__((aligned(16))) float4 box[];   // [WB][box_cap]
     const int tile = blockIdx.x, b0 = blockIdx.y * WB;
     const int ty = tile / ntx, tx = tile - ty * ntx;
@@ -328,9 +329,16 @@ __global__ __launch_bounds__(256) void warp_bwd_tiled_kernel(const float4* __res
     const int sp = live ? sy * Wp + sx : 0;
     const int e0 = live ? off[sp] : 0, e1 = live ? off[sp + 1] : 0;
     float4 xv[WB];
-    const bool need_x = clamp || (partial_ss != nullptr && prjl2_scale != 0.f);
+    // (`clamp_bits`: the gate's three comparisons as one byte per pixel from the kernel that wrote x -- spaa_step_and_track_n --: 1 byte
+    // per pixel instead of x's 16; x itself only for the prjl2 term)
+    const bool need_x = (clamp && clamp_bits == nullptr) || (partial_ss != nullptr && prjl2_scale != 0.f);
+    unsigned int cb[WB];
 #pragma unroll
-    for (int k = 0; k < WB; ++k) xv[k] = (need_x && live) ? x[(size_t)(b0 + k < B ? b0 + k : B - 1) * HWp + sp] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < WB; ++k) {
+        const size_t o = (size_t)(b0 + k < B ? b0 + k : B - 1) * HWp + sp;
+        xv[k] = (need_x && live) ? x[o] : make_float4(0.f, 0.f, 0.f, 0.f);
+        cb[k] = (clamp && clamp_bits != nullptr && live) ? clamp_bits[o] : 7u;
+    }
     int li0[4];
     float w0[4];
 #pragma unroll
@@ -390,7 +398,11 @@ __global__ __launch_bounds__(256) void warp_bwd_tiled_kernel(const float4* __res
         const size_t o = (size_t)(b0 + k) * HWp + sp;
         float r0 = a0[k], r1 = a1[k], r2 = a2[k];
         const float4 v = xv[k];
-        if (clamp) {
+        if (clamp && clamp_bits != nullptr) {
+            r0 = (cb[k] & 1u) ? r0 : 0.f;
+            r1 = (cb[k] & 2u) ? r1 : 0.f;
+            r2 = (cb[k] & 4u) ? r2 : 0.f;
+        } else if (clamp) {
             r0 = (v.x >= 0.f && v.x <= 1.f) ? r0 : 0.f;
             r1 = (v.y >= 0.f && v.y <= 1.f) ? r1 : 0.f;
             r2 = (v.z >= 0.f && v.z <= 1.f) ? r2 : 0.f;
@@ -529,7 +541,8 @@ int spaa_warp_bwd_gather(const float* g_xw, const float* g_xs, const float* x, c
 
 static int launch_warp_bwd_tiled(const float* g_xw, const float* x, const int32_t* off, const int32_t* lidx, const float* w_e,
                                  const int32_t* tbox, int box_cap, float* g_x, int B, int Hp, int Wp, int Hc, int Wc, int clamp,
-                                 float* partial_ss, const int32_t* state, float gray, float prjl2_scale, spaa_stream_t stream) {
+                                 float* partial_ss, const int32_t* state, float gray, float prjl2_scale, const uint8_t* clamp_bits,
+                                 spaa_stream_t stream) {
     if (!g_xw || !x || !off || !lidx || !w_e || !tbox || !g_x || B < 1 || Hp < 1 || Wp < 1 || Hc < 1 || Wc < 1 || box_cap < 1 ||
         (size_t)box_cap * WB * 16 > 64 * 1024)
         return hipErrorInvalidValue;
@@ -540,22 +553,23 @@ static int launch_warp_bwd_tiled(const float* g_xw, const float* x, const int32_
     if (partial_ss != nullptr && smem < 4 * WB * sizeof(float)) smem = 4 * WB * sizeof(float);
     hipLaunchKernelGGL(warp_bwd_tiled_kernel, dim3(ntx * nty, (B + WB - 1) / WB), dim3(256), smem,
                        (hipStream_t)stream, (const float4*)g_xw, (const float4*)x, off, lidx, w_e, tbox, (float4*)g_x, B, Hp, Wp,
-                       Hc, Wc, ntx, box_cap, clamp, partial_ss, state, gray, prjl2_scale);
+                       Hc, Wc, ntx, box_cap, clamp, partial_ss, state, gray, prjl2_scale, clamp_bits);
     return (int)hipGetLastError();
 }
 
 int spaa_warp_bwd_tiled(const float* g_xw, const float* x, const int32_t* off, const int32_t* lidx, const float* w_e,
                         const int32_t* tbox, int box_cap, float* g_x, int B, int Hp, int Wp, int Hc, int Wc, int clamp,
                         spaa_stream_t stream) {
-    return launch_warp_bwd_tiled(g_xw, x, off, lidx, w_e, tbox, box_cap, g_x, B, Hp, Wp, Hc, Wc, clamp, nullptr, nullptr, 0.f, 0.f, stream);
+    return launch_warp_bwd_tiled(g_xw, x, off, lidx, w_e, tbox, box_cap, g_x, B, Hp, Wp, Hc, Wc, clamp, nullptr, nullptr, 0.f, 0.f, nullptr, stream);
 }
 
 int spaa_warp_bwd_tiled_sumsq(const float* g_xw, const float* x, const int32_t* off, const int32_t* lidx, const float* w_e,
                               const int32_t* tbox, int box_cap, float* g_x, int B, int Hp, int Wp, int Hc, int Wc, int clamp,
-                              float gray, float prjl2_scale, const int32_t* state, float* partial_ss, spaa_stream_t stream) {
+                              float gray, float prjl2_scale, const int32_t* state, float* partial_ss, const uint8_t* clamp_bits,
+                              spaa_stream_t stream) {
     if (!partial_ss || (prjl2_scale != 0.f && !state)) return hipErrorInvalidValue;
     return launch_warp_bwd_tiled(g_xw, x, off, lidx, w_e, tbox, box_cap, g_x, B, Hp, Wp, Hc, Wc, clamp, partial_ss, state, gray, prjl2_scale,
-                                 stream);
+                                 clamp_bits, stream);
 }
 
 int spaa_warp_fwd_taps(const float* x, const int32_t* tap_src, const float* tap_wgt, float* xw, int B, int Hp, int Wp, int Hc, int Wc,

@@ -268,6 +268,7 @@ TILED_WARP_BWD = os.environ.get('SPAA_TILED_WARP_BWD', '1') != '0'   # LDS-stage
 TAP_TABLE_FWD = os.environ.get('SPAA_TAP_TABLE_FWD', '1') != '0'     # grid_sample forward from the per-attack tap table, 32 x 8 tiles (0: the grid kernel)
 GATE_BYTE_Y = os.environ.get('SPAA_GATE_BYTE_Y', '1') != '0'         # fused tail / head: the output's clamp gate as one byte per pixel, no pre-clamp tensor in HBM (0: Ypre written and read)
 S2F_H16 = os.environ.get('SPAA_S2F_H16', '1') != '0'                 # fp16 storage: the stride-2 forward forms on csrc/s2f_h16.hip (0: the patch-staged kernel's stride-2 form)
+S2F_X6 = os.environ.get('SPAA_S2F_X6', '1') != '0'                   # fp32: conv2 / conv2_s on csrc/s2f_x6.hip (0: the implicit-GEMM bf16x6 tile)
 FS2_H16 = os.environ.get('SPAA_FS2_H16', '1') != '0'                 # fp16 storage: the fractional-stride 3 x 3 layers on csrc/fs2_h16.hip (0: the patch-staged kernel's folded form)
 FUSE_C1BWD = os.environ.get('SPAA_FUSE_C1BWD', '1') != '0'           # fp16 storage: the input gradients of conv1 / conv1_s as one launch (0: two thin-output launches)
 FUSE_SUMSQ = os.environ.get('SPAA_FUSE_SUMSQ', '1') != '0'           # spaa_grad_sumsq as the epilogue of the tiled grid_sample adjoint (0: its own launch)
@@ -371,6 +372,20 @@ def pack_s2f(w_eff):
     Returns fp16 [K/32][9][N/16][64][8]."""
     w_eff = w_eff.detach().float().cpu()
     return torch.stack([_fs2_lanes(w_eff[t // 3, t % 3]) for t in range(9)], 1).half().contiguous()
+
+
+def pack_s2f_x6(w_eff):
+    """Weight image of spaa_s2f_x6 (include/spaa_hip.h): `w_eff` [3, 3, N, K] as for pack_s2f, every entry split exactly into three bf16 planes
+    (cp.split_planes).  Returns int16 (bf16 bits) [K/32][9][3][N/16][64][8]."""
+    w_eff = w_eff.detach().float().cpu()
+    # K index 8 g + e of a 32-channel step = channel 4 g + e (e < 4) / 16 + 4 g + e - 4: the kernel's two 16-byte loads per lane are bytes
+    # [16 g, 16 g + 16) of the pixel's first and second 64 bytes (whole 64-byte segments per load instruction)
+    kk = torch.arange(w_eff.shape[3])
+    ge, e = (kk % 32) // 8, kk % 8
+    perm = (kk // 32) * 32 + torch.where(e < 4, 4 * ge + e, 16 + 4 * ge + e - 4)
+    w_eff = w_eff[..., perm]
+    img = torch.stack([_fs2_lanes(w_eff[t // 3, t % 3]) for t in range(9)], 1)          # [ks][9][rb][64][8] fp32
+    return cp.split_planes(img).permute(1, 2, 0, 3, 4, 5).contiguous()                    # [3][ks][9][...] -> [ks][9][3][rb][64][8]
 
 
 def pack_pair1_bwd(w_conv1, w_conv1_s):
@@ -509,6 +524,12 @@ class PCNetEngine:
                 self.fs2.update(f2=(pack_s2f(sn.conv2.weight.permute(2, 3, 0, 1)).to(dev), sn.conv2.bias.detach().float().contiguous().to(dev)),
                                 f2s=(pack_s2f(sn.conv2_s.weight.permute(2, 3, 0, 1)).to(dev), sn.conv2_s.bias.detach().float().contiguous().to(dev)),
                                 tcd=(pack_s2f(sn.transConv1.weight.permute(2, 3, 0, 1)).to(dev),))
+        # fp32: conv2 / conv2_s (32 -> 64, stride 2) on the persistent weights-in-LDS bf16x6 kernel (csrc/s2f_x6.hip)
+        self.s2fx = None
+        if (S2F_X6 and storage == 'f32' and self.Hc % 4 == 0 and self.Wc % 4 == 0 and tuple(sn.conv2.weight.shape) == (64, 32, 3, 3)
+                and tuple(sn.conv2_s.weight.shape) == (64, 32, 3, 3)):
+            self.s2fx = dict(f2=(pack_s2f_x6(sn.conv2.weight.permute(2, 3, 0, 1)).to(dev), sn.conv2.bias.detach().float().contiguous().to(dev)),
+                             f2s=(pack_s2f_x6(sn.conv2_s.weight.permute(2, 3, 0, 1)).to(dev), sn.conv2_s.bias.detach().float().contiguous().to(dev)))
         # likewise `conv5(x4) + skipConv3(x2)` (models.py:294,298) and `conv3^T(g3) + skipConv3^T(g5)`: one Winograd launch each over
         # the concatenated input channels, read from two tensors (cp.conv_fwd_plan_2src)
         self.fuse_skip3 = False
@@ -619,6 +640,10 @@ class PCNetEngine:
             w, bb = self.fs2['f2s']
             _lib.call('spaa_s2f_h16', _lib.hptr(a['S1']), 32, 32, _lib.hptr(w), _lib.ptr(bb), None, None, 1, _lib.hptr(a['S2']), _lib.ptr(m['S2']), 64,
                       self.B, self.Hc // 2, self.Wc // 2)
+        elif self.s2fx is not None:
+            w, bb = self.s2fx['f2s']
+            _lib.call('spaa_s2f_x6', _lib.ptr(a['S1']), 32, 32, C_ptr(w), _lib.ptr(bb), None, None, 1, _lib.ptr(a['S2']),
+                      _lib.ptr(m['S2']) if m['S2'] is not None else None, 64, self.B, self.Hc // 2, self.Wc // 2)
         else:
             f['conv2_s'].run(a['S1'], a['S2'], act=R, mask_out=m['S2'])
         f['conv3_s'].run(a['S2'], a['S3'], act=R, mask_out=m['S3'])
@@ -664,6 +689,10 @@ class PCNetEngine:
             w, bb = self.fs2['f2']
             _lib.call('spaa_s2f_h16', _lib.hptr(a['X1']), 32, 32, _lib.hptr(w), _lib.ptr(bb), _lib.hptr(a['S2']), None, 1, _lib.hptr(a['X2']),
                       _lib.ptr(m['X2']), 64, self.B, self.Hc // 2, self.Wc // 2)
+        elif self.s2fx is not None:
+            w, bb = self.s2fx['f2']
+            _lib.call('spaa_s2f_x6', _lib.ptr(a['X1']), 32, 32, C_ptr(w), _lib.ptr(bb), _lib.ptr(a['S2']), None, 1, _lib.ptr(a['X2']),
+                      _lib.ptr(m['X2']) if m['X2'] is not None else None, 64, self.B, self.Hc // 2, self.Wc // 2)
         else:
             f['conv2'].run(a['X1'], a['X2'], add=a['S2'], act=R, mask_out=m['X2'])
         if not self.fuse_skip3:
@@ -730,7 +759,7 @@ class PCNetEngine:
         ok = self.tiled is not None and FUSE_SUMSQ and (USE_GATE_MASKS or self.storage == 'f16')   # (SPAA_GATE_MASKS=0: the A/B backward has no such argument)
         return ((self.Wp + 15) // 16) * ((self.Hp + 15) // 16) if ok else 0
 
-    def backward(self, gP, select=None, input_grad=True, sumsq=None):
+    def backward(self, gP, select=None, input_grad=True, sumsq=None, clamp_bits=None):
         """gP: gradient w.r.t. conv6's pre-activation (already gated by 0 < Ypre <= 1), [B,Hc,Wc,4]; or None with
         `select` = (g_adv, g_col, state): the two candidate cotangents at the network output [B,Hc,Wc,4] and the loop's state
         int32 [B,4] (projector_based_attack.py:302-315), see `can_select`.
@@ -791,7 +820,7 @@ class PCNetEngine:
             d['conv2'].run(g['P2'], g['P1'], add=g['t1'], gate_bits=m['X1'])
         if not self.rough:   # the surface branch is a constant: the gradient reaches the warped image through conv1 alone
             d['conv1'].run(g['P1'], g['xw'])
-            return self.warp_backward(g['xw'], sumsq) if input_grad else g['xw']
+            return self.warp_backward(g['xw'], sumsq, clamp_bits) if input_grad else g['xw']
         # surface branch (depends on x through the rough input x*s)
         d['conv4_s'].run(g['S4'], g['S3'], add=g['P3'], gate_bits=m['S3'])
         d['conv3_s'].run(g['S3'], g['S2'], add=g['P2'], gate_bits=m['S2'])
@@ -808,7 +837,7 @@ class PCNetEngine:
         else:
             d['conv1_s'].run(g['S1'], g['xs'], gate=self.scene, gate_mode=_lib.GATE_MUL)
             d['conv1'].run(g['P1'], g['xw'], add=g['xs'])
-        return self.warp_backward(g['xw'], sumsq) if input_grad else g['xw']
+        return self.warp_backward(g['xw'], sumsq, clamp_bits) if input_grad else g['xw']
 
     def _backward_float_gates(self, gP):
         """The same backward pass reading the fp32 activations as gates (SPAA_GATE_MASKS=0: A/B measurements)."""
@@ -847,19 +876,22 @@ class PCNetEngine:
             self.f['transConv2'].run(dict.__getitem__(self.a, 'X6'), dict.__getitem__(self.a, 'X7'), act=_lib.ACT_RELU)
             self._x7_version = self.version
 
-    def warp_backward(self, g_xw, sumsq=None):
+    def warp_backward(self, g_xw, sumsq=None, clamp_bits=None):
         """Adjoint of the masked grid_sample (models.py:184,340): deterministic gather over the transposed tap lists; the
         mask is folded into the tap weights.  `sumsq` = (partial [B, sumsq_tiles()], gray, prjl2_scale, state): spaa_grad_sumsq folded
-        into the tiled kernel's epilogue (only with sumsq_tiles() > 0)."""
+        into the tiled kernel's epilogue (only with sumsq_tiles() > 0).  `clamp_bits` [B, Hp * Wp] uint8 (with `sumsq` only): the clamp
+        gate's comparisons for the x of the last forward pass, as spaa_step_and_track_n wrote them (the caller answers for that)."""
         g = self.g
         if sumsq is not None:
             assert self.sumsq_tiles() > 0
             part, gray, scale, state = sumsq
             assert part.shape == (self.B, self.sumsq_tiles()) and part.dtype == torch.float32 and part.is_contiguous()
+            if clamp_bits is not None:
+                assert clamp_bits.shape == (self.B, self.Hp * self.Wp) and clamp_bits.dtype == torch.uint8 and clamp_bits.is_contiguous()
             lidx, w_e, tbox, cap = self.tiled
             _lib.call('spaa_warp_bwd_tiled_sumsq', _lib.ptr(g_xw), _lib.ptr(self._x), C_ptr(self.tap_off), C_ptr(lidx), _lib.ptr(w_e),
                       C_ptr(tbox), cap, _lib.ptr(g['x']), self.B, self.Hp, self.Wp, self.Hc, self.Wc, self._clamp, float(gray), float(scale),
-                      _lib.ptr(state), _lib.ptr(part))
+                      _lib.ptr(state), _lib.ptr(part), _lib.ptr(clamp_bits) if clamp_bits is not None else None)
             return g['x']
         if self.tiled is not None:
             lidx, w_e, tbox, cap = self.tiled

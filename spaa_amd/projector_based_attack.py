@@ -25,6 +25,7 @@ import os
 
 # B * Hc * Wc up to which spaa() replays the iteration as a captured HIP graph (0 disables); above it the GPU is busy for
 # longer than the host needs to enqueue an iteration and eager launches lose nothing (measured: < 1 % at B = 64, 256 x 256)
+CLAMP_BITS = os.environ.get('SPAA_CLAMP_BITS', '1') == '1'   # the step writes the next backward pass's clamp gate as bytes (A/B runs: 0)
 GRAPH_MAX_PIXELS = int(os.environ.get('SPAA_GRAPH_MAX_PIXELS', str(16 * 256 * 256)))
 LAST_RUN = {}   # of the last spaa() call: executed iterations (1 eager + iters - 1 replays = iters: a capture executes nothing), graph or not
 
@@ -94,6 +95,12 @@ class AttackState:
         # adjoint computes them in its epilogue
         self.ss_tiles = self.eng.sumsq_tiles()
         self.partial_ss = torch.zeros(B, self.ss_tiles or self.nblk_p, device=dev)
+        # The clamp gate of x.clamp(0, 1) (:265) for the backward pass as one byte per projector pixel, written by the step that writes x:
+        # the grid_sample adjoint then reads 1 byte per pixel instead of x's 16.  The bytes describe self.x as long as nobody else has
+        # written it: `_bits_version` remembers torch's version counter of self.x (in-place torch writes -- tests that inject an x --
+        # bump it, this module's own kernels go through raw pointers and do not): a mismatch falls back to the comparisons on x.
+        self.clamp_bits = torch.zeros(B, self.HWp, dtype=torch.uint8, device=dev) if self.ss_tiles and CLAMP_BITS else None
+        self._bits_version = -1
         self.g_col = torch.zeros(B, Hc, Wc, 4, device=dev)
         self.gP = torch.zeros(B, Hc, Wc, 4, device=dev)
         self.g_logits = torch.zeros(B, self.clf.ncls, device=dev)
@@ -139,16 +146,19 @@ class AttackState:
         g_adv = self.clf.backward(self.g_logits)                                     # :302 (classifier part)
         prjl2_scale = self.prjl2_w / (B * self.HWp) * self.gs_col
         ss = (self.partial_ss, self.gray, prjl2_scale, self.state) if self.ss_tiles else None   # (||g||^2 from the adjoint's epilogue)
+        bits = self.clamp_bits if (self.clamp_bits is not None and self._bits_version == self.x._version) else None
         if self.eng.can_select():   # (the per-sample choice and the clamp gate as the first phase of the fused head kernel)
-            gx = self.eng.backward(None, select=(g_adv, self.g_col, self.state), sumsq=ss)   # :302 / :310 (PCNet part)
+            gx = self.eng.backward(None, select=(g_adv, self.g_col, self.state), sumsq=ss, clamp_bits=bits)   # :302 / :310 (PCNet part)
         else:
             _lib.call('spaa_select_grad', p(g_adv), p(self.g_col), p(self.state), p(self.eng.a['Ypre']), p(self.gP), B,
                       self.HWc)
-            gx = self.eng.backward(self.gP, sumsq=ss)                                # :302 / :310 (PCNet part)
+            gx = self.eng.backward(self.gP, sumsq=ss, clamp_bits=bits)               # :302 / :310 (PCNet part)
         if not self.ss_tiles:
             _lib.call('spaa_grad_sumsq', p(gx), p(self.x), self.gray, prjl2_scale, p(self.state), p(self.partial_ss), B, self.HWp)
         _lib.call('spaa_step_and_track_n', p(self.x), p(gx), p(self.partial_ss), self.partial_ss.shape[1], p(self.state), float(adv_lr),
-                  float(col_lr), p(self.x_best), p(y), p(self.cam_best), B, self.HWp, self.HWc)   # :307,315,323-328
+                  float(col_lr), p(self.x_best), p(y), p(self.cam_best), B, self.HWp, self.HWc,
+                  p(self.clamp_bits) if self.clamp_bits is not None else None)       # :307,315,323-328
+        self._bits_version = self.x._version
 
     def results(self):
         with torch.cuda.device(self.dev):

@@ -2076,7 +2076,7 @@ def test_warp_backward_tiled_equals_gather(hip, cam, prj, b):
     assert rel_inf(a[..., :3].permute(0, 3, 1, 2), xc.grad) < 5e-5   # (border pixels sum hundreds of taps: another order on the CPU)
 
 
-@pytest.mark.parametrize('cam,prj,b', [((64, 64), (64, 64), 5), ((240, 320), (256, 256), 3), ((44, 68), (56, 40), 9), ((256, 256), (256, 256), 6)])
+@pytest.mark.parametrize('cam,prj,b', [((64, 64), (64, 64), 5), ((240, 320), (256, 256), 3), ((44, 68), (56, 40), 9), ((256, 256), (256, 256), 6), ((48, 40), (45, 35), 4)])
 def test_warp_forward_from_tap_table_and_fused_sumsq(hip, cam, prj, b):
     """Round 6, csrc/warp.hip.  (a) spaa_warp_fwd_taps -- grid_sample from the per-attack tap table (32 x 8 camera tiles, four images per
     workgroup) -- against the grid kernel (same taps; weights x mask folded: equal to rounding), against F.grid_sample on the CPU, and as
@@ -2143,9 +2143,20 @@ def test_warp_forward_from_tap_table_and_fused_sumsq(hip, cam, prj, b):
         cam_im, cb_a, cb_b = torch.rand(b, cam[0], cam[1], 4, device=DEV), torch.zeros(b, cam[0], cam[1], 4, device=DEV), torch.zeros(b, cam[0], cam[1], 4, device=DEV)
         lib.call('spaa_step_and_track', lib.ptr(xa), lib.ptr(ref), lib.ptr(part_ref), lib.ptr(state), 2.0, 1.0, lib.ptr(best_a), lib.ptr(cam_im),
                  lib.ptr(cb_a), b, prj[0] * prj[1], cam[0] * cam[1])
+        bits = torch.full((b, prj[0] * prj[1]), 255, dtype=torch.uint8, device=DEV)
         lib.call('spaa_step_and_track_n', lib.ptr(xb_), lib.ptr(got), lib.ptr(part), part.shape[1], lib.ptr(state), 2.0, 1.0, lib.ptr(best_b),
-                 lib.ptr(cam_im), lib.ptr(cb_b), b, prj[0] * prj[1], cam[0] * cam[1])
+                 lib.ptr(cam_im), lib.ptr(cb_b), b, prj[0] * prj[1], cam[0] * cam[1], lib.ptr(bits))
         assert rel_inf(xb_, xa) < 1e-6 and rel_inf(best_b, best_a) < 1e-6 and torch.equal(cb_a, cb_b)
+        # the step's clamp-gate bytes describe the x it wrote; the adjoint gated by them = the adjoint gated by that x, bit for bit
+        ok = (xb_[..., :3] >= 0) & (xb_[..., :3] <= 1)
+        want_bits = (ok[..., 0].to(torch.uint8) | (ok[..., 1].to(torch.uint8) << 1) | (ok[..., 2].to(torch.uint8) << 2)).reshape(b, -1)
+        assert torch.equal(bits, want_bits) and 0 < int((bits != 7).sum()) < bits.numel()
+        eng._x = xb_
+        pa, pb = torch.zeros_like(part), torch.zeros_like(part)
+        ga = eng.warp_backward(g, sumsq=(pa, 0.5, scale, state)).clone()
+        gb = eng.warp_backward(g, sumsq=(pb, 0.5, scale, state), clamp_bits=bits).clone()
+        assert torch.equal(ga, gb) and torch.equal(pa, pb)
+        eng._x = x
 
 
 def test_vgg16_attack_loop_first_iteration(hip):
@@ -2175,7 +2186,11 @@ def test_benchmarked_configuration_first_iteration(hip):
         tiles = sorted({(name, tid) for name, _k, _f, _e0, _e1, tid, _b in convplan.PROFILE})
     finally:
         convplan.PROFILE = None
-    assert st.B == 64 and int((st.flips == 0).sum()) >= 32          # (most samples need no gate exchange at all)
+    # (Gates that differ from the oracle's sit within rounding of zero: of the ~1.6e8 ReLU / clamp gates per sample a handful at most, and a
+    # good part of the samples needs no exchange at all.  The count moves with the summation order of any layer -- 40 of 64 samples without
+    # a flip up to round 5, 24 with conv2 / conv2_s on csrc/s2f_x6.hip, whose nine taps accumulate in another order: 1-2 gates per sample.)
+    print('samples by number of gates exchanged with the oracle:', torch.bincount(st.flips.flatten().long().cpu()).tolist())
+    assert st.B == 64 and int((st.flips == 0).sum()) >= 16 and int(st.flips.max()) <= 4
     kinds = {tid % 100 for _n, tid in tiles}
     print('kernels of the benchmarked configuration:', sorted(kinds), 'split / canvas launches:', sorted({(n, t) for n, t in tiles if t >= 100})[:12])
     assert {70, 71} & kinds and any(t >= 100 and t % 100 in (70, 71) for _n, t in tiles)   # Winograd incl. its K-range (canvas) form
@@ -2796,6 +2811,46 @@ def test_s2f_h16_stride2_forward(hip, ci, co, h, w, b):
     if ci == 128:     # a weight image that does not fit the 160 KB of LDS is refused, not truncated
         with pytest.raises(RuntimeError):
             lib.call('spaa_s2f_h16', lib.hptr(xin), ci, ci, lib.hptr(w_img), None, None, None, 0, lib.hptr(out), None, 128, b, h, w)
+
+
+@pytest.mark.parametrize('h,w,b', [(32, 32, 2), (18, 70, 3), (8, 6, 5), (128, 128, 2)])
+def test_s2f_x6_stride2_forward(hip, h, w, b):
+    """csrc/s2f_x6.hip (round 6, fp32): Conv2d(32, 64, 3, 2, 1) forward -- conv2 / conv2_s -- with all weights (three bf16 planes) resident in
+    LDS and the bf16x6 arithmetic, against float64 on the same fp32 operands at the accuracy of the other fp32 kernels: plain; bias +
+    residual + ReLU + byte mask out; byte-mask gate; ragged widths, the zero padding on all four sides; bitwise run to run; and against the
+    implicit-GEMM tile it replaces."""
+    M, lib = hip['models'], hip['lib']
+    ci, co = 32, 64
+    torch.manual_seed(h + w)
+    x = torch.randn(b, ci, h, w)
+    wt = torch.randn(co, ci, 3, 3) / (ci * 9) ** 0.5
+    ref = F.conv2d(x.double(), wt.double(), None, 2, 1)
+    w_img = M.pack_s2f_x6(wt.permute(2, 3, 0, 1)).to(DEV)
+    xin = nhwc(x).contiguous().to(DEV)
+    ho, wo = h // 2, w // 2
+    bias = torch.randn(co)
+    add = torch.randn(b, co, ho, wo)
+    gate = torch.randn(b, co, ho, wo)
+
+    def run(bias_=None, add_=None, gate_=None, relu=0, mask=None):
+        out = torch.full((b, ho, wo, co), 7.0, device=DEV)
+        lib.call('spaa_s2f_x6', lib.ptr(xin), ci, ci, M.C_ptr(w_img), lib.ptr(bias_) if bias_ is not None else None,
+                 lib.ptr(add_) if add_ is not None else None, lib.ptr(gate_) if gate_ is not None else None, relu, lib.ptr(out),
+                 lib.ptr(mask) if mask is not None else None, co, b, h, w)
+        return out
+
+    out = run()
+    e0 = rel_inf(nchw(out.cpu(), co), ref)
+    assert e0 < 2e-6, e0
+    assert torch.equal(out, run())
+    mask = torch.zeros(b, ho, wo, co // 4, dtype=torch.uint8, device=DEV)
+    out1 = run(bias_=bias.to(DEV), add_=nhwc(add).contiguous().to(DEV), relu=1, mask=mask)
+    want1 = F.relu(ref + bias.view(1, -1, 1, 1).double() + add.double())
+    e1 = rel_inf(nchw(out1.cpu(), co), want1)
+    assert e1 < 2e-6 and torch.equal(mask, lib.pack_gate_mask(out1)), e1
+    out2 = run(gate_=lib.pack_gate_mask(nhwc(gate).contiguous().to(DEV)))
+    assert rel_inf(nchw(out2.cpu(), co), ref * (gate > 0)) < 2e-6
+    print(f's2f_x6 {ci}->{co} {h}x{w} B={b}: rel err vs fp64 {e0:.1e} plain, {e1:.1e} bias + residual + ReLU')
 
 
 def test_h16p_two_workgroups_per_cu(hip):

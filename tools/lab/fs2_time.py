@@ -68,3 +68,21 @@ for name, ci, co, hi, use_add, use_gate, use_mask, relu in (('conv2 (+res2_s, Re
     us = timeit(run)
     mb = (x.numel() + out.numel() + (add.numel() if use_add else 0)) * 2 / 1e6
     print(f'{name:28s} {us:7.1f} us  ({mb:.0f} MB)', flush=True)
+
+print('--- csrc/s2f_x6.hip: fp32 stride-2 forward (bf16x6)')
+for name, use_add, use_mask, relu in (('conv2 (+res2_s, ReLU, mask)', 1, 1, 1), ('conv2_s (ReLU, mask)', 0, 1, 1), ('32->64 plain', 0, 0, 0)):
+    ci, co, hi = 32, 64, 128
+    w_img = M.pack_s2f_x6(torch.randn(3, 3, co, ci) / (ci * 9) ** 0.5).to(DEV)
+    x = torch.randn(B, hi, hi, ci, device=DEV)
+    ho = hi // 2
+    out = torch.zeros(B, ho, ho, co, device=DEV)
+    bias = torch.randn(co, device=DEV)
+    add = torch.randn(B, ho, ho, co, device=DEV) if use_add else None
+    mask = torch.zeros(B, ho, ho, co // 4, device=DEV, dtype=torch.uint8) if use_mask else None
+
+    def run():
+        _lib.call('spaa_s2f_x6', _lib.ptr(x), ci, ci, M.C_ptr(w_img), _lib.ptr(bias), _lib.ptr(add) if use_add else None, None, relu, _lib.ptr(out),
+                  _lib.ptr(mask) if use_mask else None, co, B, hi, hi)
+    us = timeit(run)
+    mb = (x.numel() + out.numel() + (add.numel() if use_add else 0)) * 4 / 1e6
+    print(f'{name:28s} {us:7.1f} us  ({mb:.0f} MB)', flush=True)
