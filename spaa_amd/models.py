@@ -524,9 +524,10 @@ class PCNetEngine:
                 self.fs2.update(f2=(pack_s2f(sn.conv2.weight.permute(2, 3, 0, 1)).to(dev), sn.conv2.bias.detach().float().contiguous().to(dev)),
                                 f2s=(pack_s2f(sn.conv2_s.weight.permute(2, 3, 0, 1)).to(dev), sn.conv2_s.bias.detach().float().contiguous().to(dev)),
                                 tcd=(pack_s2f(sn.transConv1.weight.permute(2, 3, 0, 1)).to(dev),))
-        # fp32: conv2 / conv2_s (32 -> 64, stride 2) on the persistent weights-in-LDS bf16x6 kernel (csrc/s2f_x6.hip)
+        # fp32: conv2 / conv2_s (32 -> 64, stride 2) on the persistent weights-in-LDS bf16x6 kernel (csrc/s2f_x6.hip).  Frozen weights only
+        # (its weight images are packed here, once: the training step, which refreshes the separate layers' plans, passes fuse_skip2=False)
         self.s2fx = None
-        if (S2F_X6 and storage == 'f32' and self.Hc % 4 == 0 and self.Wc % 4 == 0 and tuple(sn.conv2.weight.shape) == (64, 32, 3, 3)
+        if (S2F_X6 and fuse_skip2 is not False and storage == 'f32' and self.Hc % 4 == 0 and self.Wc % 4 == 0 and tuple(sn.conv2.weight.shape) == (64, 32, 3, 3)
                 and tuple(sn.conv2_s.weight.shape) == (64, 32, 3, 3)):
             self.s2fx = dict(f2=(pack_s2f_x6(sn.conv2.weight.permute(2, 3, 0, 1)).to(dev), sn.conv2.bias.detach().float().contiguous().to(dev)),
                              f2s=(pack_s2f_x6(sn.conv2_s.weight.permute(2, 3, 0, 1)).to(dev), sn.conv2_s.bias.detach().float().contiguous().to(dev)))
