@@ -73,6 +73,37 @@ __device__ __forceinline__ f32x4 mfma6(const bf16x8 w0, const bf16x8 w1, const b
     return acc;
 }
 
+// Workgroup barrier for LDS hand-overs inside the tile loops: waits for this wave's LDS operations only.  __syncthreads() also drains
+// vmcnt -- every global load requested ahead (the next tile's operands, the residual, the gate bytes) and, on gfx950, every STORE of the
+// tile just finished would be waited for at each barrier: two to three exposed HBM round trips per tile (cdna_hip_programming.md section
+// 5, "Pipelining across barriers").  No wave reads global memory another wave of the launch wrote: nothing else needs the drain.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Buffer descriptor of image `img` of a tensor of `img_bytes` per image (NULL tensor: no records -- loads give zero, stores are dropped).
+// Every per-pixel global access of the tile loops goes through one with a 32-bit byte offset, a pixel that does not exist being the
+// out-of-range offset: NO branch around a memory operation.  (With the accesses inside `if (inside)` blocks the compiler's wait-count
+// insertion joined the paths conservatively and waited for the NEXT tile's operands at the first product of the current one -- one exposed
+// HBM round trip per tile and wave.)
+constexpr int OOB = (int)0x80000000;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t img_rsrc(const void* base, const int img, const int64_t img_bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base) + (uint64_t)(int64_t)img * (uint64_t)img_bytes;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(base != nullptr ? (int)img_bytes : 0), 0x00020000);
+}
+__device__ __forceinline__ f32x4 ld_f4(const __amdgpu_buffer_rsrc_t r, const int off) {
+    const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return f32x4{__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3])};
+}
+__device__ __forceinline__ void st_f4(const f32x4 v, const __amdgpu_buffer_rsrc_t r, const int off) {
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, r, off, 0, 0);
+}
+
 constexpr int C6 = 64, C7 = 32;        // channels of X6 and X7 (models.py:167-168)
 constexpr int RY = 8, RX = 16;         // X6 pixels of a tile
 constexpr int TY = 2 * RY, TX = 2 * RX;  // X7 pixels of a tile (16 x 32), of which the interior 14 x 30 is owned
@@ -190,31 +221,16 @@ __global__ __launch_bounds__(64 * FWD_WAVES, sizeof(T6) == 2 ? 8 : 1) void shadi
         const int tx_ = tile_ % tiles_x, ty_ = (tile_ / tiles_x) % tiles_y, img = tile_ / (tiles_x * tiles_y);
         const int ay = (OY / 2) * ty_ - 1 + row, ax = (OX / 2) * tx_ - 1 + rx;
         const bool in6 = tile_ < ntiles && (unsigned)ay < (unsigned)H2 && (unsigned)ax < (unsigned)W2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const auto rs = img_rsrc(x6, tile_ < ntiles ? img : 0, (int64_t)H2 * W2 * C6 * (int64_t)sizeof(T6));
+        const int off = in6 ? ((ay * W2 + ax) * C6 + g * 8) * (int)sizeof(T6) : OOB;   // (a pixel outside the image: zeros)
         if constexpr (H16) {
-            xh[0] = xh[1] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (in6) {
-                const T6* src = x6 + (((size_t)img * H2 + ay) * W2 + ax) * C6 + g * 8;
-                xh[0] = *reinterpret_cast<const h8*>(src);
-                xh[1] = *reinterpret_cast<const h8*>(src + 32);
-            }
-            return;
-        }
-        if (in6) {
-            const T6* src = x6 + (((size_t)img * H2 + ay) * W2 + ax) * C6 + g * 8;
-            if constexpr (sizeof(T6) == 4) {
-                xin[0] = *reinterpret_cast<const f32x4*>(src);
-                xin[1] = *reinterpret_cast<const f32x4*>(src + 4);
-                xin[2] = *reinterpret_cast<const f32x4*>(src + 32);
-                xin[3] = *reinterpret_cast<const f32x4*>(src + 36);
-            } else {
-                const h8 a = *reinterpret_cast<const h8*>(src), b = *reinterpret_cast<const h8*>(src + 32);
-                xin[0] = f32x4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
-                xin[1] = f32x4{(float)a[4], (float)a[5], (float)a[6], (float)a[7]};
-                xin[2] = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
-                xin[3] = f32x4{(float)b[4], (float)b[5], (float)b[6], (float)b[7]};
-            }
+            xh[0] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            xh[1] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 64, 0, 0));
+        } else {
+            xin[0] = ld_f4(rs, off);
+            xin[1] = ld_f4(rs, off + 16);
+            xin[2] = ld_f4(rs, off + 128);
+            xin[3] = ld_f4(rs, off + 144);
         }
     };
     load_x6(blockIdx.x);
@@ -223,6 +239,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, sizeof(T6) == 2 ? 8 : 1) void shadi
         // owned output rows [OY ty - 1, OY ty + OY - 1), X7 rows [OY ty - 2, + TY), X6 rows [(OY/2) ty - 1, + RY)
         const int a0 = (OY / 2) * ty_ - 1, b0 = (OX / 2) * tx_ - 1;   // first X6 row / column of the tile
         const bool interior = a0 >= 0 && 2 * a0 + TY <= H && b0 >= 0 && 2 * b0 + TX <= W;
+        const int64_t HW = (int64_t)H * W;     // (the image's descriptors are built where they are used: 4 SGPRs each, live for a few instructions)
         // ---- phase 1: X7 tile = relu(transConv2(X6) + bias); lane = (X6 column, 8-channel chunk)
         {
             bf16x8 pf[2][3];
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, sizeof(T6) == 2 ? 8 : 1) void shadi
                 else *reinterpret_cast<f32x4*>(tl + wofs[nq]) = v;
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- phase 2: conv6 (3x3, 32 -> 3) over this wave's 16 channels; X7's gate bytes from the centre tap (relu(t) > 0 <=> t > 0)
         if constexpr (H16) {
             // wave w < 14 owns interior row w: two groups of 16 X7 columns (0..15 and 16..31); lane = (column of the group, 8-channel
@@ -278,9 +295,8 @@ __global__ __launch_bounds__(64 * FWD_WAVES, sizeof(T6) == 2 ? 8 : 1) void shadi
                 const int ox = 16 * g + rx;                    // the output pixel this lane finishes (g < 2)
                 const int gy = 2 * a0 + 1 + oy, gx = 2 * b0 + 1 + ox;
                 const bool ok = g < 2 && ox < OX && gy >= 0 && gy < H && gx >= 0 && gx < W;
-                const size_t o = ((size_t)img * H + (ok ? gy : 0)) * W + (ok ? gx : 0);
-                f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-                if (ok) rv = *reinterpret_cast<const f32x4*>(r1 + o * 4);   // (requested early: used after the taps)
+                const int oi = gy * W + gx;                    // pixel index inside the image
+                const f32x4 rv = ld_f4(img_rsrc(r1, img, HW * 16), ok ? oi * 16 : OOB);   // (requested early: used after the taps)
                 // (one tap row in flight per wave: 64 registers = eight waves per SIMD hide the LDS latency between them)
 #pragma unroll 1
                 for (int dy = 0; dy < 3; ++dy) {
@@ -315,12 +331,13 @@ __global__ __launch_bounds__(64 * FWD_WAVES, sizeof(T6) == 2 ? 8 : 1) void shadi
                         bitsB |= (cB[e] > (_Float16)0 ? 1u : 0u) << (8 * (e >> 2) + (e & 3));
                     }
                     const int gxa = 2 * b0 + 1 + rx, gxb = gxa + 16;
-                    if (gy >= 0 && gy < H) {
-                        if (gxa >= 0 && gxa < W) *reinterpret_cast<uint16_t*>(mask7 + (((size_t)img * H + gy) * W + gxa) * (C7 / 4) + 2 * g) = (uint16_t)bitsA;
-                        if (rx + 16 < OX && gxb >= 0 && gxb < W) *reinterpret_cast<uint16_t*>(mask7 + (((size_t)img * H + gy) * W + gxb) * (C7 / 4) + 2 * g) = (uint16_t)bitsB;
-                    }
+                    const bool yok = gy >= 0 && gy < H;
+                    const bool okA = yok && gxa >= 0 && gxa < W, okB = yok && rx + 16 < OX && gxb >= 0 && gxb < W;
+                    const auto r_m7 = img_rsrc(mask7, img, HW * (C7 / 4));
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bitsA, r_m7, okA ? (gy * W + gxa) * (C7 / 4) + 2 * g : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bitsB, r_m7, okB ? (gy * W + gxb) * (C7 / 4) + 2 * g : OOB, 0, 0);
                 }
-                if (ok) {
+                {
                     f32x4 outv = {0.f, 0.f, 0.f, 0.f}, prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int n = 0; n < 3; ++n) {
@@ -328,22 +345,21 @@ __global__ __launch_bounds__(64 * FWD_WAVES, sizeof(T6) == 2 ? 8 : 1) void shadi
                         prev[n] = t;
                         outv[n] = fminf(t, 1.f);
                     }
-                    *reinterpret_cast<f32x4*>(y + o * 4) = outv;
-                    if (ypre != nullptr) *reinterpret_cast<f32x4*>(ypre + o * 4) = prev;
-                    if (gate_y != nullptr)
-                        gate_y[o] = (uint8_t)((prev[0] > 0.f && prev[0] <= 1.f ? 1u : 0u) | (prev[1] > 0.f && prev[1] <= 1.f ? 2u : 0u) |
-                                              (prev[2] > 0.f && prev[2] <= 1.f ? 4u : 0u));
+                    st_f4(outv, img_rsrc(y, img, HW * 16), ok ? oi * 16 : OOB);
+                    st_f4(prev, img_rsrc(ypre, img, HW * 16), ok ? oi * 16 : OOB);                 // (no `ypre`: no records, dropped)
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((prev[0] > 0.f && prev[0] <= 1.f ? 1u : 0u) | (prev[1] > 0.f && prev[1] <= 1.f ? 2u : 0u) |
+                                                                         (prev[2] > 0.f && prev[2] <= 1.f ? 4u : 0u)),
+                                                         img_rsrc(gate_y, img, HW), ok ? oi : OOB, 0, 0);   // (no `gate_y`: dropped)
                 }
             }
-            __syncthreads();   // the tile is free for the next one
+            lds_barrier();   // the tile is free for the next one
             continue;
         }
         f2 acc[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
         const int gy = 2 * a0 + 1 + oy_l, gx = 2 * b0 + 1 + ox_l;
         const bool ok = p2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const size_t o = ((size_t)img * H + (ok ? gy : 0)) * W + (ok ? gx : 0);
-        f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-        if (ok && ph == 0) rv = *reinterpret_cast<const f32x4*>(r1 + o * 4);   // (requested early: used after the taps)
+        const int oi = gy * W + gx;                    // pixel index inside the image
+        const f32x4 rv = ld_f4(img_rsrc(r1, img, HW * 16), (ok && ph == 0) ? oi * 16 : OOB);   // (requested early: used after the taps)
         if (p2) {
             unsigned int bits = 0;
 #pragma unroll 1
@@ -371,12 +387,12 @@ __global__ __launch_bounds__(64 * FWD_WAVES, sizeof(T6) == 2 ? 8 : 1) void shadi
                 const f32x4 a = *reinterpret_cast<const f32x4*>(p2base + (TX + 1) * 16 + u * PLANE);
                 bits |= ((a[0] > 0.f ? 1u : 0u) | (a[1] > 0.f ? 2u : 0u) | (a[2] > 0.f ? 4u : 0u) | (a[3] > 0.f ? 8u : 0u)) << (8 * u);
             }
-            if (ok) *reinterpret_cast<uint32_t*>(mask7 + o * (C7 / 4) + 4 * ph) = bits;
+            __builtin_amdgcn_raw_buffer_store_b32(bits, img_rsrc(mask7, img, HW * (C7 / 4)), ok ? oi * (C7 / 4) + 4 * ph : OOB, 0, 0);
             if (ph == 1) *reinterpret_cast<f32x4*>(rl + pix * 16) = f32x4{acc[0][0] + acc[0][1], acc[1][0] + acc[1][1], acc[2][0] + acc[2][1], 0.f};
         }
-        __syncthreads();   // the second half's sums are in LDS; the tile is free for the next one
-        if (ok && ph == 0) {
-            const f32x4 other = *reinterpret_cast<const f32x4*>(rl + pix * 16);
+        lds_barrier();   // the second half's sums are in LDS; the tile is free for the next one
+        if (ph == 0) {     // (wave-uniform)
+            const f32x4 other = *reinterpret_cast<const f32x4*>(rl + (p2 ? pix : 0) * 16);
             f32x4 outv = {0.f, 0.f, 0.f, 0.f}, prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int n = 0; n < 3; ++n) {
@@ -384,11 +400,11 @@ __global__ __launch_bounds__(64 * FWD_WAVES, sizeof(T6) == 2 ? 8 : 1) void shadi
                 prev[n] = t;
                 outv[n] = fminf(t, 1.f);
             }
-            *reinterpret_cast<f32x4*>(y + o * 4) = outv;
-            if (ypre != nullptr) *reinterpret_cast<f32x4*>(ypre + o * 4) = prev;
-            if (gate_y != nullptr)
-                gate_y[o] = (uint8_t)((prev[0] > 0.f && prev[0] <= 1.f ? 1u : 0u) | (prev[1] > 0.f && prev[1] <= 1.f ? 2u : 0u) |
-                                      (prev[2] > 0.f && prev[2] <= 1.f ? 4u : 0u));
+            st_f4(outv, img_rsrc(y, img, HW * 16), ok ? oi * 16 : OOB);
+            st_f4(prev, img_rsrc(ypre, img, HW * 16), ok ? oi * 16 : OOB);                 // (no `ypre`: no records, dropped)
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((prev[0] > 0.f && prev[0] <= 1.f ? 1u : 0u) | (prev[1] > 0.f && prev[1] <= 1.f ? 2u : 0u) |
+                                                                 (prev[2] > 0.f && prev[2] <= 1.f ? 4u : 0u)),
+                                                 img_rsrc(gate_y, img, HW), ok ? oi : OOB, 0, 0);   // (no `gate_y`: dropped)
         }
         // (the next tile's phase 1 writes `tl` only; `rl` is rewritten after its barrier: no third barrier needed, since the
         // first-half waves read `rl` before they reach that barrier)
@@ -519,7 +535,7 @@ __global__ __launch_bounds__(1024, sizeof(T6) == 2 ? 8 : 1) void shading_head_bw
                 if (gyw < H && gxw < W) mb16[grp] = *reinterpret_cast<const uint64_t*>(mask7 + (((size_t)img * H + gyw) * W + gxw) * (C7 / 4));
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- phase 1: P7[pixel][16 nh ..] = gate7 . sum_{taps, 3 ch} gP[pixel + d] w6t[tap][ch][16 nh ..]
         {
             const int pyw = wave;
@@ -572,7 +588,7 @@ __global__ __launch_bounds__(1024, sizeof(T6) == 2 ? 8 : 1) void shading_head_bw
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- phase 2: P6[m][n] = gate6 . sum_k P7[m][k] W[n][k];  lane = (X6 column, k chunk)
         {
             const int m = 16 * row + rx;
@@ -621,7 +637,7 @@ __global__ __launch_bounds__(1024, sizeof(T6) == 2 ? 8 : 1) void shading_head_bw
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
