@@ -255,7 +255,10 @@ extern "C" int spaa_fs2_h16(const void* in, int in_cstride, int Cin, const void*
     if (in2 == nullptr) Cin2 = 0;
     const size_t smem = (size_t)(Cin / 32 * 9 + Cin2 / 32) * (Cout / 16) * 1024;
     if (smem > 160 * 1024) return hipErrorInvalidValue;
-    if ((int64_t)B * Hi * Wi * 4 * 64 * 2 >= (int64_t)1 << 40) return hipErrorInvalidValue;
+    {   // 32-bit buffer offsets: every tensor below 2 GiB
+        const int64_t npx_i = (int64_t)B * Hi * Wi, lim = (int64_t)1 << 31;
+        if (npx_i * in_cstride * 2 >= lim || 4 * npx_i * Cout * 2 >= lim || (in2 != nullptr && 4 * npx_i * in2_cstride * 2 >= lim)) return hipErrorInvalidValue;
+    }
     fs2_args a;
     a.in = reinterpret_cast<const _Float16*>(in), a.in2 = reinterpret_cast<const _Float16*>(in2);
     a.w_img = reinterpret_cast<const _Float16*>(w_img), a.w2_img = reinterpret_cast<const _Float16*>(w2_img);

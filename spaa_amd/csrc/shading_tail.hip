@@ -649,6 +649,7 @@ static int launch_tail_fwd(const T6* x6, const uint16_t* w2_split, const float* 
     if (!x6 || !w2_split || !bias2 || !w6 || !bias6 || !res1 || !y || (!ypre && !gate_y) || !mask7 || B <= 0 || H2 <= 0 || W2 <= 0)
         return hipErrorInvalidValue;
     if ((int64_t)B * H2 * W2 * 4 * C7 * 4 >= (int64_t)1 << 40) return hipErrorInvalidValue;
+    if ((int64_t)H2 * W2 * C6 * 4 >= (int64_t)1 << 31) return hipErrorInvalidValue;   // (per-image buffer descriptors, 32-bit offsets inside an image)
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const int H = 2 * H2, W = 2 * W2;
     const int tiles_y = (H + 1 + OY - 1) / OY, tiles_x = (W + 1 + OX - 1) / OX;   // owned rows start at -1

@@ -510,7 +510,8 @@ class PCNetEngine:
         # round 6, fp16 storage: the three fractional-stride layers (transConv1 + skipConv2, conv2^T + skipConv2^T, conv2_s^T) on the
         # persistent per-input-pixel kernel: exactly the nine real (class, tap) products, all weights resident in LDS (csrc/fs2_h16.hip)
         self.fs2 = None
-        if (FS2_H16 and storage == 'f16' and self.fuse_skip2 and 'transConv1x' in f and 'conv2x' in d and self.rough
+        small = batch * self.Hc * self.Wc * 32 < 2 ** 31      # (the persistent stride-2 kernels address every tensor with 32-bit byte offsets; the largest -- X6 in fp16, X1 in fp32 -- holds 32 bytes per camera pixel)
+        if (FS2_H16 and small and storage == 'f16' and self.fuse_skip2 and 'transConv1x' in f and 'conv2x' in d and self.rough
                 and tuple(sn.transConv1.weight.shape) == (128, 64, 3, 3) and tuple(sn.conv2.weight.shape) == (64, 32, 3, 3)
                 and tuple(sn.conv2_s.weight.shape) == (64, 32, 3, 3) and tuple(sn.skipConv2.weight.shape) == (64, 32, 1, 1)):
             sk = sn.skipConv2.weight.detach()[:, :, 0, 0]
@@ -527,7 +528,7 @@ class PCNetEngine:
         # fp32: conv2 / conv2_s (32 -> 64, stride 2) on the persistent weights-in-LDS bf16x6 kernel (csrc/s2f_x6.hip).  Frozen weights only
         # (its weight images are packed here, once: the training step, which refreshes the separate layers' plans, passes fuse_skip2=False)
         self.s2fx = None
-        if (S2F_X6 and fuse_skip2 is not False and storage == 'f32' and self.Hc % 4 == 0 and self.Wc % 4 == 0 and tuple(sn.conv2.weight.shape) == (64, 32, 3, 3)
+        if (S2F_X6 and small and fuse_skip2 is not False and storage == 'f32' and self.Hc % 4 == 0 and self.Wc % 4 == 0 and tuple(sn.conv2.weight.shape) == (64, 32, 3, 3)
                 and tuple(sn.conv2_s.weight.shape) == (64, 32, 3, 3)):
             self.s2fx = dict(f2=(pack_s2f_x6(sn.conv2.weight.permute(2, 3, 0, 1)).to(dev), sn.conv2.bias.detach().float().contiguous().to(dev)),
                              f2s=(pack_s2f_x6(sn.conv2_s.weight.permute(2, 3, 0, 1)).to(dev), sn.conv2_s.bias.detach().float().contiguous().to(dev)))
