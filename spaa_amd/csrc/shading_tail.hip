@@ -498,6 +498,11 @@ __global__ __launch_bounds__(1024, sizeof(T6) == 2 ? 8 : 1) void shading_head_bw
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx_ = tile % tiles_x, ty_ = (tile / tiles_x) % tiles_y, img = tile / (tiles_x * tiles_y);
         const int a0 = RY * ty_, b0 = RX * tx_;   // first X6 row / column
+        // the 8 gate bytes of this lane's X6 pixel's channel half (phase 2), requested HERE -- ahead of both barriers, through the image's
+        // buffer descriptor (a pixel outside = the out-of-range offset = zeros: no branch, the wait stays counted)
+        const int ay = a0 + row, ax = b0 + rx;
+        const bool in6 = ay < H2 && ax < W2;
+        const auto g6u = __builtin_amdgcn_raw_buffer_load_b64(img_rsrc(mask6, img, (int64_t)H2 * W2 * (C6 / 4)), in6 ? (ay * W2 + ax) * (C6 / 4) + 8 * nh : OOB, 0, 0);
         // ---- phase 0: gP tile with halo (out-of-image pixels: zeros = conv6's zero padding seen from the gradient)
         if (tid < GP_W * GP_H) {
             const int qy = tid / GP_W, qx = tid - qy * GP_W;
@@ -604,10 +609,7 @@ __global__ __launch_bounds__(1024, sizeof(T6) == 2 ? 8 : 1) void shading_head_bw
                     split8(u0, u1, pf[s][0], pf[s][1], pf[s][2]);
                 }
             }
-            const int ay = a0 + row, ax = b0 + rx;
-            const bool in6 = ay < H2 && ax < W2;
-            uint64_t g6 = 0;   // the 8 gate bytes of this X6 pixel's channel half
-            if (in6) g6 = *reinterpret_cast<const uint64_t*>(mask6 + (((size_t)img * H2 + ay) * W2 + ax) * (C6 / 4) + 8 * nh);
+            const uint64_t g6 = (uint64_t)g6u[0] | ((uint64_t)g6u[1] << 32);
 #pragma unroll
             for (int nq = 0; nq < 2; ++nq) {
                 const int nb = 2 * nh + nq;
