@@ -194,13 +194,13 @@ def timed_steps(step, steps, warmup, dist, sync):
     full collection over this process's 175 000 tracked objects takes 55 ms (tools/lab/gc_probe.py) -- inside a 20-step window of 80-160 ms
     that is the whole measurement (one run of this round read 6.16 ms per step where the same run's kernels summed to 3.88)."""
     import gc
-    for _ in range(warmup):
-        step()
-    sync()
-    gc.collect()
+    gc.collect()               # (BEFORE the warm-up steps: 55 ms of idle GPU right in front of the timed window would cost its first steps their clocks)
     gc_was_on = gc.isenabled()
     gc.disable()
     try:
+        for _ in range(warmup):
+            step()
+        sync()
         if dist is not None:
             dist.barrier()
         sync()
@@ -550,7 +550,10 @@ def main():
             names.setdefault(tile_names(tid)[0], []).append((tid, ms))
         dom_name = max(names, key=lambda k: sum(m for _, m in names[k]))
         dom_ids = {tid for tid, _ in names[dom_name]}
-        convplan.PROFILE, convplan.PROFILE_ONLY = timed_events, dom_ids
+        if os.environ.get('SPAA_BENCH_NO_TIMED_EVENTS') != '1':   # (A/B: what the events inside the timed region cost)
+            convplan.PROFILE, convplan.PROFILE_ONLY = timed_events, dom_ids
+        else:
+            convplan.PROFILE = None
     log('warmup + timed region')
     dt_local = timed_steps(st.step, args.steps, args.warmup, dist, torch.cuda.synchronize)
     convplan.PROFILE, convplan.PROFILE_ONLY = None, None
